@@ -1,0 +1,203 @@
+/*
+ * ipcr_hip.h -- C ABI of the MI355X-native ipcr primer matcher (libipcr_hip.so).
+ *
+ * This is the drop-in boundary for ipcr's seeded-scan + per-hit-verify path.  The
+ * reference has no FFI today; its seam is the Go interface family in
+ * internal/pipeline/sim.go:11-39, constructed at internal/appcore/core.go:108-117.
+ * Every entry point below names the reference symbol it replaces; INTEGRATION.md
+ * shows the cgo shim that binds them behind pipeline.StreamingCompiledSimulator.
+ *
+ * Conventions: plain pointers and sizes only; every function returns an
+ * ipcr_status (0 = ok) unless stated; no pointer passed in is retained after the
+ * call returns (cgo rule); all handles are opaque; errors never abort the
+ * process (the reference panics; see ipcr_last_error()).  There is no CPU
+ * fallback: every scan runs on the HIP device or fails with IPCR_ERR_DEVICE.
+ */
+#ifndef IPCR_HIP_H
+#define IPCR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPCR_ABI_VERSION 1
+#define IPCR_MAX_PRIMER_LEN 128 /* longest primer/probe the device path accepts */
+#define IPCR_MAX_MM 16          /* largest --mismatches the device path accepts */
+
+typedef enum {
+    IPCR_OK = 0,
+    IPCR_ERR_INVALID = 1,     /* bad argument (NULL handle, negative max_mm, ...) */
+    IPCR_ERR_PRIMER = 2,      /* primer/probe is not upper-case IUPAC DNA (core/primer/rc.go:27-34 panics here) */
+    IPCR_ERR_UNSUPPORTED = 3, /* primer longer than IPCR_MAX_PRIMER_LEN, max_mm > IPCR_MAX_MM */
+    IPCR_ERR_DEVICE = 4,      /* HIP error, no device, kernel build failure */
+    IPCR_ERR_CAPACITY = 5,    /* more hits than the device buffers can hold even after regrowth */
+    IPCR_ERR_ABORTED = 6      /* emit callback returned non-zero (ForEachCompiledProduct's emit error) */
+} ipcr_status;
+
+/* engine.Config -- core/engine/engine.go:10-19.  need_sites only affects presentation
+ * (FwdSite/RevSite) and is ignored by the scan. */
+typedef struct {
+    int32_t max_mm;
+    int32_t terminal_window;
+    int32_t min_len;
+    int32_t max_len;
+    int32_t hit_cap;
+    int32_t seed_len;
+    int32_t circular;
+    int32_t need_sites;
+} ipcr_config;
+
+/* primer.Pair -- core/primer/pair.go:4-10 */
+typedef struct {
+    const char *id;
+    const char *forward;
+    const char *reverse;
+    int32_t min_product;
+    int32_t max_product;
+} ipcr_pair;
+
+/* engine.Product -- core/engine/product.go:4-35 (scan-produced fields).  ExperimentID is
+ * pairs[pair].id, SequenceID is the caller's id for `record`.  Mismatch indices are in
+ * primer 5'->3' coordinates exactly as the reference emits them (rev_idx descending). */
+typedef struct {
+    int64_t start;
+    int64_t end;
+    int64_t length;
+    int32_t pair;
+    int32_t record;
+    int32_t type; /* 0 = "forward", 1 = "revcomp" */
+    int32_t fwd_mm;
+    int32_t rev_mm;
+    int32_t n_fwd_idx;
+    int32_t n_rev_idx;
+    uint8_t fwd_idx[IPCR_MAX_MM];
+    uint8_t rev_idx[IPCR_MAX_MM];
+} ipcr_product;
+
+/* primer.Match -- core/primer/match.go:8-13, as produced on the device.  One record per
+ * (distinct pattern, start).  `mm_mask` has bit j set when pattern position j mismatches
+ * (ascending MismatchIdx = set bits in order).  This is the record exchanged between
+ * GPUs by the RCCL all-gatherv. */
+typedef struct {
+    uint64_t pos;        /* 0-based start on the forward strand, record-local */
+    uint32_t record;     /* record (or chunk) index inside the scanned genome */
+    uint32_t pattern;    /* low 24 bits: distinct-pattern id; bit 31: seed span touched a non-ACGTacgt byte */
+    uint64_t mm_mask[2];
+} ipcr_hit;
+
+/* oligo.Hit -- core/oligo/oligo.go:9-15 */
+typedef struct {
+    int32_t found;
+    int32_t strand; /* '+' or '-' */
+    int32_t pos;
+    int32_t mm;
+} ipcr_probe_hit;
+
+/* per-scan measurements, filled by the last ipcr_scan_* call on a scratch */
+typedef struct {
+    double pack_ms;       /* ASCII -> tile pack kernel (0 when the genome was already resident) */
+    double filter_ms;     /* dominant kernel: bit-sliced k-mismatch filter over the tiles (HIP events) */
+    double verify_ms;     /* per-candidate verify kernel */
+    double total_ms;      /* host wall time of the call */
+    uint64_t bases;       /* genome bases scanned */
+    uint64_t tile_bytes;  /* bytes of encoded tiles the filter kernel reads once */
+    uint64_t candidates;  /* filter survivors handed to the verifier */
+    uint64_t hits;        /* verified primer.Match records */
+    uint64_t products;
+    int32_t kernel_kind;  /* 1 = panel-specialised (runtime-compiled) filter, 2 = table-driven filter */
+    int32_t n_patterns;
+} ipcr_scan_stats;
+
+typedef struct ipcr_panel ipcr_panel;     /* engine.CompiledPanel + device tables */
+typedef struct ipcr_scratch ipcr_scratch; /* engine.SimulationScratch: one HIP stream + staging per worker */
+typedef struct ipcr_genome ipcr_genome;   /* packed reference tiles resident in HBM */
+
+/* ---- process / device ---- */
+const char *ipcr_version(void);             /* internal/version/version.go:12-15 analogue */
+const char *ipcr_last_error(void);          /* thread-local message of the last failing call */
+ipcr_status ipcr_set_device(int device);    /* one process per GPU: call once before anything else */
+int ipcr_device_count(void);                /* 0 when no HIP device is visible */
+
+/* ---- core/primer helpers used by callers of the path ---- */
+uint8_t ipcr_iupac_mask(uint8_t c);                                  /* core/primer/iupac.go:6-58 */
+int ipcr_base_match(uint8_t g, uint8_t p);                           /* core/primer/iupac.go:62-67 */
+ipcr_status ipcr_revcomp(const char *seq, size_t n, char *out);      /* core/primer/rc.go:37-56 (RevCompStrict) */
+
+/* ---- engine.New + Engine.CompilePanel -- core/engine/engine.go:27, compiled.go:96-136 ---- */
+ipcr_status ipcr_panel_create(const ipcr_config *cfg, const ipcr_pair *pairs, int32_t n_pairs,
+                              ipcr_panel **out);
+void ipcr_panel_destroy(ipcr_panel *p);
+int32_t ipcr_panel_num_pairs(const ipcr_panel *p);
+int32_t ipcr_panel_num_patterns(const ipcr_panel *p); /* distinct (sequence, protected side) patterns */
+int32_t ipcr_panel_max_primer_len(const ipcr_panel *p);
+/* compiledHas(cp.Have, pair, which) -- core/engine/compiled.go:35-37; which in 'A','B','a','b' */
+int32_t ipcr_panel_have(const ipcr_panel *p, int32_t pair, char which);
+/* 0 = table-driven filter only, 1 = allow the panel-specialised filter (default) */
+ipcr_status ipcr_panel_set_specialize(ipcr_panel *p, int32_t enable);
+/* HIP source of the panel-specialised filter kernel (what hiprtc compiles at first scan);
+ * mode 0 = records without non-ACGT bytes, 1 = with.  Writes at most cap bytes (NUL-terminated),
+ * *needed = full length + 1; an empty string means the panel is not specialisable. */
+ipcr_status ipcr_panel_filter_source(const ipcr_panel *p, int32_t mode, char *out, size_t cap, size_t *needed);
+
+/* ---- Engine.NewSimulationScratch -- core/engine/hit_collect.go:21-34 ---- */
+ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out);
+void ipcr_scratch_destroy(ipcr_scratch *s);
+ipcr_status ipcr_scratch_stats(const ipcr_scratch *s, ipcr_scan_stats *out);
+/* results of the last scan on this scratch; pointers stay valid until the next scan/destroy */
+ipcr_status ipcr_scratch_products(const ipcr_scratch *s, const ipcr_product **out, int64_t *n);
+ipcr_status ipcr_scratch_hits(const ipcr_scratch *s, const ipcr_hit **out, int64_t *n);
+
+/* ---- Engine.ForEachCompiledProduct / SimulateCompiledWithScratch -- compiled.go:141-267 ----
+ * One record or chunk of upper-cased ASCII (host memory), chunk-local coordinates, products
+ * in the reference's emission order.  emit may be NULL (fetch with ipcr_scratch_products);
+ * a non-zero return from emit aborts and yields IPCR_ERR_ABORTED. */
+typedef int (*ipcr_emit_fn)(const ipcr_product *product, void *user);
+ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t *seq, uint64_t len,
+                            ipcr_emit_fn emit, void *user);
+
+/* ---- resident genome: many records packed once, scanned by any panel ---- */
+ipcr_status ipcr_genome_create(uint64_t capacity_bases, uint32_t max_records, ipcr_genome **out);
+void ipcr_genome_destroy(ipcr_genome *g);
+/* append one record: ASCII in host memory, or in device memory (16-byte aligned) */
+ipcr_status ipcr_genome_add_record(ipcr_genome *g, const uint8_t *seq, uint64_t len);
+ipcr_status ipcr_genome_add_record_device(ipcr_genome *g, const void *dev_seq, uint64_t len);
+/* fill a device buffer with the reference's benchDNA LCG stream, generated on the device with
+ * jump-ahead (core/engine/performance_benchmark_test.go:67-76); bit-identical to the serial loop */
+ipcr_status ipcr_lcg_fill_device(void *dev_out, uint64_t len, uint32_t seed);
+/* copy bases of a resident record back to the host (decoded from the tiles; invalid -> 'N') */
+ipcr_status ipcr_genome_read(const ipcr_genome *g, uint32_t record, uint64_t pos, uint8_t *out, uint64_t len);
+uint32_t ipcr_genome_num_records(const ipcr_genome *g);
+uint64_t ipcr_genome_record_len(const ipcr_genome *g, uint32_t record);
+uint64_t ipcr_genome_total_bases(const ipcr_genome *g);
+uint64_t ipcr_genome_tile_bytes(const ipcr_genome *g);
+double ipcr_genome_pack_ms(const ipcr_genome *g); /* accumulated pack-kernel time */
+
+/* scan every record of a resident genome with one launch; products carry `record` */
+ipcr_status ipcr_scan_genome(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g,
+                             ipcr_emit_fn emit, void *user);
+/* scan only (rows 10-15 of SURVEY section 8a): verified hits, no join */
+ipcr_status ipcr_scan_genome_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g);
+/* join step alone (core/engine/engine.go:108-404) over an arbitrary hit list, e.g. the
+ * all-gathered hits of several GPUs; record_len[r] is the length of record r,
+ * record_flags[r] bit0 = record contains a non-ACGTacgt byte (may be NULL = none). */
+ipcr_status ipcr_join_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_hit *hits, int64_t n_hits,
+                           const uint64_t *record_len, const uint8_t *record_flags, uint32_t n_records,
+                           ipcr_emit_fn emit, void *user);
+uint8_t ipcr_genome_record_flags(const ipcr_genome *g, uint32_t record);
+
+/* ---- oligo.BestHit / probe.AnnotateAmplicon -- core/oligo/oligo.go:19-77 ----
+ * amplicon in host memory; runs the probe rescan on the device. */
+ipcr_status ipcr_probe_best_hit(const uint8_t *amplicon, uint64_t len, const char *probe, int32_t max_mm,
+                                ipcr_probe_hit *out);
+/* batched form for ipcr-probe: every product of the last scan on `s` against the resident
+ * genome; out[i] corresponds to product i (internal/visitors/probe.go:18-33) */
+ipcr_status ipcr_probe_products(ipcr_scratch *s, const ipcr_genome *g, const char *probe, int32_t max_mm,
+                                ipcr_probe_hit *out, int64_t n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

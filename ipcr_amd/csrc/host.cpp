@@ -1,0 +1,1156 @@
+// host.cpp -- host runtime behind the C ABI (include/ipcr_hip.h).
+//
+// Mirrors, for the scan path only, the reference's engine package:
+//   ipcr_panel_create   = engine.New + Engine.CompilePanel     (core/engine/compiled.go:96-136)
+//   ipcr_scratch_create = Engine.NewSimulationScratch          (core/engine/hit_collect.go:21-34)
+//   ipcr_scan_chunk     = Engine.ForEachCompiledProduct        (core/engine/compiled.go:162-267)
+//   join                = Engine.forEachJoinedProduct          (core/engine/engine.go:108-404)
+// The scan itself (reference rows: AC seed scan, halo rescue, verifyAt, FindMatches fallback)
+// is replaced by the bit-sliced device filter + per-candidate verifier; this file turns the
+// verified hits back into exactly the per-orientation match lists the reference would hold
+// (ordering and HitCap rules included) and joins them.
+#include "ipcr_hip.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "device_types.h"
+#include "jit.h"
+#include "launch.h"
+#include "tile_layout.h"
+
+static_assert(sizeof(ipcr_hit) == sizeof(ipcr_hit_rec), "hit layouts must agree");
+static_assert(sizeof(ipcr_probe_hit) == sizeof(ipcr_probe_rec), "probe layouts must agree");
+
+namespace {
+
+thread_local std::string g_err;
+
+ipcr_status fail(ipcr_status st, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(IPCR_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------ core/primer tables
+struct Tables {
+    uint8_t mask[256];
+    uint8_t comp[256];
+    Tables() {
+        memset(mask, 0, sizeof mask);
+        memset(comp, 0, sizeof comp);
+        const char *codes = "ACGTURYSWKMBDHVN"; // core/primer/iupac.go:19-39
+        const uint8_t bits[] = {1, 2, 4, 8, 8, 5, 10, 6, 9, 12, 3, 14, 13, 11, 7, 15};
+        for (int i = 0; codes[i]; ++i) {
+            mask[(uint8_t)codes[i]] = bits[i];
+            mask[(uint8_t)(codes[i] | 0x20)] = bits[i]; // :41-57
+        }
+        const char *from = "ACGTRYSWKMBVDHN", *to = "TGCAYRSWMKVBHDN"; // core/primer/rc.go:8-24
+        for (int i = 0; from[i]; ++i) comp[(uint8_t)from[i]] = (uint8_t)to[i];
+    }
+};
+const Tables T;
+
+bool revcomp(const std::string &in, std::string &out, size_t *bad) {
+    out.resize(in.size());
+    for (size_t i = 0; i < in.size(); ++i) {
+        size_t src = in.size() - 1 - i;
+        uint8_t c = T.comp[(uint8_t)in[src]];
+        if (!c) { if (bad) *bad = src + 1; return false; }
+        out[i] = (char)c;
+    }
+    return true;
+}
+
+int popcount4(uint8_t m) { return __builtin_popcount(m & 15u); }
+
+// --------------------------------------------------- seeded-or-not (core/engine/seed.go)
+// The device scan needs no seeds, but whether the reference WOULD have seeded an orientation
+// decides which of its two code paths (collector vs FindMatches fallback) produced the match
+// list, and those differ in hit-cap and ordering details (compiled.go:185-258).
+int configured_seed_len(int plen, int cfg) { // seed.go:104-115
+    if (cfg <= 0) return plen < 12 ? plen : 12;
+    return cfg > plen ? plen : cfg;
+}
+
+struct SeedSpan { bool seeded; int off, len; };
+
+SeedSpan reference_seed_span(const std::string &pat, int seed_len_cfg, bool prefer_right, int left_tw,
+                             int right_tw, int max_mm) {
+    SeedSpan r{false, 0, 0};
+    const int plen = (int)pat.size();
+    if (seed_len_cfg < 0 || plen == 0) return r; // seed.go:156-159,175-177
+    const int len = configured_seed_len(plen, seed_len_cfg);
+    if (len <= 0 || len > plen) return r;
+    int best_off = 0;
+    uint64_t best_score = 0;
+    for (int off = 0; off + len <= plen; ++off) { // chooseSeedSpan seed.go:260-283
+        uint64_t score = 1;
+        for (int i = 0; i < len; ++i) {
+            uint64_t n = (uint64_t)popcount4(T.mask[(uint8_t)pat[off + i]]);
+            if (n == 0) n = 5;
+            score *= n;
+        }
+        const bool tie = prefer_right ? off > best_off : off < best_off;
+        if (off == 0 || score < best_score || (score == best_score && tie)) { best_off = off; best_score = score; }
+    }
+    r.off = best_off;
+    r.len = len;
+    // count enumerateSeedVariants' output (seed.go:304-367) without enumerating: strings within
+    // <= max_mm mismatches, none at protected positions
+    if (max_mm < 0) max_mm = 0;
+    if (left_tw < 0) left_tw = 0;
+    if (right_tw < 0) right_tw = 0;
+    const uint64_t CAP = 1000000000ull;
+    std::vector<uint64_t> f((size_t)max_mm + 1, 0), g((size_t)max_mm + 1, 0);
+    f[0] = 1;
+    for (int p = 0; p < len; ++p) {
+        const int full = best_off + p;
+        const bool prot = (left_tw > 0 && full < left_tw) || (right_tw > 0 && full >= plen - right_tw);
+        const uint64_t nm = (uint64_t)popcount4(T.mask[(uint8_t)pat[full]]);
+        const uint64_t nx = 4 - nm;
+        for (int m = 0; m <= max_mm; ++m) {
+            uint64_t v = f[(size_t)m] * nm;
+            if (!prot && m > 0) v += f[(size_t)m - 1] * nx;
+            g[(size_t)m] = v > CAP ? CAP : v;
+        }
+        f.swap(g);
+    }
+    uint64_t total = 0;
+    for (int m = 0; m <= max_mm; ++m) total += f[(size_t)m];
+    // > 50000 variants, none at all, or a seed the 2-bit key cannot hold (> 32 nt) -> unseeded
+    r.seeded = total > 0 && total <= 50000 && len <= 32; // seed.go:97,188-207
+    return r;
+}
+
+} // namespace
+
+// ----------------------------------------------------------------------------- panel
+
+struct PatternDef {
+    std::string seq;
+    bool left;   // protected window on the left (rc orientations 'a','b'), else right ('A','B')
+    int tw_dev;  // protected length enforced on the device (0 = host filters)
+    int seed_off, seed_len;
+    bool seeded;
+};
+
+struct PatternSet {
+    std::vector<uint32_t> ids; // global pattern ids scanned in this mode
+    std::vector<ipcr_dev_pattern> host;
+    ipcr_dev_pattern *dev = nullptr;
+    ipcr::JitFilter *jit = nullptr;
+    bool jit_tried = false;
+    std::string jit_error;
+};
+
+struct ipcr_panel {
+    ipcr_config cfg{};
+    int tw = 0; // effective (negative -> 0)
+    std::vector<std::string> id, fwd, rev;
+    std::vector<int32_t> minp, maxp;
+    std::vector<std::array<std::string, 4>> ori; // A, B, rc(A), rc(B)  compiled.go:108-117
+    std::vector<uint8_t> have;                   // orientationMask compiled.go:6-37
+    std::vector<PatternDef> defs;                // global pattern table
+    std::vector<std::array<std::array<uint32_t, 2>, 4>> slot; // [pair][which][mode] -> global id
+    PatternSet set[2];                           // mode 0: no record holds a reset byte; mode 1: some do
+    bool modes_equal = true;
+    int max_len = 0;
+    bool specialize = true;
+    int device = -1;
+    mutable std::mutex mu;
+};
+
+namespace {
+
+void build_dev_pattern(const ipcr_panel &p, const PatternDef &d, uint32_t gid, ipcr_dev_pattern &o) {
+    memset(&o, 0, sizeof o);
+    const int L = (int)d.seq.size();
+    o.len = (uint16_t)L;
+    o.seed_off = (uint16_t)d.seed_off;
+    o.seed_len = (uint16_t)(d.seeded ? d.seed_len : 0);
+    o.global_id = gid;
+    int tw = d.tw_dev;
+    if (tw > L) tw = L;
+    for (int j = 0; j < L; ++j) {
+        uint8_t m = T.mask[(uint8_t)d.seq[(size_t)j]] & 15u;
+        const bool prot = p.cfg.max_mm == 0 || (tw > 0 && (d.left ? j < tw : j >= L - tw));
+        o.mask[j] = (uint8_t)(m | (prot ? 16u : 0u));
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char *ipcr_version(void) { return "ipcr-hip 0.1.0 (bitsliced-pigeonhole-gfx950)"; }
+const char *ipcr_last_error(void) { return g_err.c_str(); }
+
+int ipcr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+ipcr_status ipcr_set_device(int device) {
+    HIPCHK(hipSetDevice(device));
+    return IPCR_OK;
+}
+
+uint8_t ipcr_iupac_mask(uint8_t c) { return T.mask[c]; }
+
+int ipcr_base_match(uint8_t g, uint8_t p) { // core/primer/iupac.go:62-67
+    if (g != 'A' && g != 'C' && g != 'G' && g != 'T') return 0;
+    return (T.mask[p] & T.mask[g]) != 0;
+}
+
+ipcr_status ipcr_revcomp(const char *seq, size_t n, char *out) {
+    if (!seq || !out) return fail(IPCR_ERR_INVALID, "ipcr_revcomp: null argument");
+    std::string o;
+    size_t bad = 0;
+    if (!revcomp(std::string(seq, n), o, &bad))
+        return fail(IPCR_ERR_PRIMER,
+                    "invalid reverse-complement base %c at position %zu; expected normalized uppercase IUPAC DNA",
+                    seq[bad - 1], bad);
+    memcpy(out, o.data(), n);
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_panel_create(const ipcr_config *cfg, const ipcr_pair *pairs, int32_t n_pairs, ipcr_panel **out) {
+    if (!cfg || !out || n_pairs < 0 || (n_pairs > 0 && !pairs)) return fail(IPCR_ERR_INVALID, "ipcr_panel_create: null argument");
+    *out = nullptr;
+    // The reference never validates --mismatches (internal/clibase/common.go:124-174) and its two
+    // matchers disagree on negative values (ac.go:207 vs match.go:79); the boundary refuses them.
+    if (cfg->max_mm < 0) return fail(IPCR_ERR_INVALID, "max_mm must be >= 0 (got %d)", cfg->max_mm);
+    if (cfg->max_mm > IPCR_MAX_MM) return fail(IPCR_ERR_UNSUPPORTED, "max_mm %d exceeds IPCR_MAX_MM (%d)", cfg->max_mm, IPCR_MAX_MM);
+    std::unique_ptr<ipcr_panel> p(new ipcr_panel);
+    p->cfg = *cfg;
+    p->tw = cfg->terminal_window > 0 ? cfg->terminal_window : 0;
+    const int k = cfg->max_mm, tw = p->tw;
+    std::map<std::string, uint32_t> index; // key: seq | side | tw_dev
+    auto intern = [&](const std::string &seq, bool left, int tw_dev, const SeedSpan &sp) -> uint32_t {
+        std::string key = seq + (left ? "|L" : "|R") + std::to_string(tw_dev);
+        auto it = index.find(key);
+        if (it != index.end()) return it->second;
+        PatternDef d{seq, left, tw_dev, sp.off, sp.len, sp.seeded};
+        p->defs.push_back(d);
+        index.emplace(key, (uint32_t)p->defs.size() - 1);
+        return (uint32_t)p->defs.size() - 1;
+    };
+    for (int i = 0; i < n_pairs; ++i) {
+        if (!pairs[i].forward || !pairs[i].reverse) return fail(IPCR_ERR_INVALID, "pair %d: null primer", i);
+        std::array<std::string, 4> o;
+        o[0] = pairs[i].forward;
+        o[1] = pairs[i].reverse;
+        size_t bad = 0;
+        for (int w = 0; w < 2; ++w) {
+            if (o[(size_t)w].size() > IPCR_MAX_PRIMER_LEN)
+                return fail(IPCR_ERR_UNSUPPORTED, "pair %d: primer of %zu nt exceeds IPCR_MAX_PRIMER_LEN (%d)", i,
+                            o[(size_t)w].size(), IPCR_MAX_PRIMER_LEN);
+            if (!revcomp(o[(size_t)w], o[(size_t)w + 2], &bad)) // core/primer/rc.go:27-34 panics here
+                return fail(IPCR_ERR_PRIMER,
+                            "pair %d: invalid reverse-complement base %c at position %zu; expected normalized uppercase IUPAC DNA",
+                            i, o[(size_t)w][bad - 1], bad);
+        }
+        p->id.push_back(pairs[i].id ? pairs[i].id : "");
+        p->fwd.push_back(o[0]);
+        p->rev.push_back(o[1]);
+        p->minp.push_back(pairs[i].min_product);
+        p->maxp.push_back(pairs[i].max_product);
+        uint8_t have = 0;
+        std::array<std::array<uint32_t, 2>, 4> sl{};
+        for (int w = 0; w < 4; ++w) {
+            const bool left = w >= 2;
+            const std::string &s = o[(size_t)w];
+            if ((int)s.size() > p->max_len) p->max_len = (int)s.size();
+            const SeedSpan sp = reference_seed_span(s, cfg->seed_len, !left, left ? tw : 0, left ? 0 : tw, k);
+            if (sp.seeded) have |= (uint8_t)(1u << w);
+            for (int mode = 0; mode < 2; ++mode) {
+                int tw_dev = tw;
+                // rc orientations on the reference's FindMatches path are capped BEFORE the 5' window
+                // filter (compiled.go:249-256): scan them unprotected and filter on the host.
+                if (left && tw > 0 && k > 0 && cfg->hit_cap > 0 && (!sp.seeded || mode == 1)) tw_dev = 0;
+                sl[(size_t)w][(size_t)mode] = intern(s, left, tw_dev, sp);
+            }
+        }
+        p->have.push_back(have);
+        p->slot.push_back(sl);
+        p->ori.push_back(std::move(o));
+    }
+    for (int mode = 0; mode < 2; ++mode) {
+        std::vector<char> used(p->defs.size(), 0);
+        for (auto &sl : p->slot)
+            for (int w = 0; w < 4; ++w) used[sl[(size_t)w][(size_t)mode]] = 1;
+        for (uint32_t g = 0; g < p->defs.size(); ++g)
+            if (used[g] && !p->defs[g].seq.empty()) {
+                p->set[mode].ids.push_back(g);
+                ipcr_dev_pattern dp;
+                build_dev_pattern(*p, p->defs[g], g, dp);
+                p->set[mode].host.push_back(dp);
+            }
+    }
+    p->modes_equal = p->set[0].ids == p->set[1].ids;
+    *out = p.release();
+    return IPCR_OK;
+}
+
+void ipcr_panel_destroy(ipcr_panel *p) {
+    if (!p) return;
+    for (auto &s : p->set) {
+        if (s.dev) (void)hipFree(s.dev);
+        if (s.jit) ipcr::jit_destroy(s.jit);
+    }
+    delete p;
+}
+
+int32_t ipcr_panel_num_pairs(const ipcr_panel *p) { return p ? (int32_t)p->id.size() : 0; }
+int32_t ipcr_panel_num_patterns(const ipcr_panel *p) { return p ? (int32_t)p->set[0].ids.size() : 0; }
+int32_t ipcr_panel_max_primer_len(const ipcr_panel *p) { return p ? p->max_len : 0; }
+
+int32_t ipcr_panel_have(const ipcr_panel *p, int32_t pair, char which) {
+    if (!p || pair < 0 || pair >= (int32_t)p->have.size()) return 0;
+    int w = which == 'A' ? 0 : which == 'B' ? 1 : which == 'a' ? 2 : which == 'b' ? 3 : -1;
+    if (w < 0) return 0;
+    return (p->have[(size_t)pair] >> w) & 1;
+}
+
+ipcr_status ipcr_panel_filter_source(const ipcr_panel *p, int32_t mode, char *out, size_t cap, size_t *needed) {
+    if (!p || mode < 0 || mode > 1) return fail(IPCR_ERR_INVALID, "ipcr_panel_filter_source: bad argument");
+    const std::string src = ipcr::jit_source(p->set[mode].host, p->cfg.max_mm);
+    if (needed) *needed = src.size() + 1;
+    if (out && cap) {
+        const size_t n = std::min(cap - 1, src.size());
+        memcpy(out, src.data(), n);
+        out[n] = 0;
+    }
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_panel_set_specialize(ipcr_panel *p, int32_t enable) {
+    if (!p) return fail(IPCR_ERR_INVALID, "null panel");
+    p->specialize = enable != 0;
+    return IPCR_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------- genome
+
+struct ipcr_genome {
+    int device = 0;
+    uint64_t cap_cols = 0; // columns available for records (buffer holds one extra pad block beyond)
+    uint32_t max_records = 0;
+    uint32_t *planes = nullptr;
+    uint32_t *rst = nullptr;
+    uint32_t *d_flags = nullptr; // per record, bit0 = holds a non-ACGTacgt byte
+    uint64_t *d_rec_start = nullptr, *d_rec_len = nullptr;
+    std::vector<uint64_t> rec_start, rec_len; // padded start, length
+    mutable std::vector<uint8_t> flags;
+    mutable bool flags_valid = false;
+    bool tables_dirty = true;
+    uint64_t next_col = 0;
+    uint64_t padded_until = 0; // columns [next_col, padded_until) are known to be padding
+    uint64_t total_bases = 0;
+    uint8_t *staging = nullptr;
+    uint64_t staging_cap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double pack_ms = 0;
+};
+
+namespace {
+
+uint64_t record_cols(uint64_t len) { // whole column pairs, with >= IPCR_PAD_BASES of padding after the record
+    const uint64_t two = 2ull * IPCR_COLUMN_BASES;
+    return ((len + IPCR_PAD_BASES + two - 1) / two) * 2ull;
+}
+
+ipcr_status genome_alloc(ipcr_genome *g, uint64_t cap_cols, uint32_t max_records) {
+    g->cap_cols = ((cap_cols + 63) / 64) * 64;
+    g->max_records = max_records;
+    const uint64_t blocks = g->cap_cols / 64 + 1;
+    HIPCHK(hipMalloc((void **)&g->planes, blocks * IPCR_BLOCK_PLANE_WORDS * 4ull));
+    HIPCHK(hipMalloc((void **)&g->rst, blocks * IPCR_BLOCK_RST_WORDS * 4ull));
+    HIPCHK(hipMalloc((void **)&g->d_flags, (uint64_t)max_records * 4ull));
+    HIPCHK(hipMalloc((void **)&g->d_rec_start, (uint64_t)max_records * 8ull));
+    HIPCHK(hipMalloc((void **)&g->d_rec_len, (uint64_t)max_records * 8ull));
+    HIPCHK(hipMemset(g->d_flags, 0, (uint64_t)max_records * 4ull));
+    return IPCR_OK;
+}
+
+void genome_free_buffers(ipcr_genome *g) {
+    if (g->planes) (void)hipFree(g->planes);
+    if (g->rst) (void)hipFree(g->rst);
+    if (g->d_flags) (void)hipFree(g->d_flags);
+    if (g->d_rec_start) (void)hipFree(g->d_rec_start);
+    if (g->d_rec_len) (void)hipFree(g->d_rec_len);
+    g->planes = g->rst = g->d_flags = nullptr;
+    g->d_rec_start = g->d_rec_len = nullptr;
+}
+
+void genome_clear(ipcr_genome *g) { // forget the records, keep the buffers
+    if (!g->rec_start.empty() && g->d_flags) (void)hipMemsetAsync(g->d_flags, 0, g->rec_start.size() * 4ull, g->stream);
+    g->rec_start.clear();
+    g->rec_len.clear();
+    g->flags.clear();
+    g->flags_valid = false;
+    g->tables_dirty = true;
+    g->next_col = 0;
+    g->padded_until = 0;
+    g->total_bases = 0;
+}
+
+ipcr_status genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len) {
+    const uint64_t cols = record_cols(len);
+    if (g->rec_start.size() >= g->max_records) return fail(IPCR_ERR_CAPACITY, "genome holds its maximum of %u records", g->max_records);
+    if (g->next_col + cols > g->cap_cols)
+        return fail(IPCR_ERR_CAPACITY, "genome capacity exceeded (%llu + %llu columns > %llu)",
+                    (unsigned long long)g->next_col, (unsigned long long)cols, (unsigned long long)g->cap_cols);
+    if ((reinterpret_cast<uintptr_t>(dseq) & 15u) != 0) return fail(IPCR_ERR_INVALID, "device sequence pointer must be 16-byte aligned");
+    const uint32_t rec = (uint32_t)g->rec_start.size();
+    HIPCHK(hipEventRecord(g->e0, g->stream));
+    HIPCHK(ipcr::launch_pack(g->stream, dseq, len, g->next_col, cols, g->planes, g->rst, g->d_flags + rec));
+    HIPCHK(hipEventRecord(g->e1, g->stream));
+    HIPCHK(hipEventSynchronize(g->e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, g->e0, g->e1));
+    g->pack_ms += ms;
+    g->rec_start.push_back(g->next_col * IPCR_COLUMN_BASES);
+    g->rec_len.push_back(len);
+    g->next_col += cols;
+    if (g->padded_until < g->next_col) g->padded_until = g->next_col;
+    g->total_bases += len;
+    g->tables_dirty = true;
+    g->flags_valid = false;
+    return IPCR_OK;
+}
+
+// before a scan: the rest of the last block and one block beyond must be padding, and the
+// record tables must be on the device
+ipcr_status genome_finalize(ipcr_genome *g) {
+    const uint64_t need = (g->next_col + 63) / 64 * 64 + 64;
+    if (g->padded_until < need) {
+        const uint64_t from = std::max(g->next_col, g->padded_until);
+        HIPCHK(ipcr::launch_fill_pad(g->stream, g->planes, g->rst, from, need));
+        g->padded_until = need;
+    }
+    if (g->tables_dirty && !g->rec_start.empty()) {
+        HIPCHK(hipMemcpyAsync(g->d_rec_start, g->rec_start.data(), g->rec_start.size() * 8ull, hipMemcpyHostToDevice, g->stream));
+        HIPCHK(hipMemcpyAsync(g->d_rec_len, g->rec_len.data(), g->rec_len.size() * 8ull, hipMemcpyHostToDevice, g->stream));
+        g->tables_dirty = false;
+    }
+    if (!g->flags_valid) {
+        std::vector<uint32_t> f(g->rec_start.size());
+        if (!f.empty()) HIPCHK(hipMemcpyAsync(f.data(), g->d_flags, f.size() * 4ull, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        g->flags.assign(f.size(), 0);
+        for (size_t i = 0; i < f.size(); ++i) g->flags[i] = (uint8_t)(f[i] & 1u);
+        g->flags_valid = true;
+    } else {
+        HIPCHK(hipStreamSynchronize(g->stream));
+    }
+    return IPCR_OK;
+}
+
+bool genome_any_reset(const ipcr_genome *g) {
+    for (uint8_t f : g->flags)
+        if (f & 1u) return true;
+    return false;
+}
+
+} // namespace
+
+extern "C" {
+
+ipcr_status ipcr_genome_create(uint64_t capacity_bases, uint32_t max_records, ipcr_genome **out) {
+    if (!out) return fail(IPCR_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (max_records == 0) max_records = 1;
+    std::unique_ptr<ipcr_genome> g(new ipcr_genome);
+    HIPCHK(hipGetDevice(&g->device));
+    HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&g->e0));
+    HIPCHK(hipEventCreate(&g->e1));
+    const uint64_t cols = (capacity_bases + IPCR_COLUMN_BASES - 1) / IPCR_COLUMN_BASES + 3ull * max_records;
+    ipcr_status st = genome_alloc(g.get(), cols, max_records);
+    if (st != IPCR_OK) { ipcr_genome_destroy(g.release()); return st; }
+    *out = g.release();
+    return IPCR_OK;
+}
+
+void ipcr_genome_destroy(ipcr_genome *g) {
+    if (!g) return;
+    genome_free_buffers(g);
+    if (g->staging) (void)hipFree(g->staging);
+    if (g->e0) (void)hipEventDestroy(g->e0);
+    if (g->e1) (void)hipEventDestroy(g->e1);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+ipcr_status ipcr_genome_add_record(ipcr_genome *g, const uint8_t *seq, uint64_t len) {
+    if (!g || (!seq && len)) return fail(IPCR_ERR_INVALID, "ipcr_genome_add_record: null argument");
+    if (len + 16 > g->staging_cap) {
+        if (g->staging) (void)hipFree(g->staging);
+        g->staging = nullptr;
+        g->staging_cap = len + 16 + (len >> 3);
+        HIPCHK(hipMalloc((void **)&g->staging, g->staging_cap));
+    }
+    if (len) HIPCHK(hipMemcpyAsync(g->staging, seq, len, hipMemcpyHostToDevice, g->stream));
+    return genome_add_device(g, g->staging, len);
+}
+
+ipcr_status ipcr_genome_add_record_device(ipcr_genome *g, const void *dev_seq, uint64_t len) {
+    if (!g || (!dev_seq && len)) return fail(IPCR_ERR_INVALID, "ipcr_genome_add_record_device: null argument");
+    HIPCHK(hipDeviceSynchronize()); // the caller's producer may live on another stream
+    return genome_add_device(g, static_cast<const uint8_t *>(dev_seq), len);
+}
+
+ipcr_status ipcr_lcg_fill_device(void *dev_out, uint64_t len, uint32_t seed) {
+    if (!dev_out && len) return fail(IPCR_ERR_INVALID, "ipcr_lcg_fill_device: null argument");
+    HIPCHK(ipcr::launch_lcg(nullptr, static_cast<uint8_t *>(dev_out), len, seed));
+    HIPCHK(hipDeviceSynchronize());
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_genome_read(const ipcr_genome *g, uint32_t record, uint64_t pos, uint8_t *out, uint64_t len) {
+    if (!g || !out) return fail(IPCR_ERR_INVALID, "ipcr_genome_read: null argument");
+    if (record >= g->rec_start.size() || pos + len > g->rec_len[record]) return fail(IPCR_ERR_INVALID, "ipcr_genome_read: range outside record");
+    if (len == 0) return IPCR_OK;
+    uint8_t *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, len));
+    hipError_t e = ipcr::launch_unpack(g->stream, g->planes, g->rst, g->rec_start[record] + pos, len, d);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, len, hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    (void)hipFree(d);
+    HIPCHK(e);
+    return IPCR_OK;
+}
+
+uint32_t ipcr_genome_num_records(const ipcr_genome *g) { return g ? (uint32_t)g->rec_start.size() : 0; }
+uint64_t ipcr_genome_record_len(const ipcr_genome *g, uint32_t r) { return (g && r < g->rec_len.size()) ? g->rec_len[r] : 0; }
+uint64_t ipcr_genome_total_bases(const ipcr_genome *g) { return g ? g->total_bases : 0; }
+uint64_t ipcr_genome_tile_bytes(const ipcr_genome *g) { // bytes the filter kernel streams: whole blocks of lo/hi/inv
+    return g ? ((g->next_col + 63) / 64) * IPCR_BLOCK_PLANE_WORDS * 4ull : 0;
+}
+double ipcr_genome_pack_ms(const ipcr_genome *g) { return g ? g->pack_ms : 0; }
+
+uint8_t ipcr_genome_record_flags(const ipcr_genome *g, uint32_t record) {
+    if (!g || record >= g->rec_start.size()) return 0;
+    if (!g->flags_valid) {
+        if (genome_finalize(const_cast<ipcr_genome *>(g)) != IPCR_OK) return 0;
+    }
+    return (uint8_t)((g->flags[record] & 1u) | (genome_any_reset(g) ? 2u : 0u));
+}
+
+} // extern "C"
+
+// --------------------------------------------------------------------------- scratch
+
+struct ipcr_scratch {
+    const ipcr_panel *panel = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t *d_queue = nullptr;
+    uint64_t qcap = 0;
+    ipcr_hit_rec *d_hits = nullptr;
+    uint64_t hcap = 0;
+    unsigned long long *d_counts = nullptr; // [0] candidates, [1] hits
+    void *pinned = nullptr;                 // counts (16 B) + first PREFIX hits
+    std::vector<ipcr_hit> hits;
+    std::vector<ipcr_product> products;
+    std::vector<uint64_t> last_rec_len; // of the last scanned genome (for probe)
+    std::vector<uint64_t> last_rec_start;
+    ipcr_scan_stats stats{};
+    ipcr_genome *chunk = nullptr; // private genome of ipcr_scan_chunk
+    // probe buffers
+    uint8_t *d_amps = nullptr; uint64_t amps_cap = 0;
+    void *d_probe_misc = nullptr; uint64_t probe_misc_cap = 0;
+};
+
+namespace {
+
+constexpr uint64_t PREFIX_HITS = 4096;
+constexpr uint64_t QCAP_INIT = 1ull << 22;  // 4 Mi candidates (32 MiB)
+constexpr uint64_t HCAP_INIT = 1ull << 20;  // 1 Mi hits (32 MiB)
+constexpr uint64_t QCAP_MAX = 1ull << 30;
+constexpr uint64_t HCAP_MAX = 1ull << 28;
+
+ipcr_status panel_upload(const ipcr_panel *cp, int mode) {
+    ipcr_panel *p = const_cast<ipcr_panel *>(cp);
+    std::lock_guard<std::mutex> lock(p->mu);
+    PatternSet &s = p->set[mode];
+    if (!s.dev && !s.host.empty()) {
+        HIPCHK(hipMalloc((void **)&s.dev, s.host.size() * sizeof(ipcr_dev_pattern)));
+        HIPCHK(hipMemcpy(s.dev, s.host.data(), s.host.size() * sizeof(ipcr_dev_pattern), hipMemcpyHostToDevice));
+    }
+    if (p->specialize && !s.jit_tried && !s.host.empty()) {
+        s.jit_tried = true;
+        s.jit = ipcr::jit_build(s.host, p->cfg.max_mm, s.jit_error);
+    }
+    return IPCR_OK;
+}
+
+struct HitLess {
+    bool operator()(const ipcr_hit &a, const ipcr_hit &b) const {
+        if (a.record != b.record) return a.record < b.record;
+        const uint32_t pa = a.pattern & 0x7FFFFFFFu, pb = b.pattern & 0x7FFFFFFFu;
+        if (pa != pb) return pa < pb;
+        return a.pos < b.pos;
+    }
+};
+
+ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
+    const auto t0 = std::chrono::steady_clock::now();
+    s->hits.clear();
+    s->products.clear();
+    const double pack_ms_keep = s->stats.pack_ms;
+    memset(&s->stats, 0, sizeof s->stats);
+    s->stats.pack_ms = pack_ms_keep;
+    ipcr_status st = genome_finalize(g);
+    if (st != IPCR_OK) return st;
+    s->last_rec_len = g->rec_len;
+    s->last_rec_start = g->rec_start;
+    const int mode = (!p->modes_equal && genome_any_reset(g)) ? 1 : 0;
+    st = panel_upload(p, mode);
+    if (st != IPCR_OK) return st;
+    const PatternSet &set = p->set[mode];
+    const uint32_t nrec = (uint32_t)g->rec_start.size();
+    const uint64_t nblocks = (g->next_col + 63) / 64;
+    s->stats.bases = g->total_bases;
+    s->stats.tile_bytes = nblocks * IPCR_BLOCK_PLANE_WORDS * 4ull;
+    s->stats.n_patterns = (int32_t)set.ids.size();
+    if (nrec == 0 || set.ids.empty()) return IPCR_OK;
+    const uint32_t check_rst = genome_any_reset(g) ? 1u : 0u;
+
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        HIPCHK(hipMemsetAsync(s->d_counts, 0, 16, s->stream));
+        HIPCHK(hipEventRecord(s->ev[0], s->stream));
+        if (set.jit) {
+            HIPCHK(ipcr::jit_launch(set.jit, s->stream, g->planes, nblocks, s->d_queue, s->qcap, s->d_counts));
+            s->stats.kernel_kind = 1;
+        } else {
+            HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)set.ids.size(),
+                                               (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, s->d_counts));
+            s->stats.kernel_kind = 2;
+        }
+        HIPCHK(hipEventRecord(s->ev[1], s->stream));
+        HIPCHK(ipcr::launch_verify(s->stream, g->planes, g->rst, set.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
+                                   g->d_rec_len, nrec, check_rst, s->d_queue, s->qcap, s->d_counts, s->d_hits,
+                                   s->hcap, s->d_counts + 1));
+        HIPCHK(hipEventRecord(s->ev[2], s->stream));
+        unsigned long long *pc = static_cast<unsigned long long *>(s->pinned);
+        ipcr_hit *ph = reinterpret_cast<ipcr_hit *>(pc + 2);
+        HIPCHK(hipMemcpyAsync(pc, s->d_counts, 16, hipMemcpyDeviceToHost, s->stream));
+        const uint64_t pre = std::min<uint64_t>(PREFIX_HITS, s->hcap);
+        HIPCHK(hipMemcpyAsync(ph, s->d_hits, pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        const uint64_t ncand = pc[0], nhit = pc[1];
+        if (ncand > s->qcap) { // candidate queue overflowed: regrow and rescan
+            uint64_t want = s->qcap;
+            while (want < ncand) want *= 2;
+            if (want > QCAP_MAX) return fail(IPCR_ERR_CAPACITY, "%llu filter candidates exceed the device queue limit", (unsigned long long)ncand);
+            HIPCHK(hipFree(s->d_queue));
+            s->d_queue = nullptr;
+            HIPCHK(hipMalloc((void **)&s->d_queue, want * 8ull));
+            s->qcap = want;
+            continue;
+        }
+        if (nhit > s->hcap) {
+            uint64_t want = s->hcap;
+            while (want < nhit) want *= 2;
+            if (want > HCAP_MAX) return fail(IPCR_ERR_CAPACITY, "%llu hits exceed the device hit-buffer limit", (unsigned long long)nhit);
+            HIPCHK(hipFree(s->d_hits));
+            s->d_hits = nullptr;
+            HIPCHK(hipMalloc((void **)&s->d_hits, want * sizeof(ipcr_hit_rec)));
+            s->hcap = want;
+            continue;
+        }
+        s->hits.resize(nhit);
+        const uint64_t got = std::min<uint64_t>(nhit, pre);
+        if (got) memcpy(s->hits.data(), ph, got * sizeof(ipcr_hit));
+        if (nhit > got) HIPCHK(hipMemcpy(s->hits.data() + got, s->d_hits + got, (nhit - got) * sizeof(ipcr_hit), hipMemcpyDeviceToHost));
+        float fms = 0, vms = 0;
+        HIPCHK(hipEventElapsedTime(&fms, s->ev[0], s->ev[1]));
+        HIPCHK(hipEventElapsedTime(&vms, s->ev[1], s->ev[2]));
+        s->stats.filter_ms = fms;
+        s->stats.verify_ms = vms;
+        s->stats.candidates = ncand;
+        s->stats.hits = nhit;
+        std::sort(s->hits.begin(), s->hits.end(), HitLess());
+        s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return IPCR_OK;
+    }
+    return fail(IPCR_ERR_CAPACITY, "scan buffers kept overflowing");
+}
+
+// ---------------------------------------------------------------------------- join
+struct MatchRef {
+    int64_t pos;
+    const ipcr_hit *h;
+};
+
+inline int hit_mm(const ipcr_hit *h) { return __builtin_popcountll(h->mm_mask[0]) + __builtin_popcountll(h->mm_mask[1]); }
+
+inline bool hit_has_idx_below(const ipcr_hit *h, int tw) { // filterLeftTW engine.go:53-68
+    if (tw <= 0) return false;
+    if (tw >= 64) {
+        if (h->mm_mask[0]) return true;
+        if (tw >= 128) return h->mm_mask[1] != 0;
+        return (h->mm_mask[1] & ((1ull << (tw - 64)) - 1ull)) != 0;
+    }
+    return (h->mm_mask[0] & ((1ull << tw) - 1ull)) != 0;
+}
+
+int fill_idx(const ipcr_hit *h, uint8_t *out, bool flip, int plen) {
+    int n = 0;
+    for (int w = 0; w < 2; ++w) {
+        uint64_t m = h->mm_mask[w];
+        while (m && n < IPCR_MAX_MM) {
+            const int j = __builtin_ctzll(m) + 64 * w;
+            m &= m - 1;
+            out[n++] = (uint8_t)(flip ? plen - 1 - j : j); // engine.go:127-136
+        }
+    }
+    return n;
+}
+
+struct JoinCtx {
+    const ipcr_panel *p;
+    std::vector<ipcr_product> *out;
+    ipcr_emit_fn emit;
+    void *user;
+    bool aborted = false;
+};
+
+bool push_product(JoinCtx &c, int pair, uint32_t rec, int64_t start, int64_t end, int64_t length, int type,
+                  const MatchRef &mf, const MatchRef &mr, int rlen) {
+    ipcr_product pr;
+    memset(&pr, 0, sizeof pr);
+    pr.start = start; pr.end = end; pr.length = length;
+    pr.pair = pair; pr.record = (int32_t)rec; pr.type = type;
+    pr.fwd_mm = hit_mm(mf.h);
+    pr.rev_mm = hit_mm(mr.h);
+    pr.n_fwd_idx = fill_idx(mf.h, pr.fwd_idx, false, 0);
+    pr.n_rev_idx = fill_idx(mr.h, pr.rev_idx, true, rlen);
+    c.out->push_back(pr);
+    if (c.emit && c.emit(&c.out->back(), c.user) != 0) { c.aborted = true; return false; }
+    return true;
+}
+
+// one direction of forEachJoinedProduct (engine.go:143-272 / :274-401)
+bool join_direction(JoinCtx &c, int pair, uint32_t rec, int64_t seqlen, int64_t minL, int64_t maxL,
+                    const std::vector<MatchRef> &left, const std::vector<MatchRef> &right, int rlen, int type) {
+    auto lower = [&](int64_t pos) { return std::lower_bound(right.begin(), right.end(), pos, [](const MatchRef &m, int64_t v) { return m.pos < v; }) - right.begin(); };
+    auto upper = [&](int64_t pos) { return std::upper_bound(right.begin(), right.end(), pos, [](int64_t v, const MatchRef &m) { return v < m.pos; }) - right.begin(); };
+    for (const MatchRef &ma : left) {
+        const int64_t last = seqlen - rlen;
+        int64_t lo = ma.pos + 1;
+        if (minL > 0) {
+            lo = ma.pos + minL - rlen;
+            if (lo <= ma.pos) lo = ma.pos + 1;
+        }
+        if (lo < 0) lo = 0;
+        int64_t hi = last;
+        if (maxL > 0) {
+            hi = ma.pos + maxL - rlen;
+            if (hi > last) hi = last;
+        }
+        if (hi >= lo) {
+            const int64_t iMin = lower(lo), iMax = upper(hi) - 1;
+            for (int64_t j = iMax; j >= iMin; --j) {
+                const MatchRef &mb = right[(size_t)j];
+                const int64_t end = mb.pos + rlen, length = end - ma.pos;
+                if ((minL != 0 && length < minL) || (maxL != 0 && length > maxL)) continue;
+                if (!push_product(c, pair, rec, ma.pos, end, length, type, ma, mb, rlen)) return false;
+            }
+        }
+        if (c.p->cfg.circular) {
+            const int64_t X = seqlen - ma.pos;
+            int64_t loWrap = 0;
+            if (minL > 0) {
+                int64_t needed = minL - X - rlen;
+                if (needed < 0) needed = 0;
+                loWrap = needed;
+            }
+            int64_t hiWrap = ma.pos - 1;
+            if (maxL > 0) {
+                const int64_t allowed = maxL - X - rlen;
+                if (allowed < hiWrap) hiWrap = allowed;
+            }
+            if (hiWrap >= loWrap) {
+                const int64_t iMinW = lower(loWrap), iMaxW = upper(hiWrap) - 1;
+                for (int64_t j = iMaxW; j >= iMinW; --j) {
+                    const MatchRef &mb = right[(size_t)j];
+                    if (mb.pos >= ma.pos) continue;
+                    const int64_t end = mb.pos + rlen, length = (seqlen - ma.pos) + end;
+                    if ((minL != 0 && length < minL) || (maxL != 0 && length > maxL)) continue;
+                    if (!push_product(c, pair, rec, ma.pos, end, length, type, ma, mb, rlen)) return false;
+                }
+            }
+        }
+    }
+    return true;
+}
+
+// Rebuild the match list the reference would hold for one orientation of one record
+// (compiled.go:185-258) from the device hits of its pattern (ascending position).
+void orientation_matches(const ipcr_panel *p, int pair, int w, bool rec_reset, const ipcr_hit *begin,
+                         const ipcr_hit *end, std::vector<MatchRef> &out) {
+    out.clear();
+    const bool left = w >= 2;
+    const bool seeded = (p->have[(size_t)pair] >> w) & 1;
+    const int tw = p->tw, k = p->cfg.max_mm, cap = p->cfg.hit_cap;
+    const bool fallback = !seeded || (rec_reset && k > 0 && cap > 0); // compiled.go:189-190,238-258
+    const bool cap_before_filter = left && tw > 0 && k > 0 && cap > 0 && fallback;
+    if (cap_before_filter) {
+        int64_t n = 0;
+        for (const ipcr_hit *h = begin; h != end; ++h) {
+            if (n >= cap) break; // FindMatches stops at capHits raw matches (match.go:86-88)
+            ++n;
+            if (!hit_has_idx_below(h, tw)) out.push_back({(int64_t)h->pos, h});
+        }
+        return;
+    }
+    for (const ipcr_hit *h = begin; h != end; ++h) {
+        if (left && hit_has_idx_below(h, tw)) continue; // device scanned this pattern unprotected
+        if (cap > 0 && (int64_t)out.size() >= cap) break;
+        out.push_back({(int64_t)h->pos, h});
+    }
+    // collector order when HitCap == 0: automaton hits first, then non-ACGT halo hits
+    // (compiled.go:211-232; a start is halo-only iff its seed span holds a reset byte)
+    if (seeded && cap <= 0 && k > 0 && rec_reset)
+        std::stable_partition(out.begin(), out.end(), [](const MatchRef &m) { return (m.h->pattern >> 31) == 0; });
+}
+
+ipcr_status join_sorted_hits(const ipcr_panel *p, ipcr_scratch *s, const uint64_t *rec_len, const uint8_t *rec_flags,
+                             uint32_t nrec, ipcr_emit_fn emit, void *user) {
+    JoinCtx c{p, &s->products, emit, user};
+    const std::vector<ipcr_hit> &H = s->hits;
+    const size_t npairs = p->id.size();
+    std::vector<MatchRef> m[4];
+    std::vector<MatchRef> sorted_right;
+    size_t i = 0;
+    while (i < H.size()) {
+        const uint32_t rec = H[i].record;
+        size_t j = i;
+        while (j < H.size() && H[j].record == rec) ++j;
+        if (rec >= nrec) return fail(IPCR_ERR_INVALID, "hit refers to record %u of %u", rec, nrec);
+        const uint8_t fl = rec_flags ? rec_flags[rec] : 0;
+        const bool rec_reset = fl & 1u;
+        const int mode = (!p->modes_equal && (fl & 2u)) ? 1 : 0;
+        for (size_t pi = 0; pi < npairs; ++pi) {
+            bool any = false;
+            for (int w = 0; w < 4; ++w) {
+                const ipcr_hit *b = nullptr, *e = nullptr;
+                if (i < j) {
+                    auto it = std::lower_bound(H.begin() + (long)i, H.begin() + (long)j, p->slot[pi][(size_t)w][(size_t)mode],
+                                               [](const ipcr_hit &h, uint32_t gid) { return (h.pattern & 0x7FFFFFFFu) < gid; });
+                    b = H.data() + (it - H.begin());
+                    e = b;
+                    const ipcr_hit *stop = H.data() + j;
+                    const uint32_t gid = p->slot[pi][(size_t)w][(size_t)mode];
+                    while (e != stop && (e->pattern & 0x7FFFFFFFu) == gid) ++e;
+                }
+                orientation_matches(p, (int)pi, w, rec_reset, b, e, m[w]);
+                any |= !m[w].empty();
+            }
+            if (!any) continue;
+            int64_t minL = p->minp[pi], maxL = p->maxp[pi]; // engine.go:113-120
+            if (minL == 0) minL = p->cfg.min_len;
+            if (maxL == 0) maxL = p->cfg.max_len;
+            const int alen = (int)p->fwd[pi].size(), blen = (int)p->rev[pi].size();
+            const int64_t seqlen = (int64_t)rec_len[rec];
+            auto by_pos = [](const MatchRef &a, const MatchRef &b) { return a.pos < b.pos; };
+            // "forward": A x rc(B)   (rc list sorted by position, engine.go:144)
+            sorted_right = m[3];
+            std::stable_sort(sorted_right.begin(), sorted_right.end(), by_pos);
+            if (!join_direction(c, (int)pi, rec, seqlen, minL, maxL, m[0], sorted_right, blen, 0)) return fail(IPCR_ERR_ABORTED, "emit callback aborted the scan");
+            // "revcomp": B x rc(A)   (engine.go:275)
+            sorted_right = m[2];
+            std::stable_sort(sorted_right.begin(), sorted_right.end(), by_pos);
+            if (!join_direction(c, (int)pi, rec, seqlen, minL, maxL, m[1], sorted_right, alen, 1)) return fail(IPCR_ERR_ABORTED, "emit callback aborted the scan");
+        }
+        i = j;
+    }
+    s->stats.products = s->products.size();
+    return IPCR_OK;
+}
+
+ipcr_status scratch_ready(const ipcr_panel *p, ipcr_scratch *s) {
+    if (!p || !s) return fail(IPCR_ERR_INVALID, "null panel or scratch");
+    if (s->panel != p) return fail(IPCR_ERR_INVALID, "scratch was created for a different panel");
+    return IPCR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out) {
+    if (!p || !out) return fail(IPCR_ERR_INVALID, "ipcr_scratch_create: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(IPCR_ERR_DEVICE, "no HIP device visible: the ipcr scan path has no CPU fallback");
+    std::unique_ptr<ipcr_scratch> s(new ipcr_scratch);
+    s->panel = p;
+    ipcr_scratch *raw = s.get();
+    auto build = [&]() -> ipcr_status {
+        HIPCHK(hipGetDevice(&raw->device));
+        HIPCHK(hipStreamCreateWithFlags(&raw->stream, hipStreamNonBlocking));
+        for (auto &e : raw->ev) HIPCHK(hipEventCreate(&e));
+        raw->qcap = QCAP_INIT;
+        raw->hcap = HCAP_INIT;
+        HIPCHK(hipMalloc((void **)&raw->d_queue, raw->qcap * 8ull));
+        HIPCHK(hipMalloc((void **)&raw->d_hits, raw->hcap * sizeof(ipcr_hit_rec)));
+        HIPCHK(hipMalloc((void **)&raw->d_counts, 16));
+        HIPCHK(hipHostMalloc(&raw->pinned, 16 + PREFIX_HITS * sizeof(ipcr_hit), hipHostMallocDefault));
+        return IPCR_OK;
+    };
+    ipcr_status st = build();
+    if (st != IPCR_OK) { ipcr_scratch_destroy(s.release()); return st; }
+    *out = s.release();
+    return IPCR_OK;
+}
+
+void ipcr_scratch_destroy(ipcr_scratch *s) {
+    if (!s) return;
+    if (s->chunk) ipcr_genome_destroy(s->chunk);
+    if (s->d_queue) (void)hipFree(s->d_queue);
+    if (s->d_hits) (void)hipFree(s->d_hits);
+    if (s->d_counts) (void)hipFree(s->d_counts);
+    if (s->d_amps) (void)hipFree(s->d_amps);
+    if (s->d_probe_misc) (void)hipFree(s->d_probe_misc);
+    if (s->pinned) (void)hipHostFree(s->pinned);
+    for (auto &e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+ipcr_status ipcr_scratch_stats(const ipcr_scratch *s, ipcr_scan_stats *out) {
+    if (!s || !out) return fail(IPCR_ERR_INVALID, "null argument");
+    *out = s->stats;
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_scratch_products(const ipcr_scratch *s, const ipcr_product **out, int64_t *n) {
+    if (!s || !out || !n) return fail(IPCR_ERR_INVALID, "null argument");
+    *out = s->products.data();
+    *n = (int64_t)s->products.size();
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_scratch_hits(const ipcr_scratch *s, const ipcr_hit **out, int64_t *n) {
+    if (!s || !out || !n) return fail(IPCR_ERR_INVALID, "null argument");
+    *out = s->hits.data();
+    *n = (int64_t)s->hits.size();
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_scan_genome_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g) {
+    ipcr_status st = scratch_ready(p, s);
+    if (st != IPCR_OK) return st;
+    if (!g) return fail(IPCR_ERR_INVALID, "null genome");
+    s->stats.pack_ms = 0;
+    return scan_hits(p, s, const_cast<ipcr_genome *>(g));
+}
+
+ipcr_status ipcr_scan_genome(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g, ipcr_emit_fn emit, void *user) {
+    const auto t0 = std::chrono::steady_clock::now();
+    ipcr_status st = ipcr_scan_genome_hits(p, s, g);
+    if (st != IPCR_OK) return st;
+    std::vector<uint8_t> fl(g->rec_start.size());
+    const bool any = genome_any_reset(g);
+    for (size_t r = 0; r < fl.size(); ++r) fl[r] = (uint8_t)((g->flags[r] & 1u) | (any ? 2u : 0u));
+    st = join_sorted_hits(p, s, g->rec_len.data(), fl.data(), (uint32_t)fl.size(), emit, user);
+    s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+}
+
+ipcr_status ipcr_join_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_hit *hits, int64_t n_hits,
+                           const uint64_t *record_len, const uint8_t *record_flags, uint32_t n_records,
+                           ipcr_emit_fn emit, void *user) {
+    ipcr_status st = scratch_ready(p, s);
+    if (st != IPCR_OK) return st;
+    if ((n_hits > 0 && !hits) || (n_records > 0 && !record_len) || n_hits < 0) return fail(IPCR_ERR_INVALID, "ipcr_join_hits: null argument");
+    if (hits != s->hits.data()) s->hits.assign(hits, hits + n_hits);
+    std::sort(s->hits.begin(), s->hits.end(), HitLess());
+    s->products.clear();
+    return join_sorted_hits(p, s, record_len, record_flags, n_records, emit, user);
+}
+
+ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t *seq, uint64_t len,
+                            ipcr_emit_fn emit, void *user) {
+    const auto t0 = std::chrono::steady_clock::now();
+    ipcr_status st = scratch_ready(p, s);
+    if (st != IPCR_OK) return st;
+    if (!seq && len) return fail(IPCR_ERR_INVALID, "null sequence");
+    s->hits.clear();
+    s->products.clear();
+    memset(&s->stats, 0, sizeof s->stats);
+    if (p->id.empty()) return IPCR_OK; // compiled.go:163-165
+    const uint64_t need_cols = record_cols(len) + 64;
+    if (!s->chunk || s->chunk->cap_cols < need_cols) {
+        if (s->chunk) ipcr_genome_destroy(s->chunk);
+        s->chunk = nullptr;
+        st = ipcr_genome_create((need_cols + (need_cols >> 2)) * IPCR_COLUMN_BASES, 1, &s->chunk);
+        if (st != IPCR_OK) return st;
+    }
+    genome_clear(s->chunk);
+    const double before = s->chunk->pack_ms;
+    st = ipcr_genome_add_record(s->chunk, seq, len);
+    if (st != IPCR_OK) return st;
+    s->stats.pack_ms = s->chunk->pack_ms - before;
+    st = scan_hits(p, s, s->chunk);
+    if (st != IPCR_OK) return st;
+    uint8_t fl = (uint8_t)((s->chunk->flags[0] & 1u) ? 3u : 0u);
+    st = join_sorted_hits(p, s, s->chunk->rec_len.data(), &fl, 1, emit, user);
+    s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+}
+
+// ------------------------------------------------------------------------------ probe
+
+static ipcr_status normalize_probe(const char *probe, std::string &prb) {
+    prb.clear();
+    for (const char *q = probe; *q; ++q) { // core/primer/validate.go:12-22 Normalize
+        char ch = *q;
+        if (ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r' || ch == '\v' || ch == '\f' || ch == '\'' || ch == '"') continue;
+        if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+        prb.push_back(ch);
+    }
+    for (size_t i = 0; i < prb.size(); ++i) // validate.go:27-36
+        if (!strchr("ACGTRYSWKMBDHVN", prb[i]))
+            return fail(IPCR_ERR_PRIMER, "invalid probe base %c at position %zu; allowed: A C G T R Y S W K M B D H V N", prb[i], i + 1);
+    if (prb.size() > IPCR_MAX_PRIMER_LEN) return fail(IPCR_ERR_UNSUPPORTED, "probe of %zu nt exceeds IPCR_MAX_PRIMER_LEN", prb.size());
+    return IPCR_OK;
+}
+
+static ipcr_status run_probe(hipStream_t st, const uint8_t *d_amps, const uint64_t *d_off, uint32_t namp,
+                             const std::string &prb, int32_t max_mm, void *d_misc, ipcr_probe_hit *out) {
+    // d_misc: [0,128) probe masks, [128,256) rc masks, [256, ...) results
+    std::string rc;
+    revcomp(prb, rc, nullptr);
+    uint8_t masks[256];
+    memset(masks, 0, sizeof masks);
+    bool strict = !prb.empty();
+    for (size_t i = 0; i < prb.size(); ++i) {
+        masks[i] = T.mask[(uint8_t)prb[i]];
+        masks[128 + i] = T.mask[(uint8_t)rc[i]];
+        if (prb[i] != 'A' && prb[i] != 'C' && prb[i] != 'G' && prb[i] != 'T') strict = false;
+    }
+    uint8_t *dm = static_cast<uint8_t *>(d_misc);
+    HIPCHK(hipMemcpyAsync(dm, masks, 256, hipMemcpyHostToDevice, st));
+    ipcr_probe_rec *dres = reinterpret_cast<ipcr_probe_rec *>(dm + 256);
+    const uint32_t fast = (max_mm == 0 && strict) ? 1u : 0u; // oligo.go:33-42
+    HIPCHK(ipcr::launch_probe(st, d_amps, d_off, namp, dm, dm + 128, (uint32_t)prb.size(),
+                              (uint32_t)(max_mm < 0 ? 0 : max_mm), fast, dres));
+    HIPCHK(hipMemcpyAsync(out, dres, (uint64_t)namp * sizeof(ipcr_probe_hit), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_probe_best_hit(const uint8_t *amplicon, uint64_t len, const char *probe, int32_t max_mm,
+                                ipcr_probe_hit *out) {
+    if (!out || !probe || (!amplicon && len)) return fail(IPCR_ERR_INVALID, "ipcr_probe_best_hit: null argument");
+    memset(out, 0, sizeof *out);
+    std::string prb;
+    ipcr_status st = normalize_probe(probe, prb);
+    if (st != IPCR_OK) return st;
+    if (prb.empty()) return IPCR_OK; // oligo.go:21-23
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(IPCR_ERR_DEVICE, "no HIP device visible: the probe rescan has no CPU fallback");
+    uint8_t *d = nullptr;
+    const uint64_t bytes = len + 16 + 16 + 256 + sizeof(ipcr_probe_rec);
+    HIPCHK(hipMalloc((void **)&d, bytes + 64));
+    // layout: offsets (16 B) | misc (256 + result, 16-aligned) | amplicon
+    uint64_t offs[2] = {0, len};
+    hipError_t e = hipMemcpy(d, offs, 16, hipMemcpyHostToDevice);
+    uint8_t *misc = d + 16;
+    uint8_t *amps = d + 16 + 256 + 32;
+    if (e == hipSuccess && len) e = hipMemcpy(amps, amplicon, len, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); HIPCHK(e); }
+    st = run_probe(nullptr, amps, reinterpret_cast<const uint64_t *>(d), 1, prb, max_mm, misc, out);
+    (void)hipFree(d);
+    return st;
+}
+
+ipcr_status ipcr_probe_products(ipcr_scratch *s, const ipcr_genome *g, const char *probe, int32_t max_mm,
+                                ipcr_probe_hit *out, int64_t n_out) {
+    if (!s || !g || !probe || (!out && n_out)) return fail(IPCR_ERR_INVALID, "ipcr_probe_products: null argument");
+    const size_t n = s->products.size();
+    if ((int64_t)n != n_out) return fail(IPCR_ERR_INVALID, "n_out (%lld) != products of the last scan (%zu)", (long long)n_out, n);
+    if (n == 0) return IPCR_OK;
+    memset(out, 0, n * sizeof *out);
+    std::string prb;
+    ipcr_status st = normalize_probe(probe, prb);
+    if (st != IPCR_OK) return st;
+    if (prb.empty()) return IPCR_OK;
+    // amplicon = record[start:end], or record[start:] ++ record[:end] for wrap-around products
+    // (internal/pipeline/pipeline.go:80-89)
+    std::vector<ipcr_amp_seg> segs(n);
+    std::vector<uint64_t> offs(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const ipcr_product &pr = s->products[i];
+        if ((size_t)pr.record >= g->rec_start.size()) return fail(IPCR_ERR_INVALID, "product record outside genome");
+        const uint64_t rs = g->rec_start[(size_t)pr.record], rl = g->rec_len[(size_t)pr.record];
+        ipcr_amp_seg sg{};
+        if (pr.start <= pr.end) { sg.pa = rs + (uint64_t)pr.start; sg.len_a = (uint64_t)(pr.end - pr.start); sg.pb = rs; sg.len_b = 0; }
+        else { sg.pa = rs + (uint64_t)pr.start; sg.len_a = rl - (uint64_t)pr.start; sg.pb = rs; sg.len_b = (uint64_t)pr.end; }
+        sg.out_off = offs[i];
+        offs[i + 1] = offs[i] + sg.len_a + sg.len_b;
+        segs[i] = sg;
+    }
+    const uint64_t amp_bytes = offs[n] + 16;
+    if (amp_bytes > s->amps_cap) {
+        if (s->d_amps) (void)hipFree(s->d_amps);
+        s->d_amps = nullptr;
+        s->amps_cap = amp_bytes + (amp_bytes >> 2);
+        HIPCHK(hipMalloc((void **)&s->d_amps, s->amps_cap));
+    }
+    const uint64_t misc_bytes = 512 + n * sizeof(ipcr_probe_rec) + n * sizeof(ipcr_amp_seg) + (n + 1) * 8 + 64;
+    if (misc_bytes > s->probe_misc_cap) {
+        if (s->d_probe_misc) (void)hipFree(s->d_probe_misc);
+        s->d_probe_misc = nullptr;
+        s->probe_misc_cap = misc_bytes * 2;
+        HIPCHK(hipMalloc(&s->d_probe_misc, s->probe_misc_cap));
+    }
+    uint8_t *base = static_cast<uint8_t *>(s->d_probe_misc);
+    uint8_t *misc = base; // 256 masks + results
+    uint64_t o = 256 + n * sizeof(ipcr_probe_rec);
+    o = (o + 15) & ~15ull;
+    ipcr_amp_seg *dsegs = reinterpret_cast<ipcr_amp_seg *>(base + o);
+    o += n * sizeof(ipcr_amp_seg);
+    uint64_t *doffs = reinterpret_cast<uint64_t *>(base + o);
+    HIPCHK(hipMemcpyAsync(dsegs, segs.data(), n * sizeof(ipcr_amp_seg), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(doffs, offs.data(), (n + 1) * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(ipcr::launch_gather(s->stream, g->planes, g->rst, dsegs, (uint32_t)n, s->d_amps));
+    return run_probe(s->stream, s->d_amps, doffs, (uint32_t)n, prb, max_mm, misc, out);
+}
+
+} // extern "C"

@@ -1,0 +1,322 @@
+// jit.cpp -- panel-specialised k-mismatch filter for gfx950.
+//
+// The table-driven filter (kernels.hip) pays ~20 VALU ops per (pattern, position, word)
+// because which base a pattern position wants is only known at run time.  A compiled
+// ipcr panel is fixed for the whole run (CompilePanel is called once,
+// internal/pipeline/pipeline.go:55-58), so -- like the reference compiling the panel into
+// an Aho-Corasick automaton -- we compile it into straight-line HIP source:
+//
+//  * one wavefront streams one block (64 columns x 128 rows, tile_layout.h) top to bottom,
+//    lane = column, 16 B/lane loads, next row-quad prefetched while the current one is used;
+//  * each incoming row is expanded once into four one-hot MISMATCH planes (base != A/C/G/T,
+//    invalid bases mismatch everything) kept in a register window of the last W rows;
+//  * pattern position j of a window starting at row r is row r+j of the window: a register,
+//    no shift.  Every pattern becomes OR-trees over named registers:
+//      protected window (3' terminal window, or everything when k = 0): must be clean;
+//      the other positions are cut into B blocks; a block with any mismatch is "bad";
+//      at most k bad blocks may occur (generalised pigeonhole; B = #positions is exact);
+//  * survivors (rare) are appended to the candidate queue for the exact verifier.
+//
+// The filter is sound for any block split (a window with <= k mismatches has <= k bad
+// blocks); B only trades ALU work against how many false candidates reach the verifier.
+#include "jit.h"
+
+#include <hip/hiprtc.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+
+namespace ipcr {
+
+struct JitFilter {
+    hipModule_t module = nullptr;
+    hipFunction_t fn = nullptr;
+};
+
+namespace {
+
+struct Plan {
+    int L = 0;
+    std::vector<int> prot;                // protected positions
+    std::vector<std::vector<int>> blocks; // unprotected positions, contiguous groups
+    bool counted = false;                 // false: the unprotected part cannot exceed k mismatches
+};
+
+double match_prob(uint8_t m) { return __builtin_popcount(m & 15u) / 4.0; }
+
+// probability that a random window passes (prot clean and <= k bad blocks)
+double pass_prob(const ipcr_dev_pattern &p, const Plan &pl, int k) {
+    double pp = 1.0;
+    for (int j : pl.prot) pp *= match_prob(p.mask[j]);
+    if (!pl.counted) return pp;
+    std::vector<double> f((size_t)k + 2, 0.0); // f[t] = P(t bad blocks), last bucket = > k
+    f[0] = 1.0;
+    for (const auto &b : pl.blocks) {
+        double clean = 1.0;
+        for (int j : b) clean *= match_prob(p.mask[j]);
+        std::vector<double> g((size_t)k + 2, 0.0);
+        for (int t = 0; t <= k + 1; ++t) {
+            g[(size_t)t] += f[(size_t)t] * clean;
+            g[(size_t)std::min(t + 1, k + 1)] += f[(size_t)t] * (1.0 - clean);
+        }
+        f.swap(g);
+    }
+    double ok = 0;
+    for (int t = 0; t <= k; ++t) ok += f[(size_t)t];
+    return pp * ok;
+}
+
+Plan make_plan(const ipcr_dev_pattern &p, int k, int B) {
+    Plan pl;
+    pl.L = p.len;
+    std::vector<int> un;
+    for (int j = 0; j < p.len; ++j) {
+        if (p.mask[j] & 16u) pl.prot.push_back(j);
+        else un.push_back(j);
+    }
+    const int U = (int)un.size();
+    if (U <= k) return pl; // any number of mismatches outside the protected window is fine
+    pl.counted = true;
+    if (B > U) B = U;
+    if (B < k + 1) B = k + 1;
+    pl.blocks.resize((size_t)B);
+    for (int i = 0; i < U; ++i) pl.blocks[(size_t)((long)i * B / U)].push_back(un[(size_t)i]);
+    return pl;
+}
+
+Plan choose_plan(const ipcr_dev_pattern &p, int k) {
+    int U = 0;
+    for (int j = 0; j < p.len; ++j)
+        if (!(p.mask[j] & 16u)) ++U;
+    if (U <= k) return make_plan(p, k, k + 1);
+    Plan best = make_plan(p, k, k + 1);
+    const double target = 2e-6; // <= ~6000 false candidates per pattern per 3 Gb
+    if (pass_prob(p, best, k) <= target) return best;
+    for (int B = k + 2; B <= U; ++B) {
+        Plan pl = make_plan(p, k, B);
+        best = pl;
+        if (pass_prob(p, pl, k) <= target) break;
+    }
+    return best;
+}
+
+std::string plane_expr(uint8_t mask, int slot, bool &uses_n) {
+    const uint8_t m = mask & 15u;
+    const std::string s = std::to_string(slot);
+    if (m == 15u) { uses_n = true; return "n" + s; }
+    if (m == 0u) return "0xFFFFFFFFu";
+    std::string e;
+    int cnt = 0;
+    const char *names = "acgt";
+    for (int b = 0; b < 4; ++b)
+        if (m & (1u << b)) {
+            if (cnt++) e += " & ";
+            e += std::string(1, names[b]) + s;
+        }
+    return cnt > 1 ? "(" + e + ")" : e;
+}
+
+} // namespace
+
+std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
+    if (pats.empty() || pats.size() > 48) return "";
+    int Lmax = 0;
+    for (const auto &p : pats) {
+        if (p.len == 0 || p.len > 32) return "";
+        Lmax = std::max<int>(Lmax, p.len);
+    }
+    const int W = (Lmax + 3) / 4 * 4; // window rows, multiple of the row-quad
+    const int QPI = W / 4;            // quads per unrolled iteration
+    const int LM1 = Lmax - 1;
+    const int QTOTAL = (128 + LM1 + 3) / 4;
+    const int NIT = (QTOTAL + QPI - 1) / QPI;
+
+    bool uses_n = false;
+    std::vector<Plan> plans;
+    for (const auto &p : pats) plans.push_back(choose_plan(p, k));
+    // evaluation code for one output row; slot of row r+j = (sr + j) % W with sr given per step
+    auto eval_code = [&](int sr) {
+        std::ostringstream o;
+        for (size_t q = 0; q < pats.size(); ++q) {
+            const Plan &pl = plans[q];
+            const auto &p = pats[q];
+            auto orchain = [&](const std::vector<int> &js) {
+                std::string e;
+                for (size_t i = 0; i < js.size(); ++i) {
+                    if (i) e += " | ";
+                    e += plane_expr(p.mask[js[i]], (sr + js[i]) % W, uses_n);
+                }
+                return e.empty() ? std::string("0u") : e;
+            };
+            o << "        { // pattern " << q << " (len " << pl.L << ", " << pl.prot.size() << " protected, "
+              << pl.blocks.size() << " blocks)\n";
+            o << "          u32 f = " << orchain(pl.prot) << ";\n";
+            if (pl.counted) {
+                const int B = (int)pl.blocks.size();
+                // thermometer counter over block flags: u[t] = at least t bad blocks so far
+                for (int i = 0; i < B; ++i) {
+                    o << "          const u32 e" << i << " = " << orchain(pl.blocks[(size_t)i]) << ";\n";
+                }
+                std::vector<bool> live((size_t)k + 2, false);
+                for (int i = 0; i < B; ++i) {
+                    for (int t = std::min(i + 1, k + 1); t >= 1; --t) {
+                        const std::string prev = (t == 1) ? "" : "u" + std::to_string(t - 1) + " & ";
+                        if (t >= 2 && !live[(size_t)t - 1]) continue;
+                        if (!live[(size_t)t]) {
+                            o << "          u32 u" << t << " = " << prev << "e" << i << ";\n";
+                            live[(size_t)t] = true;
+                        } else {
+                            o << "          u" << t << " |= " << prev << "e" << i << ";\n";
+                        }
+                    }
+                }
+                o << "          f |= u" << (k + 1) << ";\n";
+            }
+            o << "          f" << q << " = f;\n        }\n";
+        }
+        return o.str();
+    };
+
+    std::ostringstream s;
+    s << "// generated by ipcr_amd/csrc/jit.cpp for a panel of " << pats.size() << " patterns, k = " << k << "\n";
+    s << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
+    s << "typedef unsigned int u32;\ntypedef unsigned long long u64;\n";
+    s << "typedef u32 v4 __attribute__((ext_vector_type(4)));\n";
+    s << "__device__ __forceinline__ void emit(u32 cand, u64 q, u64 pos, u64* queue, u64 qcap, u64* qcount) {\n"
+         "  while (cand) {\n"
+         "    const u32 b = (u32)__builtin_ctz(cand);\n"
+         "    cand &= cand - 1u;\n"
+         "    const u64 idx = atomicAdd(qcount, 1ull);\n"
+         "    if (idx < qcap) queue[idx] = (q << 48) | (pos + ((u64)b << 7));\n"
+         "  }\n}\n";
+    s << "extern \"C\" __global__ void __launch_bounds__(256) ipcr_filter(const v4* __restrict__ planes, u64 nblocks,\n"
+         "    u64* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {\n";
+    s << "  const u32 lane = threadIdx.x & 63u;\n";
+    s << "  const u64 block = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);\n";
+    s << "  if (block >= nblocks) return;\n";
+    s << "  const v4* own = planes + block * 6144ull + lane;\n";
+    s << "  const v4* nxt = (lane < 63u) ? own + 1 : planes + (block + 1ull) * 6144ull;\n";
+    s << "  const u64 posbase = ((block * 64ull + lane) * 32ull) << 7;\n";
+    // window registers
+    std::string body; // build iteration body first so uses_n is known
+    {
+        std::ostringstream b;
+        for (int u4 = 0; u4 < QPI; ++u4) {
+            b << "    { // quad " << u4 << " of the iteration\n";
+            b << "      const u32 qi = it * " << QPI << "u + " << u4 << "u;\n";
+            b << "      const v4 clo = plo, chi = phi, cinv = pinv;\n";
+            b << "      const u32 qn = qi + 1u;\n";
+            b << "      if (qn < 32u) {\n"
+                 "        plo = own[qn * 192u]; phi = own[qn * 192u + 64u]; pinv = own[qn * 192u + 128u];\n"
+                 "      } else if (qn < " << QTOTAL << "u) { // rows past the strand end: next strand = same words >> 1\n"
+                 "        const u32 w = (qn - 32u) * 192u;\n"
+                 "        plo = (own[w] >> 1) | (nxt[w] << 31);\n"
+                 "        phi = (own[w + 64u] >> 1) | (nxt[w + 64u] << 31);\n"
+                 "        pinv = (own[w + 128u] >> 1) | (nxt[w + 128u] << 31);\n"
+                 "      }\n";
+            for (int c = 0; c < 4; ++c) {
+                const int step = u4 * 4 + c;
+                const char comp = "xyzw"[c];
+                const std::string sl = std::to_string(step);
+                b << "      { // row step " << step << "\n";
+                b << "        const u32 lo = clo." << comp << ", hi = chi." << comp << ", iv = cinv." << comp << ";\n";
+                b << "        const u32 nlo = ~lo, nhi = ~hi;\n";
+                b << "        a" << sl << " = lo | hi | iv; c" << sl << " = nlo | hi | iv; g" << sl
+                  << " = lo | nhi | iv; t" << sl << " = nlo | nhi | iv; n" << sl << " = iv;\n";
+                b << "        const u32 x = qi * 4u + " << c << "u;\n";
+                b << "        if (x >= " << LM1 << "u && x < " << (128 + LM1) << "u) {\n";
+                b << "        u32 ";
+                for (size_t q = 0; q < pats.size(); ++q) b << (q ? ", f" : "f") << q;
+                b << ";\n";
+                const int sr = ((step - LM1) % W + W) % W;
+                b << eval_code(sr);
+                b << "          u32 all = f0";
+                for (size_t q = 1; q < pats.size(); ++q) b << " & f" << q;
+                b << ";\n";
+                b << "          if (all != 0xFFFFFFFFu) {\n";
+                b << "            const u64 pos = posbase + (u64)(x - " << LM1 << "u);\n";
+                for (size_t q = 0; q < pats.size(); ++q)
+                    b << "            emit(~f" << q << ", " << q << "ull, pos, queue, qcap, qcount);\n";
+                b << "          }\n";
+                b << "        }\n";
+                b << "      }\n";
+            }
+            b << "    }\n";
+        }
+        body = b.str();
+    }
+    s << "  u32 ";
+    for (int i = 0; i < W; ++i) {
+        if (i) s << ", ";
+        s << "a" << i << " = 0, c" << i << " = 0, g" << i << " = 0, t" << i << " = 0, n" << i << " = 0";
+    }
+    s << ";\n";
+    s << "  v4 plo = own[0], phi = own[64], pinv = own[128];\n";
+    s << "  for (u32 it = 0; it < " << NIT << "u; ++it) {\n";
+    s << body;
+    s << "  }\n}\n";
+    (void)uses_n;
+    return s.str();
+}
+
+JitFilter *jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err) {
+    const std::string src = jit_source(pats, max_mm);
+    if (src.empty()) { err = "panel not specialisable (more than 48 patterns or a primer longer than 32 nt)"; return nullptr; }
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "ipcr_filter.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+        err = "hiprtcCreateProgram failed";
+        return nullptr;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    std::string arch = "gfx950";
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0]) {
+        arch = prop.gcnArchName;
+        const size_t colon = arch.find(':');
+        if (colon != std::string::npos) arch = arch.substr(0, colon);
+    }
+    const std::string archopt = "--offload-arch=" + arch;
+    const char *opts[] = {archopt.c_str(), "-O3"};
+    const hiprtcResult r = hiprtcCompileProgram(prog, 2, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        err = std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log;
+        hiprtcDestroyProgram(&prog);
+        return nullptr;
+    }
+    size_t csize = 0;
+    hiprtcGetCodeSize(prog, &csize);
+    std::vector<char> code(csize);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    JitFilter *f = new JitFilter;
+    if (hipModuleLoadData(&f->module, code.data()) != hipSuccess ||
+        hipModuleGetFunction(&f->fn, f->module, "ipcr_filter") != hipSuccess) {
+        err = "hipModuleLoadData/GetFunction failed for the specialised filter";
+        jit_destroy(f);
+        return nullptr;
+    }
+    return f;
+}
+
+hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint64_t *queue,
+                      uint64_t qcap, unsigned long long *qcount) {
+    if (nblocks == 0) return hipSuccess;
+    void *args[] = {(void *)&planes, (void *)&nblocks, (void *)&queue, (void *)&qcap, (void *)&qcount};
+    const unsigned grid = (unsigned)((nblocks + 3) / 4);
+    return hipModuleLaunchKernel(f->fn, grid, 1, 1, 256, 1, 1, 0, st, args, nullptr);
+}
+
+void jit_destroy(JitFilter *f) {
+    if (!f) return;
+    if (f->module) (void)hipModuleUnload(f->module);
+    delete f;
+}
+
+} // namespace ipcr

@@ -1,0 +1,24 @@
+// jit.h -- panel-specialised filter kernel: generated as HIP source for the concrete primer
+// panel and compiled for gfx950 with hiprtc when the panel is first scanned.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "device_types.h"
+
+namespace ipcr {
+
+struct JitFilter;
+
+// HIP source of the specialised filter for these patterns (also used by the build check)
+std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int max_mm);
+// nullptr (and `err` set) when the panel cannot be specialised or hiprtc fails
+JitFilter *jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err);
+hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint64_t *queue,
+                      uint64_t qcap, unsigned long long *qcount);
+void jit_destroy(JitFilter *f);
+
+} // namespace ipcr

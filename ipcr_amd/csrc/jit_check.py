@@ -1,0 +1,35 @@
+"""Build check for the run-time specialised filter: emit its HIP source for the benchmark
+panel (config C2) and an IUPAC k=3 panel (config C3) and compile both for gfx950 with hipcc."""
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from ipcr_amd import engine, primer  # noqa: E402
+from ipcr_amd.workloads import c2_pairs, c3_pairs  # noqa: E402
+
+
+def main() -> None:
+    cases = [("c2", engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12), c2_pairs()),
+             ("c3", engine.Config(MaxMM=3, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12, Circular=True), c3_pairs())]
+    outdir = os.path.join(ROOT, "ipcr_amd", "csrc", "build")
+    os.makedirs(outdir, exist_ok=True)
+    for name, cfg, pairs in cases:
+        cp = engine.New(cfg).CompilePanel(pairs)
+        for mode in (0, 1):
+            src = cp.filter_source(mode)
+            assert src, f"{name}: panel unexpectedly not specialisable"
+            path = os.path.join(outdir, f"filter_{name}_m{mode}.hip")
+            with open(path, "w") as f:
+                f.write(src)
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-c", path,
+                                   "-o", path[:-4] + ".o"])
+        cp.close()
+    print("jit_check: specialised filter sources compile for gfx950")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,450 @@
+// kernels.hip -- hand-written gfx950 kernels of the ipcr primer matcher.
+//
+//  pack_kernel            ASCII record -> strand-major bit planes (tile_layout.h)
+//  lcg_fill_kernel        reference benchDNA generator on the device (jump-ahead LCG)
+//  filter_generic_kernel  table-driven bit-sliced k-mismatch scan (any panel)
+//  verify_kernel          exact per-candidate verification -> ipcr_hit records
+//  unpack_kernel          tiles -> ASCII (tests, amplicon extraction)
+//  probe_kernel           oligo.BestHit over a batch of amplicons
+//
+// The panel-specialised filter is generated and compiled at panel-compile time (jit.cpp);
+// it shares the queue format and the verifier below.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+#include "tile_layout.h"
+
+// ------------------------------------------------------------------------------- pack
+// One wavefront packs 64 consecutive strands (two columns).  Lane = strand: it walks its
+// own 128 contiguous bytes (16 B per load, all 8 loads of a strand hit one 128-B line),
+// and every row is transposed into words with four wave ballots -- no LDS, no atomics.
+// Semantics: inv = byte is not an upper-case A/C/G/T (core/primer/iupac.go:62-67);
+// rst = byte is outside ACGTacgt (core/engine/ac.go:16-30); bases past the record end are
+// inv=1,rst=0 padding.
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ seq, uint64_t len,
+                                                   uint64_t col0, uint64_t ncol,
+                                                   uint32_t *__restrict__ planes,
+                                                   uint32_t *__restrict__ rst,
+                                                   uint32_t *__restrict__ rec_flags) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t pairidx = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (pairidx * 2u >= ncol) return;
+    const uint64_t gcol = col0 + pairidx * 2u;
+    const uint64_t base = (pairidx * 64u + lane) * IPCR_TILE_N; // record-local first base of my strand
+    uint32_t saw_rst = 0;
+
+    for (uint32_t rg = 0; rg < 8; ++rg) {
+        const uint64_t p0 = base + rg * 16u;
+        uint32_t w[4] = {0, 0, 0, 0};
+        uint32_t realmask; // bit t: byte t is inside the record
+        if (p0 + 16u <= len) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(seq + p0);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            realmask = 0xFFFFu;
+        } else {
+            realmask = 0;
+            for (uint32_t t = 0; t < 16; ++t) {
+                if (p0 + t < len) {
+                    w[t >> 2] |= (uint32_t)seq[p0 + t] << ((t & 3u) * 8u);
+                    realmask |= 1u << t;
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0; // lanes 0..7 collect rows 4q..4q+3
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t b = (w[q] >> (k * 8u)) & 0xFFu;
+                const bool real = (realmask >> (q * 4u + k)) & 1u;
+                const uint32_t u = b & 0xDFu;
+                const bool isacgt = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+                const bool valid = isacgt & (b == u) & real;
+                uint32_t c = (b >> 1) & 3u; // A0 C1 G3 T2
+                c ^= c >> 1;                // A0 C1 G2 T3
+                const bool reset = real & !isacgt;
+                saw_rst |= reset ? 1u : 0u;
+                const uint64_t blo = __ballot(isacgt && (c & 1u));
+                const uint64_t bhi = __ballot(isacgt && (c & 2u));
+                const uint64_t binv = __ballot(!valid);
+                const uint64_t brs = __ballot(reset);
+                // lane 2*plane + half keeps the word of (plane, column half) for this row
+                const uint64_t bsel = (lane < 2u) ? blo : (lane < 4u) ? bhi : (lane < 6u) ? binv : brs;
+                const uint32_t o = (lane & 1u) ? (uint32_t)(bsel >> 32) : (uint32_t)bsel;
+                if (k == 0) o0 = o; else if (k == 1) o1 = o; else if (k == 2) o2 = o; else o3 = o;
+            }
+            const uint32_t row = rg * 16u + q * 4u;
+            if (lane < 8u) {
+                const uint64_t col = gcol + (lane & 1u);
+                const uint64_t block = col >> 6;
+                const uint32_t ln = (uint32_t)(col & 63u);
+                const uint4 out = make_uint4(o0, o1, o2, o3);
+                if (lane < 6u)
+                    *reinterpret_cast<uint4 *>(planes + ipcr_plane_word(block, row, lane >> 1, ln)) = out;
+                else
+                    *reinterpret_cast<uint4 *>(rst + ipcr_rst_word(block, row, ln)) = out;
+            }
+        }
+    }
+    if (__ballot(saw_rst) != 0 && lane == 0) atomicOr(rec_flags, 1u);
+}
+
+// fill columns [col_begin, col_end) with padding (inv=1, everything else 0)
+__global__ void fill_pad_kernel(uint32_t *__restrict__ planes, uint32_t *__restrict__ rst,
+                                uint64_t col_begin, uint64_t col_end) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // (column, row)
+    const uint64_t col = col_begin + (i >> 7);
+    const uint32_t row = (uint32_t)(i & 127u);
+    if (col >= col_end) return;
+    const uint64_t block = col >> 6;
+    const uint32_t ln = (uint32_t)(col & 63u);
+    planes[ipcr_plane_word(block, row, 0, ln)] = 0u;
+    planes[ipcr_plane_word(block, row, 1, ln)] = 0u;
+    planes[ipcr_plane_word(block, row, 2, ln)] = 0xFFFFFFFFu;
+    rst[ipcr_rst_word(block, row, ln)] = 0u;
+}
+
+// -------------------------------------------------------------------------- LCG genome
+// benchDNA (core/engine/performance_benchmark_test.go:67-76): x = x*1664525 + 1013904223,
+// base = "ACGT"[(x>>30)&3].  Each thread jumps ahead to its 64-base run by composing the
+// affine map with itself (O(log n)), so the sequence is bit-identical to the serial loop.
+__global__ void lcg_fill_kernel(uint8_t *__restrict__ out, uint64_t n, uint32_t seed) {
+    const uint64_t run = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t start = run * 64u;
+    if (start >= n) return;
+    uint32_t a = 1664525u, c = 1013904223u; // map for one step
+    uint32_t ja = 1u, jc = 0u;              // identity
+    uint64_t e = start;
+    while (e) {
+        if (e & 1u) { jc = a * jc + c; ja = a * ja; }
+        c = a * c + c;
+        a = a * a;
+        e >>= 1;
+    }
+    uint32_t x = ja * seed + jc; // state after `start` steps
+    const uint64_t end = (start + 64u < n) ? start + 64u : n;
+    for (uint64_t i = start; i < end; ++i) {
+        x = x * 1664525u + 1013904223u;
+        out[i] = (uint8_t)"ACGT"[(x >> 30) & 3u];
+    }
+}
+
+// ------------------------------------------------------------- row fetch with strand wrap
+// Row `row` of my lane's column; rows >= 128 continue in the next strand: same word shifted
+// down one bit, with bit 0 of the next column's word entering at the top.
+__device__ __forceinline__ uint32_t fetch_row(const uint32_t *__restrict__ planes, uint64_t block,
+                                              uint32_t row, uint32_t plane, uint32_t lane) {
+    if (row < IPCR_TILE_N) return planes[ipcr_plane_word(block, row, plane, lane)];
+    const uint32_t r2 = row - IPCR_TILE_N;
+    const uint32_t own = planes[ipcr_plane_word(block, r2, plane, lane)];
+    const uint32_t nxt = (lane < 63u) ? planes[ipcr_plane_word(block, r2, plane, lane + 1u)]
+                                      : planes[ipcr_plane_word(block + 1u, r2, plane, 0u)];
+    return (own >> 1) | (nxt << 31);
+}
+
+// --------------------------------------------------------------- table-driven filter
+// Exact bit-sliced k-mismatch count for every pattern of the panel: each lane owns one word
+// (32 strands) of one row; pattern position j compares row r+j.  Mismatches outside the
+// protected window feed a thermometer counter u[t] = "count >= t"; a mismatch inside it, or
+// count > k, kills the position.  Survivors go to the candidate queue.
+template <int KMAX>
+__global__ __launch_bounds__(256) void filter_generic_kernel(const uint32_t *__restrict__ planes,
+                                                             uint64_t nblocks,
+                                                             const ipcr_dev_pattern *__restrict__ pats,
+                                                             uint32_t npat, uint32_t max_mm,
+                                                             uint64_t *__restrict__ queue, uint64_t qcap,
+                                                             unsigned long long *__restrict__ qcount) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t tile = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); // (block, row)
+    const uint64_t block = tile >> 7;
+    const uint32_t row = (uint32_t)(tile & 127u);
+    if (block >= nblocks) return;
+
+    for (uint32_t q = 0; q < npat; ++q) {
+        const ipcr_dev_pattern *pp = pats + q;
+        const uint32_t L = pp->len;
+        uint32_t u[KMAX + 1];
+#pragma unroll
+        for (int t = 0; t <= KMAX; ++t) u[t] = 0u;
+        uint32_t dead = 0u;
+        for (uint32_t j = 0; j < L; ++j) {
+            const uint32_t m = pp->mask[j]; // wave-uniform
+            const uint32_t lo = fetch_row(planes, block, row + j, 0, lane);
+            const uint32_t hi = fetch_row(planes, block, row + j, 1, lane);
+            const uint32_t inv = fetch_row(planes, block, row + j, 2, lane);
+            const uint32_t sA = (m & 1u) ? 0xFFFFFFFFu : 0u, sC = (m & 2u) ? 0xFFFFFFFFu : 0u;
+            const uint32_t sG = (m & 4u) ? 0xFFFFFFFFu : 0u, sT = (m & 8u) ? 0xFFFFFFFFu : 0u;
+            const uint32_t match = ((~lo & ~hi) & sA) | ((lo & ~hi) & sC) | ((~lo & hi) & sG) | ((lo & hi) & sT);
+            const uint32_t mm = ~match | inv;
+            if (m & 16u) {
+                dead |= mm;
+            } else {
+#pragma unroll
+                for (int t = KMAX; t >= 1; --t)
+                    if ((uint32_t)t <= max_mm + 1u) u[t] |= ((t == 1) ? 0xFFFFFFFFu : u[t - 1]) & mm;
+            }
+            uint32_t over = 0u;
+#pragma unroll
+            for (int t = 1; t <= KMAX; ++t)
+                if ((uint32_t)t == max_mm + 1u) over = u[t];
+            if (__ballot((dead | over) != 0xFFFFFFFFu) == 0ull) { dead = 0xFFFFFFFFu; break; }
+        }
+        uint32_t over = 0u;
+#pragma unroll
+        for (int t = 1; t <= KMAX; ++t)
+            if ((uint32_t)t == max_mm + 1u) over = u[t];
+        uint32_t alive = ~(dead | over);
+        while (alive) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(alive);
+            alive &= alive - 1u;
+            const uint64_t P = ipcr_join_pos(block * 64u + lane, bit, row);
+            const unsigned long long idx = atomicAdd(qcount, 1ull);
+            if (idx < qcap) queue[idx] = ((uint64_t)q << 48) | P;
+        }
+    }
+}
+
+template __global__ void filter_generic_kernel<4>(const uint32_t *, uint64_t, const ipcr_dev_pattern *, uint32_t,
+                                                  uint32_t, uint64_t *, uint64_t, unsigned long long *);
+template __global__ void filter_generic_kernel<17>(const uint32_t *, uint64_t, const ipcr_dev_pattern *, uint32_t,
+                                                   uint32_t, uint64_t *, uint64_t, unsigned long long *);
+
+// ------------------------------------------------------------------------------ verify
+// verifyAt (core/engine/ac.go:186-213) / the inner loop of FindMatches
+// (core/primer/match.go:67-84) for one candidate per thread, straight from the tiles.
+__device__ __forceinline__ uint32_t base_bits(const uint32_t *__restrict__ planes, uint64_t P) {
+    uint64_t col; uint32_t bit, row;
+    ipcr_split_pos(P, &col, &bit, &row);
+    const uint64_t block = col >> 6;
+    const uint32_t ln = (uint32_t)(col & 63u);
+    const uint64_t w = ipcr_plane_word(block, row, 0, ln);
+    const uint32_t lo = (planes[w] >> bit) & 1u;
+    const uint32_t hi = (planes[w + 256u] >> bit) & 1u;  // next plane: +64 lanes * 4
+    const uint32_t inv = (planes[w + 512u] >> bit) & 1u;
+    return lo | (hi << 1) | (inv << 2);
+}
+
+__device__ __forceinline__ uint32_t rst_bit(const uint32_t *__restrict__ rst, uint64_t P) {
+    uint64_t col; uint32_t bit, row;
+    ipcr_split_pos(P, &col, &bit, &row);
+    return (rst[ipcr_rst_word(col >> 6, row, (uint32_t)(col & 63u))] >> bit) & 1u;
+}
+
+__global__ __launch_bounds__(256) void verify_kernel(const uint32_t *__restrict__ planes,
+                                                     const uint32_t *__restrict__ rst,
+                                                     const ipcr_dev_pattern *__restrict__ pats, uint32_t max_mm,
+                                                     const uint64_t *__restrict__ rec_start,
+                                                     const uint64_t *__restrict__ rec_len, uint32_t nrec,
+                                                     uint32_t check_rst,
+                                                     const uint64_t *__restrict__ queue, uint64_t qcap,
+                                                     const unsigned long long *__restrict__ qcount,
+                                                     ipcr_hit_rec *__restrict__ hits, uint64_t hcap,
+                                                     unsigned long long *__restrict__ hcount) {
+    unsigned long long n = *qcount;
+    if (n > qcap) n = qcap;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t cand = queue[i];
+        const uint32_t q = (uint32_t)(cand >> 48);
+        const uint64_t P = cand & 0xFFFFFFFFFFFFull;
+        // record lookup: last record with start <= P
+        uint32_t lo = 0, hi = nrec;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rec_start[mid] <= P) lo = mid; else hi = mid;
+        }
+        const uint64_t local = P - rec_start[lo];
+        const ipcr_dev_pattern *pp = pats + q;
+        const uint32_t L = pp->len;
+        if (local + L > rec_len[lo]) continue; // window leaves the record (ac.go:188-190)
+        uint32_t mm = 0;
+        uint64_t m0 = 0, m1 = 0;
+        bool ok = true;
+        for (uint32_t j = 0; j < L; ++j) {
+            const uint32_t g = base_bits(planes, P + j);
+            const uint32_t onehot = (g & 4u) ? 0u : (1u << (g & 3u));
+            const uint32_t m = pp->mask[j];
+            if ((m & onehot) == 0u) {
+                if (m & 16u) { ok = false; break; }
+                if (++mm > max_mm) { ok = false; break; }
+                if (j < 64u) m0 |= 1ull << j; else m1 |= 1ull << (j - 64u);
+            }
+        }
+        if (!ok) continue;
+        uint32_t flag = 0;
+        if (check_rst && pp->seed_len) {
+            for (uint32_t j = 0; j < pp->seed_len; ++j) flag |= rst_bit(rst, P + pp->seed_off + j);
+        }
+        const unsigned long long idx = atomicAdd(hcount, 1ull);
+        if (idx < hcap) {
+            ipcr_hit_rec h;
+            h.pos = local;
+            h.record = lo;
+            h.pattern = pp->global_id | (flag << 31);
+            h.mm_mask[0] = m0;
+            h.mm_mask[1] = m1;
+            hits[idx] = h;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ unpack
+// tiles -> ASCII for [P0, P0+n): valid -> ACGT, lower-case acgt (inv, !rst) -> acgt, else 'N'
+__global__ void unpack_kernel(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ rst,
+                              uint64_t P0, uint64_t n, uint8_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = base_bits(planes, P0 + i);
+    uint8_t ch;
+    if (!(g & 4u)) ch = (uint8_t)"ACGT"[g & 3u];
+    else if (!rst_bit(rst, P0 + i)) ch = (uint8_t)"acgt"[g & 3u];
+    else ch = 'N';
+    out[i] = ch;
+}
+
+// gather amplicons of products: seg[i] = {P_start_a, len_a, P_start_b, len_b, out_offset}
+__global__ void gather_amplicons_kernel(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ rst,
+                                        const ipcr_amp_seg *__restrict__ segs, uint8_t *__restrict__ out) {
+    const ipcr_amp_seg s = segs[blockIdx.x];
+    const uint64_t total = s.len_a + s.len_b;
+    for (uint64_t i = threadIdx.x; i < total; i += blockDim.x) {
+        const uint64_t P = (i < s.len_a) ? s.pa + i : s.pb + (i - s.len_a);
+        const uint32_t g = base_bits(planes, P);
+        uint8_t ch;
+        if (!(g & 4u)) ch = (uint8_t)"ACGT"[g & 3u];
+        else if (!rst_bit(rst, P)) ch = (uint8_t)"acgt"[g & 3u];
+        else ch = 'N';
+        out[s.out_off + i] = ch;
+    }
+}
+
+// ------------------------------------------------------------------------------- probe
+// oligo.BestHit (core/oligo/oligo.go:19-77): one wavefront per amplicon, lanes stride the
+// start offsets; both strands; best = fewest mismatches, then leftmost; '+' wins exact
+// ties; the k=0 strict-ACGT fast path returns the first '+' occurrence when one exists.
+__global__ __launch_bounds__(64) void probe_kernel(const uint8_t *__restrict__ amps,
+                                                   const uint64_t *__restrict__ amp_off, // n+1 offsets
+                                                   const uint8_t *__restrict__ pmask,    // probe IUPAC masks
+                                                   const uint8_t *__restrict__ rmask,    // rc(probe) masks
+                                                   uint32_t plen, uint32_t max_mm, uint32_t fastpath,
+                                                   ipcr_probe_rec *__restrict__ out) {
+    const uint64_t a0 = amp_off[blockIdx.x], a1 = amp_off[blockIdx.x + 1];
+    const uint64_t n = a1 - a0;
+    const uint32_t lane = threadIdx.x;
+    unsigned long long best[2] = {~0ull, ~0ull}; // key = mm<<40 | pos
+    if (plen > 0 && n >= plen) {
+        for (uint64_t pos = lane; pos + plen <= n; pos += 64u) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const uint8_t *mk = s ? rmask : pmask;
+                uint32_t mm = 0;
+                for (uint32_t j = 0; j < plen; ++j) {
+                    const uint32_t b = amps[a0 + pos + j] & 0xDFu; // strings.ToUpper (oligo.go:20)
+                    uint32_t oh = (b == 'A') ? 1u : (b == 'C') ? 2u : (b == 'G') ? 4u : (b == 'T') ? 8u : 0u;
+                    if ((mk[j] & oh) == 0u && ++mm > max_mm) break;
+                }
+                if (mm <= max_mm) {
+                    const unsigned long long key = ((unsigned long long)mm << 40) | pos;
+                    if (key < best[s]) best[s] = key;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best[s], off);
+            if (o < best[s]) best[s] = o;
+        }
+    if (lane == 0) {
+        ipcr_probe_rec r = {0, 0, 0, 0};
+        const bool hp = best[0] != ~0ull, hm = best[1] != ~0ull;
+        int pick = -1;
+        if (fastpath) pick = hp ? 0 : (hm ? 1 : -1);           // oligo.go:33-42
+        else if (hp && hm) pick = (best[1] < best[0]) ? 1 : 0;  // oligo.go:48-76, '+' wins ties
+        else pick = hp ? 0 : (hm ? 1 : -1);
+        if (pick >= 0) {
+            r.found = 1;
+            r.strand = pick ? '-' : '+';
+            r.pos = (int32_t)(best[pick] & 0xFFFFFFFFFFull);
+            r.mm = (int32_t)(best[pick] >> 40);
+        }
+        out[blockIdx.x] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------- launchers
+#include "launch.h"
+namespace ipcr {
+
+hipError_t launch_pack(hipStream_t st, const uint8_t *seq, uint64_t len, uint64_t col0, uint64_t ncol,
+                       uint32_t *planes, uint32_t *rst, uint32_t *rec_flags) {
+    const uint64_t pairs = (ncol + 1u) / 2u;
+    const uint64_t grid = (pairs + 3u) / 4u;
+    if (grid == 0) return hipSuccess;
+    pack_kernel<<<dim3((uint32_t)grid), dim3(256), 0, st>>>(seq, len, col0, ncol, planes, rst, rec_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_pad(hipStream_t st, uint32_t *planes, uint32_t *rst, uint64_t col_begin, uint64_t col_end) {
+    if (col_end <= col_begin) return hipSuccess;
+    const uint64_t n = (col_end - col_begin) * 128u;
+    fill_pad_kernel<<<dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, st>>>(planes, rst, col_begin, col_end);
+    return hipGetLastError();
+}
+
+hipError_t launch_lcg(hipStream_t st, uint8_t *out, uint64_t n, uint32_t seed) {
+    if (n == 0) return hipSuccess;
+    const uint64_t runs = (n + 63u) / 64u;
+    lcg_fill_kernel<<<dim3((uint32_t)((runs + 255u) / 256u)), dim3(256), 0, st>>>(out, n, seed);
+    return hipGetLastError();
+}
+
+hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_t nblocks,
+                                 const ipcr_dev_pattern *pats, uint32_t npat, uint32_t max_mm,
+                                 uint64_t *queue, uint64_t qcap, unsigned long long *qcount) {
+    if (nblocks == 0 || npat == 0) return hipSuccess;
+    const uint64_t tiles = nblocks * 128u; // one wave per (block, row)
+    const dim3 grid((uint32_t)((tiles + 3u) / 4u));
+    if (max_mm <= 3u)
+        filter_generic_kernel<4><<<grid, dim3(256), 0, st>>>(planes, nblocks, pats, npat, max_mm, queue, qcap, qcount);
+    else
+        filter_generic_kernel<17><<<grid, dim3(256), 0, st>>>(planes, nblocks, pats, npat, max_mm, queue, qcap, qcount);
+    return hipGetLastError();
+}
+
+hipError_t launch_verify(hipStream_t st, const uint32_t *planes, const uint32_t *rst,
+                         const ipcr_dev_pattern *pats, uint32_t max_mm, const uint64_t *rec_start,
+                         const uint64_t *rec_len, uint32_t nrec, uint32_t check_rst, const uint64_t *queue,
+                         uint64_t qcap, const unsigned long long *qcount, ipcr_hit_rec *hits, uint64_t hcap,
+                         unsigned long long *hcount) {
+    if (nrec == 0) return hipSuccess;
+    verify_kernel<<<dim3(1024), dim3(256), 0, st>>>(planes, rst, pats, max_mm, rec_start, rec_len, nrec, check_rst,
+                                                    queue, qcap, qcount, hits, hcap, hcount);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack(hipStream_t st, const uint32_t *planes, const uint32_t *rst, uint64_t P0, uint64_t n,
+                         uint8_t *out) {
+    if (n == 0) return hipSuccess;
+    unpack_kernel<<<dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, st>>>(planes, rst, P0, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(hipStream_t st, const uint32_t *planes, const uint32_t *rst, const ipcr_amp_seg *segs,
+                         uint32_t nseg, uint8_t *out) {
+    if (nseg == 0) return hipSuccess;
+    gather_amplicons_kernel<<<dim3(nseg), dim3(256), 0, st>>>(planes, rst, segs, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_probe(hipStream_t st, const uint8_t *amps, const uint64_t *amp_off, uint32_t namp,
+                        const uint8_t *pmask, const uint8_t *rmask, uint32_t plen, uint32_t max_mm,
+                        uint32_t fastpath, ipcr_probe_rec *out) {
+    if (namp == 0) return hipSuccess;
+    probe_kernel<<<dim3(namp), dim3(64), 0, st>>>(amps, amp_off, pmask, rmask, plen, max_mm, fastpath, out);
+    return hipGetLastError();
+}
+
+} // namespace ipcr

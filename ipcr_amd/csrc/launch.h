@@ -1,0 +1,28 @@
+// launch.h -- host-callable launchers of the kernels in kernels.hip
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "device_types.h"
+
+namespace ipcr {
+hipError_t launch_pack(hipStream_t st, const uint8_t *seq, uint64_t len, uint64_t col0, uint64_t ncol,
+                       uint32_t *planes, uint32_t *rst, uint32_t *rec_flags);
+hipError_t launch_fill_pad(hipStream_t st, uint32_t *planes, uint32_t *rst, uint64_t col_begin, uint64_t col_end);
+hipError_t launch_lcg(hipStream_t st, uint8_t *out, uint64_t n, uint32_t seed);
+hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_t nblocks,
+                                 const ipcr_dev_pattern *pats, uint32_t npat, uint32_t max_mm,
+                                 uint64_t *queue, uint64_t qcap, unsigned long long *qcount);
+hipError_t launch_verify(hipStream_t st, const uint32_t *planes, const uint32_t *rst,
+                         const ipcr_dev_pattern *pats, uint32_t max_mm, const uint64_t *rec_start,
+                         const uint64_t *rec_len, uint32_t nrec, uint32_t check_rst, const uint64_t *queue,
+                         uint64_t qcap, const unsigned long long *qcount, ipcr_hit_rec *hits, uint64_t hcap,
+                         unsigned long long *hcount);
+hipError_t launch_unpack(hipStream_t st, const uint32_t *planes, const uint32_t *rst, uint64_t P0, uint64_t n,
+                         uint8_t *out);
+hipError_t launch_gather(hipStream_t st, const uint32_t *planes, const uint32_t *rst, const ipcr_amp_seg *segs,
+                         uint32_t nseg, uint8_t *out);
+hipError_t launch_probe(hipStream_t st, const uint8_t *amps, const uint64_t *amp_off, uint32_t namp,
+                        const uint8_t *pmask, const uint8_t *rmask, uint32_t plen, uint32_t max_mm,
+                        uint32_t fastpath, ipcr_probe_rec *out);
+} // namespace ipcr

@@ -1,0 +1,367 @@
+"""Mirror of the reference's core/engine API for the scan path, over the C ABI.
+
+Same names and argument meaning as the Go package so parity tests read like the
+reference's own tests:
+
+    eng = engine.New(engine.Config(MaxMM=1, TerminalWindow=3))
+    products = eng.SimulateBatch("seq", b"ACGT...", [primer.Pair(...)])
+
+Everything here is thin glue; panel compilation, the scan, hit ordering/capping and the
+amplicon join all live behind libipcr_hip.so (ipcr_amd/csrc).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+from . import _lib
+from .primer import Oligo, Pair, SelfPairs
+
+
+@dataclass
+class Config:
+    """engine.Config -- core/engine/engine.go:10-19"""
+    MaxMM: int = 0
+    TerminalWindow: int = 0
+    MinLen: int = 0
+    MaxLen: int = 0
+    HitCap: int = 0
+    NeedSites: bool = False
+    SeedLen: int = 0
+    Circular: bool = False
+
+    def _c(self) -> _lib.Config:
+        return _lib.Config(self.MaxMM, self.TerminalWindow, self.MinLen, self.MaxLen, self.HitCap,
+                           self.SeedLen, 1 if self.Circular else 0, 1 if self.NeedSites else 0)
+
+
+@dataclass
+class Product:
+    """engine.Product -- core/engine/product.go:4-35 (scan-produced fields)"""
+    ExperimentID: str
+    SequenceID: str
+    Start: int
+    End: int
+    Length: int
+    Type: str
+    FwdMM: int
+    RevMM: int
+    FwdMismatchIdx: Tuple[int, ...]
+    RevMismatchIdx: Tuple[int, ...]
+    FwdPrimer: str = ""
+    RevPrimer: str = ""
+    Record: int = 0
+
+    def sig(self):
+        """core/engine/approx_seed_oracle_test.go:12-41 signature (minus SequenceID)."""
+        return (self.ExperimentID, self.Start, self.End, self.Length, self.Type, self.FwdMM,
+                self.RevMM, self.FwdMismatchIdx, self.RevMismatchIdx)
+
+
+@dataclass
+class Hit:
+    """primer.Match as found on the device, per distinct pattern."""
+    Record: int
+    Pattern: int
+    Pos: int
+    Mismatches: int
+    MismatchIdx: Tuple[int, ...]
+    SeedSpanReset: bool
+
+
+def _idx_from_mask(m0: int, m1: int) -> Tuple[int, ...]:
+    out = []
+    for w, m in enumerate((m0, m1)):
+        while m:
+            b = (m & -m).bit_length() - 1
+            out.append(b + 64 * w)
+            m &= m - 1
+    return tuple(out)
+
+
+class CompiledPanel:
+    """engine.CompiledPanel -- core/engine/compiled.go:77-91 (exported fields Pairs, Cfg)."""
+
+    def __init__(self, cfg: Config, pairs: Sequence[Pair]):
+        self.Cfg = cfg
+        self.Pairs = list(pairs)
+        n = len(self.Pairs)
+        self._keep = [(p.ID.encode(), p.Forward.encode(), p.Reverse.encode()) for p in self.Pairs]
+        arr = (_lib.Pair * max(n, 1))()
+        for i, p in enumerate(self.Pairs):
+            arr[i] = _lib.Pair(self._keep[i][0], self._keep[i][1], self._keep[i][2], p.MinProduct, p.MaxProduct)
+        h = C.c_void_p()
+        cc = cfg._c()
+        _lib.check(_lib.lib().ipcr_panel_create(C.byref(cc), arr, n, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().ipcr_panel_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def have(self, pair: int, which: str) -> bool:
+        """compiledHas(cp.Have, pair, which) -- core/engine/compiled.go:35-37"""
+        return bool(_lib.lib().ipcr_panel_have(self._h, pair, which.encode()))
+
+    @property
+    def num_patterns(self) -> int:
+        return _lib.lib().ipcr_panel_num_patterns(self._h)
+
+    def filter_source(self, mode: int = 0) -> str:
+        """HIP source of the panel-specialised filter ('' when the panel is not specialisable)."""
+        need = C.c_size_t()
+        _lib.check(_lib.lib().ipcr_panel_filter_source(self._h, mode, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        _lib.check(_lib.lib().ipcr_panel_filter_source(self._h, mode, buf, need.value, None))
+        return buf.value.decode()
+
+    def set_specialize(self, enable: bool) -> None:
+        _lib.check(_lib.lib().ipcr_panel_set_specialize(self._h, 1 if enable else 0))
+
+
+class SimulationScratch:
+    """engine.SimulationScratch -- core/engine/hit_collect.go:12-34: one HIP stream + device
+    staging buffers per worker; never shared between workers."""
+
+    def __init__(self, cp: CompiledPanel):
+        self._cp = cp
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ipcr_scratch_create(cp._h, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().ipcr_scratch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stats(self) -> _lib.ScanStats:
+        st = _lib.ScanStats()
+        _lib.check(_lib.lib().ipcr_scratch_stats(self._h, C.byref(st)))
+        return st
+
+    def hits(self) -> List[Hit]:
+        ptr = C.POINTER(_lib.Hit)()
+        n = C.c_int64()
+        _lib.check(_lib.lib().ipcr_scratch_hits(self._h, C.byref(ptr), C.byref(n)))
+        out = []
+        for i in range(n.value):
+            h = ptr[i]
+            idx = _idx_from_mask(h.mm_mask[0], h.mm_mask[1])
+            out.append(Hit(h.record, h.pattern & 0x7FFFFFFF, h.pos, len(idx), idx, bool(h.pattern >> 31)))
+        return out
+
+    def raw_hits(self):
+        """(pointer, count) of the ipcr_hit array of the last scan."""
+        ptr = C.POINTER(_lib.Hit)()
+        n = C.c_int64()
+        _lib.check(_lib.lib().ipcr_scratch_hits(self._h, C.byref(ptr), C.byref(n)))
+        return ptr, n.value
+
+    def num_products(self) -> int:
+        ptr = C.POINTER(_lib.Product)()
+        n = C.c_int64()
+        _lib.check(_lib.lib().ipcr_scratch_products(self._h, C.byref(ptr), C.byref(n)))
+        return n.value
+
+    def products(self, seq_ids: Sequence[str]) -> List[Product]:
+        ptr = C.POINTER(_lib.Product)()
+        n = C.c_int64()
+        _lib.check(_lib.lib().ipcr_scratch_products(self._h, C.byref(ptr), C.byref(n)))
+        return [_product(self._cp, ptr[i], seq_ids) for i in range(n.value)]
+
+
+def _product(cp: CompiledPanel, p: _lib.Product, seq_ids: Sequence[str]) -> Product:
+    pair = cp.Pairs[p.pair]
+    fwd = p.type == 0
+    return Product(
+        ExperimentID=pair.ID,
+        SequenceID=seq_ids[p.record] if p.record < len(seq_ids) else str(p.record),
+        Start=p.start, End=p.end, Length=p.length,
+        Type="forward" if fwd else "revcomp",
+        FwdMM=p.fwd_mm, RevMM=p.rev_mm,
+        FwdMismatchIdx=tuple(p.fwd_idx[k] for k in range(p.n_fwd_idx)),
+        RevMismatchIdx=tuple(p.rev_idx[k] for k in range(p.n_rev_idx)),
+        FwdPrimer=pair.Forward if fwd else pair.Reverse,   # core/engine/engine.go:197-198,385-386
+        RevPrimer=pair.Reverse if fwd else pair.Forward,
+        Record=p.record,
+    )
+
+
+class Genome:
+    """Reference records packed once into 2-bit + invalid-bit tiles resident in HBM."""
+
+    def __init__(self, capacity_bases: int, max_records: int = 1):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ipcr_genome_create(capacity_bases, max_records, C.byref(h)))
+        self._h = h
+        self.ids: List[str] = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().ipcr_genome_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_record(self, seq_id: str, seq) -> None:
+        b = seq if isinstance(seq, (bytes, bytearray)) else seq.encode()
+        _lib.check(_lib.lib().ipcr_genome_add_record(self._h, bytes(b), len(b)))
+        self.ids.append(seq_id)
+
+    def add_record_device(self, seq_id: str, dev_ptr: int, length: int) -> None:
+        _lib.check(_lib.lib().ipcr_genome_add_record_device(self._h, C.c_void_p(dev_ptr), length))
+        self.ids.append(seq_id)
+
+    def read(self, record: int, pos: int, length: int) -> bytes:
+        buf = C.create_string_buffer(max(length, 1))
+        _lib.check(_lib.lib().ipcr_genome_read(self._h, record, pos, buf, length))
+        return buf.raw[:length]
+
+    @property
+    def num_records(self) -> int:
+        return _lib.lib().ipcr_genome_num_records(self._h)
+
+    def record_len(self, r: int) -> int:
+        return _lib.lib().ipcr_genome_record_len(self._h, r)
+
+    def record_flags(self, r: int) -> int:
+        return _lib.lib().ipcr_genome_record_flags(self._h, r)
+
+    @property
+    def total_bases(self) -> int:
+        return _lib.lib().ipcr_genome_total_bases(self._h)
+
+    @property
+    def tile_bytes(self) -> int:
+        return _lib.lib().ipcr_genome_tile_bytes(self._h)
+
+    @property
+    def pack_ms(self) -> float:
+        return _lib.lib().ipcr_genome_pack_ms(self._h)
+
+
+def lcg_fill_device(dev_ptr: int, length: int, seed: int) -> None:
+    """benchDNA on the device -- core/engine/performance_benchmark_test.go:67-76"""
+    _lib.check(_lib.lib().ipcr_lcg_fill_device(C.c_void_p(dev_ptr), length, seed & 0xFFFFFFFF))
+
+
+class Engine:
+    """engine.Engine -- core/engine/engine.go:21-30"""
+
+    def __init__(self, cfg: Config):
+        self.cfg = cfg
+
+    def SetHitCap(self, n: int) -> None:  # engine.go:30
+        self.cfg = Config(**{**self.cfg.__dict__, "HitCap": n})
+
+    # -- compiled.go:96-136
+    def CompilePanel(self, pairs: Sequence[Pair]) -> CompiledPanel:
+        return CompiledPanel(self.cfg, pairs)
+
+    # -- hit_collect.go:31-34
+    def NewSimulationScratch(self, cp: CompiledPanel) -> SimulationScratch:
+        return SimulationScratch(cp)
+
+    # -- compiled.go:162-267
+    def ForEachCompiledProduct(self, seqID: str, seq, cp: Optional[CompiledPanel],
+                               scratch: Optional[SimulationScratch],
+                               emit: Optional[Callable[[Product], Optional[Exception]]]):
+        """Calls emit(product) in the reference's emission order.  A truthy return from emit
+        aborts the scan and is returned (the reference returns emit's error)."""
+        if cp is None or not cp.Pairs or emit is None:  # compiled.go:163-165
+            return None
+        own = scratch is None
+        if own:
+            scratch = SimulationScratch(cp)
+        b = seq if isinstance(seq, (bytes, bytearray)) else seq.encode()
+        err_box = []
+
+        def _cb(pp, _user):
+            r = emit(_product(cp, pp.contents, [seqID]))
+            if r:
+                err_box.append(r)
+                return 1
+            return 0
+
+        cb = _lib.EMIT_FN(_cb)
+        st = _lib.lib().ipcr_scan_chunk(cp._h, scratch._h, bytes(b), len(b), C.cast(cb, C.c_void_p), None)
+        if own:
+            scratch.close()
+        if st == _lib.ERR_ABORTED and err_box:
+            return err_box[0]
+        _lib.check(st)
+        return None
+
+    # -- compiled.go:148-156
+    def SimulateCompiledWithScratch(self, seqID: str, seq, cp: CompiledPanel,
+                                    scratch: Optional[SimulationScratch]) -> List[Product]:
+        if cp is None or not cp.Pairs:
+            return []
+        own = scratch is None
+        if own:
+            scratch = SimulationScratch(cp)
+        b = seq if isinstance(seq, (bytes, bytearray)) else seq.encode()
+        _lib.check(_lib.lib().ipcr_scan_chunk(cp._h, scratch._h, bytes(b), len(b), None, None))
+        out = scratch.products([seqID])
+        if own:
+            scratch.close()
+        return out
+
+    # -- compiled.go:141-143
+    def SimulateCompiled(self, seqID: str, seq, cp: CompiledPanel) -> List[Product]:
+        return self.SimulateCompiledWithScratch(seqID, seq, cp, None)
+
+    # -- engine.go:49-51
+    def SimulateBatch(self, seqID: str, seq, pairs: Sequence[Pair]) -> List[Product]:
+        cp = self.CompilePanel(pairs)
+        try:
+            return self.SimulateCompiled(seqID, seq, cp)
+        finally:
+            cp.close()
+
+    # -- engine.go:33-36
+    def Simulate(self, seqID: str, seq, p: Pair) -> List[Product]:
+        return self.SimulateBatch(seqID, seq, [p])
+
+    # -- self.go:10-16
+    def SimulateSelf(self, seqID: str, seq, oligos: Sequence[Oligo]) -> List[Product]:
+        if not oligos:
+            return []
+        return self.SimulateBatch(seqID, seq, SelfPairs(oligos))
+
+    # -- resident-genome form of ForEachCompiledProduct: all records in one launch
+    def ScanGenome(self, genome: Genome, cp: CompiledPanel, scratch: SimulationScratch) -> List[Product]:
+        _lib.check(_lib.lib().ipcr_scan_genome(cp._h, scratch._h, genome._h, None, None))
+        return scratch.products(genome.ids)
+
+    def ScanGenomeCount(self, genome: Genome, cp: CompiledPanel, scratch: SimulationScratch) -> int:
+        """Same scan + join, products left in the scratch (no Python object per product)."""
+        _lib.check(_lib.lib().ipcr_scan_genome(cp._h, scratch._h, genome._h, None, None))
+        return scratch.num_products()
+
+    def ScanGenomeHits(self, genome: Genome, cp: CompiledPanel, scratch: SimulationScratch) -> List[Hit]:
+        _lib.check(_lib.lib().ipcr_scan_genome_hits(cp._h, scratch._h, genome._h))
+        return scratch.hits()
+
+
+def New(c: Config) -> Engine:
+    """engine.New -- core/engine/engine.go:27"""
+    return Engine(c)

@@ -1,0 +1,359 @@
+"""GPU parity: the HIP path (through the C ABI, via the ipcr_amd mirror of the reference API)
+against the CPU oracle on the same inputs.  Bit-exact, including emission order."""
+import random
+from collections import Counter
+
+import pytest
+
+import ipcr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from ipcr_amd import _lib, engine, oligo, primer, probe
+    assert _lib.lib().ipcr_device_count() > 0, "needs a HIP device"
+
+    class NS:
+        pass
+    ns = NS()
+    ns.lib, ns.engine, ns.primer, ns.oligo, ns.probe = _lib, engine, primer, oligo, probe
+    return ns
+
+
+def ocfg(c):
+    return O.Config(max_mm=c.MaxMM, terminal_window=c.TerminalWindow, min_len=c.MinLen, max_len=c.MaxLen,
+                    hit_cap=c.HitCap, seed_len=c.SeedLen, circular=c.Circular)
+
+
+def opairs(pairs):
+    return [O.Pair(p.ID, p.Forward, p.Reverse, p.MinProduct, p.MaxProduct) for p in pairs]
+
+
+def check(hip, cfg, seq, pairs, specialize=None):
+    eng = hip.engine.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    if specialize is not None:
+        cp.set_specialize(specialize)
+    got = eng.SimulateCompiled("seq", seq, cp)
+    want = O.simulate_batch(ocfg(cfg), seq, opairs(pairs))
+    assert [g.sig() for g in got] == [w.sig() for w in want]
+    op = O.Panel(ocfg(cfg), opairs(pairs))
+    for i in range(len(pairs)):
+        for w in "ABab":
+            assert cp.have(i, w) == op.have(i, w)
+    cp.close()
+    return got
+
+
+# ---- the reference's own engine tests, run against the HIP engine ----------------------------
+
+def test_simulate_minimal(hip):  # core/engine/engine_test.go:11-35
+    P = hip.primer.Pair
+    got = hip.engine.New(hip.engine.Config()).Simulate("dummySeq", b"ACGTACGTACGT", P("test", "ACG", "ACG"))
+    assert got and (got[0].Start, got[0].End, got[0].Length) == (0, 12, 12)
+    assert len(got) == 12
+
+
+def test_length_filtering_and_type(hip):  # engine_test.go:38-78
+    P = hip.primer.Pair
+    eng = hip.engine.New(hip.engine.Config())
+    hits = eng.Simulate("seq", b"ACGTACGTACGT", P("t", "ACG", "ACG", 10, 12))
+    assert hits and all(10 <= p.Length <= 12 for p in hits)
+    assert eng.Simulate("seq", b"ACGTACGTACGT", P("t2", "ACG", "ACG", 5, 7)) == []
+
+
+def test_revcomp_product(hip):  # engine_test.go:81-101
+    hits = hip.engine.New(hip.engine.Config()).Simulate("s", b"TTTACGACGTAAA", hip.primer.Pair("rev", "ACG", "TTT"))
+    assert any(h.Type == "revcomp" for h in hits)
+
+
+def test_circular_amplicon(hip):  # engine_test.go:104-129
+    E, P = hip.engine, hip.primer.Pair
+    assert E.New(E.Config(Circular=False)).Simulate("seq1", b"TGACAAG", P("p1", "AG", "TC")) == []
+    hits = E.New(E.Config(Circular=True)).Simulate("seq1", b"TGACAAG", P("p1", "AG", "TC"))
+    assert len(hits) == 1 and hits[0].Start > hits[0].End
+    assert hits[0].Length == 7 - hits[0].Start + hits[0].End
+
+
+def test_seeded_mismatch_cases(hip):  # engine_test.go:131-168
+    E, P = hip.engine, hip.primer.Pair
+    hits = E.New(E.Config(MaxMM=1, TerminalWindow=3, SeedLen=12, MinLen=10)).Simulate(
+        "seq", b"CAGTACAAAAAAGGTACC", P("seed-mm", "AAGTAC", "GGTACC"))
+    assert len(hits) == 1 and hits[0].FwdMM == 1 and hits[0].FwdMismatchIdx == (0,)
+    eng = E.New(E.Config(MaxMM=1, TerminalWindow=0, SeedLen=12, MinLen=10))
+    cp = eng.CompilePanel([P("seed-mm-no-tw", "AAGTAC", "GGTACC")])
+    assert cp.have(0, "A")
+    assert len(eng.Simulate("seq", b"CAGTACAAAAAAGGTACC", P("seed-mm-no-tw", "AAGTAC", "GGTACC"))) == 1
+
+
+ORACLE_CASES = [  # core/engine/approx_seed_oracle_test.go:95-176
+    ("TTTACGTACAAAAGGTACCTTT", [("forward_exact", "ACGTAC", "GGTACC")]),
+    ("TTTGGTACCAAAAGTACGTTTT", [("revcomp_exact", "ACGTAC", "GGTACC")]),
+    ("TTTTCGTACAAAAGGTACCTTT", [("forward_mismatch_5prime", "ACGTAC", "GGTACC")]),
+    ("TTTACGTACAAAAGGTACCTTT", [("primer_ry", "ACRTAC", "GGTACC")]),
+    ("TTTACGTACAAAAGGTACCTTT", [("primer_internal_n", "ACNTAC", "GGTACC")]),
+    ("TTTACGTACAAAAGGTACCTTT", [("primer_3prime_n", "ACGTAN", "GGTACC")]),
+    ("TTTNCGTACAAAAGGTACCTTT", [("reference_n", "ACGTAC", "GGTACC")]),
+    ("TTTacgtacAAAAGGTACCTTT", [("lowercase_reference", "ACGTAC", "GGTACC")]),
+    ("TTTACGTACAAAAGGTACCTTTGGGGGGGGGG", [("panel_hit", "ACGTAC", "GGTACC"), ("panel_decoy", "TTAACC", "CCAATT")]),
+]
+
+
+@pytest.mark.parametrize("spec", [False, True])
+def test_oracle_matrix(hip, spec):  # approx_seed_oracle_test.go:88-203 (9 sequences x 9 configs)
+    for seq, ps in ORACLE_CASES:
+        pairs = [hip.primer.Pair(*p) for p in ps]
+        for k in (0, 1, 2):
+            for tw in (0, 1, 3):
+                cfg = hip.engine.Config(MaxMM=k, TerminalWindow=tw, MinLen=1, MaxLen=100, SeedLen=12)
+                check(hip, cfg, seq.encode(), pairs, specialize=spec)
+
+
+def test_length_boundary_circular_self(hip):  # approx_seed_oracle_test.go:205-259
+    E, P = hip.engine, hip.primer.Pair
+    for mn, mx in [(16, 16), (17, 100), (1, 15)]:
+        check(hip, E.Config(MinLen=mn, MaxLen=mx, SeedLen=12), b"TTTACGTACAAAAGGTACCTTT", [P("length", "ACGTAC", "GGTACC")])
+    for circ in (False, True):
+        check(hip, E.Config(Circular=circ), b"TGACAAG", [P("circular", "AG", "TC")])
+    pairs = hip.primer.SelfPairs([hip.primer.Oligo("self", "ACGTAC")])
+    for k, tw in [(0, 0), (1, 3), (2, 0)]:
+        check(hip, E.Config(MaxMM=k, TerminalWindow=tw, MinLen=1, MaxLen=100, SeedLen=12), b"TTTACGTACAAAAGTACGTTTT", pairs)
+
+
+def test_halo_case(hip):  # non_acgt_halo_test.go:32-52
+    got = check(hip, hip.engine.Config(MaxMM=1, TerminalWindow=0, MinLen=1, MaxLen=100, SeedLen=6),
+                b"TTTACNTACAAAAGGTACCTTT", [hip.primer.Pair("reference_n_inside_seed", "ACGTAC", "GGTACC")])
+    assert len(got) >= 1
+
+
+@pytest.mark.parametrize("spec", [False, True])
+@pytest.mark.parametrize("mutate,refn,k,n", [(True, True, 2, 12), (True, False, 1, 16), (False, False, 0, 64), (False, True, 1, 16)])
+def test_bench_fixtures(hip, spec, mutate, refn, k, n):  # performance_gate_test.go:51-59, performance_benchmark_test.go:155-213
+    seq, op = O.make_bench_fixture(n, 250000 if n >= 16 else 20000, mutate, refn)
+    pairs = [hip.primer.Pair(p.id, p.forward, p.reverse, p.min_product, p.max_product) for p in op]
+    got = check(hip, hip.engine.Config(MaxMM=k, TerminalWindow=0, MinLen=100, MaxLen=240, SeedLen=12), seq, pairs, specialize=spec)
+    assert len(got) >= n
+
+
+# ---- randomised differential tests -------------------------------------------------------------
+
+def rand_case(rng, n, with_junk):
+    alpha = "ACGT"
+    seq = [rng.choice(alpha) for _ in range(n)]
+    if with_junk:
+        for _ in range(rng.randint(0, 6)):
+            p = rng.randrange(n)
+            run = rng.randint(1, 12)
+            ch = rng.choice("NNNRYacgtn")
+            for i in range(p, min(n, p + run)):
+                seq[i] = ch
+    return seq
+
+
+def plant(rng, seq, primer_seq, pos, nmut):
+    s = list(primer_seq)
+    concrete = []
+    for ch in s:
+        opts = [b for b in "ACGT" if O.base_match(b, ch)]
+        concrete.append(rng.choice(opts))
+    for _ in range(nmut):
+        j = rng.randrange(len(concrete))
+        concrete[j] = O.different_base(concrete[j])
+    seq[pos:pos + len(concrete)] = concrete
+
+
+@pytest.mark.parametrize("spec", [False, True])
+@pytest.mark.parametrize("seed", range(6))
+def test_random_differential(hip, spec, seed):
+    rng = random.Random(1234 + seed)
+    E, P = hip.engine, hip.primer.Pair
+    for it in range(10):
+        n = rng.choice([60, 300, 5000, 70000])
+        seq = rand_case(rng, n, with_junk=rng.random() < 0.6)
+        npairs = rng.randint(1, 4)
+        pairs = []
+        lmin = 4 if n <= 300 else (8 if n <= 5000 else 14)  # keeps the product lists small
+        for i in range(npairs):
+            def mk():
+                L = rng.randint(lmin, 30)
+                s = [rng.choice("ACGT") for _ in range(L)]
+                for _ in range(rng.choice([0, 0, 1, 2])):
+                    s[rng.randrange(L)] = rng.choice("RYSWKMBDHVN")
+                return "".join(s)
+            pairs.append(P("p%d" % i, mk(), mk(), rng.choice([0, 0, 20]), rng.choice([0, 0, 400])))
+        # plant amplicons so products exist
+        for p in pairs:
+            for _ in range(rng.randint(1, 3)):
+                a = rng.randrange(0, max(1, n - 200))
+                ln = rng.randint(len(p.Forward) + len(p.Reverse), 150)
+                if a + ln > n:
+                    continue
+                plant(rng, seq, p.Forward, a, rng.choice([0, 0, 1, 2]))
+                rc = O.revcomp(p.Reverse).decode()
+                plant(rng, seq, rc, a + ln - len(rc), rng.choice([0, 0, 1]))
+        cfg = E.Config(MaxMM=rng.choice([0, 1, 2, 3] if n <= 5000 else [0, 1, 2]), TerminalWindow=rng.choice([0, 1, 3, 5]),
+                       MinLen=rng.choice([0, 10]), MaxLen=rng.choice([0, 200, 2000]),
+                       HitCap=rng.choice([0, 0, 3, 10000]), SeedLen=rng.choice([0, 12, 6, -1]),
+                       Circular=rng.random() < 0.3)
+        if rng.random() < 0.5:
+            pairs = hip.primer.AddSelfPairs(pairs)
+        check(hip, cfg, "".join(seq).encode(), pairs, specialize=spec)
+
+
+def test_hit_cap_quirks(hip):
+    """HitCap truncation per orientation, incl. the reference's cap-before-5'-filter order on the
+    FindMatches path (core/engine/compiled.go:249-256) with and without non-ACGT bytes."""
+    E, P = hip.engine, hip.primer.Pair
+    rng = random.Random(7)
+    base = "ACGTTGCA" * 40
+    for junk in ("", "N"):
+        for cap in (1, 2, 5, 0):
+            for k, tw in [(1, 2), (2, 3), (0, 3), (1, 0)]:
+                seq = (base[:100] + junk + base[100:]).encode()
+                cfg = E.Config(MaxMM=k, TerminalWindow=tw, MaxLen=60, HitCap=cap, SeedLen=rng.choice([4, 12, -1]))
+                check(hip, cfg, seq, [P("q", "ACGTTG", "TGCAAC"), P("r", "CGTT", "GCAA")])
+
+
+def test_edge_inputs(hip):
+    E, P = hip.engine, hip.primer.Pair
+    eng = E.New(E.Config(MaxMM=1, TerminalWindow=2, MaxLen=100))
+    assert eng.SimulateBatch("s", b"", [P("x", "ACGT", "ACGT")]) == []
+    assert eng.SimulateBatch("s", b"ACG", [P("x", "ACGT", "ACGT")]) == []  # shorter than the primer
+    assert eng.SimulateBatch("s", b"ACGTACGT", []) == []
+    check(hip, E.Config(MaxMM=3, TerminalWindow=9, MaxLen=100), b"ACGTACGTTTACGTAAACGT", [P("x", "ACGT", "ACGT")])  # tw > primer
+    check(hip, E.Config(MaxMM=0), b"A" * 9000, [P("x", "AAAA", "TTTT", 0, 20)])  # dense hits, many products
+    long_primer = "ACGTTGCAAGGCTTAACCGGTTAAGGCCTTAACCGGATATCGCGATATGGCCAATT" * 2
+    seq = "TTT" + long_primer + "GGGG" + O.revcomp(long_primer).decode() + "AAA"
+    check(hip, E.Config(MaxMM=2, TerminalWindow=3, MaxLen=1000), seq.encode(), [P("long", long_primer, long_primer)])
+
+
+def test_errors(hip):
+    E, P = hip.engine, hip.primer.Pair
+    with pytest.raises(hip.lib.IpcrError) as e:
+        E.New(E.Config(MaxMM=-1)).CompilePanel([P("x", "ACGT", "ACGT")])
+    assert e.value.status == hip.lib.ERR_INVALID
+    with pytest.raises(hip.lib.IpcrError) as e:
+        E.New(E.Config()).CompilePanel([P("x", "ACGX", "ACGT")])  # the reference panics (rc.go:27-34)
+    assert e.value.status == hip.lib.ERR_PRIMER
+    with pytest.raises(hip.lib.IpcrError) as e:
+        E.New(E.Config()).CompilePanel([P("x", "A" * 129, "ACGT")])
+    assert e.value.status == hip.lib.ERR_UNSUPPORTED
+
+
+def test_emit_error_aborts(hip):  # core/engine/join_stream_test.go:48-58
+    E, P = hip.engine, hip.primer.Pair
+    eng = E.New(E.Config(MinLen=6, MaxLen=60))
+    cp = eng.CompilePanel([P("join_error", "ACGTAC", "GGTACC", 6, 60)])
+    sentinel = RuntimeError("stop joined product stream")
+    seen = []
+
+    def emit(p):
+        seen.append(p)
+        return sentinel
+
+    assert eng.ForEachCompiledProduct("seq", b"TTTACGTACAAAAGGTACCTTT", cp, None, emit) is sentinel
+    assert len(seen) == 1
+
+
+def test_scratch_reuse(hip):  # core/engine/hit_collect_test.go:98-112, compiled_panel_test.go
+    E, P = hip.engine, hip.primer.Pair
+    eng = E.New(E.Config(MaxMM=0, MinLen=6, MaxLen=60, SeedLen=4))
+    cp = eng.CompilePanel([P("x", "ACGTAC", "GGTACC")])
+    sc = eng.NewSimulationScratch(cp)
+    assert len(eng.SimulateCompiledWithScratch("seq1", b"TTTACGTACAAAAGGTACCTTT", cp, sc)) > 0
+    assert eng.SimulateCompiledWithScratch("seq2", b"TTTACGTACAAAACCCCCCCTTT", cp, sc) == []
+    big = O.bench_dna(600000, 99)
+    eng.SimulateCompiledWithScratch("big", big, cp, sc)   # grows the private tile buffer
+    assert len(eng.SimulateCompiledWithScratch("seq1", b"TTTACGTACAAAAGGTACCTTT", cp, sc)) > 0
+
+
+# ---- tiles, generators -------------------------------------------------------------------------
+
+def test_pack_roundtrip_and_lcg(hip):
+    import ctypes as C
+    rng = random.Random(5)
+    g = hip.engine.Genome(3_000_000, 16)
+    recs = []
+    for n in (1, 127, 128, 129, 4095, 8192, 8193, 300000, 0):
+        s = "".join(rng.choice("ACGTACGTACGTNRacgtn") for _ in range(n)).encode()
+        g.add_record("r%d" % n, s)
+        recs.append(s)
+    for i, s in enumerate(recs):
+        assert g.record_len(i) == len(s)
+        want = bytes(ch if ch in b"ACGTacgt" else ord("N") for ch in s)
+        assert g.read(i, 0, len(s)) == want
+        assert bool(g.record_flags(i) & 1) == any(ch not in b"ACGTacgt" for ch in s)
+    g.close()
+
+
+def test_lcg_device_matches_reference_generator(hip):
+    torch = pytest.importorskip("torch")
+    n = 1_000_003
+    t = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    hip.engine.lcg_fill_device(t.data_ptr(), n, 0x5eed1234)
+    assert bytes(t.cpu().numpy().tobytes()) == O.bench_dna(n, 0x5eed1234)
+
+
+def test_resident_genome_multi_record(hip):
+    E, P = hip.engine, hip.primer.Pair
+    rng = random.Random(11)
+    cfg = E.Config(MaxMM=2, TerminalWindow=3, MaxLen=300, HitCap=10000, SeedLen=12)
+    pair = P("p", "ACGTTGCATGCAAGCT", "GGCCTTAAGGCCATAT", 0, 0)
+    pairs = hip.primer.AddSelfPairs([pair])
+    g = E.Genome(2_000_000, 16)
+    seqs = []
+    for r in range(7):
+        n = rng.choice([5000, 100000, 262144, 262145, 8192 * 3])
+        s = rand_case(rng, n, with_junk=(r % 3 == 0))
+        for _ in range(5):
+            a = rng.randrange(0, n - 300)
+            plant(rng, s, pair.Forward, a, rng.choice([0, 1, 2]))
+            rc = O.revcomp(pair.Reverse).decode()
+            plant(rng, s, rc, a + rng.randint(40, 250), rng.choice([0, 1]))
+        s = "".join(s).encode()
+        seqs.append(s)
+        g.add_record("rec%d" % r, s)
+    eng = E.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    sc = eng.NewSimulationScratch(cp)
+    got = eng.ScanGenome(g, cp, sc)
+    want = []
+    op = O.Panel(ocfg(cfg), opairs(pairs))
+    for r, s in enumerate(seqs):
+        want += [("rec%d" % r,) + w.sig() for w in op.scan(s)]
+    assert [(p.SequenceID,) + p.sig() for p in got] == want
+    assert len(got) >= 20
+    g.close()
+
+
+# ---- probe -------------------------------------------------------------------------------------
+
+def test_probe_known_answers(hip):  # core/oligo/oligo_test.go:5-21, core/probe/annotate_test.go:5-19
+    h = hip.oligo.BestHit("ACGTACGTACGT", "GTAC", 0)
+    assert (h.Found, h.Pos, h.MM, h.Strand, h.Site) == (True, 2, 0, "+", "GTAC")
+    assert hip.oligo.BestHit("ACGTACGTACGT", "GTGC", 1).Found
+    h = hip.oligo.BestHit("AAAGACCC", "GAY", 0)
+    assert (h.Found, h.Strand, h.Pos, h.Site) == (True, "+", 3, "GAC")
+    a = hip.probe.AnnotateAmplicon("ACGTACGTACGT", "GTAC", 0)
+    assert a.Found and a.MM == 0 and a.Pos == 2 and a.Site == "GTAC"
+    assert not hip.oligo.BestHit("ACGT", "  ", 0).Found
+
+
+def test_probe_random_vs_oracle(hip):
+    rng = random.Random(3)
+    for _ in range(60):
+        n = rng.randint(5, 400)
+        amp = "".join(rng.choice("ACGTACGTacgtN") for _ in range(n))
+        L = rng.randint(3, 25)
+        prb = "".join(rng.choice("ACGTACGTACGTRYN") for _ in range(L))
+        if rng.random() < 0.5 and n > L + 2:
+            p = rng.randrange(0, n - L)
+            src = prb if rng.random() < 0.5 else O.revcomp(prb).decode()
+            conc = "".join(rng.choice([b for b in "ACGT" if O.base_match(b, ch)]) for ch in src)
+            amp = amp[:p] + conc + amp[p + L:]
+        k = rng.choice([0, 0, 1, 2])
+        w = O.best_hit(amp, prb, k)
+        g = hip.oligo.BestHit(amp, prb, k)
+        assert (g.Found, g.Strand, g.Pos, g.MM, g.Site) == (w.found, w.strand, w.pos, w.mm, w.site)
