@@ -142,8 +142,23 @@ ipcr_status ipcr_panel_set_specialize(ipcr_panel *p, int32_t enable);
  * *needed = full length + 1; an empty string means the panel is not specialisable. */
 ipcr_status ipcr_panel_filter_source(const ipcr_panel *p, int32_t mode, char *out, size_t cap, size_t *needed);
 
+/* introspection of the compiled panel: the distinct patterns the device scans.
+ * A pattern is one primer orientation string plus which end carries the protected terminal
+ * window and how many of its bases the device enforces (tw_dev; 0 = the host filters).
+ * seed_off/seed_len: the span the reference would seed (core/engine/seed.go:260-283), 0 length
+ * when it would leave the orientation unseeded. */
+int32_t ipcr_panel_num_patterns_total(const ipcr_panel *p);
+ipcr_status ipcr_panel_pattern_info(const ipcr_panel *p, int32_t pattern, char *seq_out, size_t cap,
+                                    int32_t *left_window, int32_t *tw_dev, int32_t *seed_off,
+                                    int32_t *seed_len);
+/* pattern id scanned for orientation `which` of `pair`; mode as in ipcr_panel_filter_source */
+int32_t ipcr_panel_slot_pattern(const ipcr_panel *p, int32_t pair, char which, int32_t mode);
+
 /* ---- Engine.NewSimulationScratch -- core/engine/hit_collect.go:21-34 ---- */
 ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out);
+/* host-only scratch: holds results of ipcr_join_hits, owns no device resources; every
+ * ipcr_scan_* call on it fails with IPCR_ERR_DEVICE */
+ipcr_status ipcr_scratch_create_host(const ipcr_panel *p, ipcr_scratch **out);
 void ipcr_scratch_destroy(ipcr_scratch *s);
 ipcr_status ipcr_scratch_stats(const ipcr_scratch *s, ipcr_scan_stats *out);
 /* results of the last scan on this scratch; pointers stay valid until the next scan/destroy */
@@ -165,8 +180,9 @@ void ipcr_genome_destroy(ipcr_genome *g);
 ipcr_status ipcr_genome_add_record(ipcr_genome *g, const uint8_t *seq, uint64_t len);
 ipcr_status ipcr_genome_add_record_device(ipcr_genome *g, const void *dev_seq, uint64_t len);
 /* fill a device buffer with the reference's benchDNA LCG stream, generated on the device with
- * jump-ahead (core/engine/performance_benchmark_test.go:67-76); bit-identical to the serial loop */
-ipcr_status ipcr_lcg_fill_device(void *dev_out, uint64_t len, uint32_t seed);
+ * jump-ahead (core/engine/performance_benchmark_test.go:67-76); bit-identical to bases
+ * [stream_offset, stream_offset + len) of the serial loop started from `seed` */
+ipcr_status ipcr_lcg_fill_device(void *dev_out, uint64_t len, uint32_t seed, uint64_t stream_offset);
 /* copy bases of a resident record back to the host (decoded from the tiles; invalid -> 'N') */
 ipcr_status ipcr_genome_read(const ipcr_genome *g, uint32_t record, uint64_t pos, uint8_t *out, uint64_t len);
 uint32_t ipcr_genome_num_records(const ipcr_genome *g);

@@ -76,7 +76,11 @@ SYMBOLS = {
     "ipcr_panel_have": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char]),
     "ipcr_panel_set_specialize": (C.c_int, [C.c_void_p, C.c_int32]),
     "ipcr_panel_filter_source": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ipcr_panel_num_patterns_total": (C.c_int32, [C.c_void_p]),
+    "ipcr_panel_pattern_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ipcr_panel_slot_pattern": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char, C.c_int32]),
     "ipcr_scratch_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ipcr_scratch_create_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ipcr_scratch_destroy": (None, [C.c_void_p]),
     "ipcr_scratch_stats": (C.c_int, [C.c_void_p, C.POINTER(ScanStats)]),
     "ipcr_scratch_products": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(Product)), C.POINTER(C.c_int64)]),
@@ -86,7 +90,7 @@ SYMBOLS = {
     "ipcr_genome_destroy": (None, [C.c_void_p]),
     "ipcr_genome_add_record": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64]),
     "ipcr_genome_add_record_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
-    "ipcr_lcg_fill_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
+    "ipcr_lcg_fill_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64]),
     "ipcr_genome_read": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_char_p, C.c_uint64]),
     "ipcr_genome_num_records": (C.c_uint32, [C.c_void_p]),
     "ipcr_genome_record_len": (C.c_uint64, [C.c_void_p, C.c_uint32]),

@@ -335,6 +335,32 @@ int32_t ipcr_panel_have(const ipcr_panel *p, int32_t pair, char which) {
     return (p->have[(size_t)pair] >> w) & 1;
 }
 
+int32_t ipcr_panel_num_patterns_total(const ipcr_panel *p) { return p ? (int32_t)p->defs.size() : 0; }
+
+ipcr_status ipcr_panel_pattern_info(const ipcr_panel *p, int32_t pattern, char *seq_out, size_t cap,
+                                    int32_t *left_window, int32_t *tw_dev, int32_t *seed_off,
+                                    int32_t *seed_len) {
+    if (!p || pattern < 0 || pattern >= (int32_t)p->defs.size()) return fail(IPCR_ERR_INVALID, "pattern index out of range");
+    const PatternDef &d = p->defs[(size_t)pattern];
+    if (seq_out && cap) {
+        const size_t n = std::min(cap - 1, d.seq.size());
+        memcpy(seq_out, d.seq.data(), n);
+        seq_out[n] = 0;
+    }
+    if (left_window) *left_window = d.left ? 1 : 0;
+    if (tw_dev) *tw_dev = p->cfg.max_mm == 0 ? (int32_t)d.seq.size() : d.tw_dev;
+    if (seed_off) *seed_off = d.seed_off;
+    if (seed_len) *seed_len = d.seeded ? d.seed_len : 0;
+    return IPCR_OK;
+}
+
+int32_t ipcr_panel_slot_pattern(const ipcr_panel *p, int32_t pair, char which, int32_t mode) {
+    if (!p || pair < 0 || pair >= (int32_t)p->slot.size() || mode < 0 || mode > 1) return -1;
+    const int w = which == 'A' ? 0 : which == 'B' ? 1 : which == 'a' ? 2 : which == 'b' ? 3 : -1;
+    if (w < 0) return -1;
+    return (int32_t)p->slot[(size_t)pair][(size_t)w][(size_t)mode];
+}
+
 ipcr_status ipcr_panel_filter_source(const ipcr_panel *p, int32_t mode, char *out, size_t cap, size_t *needed) {
     if (!p || mode < 0 || mode > 1) return fail(IPCR_ERR_INVALID, "ipcr_panel_filter_source: bad argument");
     const std::string src = ipcr::jit_source(p->set[mode].host, p->cfg.max_mm);
@@ -527,9 +553,9 @@ ipcr_status ipcr_genome_add_record_device(ipcr_genome *g, const void *dev_seq, u
     return genome_add_device(g, static_cast<const uint8_t *>(dev_seq), len);
 }
 
-ipcr_status ipcr_lcg_fill_device(void *dev_out, uint64_t len, uint32_t seed) {
+ipcr_status ipcr_lcg_fill_device(void *dev_out, uint64_t len, uint32_t seed, uint64_t stream_offset) {
     if (!dev_out && len) return fail(IPCR_ERR_INVALID, "ipcr_lcg_fill_device: null argument");
-    HIPCHK(ipcr::launch_lcg(nullptr, static_cast<uint8_t *>(dev_out), len, seed));
+    HIPCHK(ipcr::launch_lcg(nullptr, static_cast<uint8_t *>(dev_out), len, seed, stream_offset));
     HIPCHK(hipDeviceSynchronize());
     return IPCR_OK;
 }
@@ -899,9 +925,10 @@ ipcr_status join_sorted_hits(const ipcr_panel *p, ipcr_scratch *s, const uint64_
     return IPCR_OK;
 }
 
-ipcr_status scratch_ready(const ipcr_panel *p, ipcr_scratch *s) {
+ipcr_status scratch_ready(const ipcr_panel *p, ipcr_scratch *s, bool need_device = true) {
     if (!p || !s) return fail(IPCR_ERR_INVALID, "null panel or scratch");
     if (s->panel != p) return fail(IPCR_ERR_INVALID, "scratch was created for a different panel");
+    if (need_device && !s->stream) return fail(IPCR_ERR_DEVICE, "host-only scratch cannot scan: the ipcr scan path has no CPU fallback");
     return IPCR_OK;
 }
 
@@ -933,6 +960,14 @@ ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out) {
     ipcr_status st = build();
     if (st != IPCR_OK) { ipcr_scratch_destroy(s.release()); return st; }
     *out = s.release();
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_scratch_create_host(const ipcr_panel *p, ipcr_scratch **out) {
+    if (!p || !out) return fail(IPCR_ERR_INVALID, "ipcr_scratch_create_host: null argument");
+    ipcr_scratch *s = new ipcr_scratch;
+    s->panel = p;
+    *out = s;
     return IPCR_OK;
 }
 
@@ -994,7 +1029,7 @@ ipcr_status ipcr_scan_genome(const ipcr_panel *p, ipcr_scratch *s, const ipcr_ge
 ipcr_status ipcr_join_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_hit *hits, int64_t n_hits,
                            const uint64_t *record_len, const uint8_t *record_flags, uint32_t n_records,
                            ipcr_emit_fn emit, void *user) {
-    ipcr_status st = scratch_ready(p, s);
+    ipcr_status st = scratch_ready(p, s, false);
     if (st != IPCR_OK) return st;
     if ((n_hits > 0 && !hits) || (n_records > 0 && !record_len) || n_hits < 0) return fail(IPCR_ERR_INVALID, "ipcr_join_hits: null argument");
     if (hits != s->hits.data()) s->hits.assign(hits, hits + n_hits);

@@ -109,13 +109,13 @@ __global__ void fill_pad_kernel(uint32_t *__restrict__ planes, uint32_t *__restr
 // benchDNA (core/engine/performance_benchmark_test.go:67-76): x = x*1664525 + 1013904223,
 // base = "ACGT"[(x>>30)&3].  Each thread jumps ahead to its 64-base run by composing the
 // affine map with itself (O(log n)), so the sequence is bit-identical to the serial loop.
-__global__ void lcg_fill_kernel(uint8_t *__restrict__ out, uint64_t n, uint32_t seed) {
+__global__ void lcg_fill_kernel(uint8_t *__restrict__ out, uint64_t n, uint32_t seed, uint64_t offset) {
     const uint64_t run = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t start = run * 64u;
     if (start >= n) return;
     uint32_t a = 1664525u, c = 1013904223u; // map for one step
     uint32_t ja = 1u, jc = 0u;              // identity
-    uint64_t e = start;
+    uint64_t e = start + offset; // steps already taken by the stream
     while (e) {
         if (e & 1u) { jc = a * jc + c; ja = a * ja; }
         c = a * c + c;
@@ -394,10 +394,10 @@ hipError_t launch_fill_pad(hipStream_t st, uint32_t *planes, uint32_t *rst, uint
     return hipGetLastError();
 }
 
-hipError_t launch_lcg(hipStream_t st, uint8_t *out, uint64_t n, uint32_t seed) {
+hipError_t launch_lcg(hipStream_t st, uint8_t *out, uint64_t n, uint32_t seed, uint64_t offset) {
     if (n == 0) return hipSuccess;
     const uint64_t runs = (n + 63u) / 64u;
-    lcg_fill_kernel<<<dim3((uint32_t)((runs + 255u) / 256u)), dim3(256), 0, st>>>(out, n, seed);
+    lcg_fill_kernel<<<dim3((uint32_t)((runs + 255u) / 256u)), dim3(256), 0, st>>>(out, n, seed, offset);
     return hipGetLastError();
 }
 

@@ -1,0 +1,119 @@
+"""Multi-GPU form of the path: one process per GPU, records sharded over ranks, and one
+all-gatherv of verified hit records (RCCL over xGMI on GPUs; gloo on CPU for tests).
+
+The reference has no distributed mode; its unit of parallelism is the independent FASTA
+record/chunk (internal/pipeline/pipeline.go:60-125).  Here every rank scans its own records
+with the whole panel -- no data-path collective -- and only the hit records (32 B each, tens of
+KB per genome) are exchanged, after which the amplicon join (core/engine/engine.go:108-404)
+runs on the gathered list.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# layout of ipcr_hit (include/ipcr_hip.h)
+HIT_DTYPE = np.dtype([("pos", "<u8"), ("record", "<u4"), ("pattern", "<u4"), ("mm0", "<u8"), ("mm1", "<u8")])
+assert HIT_DTYPE.itemsize == 32
+
+
+def env_rank() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torchrun environment (1-process default)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_process_group(backend: Optional[str] = None):
+    """Join the job.  backend 'nccl' IS RCCL on ROCm; 'gloo' for CPU tests."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local = env_rank()
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local, backend
+
+
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """Contiguous, balanced split of records (or genomes) over ranks."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def hits_from_scratch(scratch) -> np.ndarray:
+    """Copy of the ipcr_hit array of the last scan on `scratch` as a HIT_DTYPE array."""
+    import ctypes as C
+    ptr, n = scratch.raw_hits()
+    if n == 0:
+        return np.zeros(0, dtype=HIT_DTYPE)
+    buf = (C.c_uint8 * (n * 32)).from_address(C.addressof(ptr.contents))
+    return np.frombuffer(buf, dtype=HIT_DTYPE, count=n).copy()
+
+
+def allgather_hits(local: np.ndarray, n_local_records: int, device=None, group=None):
+    """All-gatherv of hit records.  Returns (hits, record_offset_per_rank): every rank's hits
+    concatenated in rank order with `record` rebased to a job-global record index."""
+    import torch
+    import torch.distributed as dist
+    assert local.dtype == HIT_DTYPE
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local.copy(), [0]
+    world = dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cpu")
+    meta = torch.tensor([len(local), n_local_records], dtype=torch.int64, device=dev)
+    metas = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(metas, meta, group=group)          # collective 1: counts
+    metas = metas.cpu().view(world, 2)
+    counts = [int(c) for c in metas[:, 0]]
+    nrecs = [int(c) for c in metas[:, 1]]
+    cmax = max(max(counts), 1)
+    send = torch.zeros(cmax * 32, dtype=torch.uint8, device=dev)   # max-padded payload
+    if len(local):
+        send[:len(local) * 32] = torch.from_numpy(local.view(np.uint8).reshape(-1)).to(dev)
+    recv = torch.empty(world * cmax * 32, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)           # collective 2: records
+    recv = recv.cpu().numpy().reshape(world, cmax * 32)
+    offsets, parts, off = [], [], 0
+    for r in range(world):
+        offsets.append(off)
+        part = recv[r, :counts[r] * 32].copy().view(HIT_DTYPE)
+        part["record"] += np.uint32(off)
+        parts.append(part)
+        off += nrecs[r]
+    return (np.concatenate(parts) if parts else np.zeros(0, dtype=HIT_DTYPE)), offsets
+
+
+def allgather_record_meta(lens: Sequence[int], flags: Sequence[int], device=None, group=None):
+    """Gather every rank's record lengths and flags (bit0 = holds a non-ACGTacgt byte, bit1 =
+    scanned in the unprotected-rc mode) in job-global record order."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return list(lens), list(flags)
+    world = dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cpu")
+    n = torch.tensor([len(lens)], dtype=torch.int64, device=dev)
+    ns = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(ns, n, group=group)
+    ns = [int(v) for v in ns.cpu()]
+    nmax = max(max(ns), 1)
+    send = torch.zeros(nmax * 2, dtype=torch.int64, device=dev)
+    if len(lens):
+        send[:len(lens)] = torch.tensor(list(lens), dtype=torch.int64)
+        send[nmax:nmax + len(flags)] = torch.tensor(list(flags), dtype=torch.int64)
+    recv = torch.empty(world * nmax * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.cpu().view(world, 2, nmax)
+    all_lens, all_flags = [], []
+    for r in range(world):
+        all_lens += [int(v) for v in recv[r, 0, :ns[r]]]
+        all_flags += [int(v) for v in recv[r, 1, :ns[r]]]
+    return all_lens, all_flags

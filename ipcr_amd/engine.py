@@ -115,6 +115,21 @@ class CompiledPanel:
     def num_patterns(self) -> int:
         return _lib.lib().ipcr_panel_num_patterns(self._h)
 
+    @property
+    def num_patterns_total(self) -> int:
+        return _lib.lib().ipcr_panel_num_patterns_total(self._h)
+
+    def pattern_info(self, pattern: int):
+        """(sequence, window_on_left, window_bases_enforced_on_device, seed_off, seed_len)."""
+        buf = C.create_string_buffer(_lib.IPCR_MAX_PRIMER_LEN + 1)
+        left, tw, so, sl = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().ipcr_panel_pattern_info(self._h, pattern, buf, len(buf), C.byref(left), C.byref(tw),
+                                                      C.byref(so), C.byref(sl)))
+        return buf.value.decode(), bool(left.value), tw.value, so.value, sl.value
+
+    def slot_pattern(self, pair: int, which: str, mode: int = 0) -> int:
+        return _lib.lib().ipcr_panel_slot_pattern(self._h, pair, which.encode(), mode)
+
     def filter_source(self, mode: int = 0) -> str:
         """HIP source of the panel-specialised filter ('' when the panel is not specialisable)."""
         need = C.c_size_t()
@@ -131,10 +146,13 @@ class SimulationScratch:
     """engine.SimulationScratch -- core/engine/hit_collect.go:12-34: one HIP stream + device
     staging buffers per worker; never shared between workers."""
 
-    def __init__(self, cp: CompiledPanel):
+    def __init__(self, cp: CompiledPanel, host_only: bool = False):
         self._cp = cp
         h = C.c_void_p()
-        _lib.check(_lib.lib().ipcr_scratch_create(cp._h, C.byref(h)))
+        if host_only:  # results of JoinHits only; cannot scan
+            _lib.check(_lib.lib().ipcr_scratch_create_host(cp._h, C.byref(h)))
+        else:
+            _lib.check(_lib.lib().ipcr_scratch_create(cp._h, C.byref(h)))
         self._h = h
 
     def close(self):
@@ -258,9 +276,10 @@ class Genome:
         return _lib.lib().ipcr_genome_pack_ms(self._h)
 
 
-def lcg_fill_device(dev_ptr: int, length: int, seed: int) -> None:
-    """benchDNA on the device -- core/engine/performance_benchmark_test.go:67-76"""
-    _lib.check(_lib.lib().ipcr_lcg_fill_device(C.c_void_p(dev_ptr), length, seed & 0xFFFFFFFF))
+def lcg_fill_device(dev_ptr: int, length: int, seed: int, stream_offset: int = 0) -> None:
+    """benchDNA on the device -- core/engine/performance_benchmark_test.go:67-76: bases
+    [stream_offset, stream_offset + length) of the LCG stream started from `seed`."""
+    _lib.check(_lib.lib().ipcr_lcg_fill_device(C.c_void_p(dev_ptr), length, seed & 0xFFFFFFFF, stream_offset))
 
 
 class Engine:
@@ -356,6 +375,20 @@ class Engine:
         """Same scan + join, products left in the scratch (no Python object per product)."""
         _lib.check(_lib.lib().ipcr_scan_genome(cp._h, scratch._h, genome._h, None, None))
         return scratch.num_products()
+
+    def JoinHits(self, cp: CompiledPanel, scratch: SimulationScratch, hits, record_len: Sequence[int],
+                 record_flags: Sequence[int], seq_ids: Optional[Sequence[str]] = None) -> List[Product]:
+        """Join step alone (core/engine/engine.go:108-404) over hit records, e.g. the all-gathered
+        hits of several GPUs.  `hits` is a numpy array of dist.HIT_DTYPE (or anything exposing
+        ctypes.data / len)."""
+        n = len(hits)
+        nrec = len(record_len)
+        lens = (C.c_uint64 * max(nrec, 1))(*record_len)
+        flags = (C.c_uint8 * max(nrec, 1))(*record_flags)
+        ptr = C.c_void_p(hits.ctypes.data) if n else None
+        _lib.check(_lib.lib().ipcr_join_hits(cp._h, scratch._h, ptr, n, lens, flags, nrec, None, None))
+        ids = list(seq_ids) if seq_ids is not None else [str(r) for r in range(nrec)]
+        return scratch.products(ids)
 
     def ScanGenomeHits(self, genome: Genome, cp: CompiledPanel, scratch: SimulationScratch) -> List[Hit]:
         _lib.check(_lib.lib().ipcr_scan_genome_hits(cp._h, scratch._h, genome._h))

@@ -1,0 +1,73 @@
+"""N>1 path on CPU: world_size-2 gloo job running the shard -> all-gatherv of hit records -> join
+pipeline of ipcr_amd.dist (hits synthesised on the CPU, as in test_host_logic)."""
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json, random
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle")); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import torch.distributed as tdist
+import ipcr_oracle as O
+from ipcr_amd import dist, engine, primer
+from test_host_logic import synth_hits, rand_seq, plant
+
+rank, world, local, backend = dist.init_process_group("gloo")
+assert world == 2 and backend == "gloo"
+rng = random.Random(5)  # same stream on both ranks: both build the same 5 records
+pair = primer.Pair("p", "ACGTTGCATGCAAGCT", "GGCCTTAAGGCCATAT")
+pairs = primer.AddSelfPairs([pair])
+cfg = engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=300, HitCap=10000, SeedLen=12)
+seqs = []
+for r in range(5):
+    s = rand_seq(rng, 4000, junk=(r == 3))
+    for _ in range(4):
+        a = rng.randrange(0, 3500)
+        plant(rng, s, pair.Forward, a, rng.choice([0, 1, 2]))
+        plant(rng, s, O.revcomp(pair.Reverse).decode(), a + rng.randint(40, 250), rng.choice([0, 1]))
+    seqs.append("".join(s).encode())
+mine = dist.shard_range(len(seqs), rank, world)          # records sharded over ranks
+assert list(mine) == ([0, 1, 2] if rank == 0 else [3, 4])
+eng = engine.New(cfg)
+cp = eng.CompilePanel(pairs)
+reset = [any(ch not in b"ACGTacgt" for ch in seqs[g]) for g in mine]
+mode = 1 if any(reset) else 0
+local_hits = np.concatenate([synth_hits(cp, seqs[g], cfg.MaxMM, i, mode) for i, g in enumerate(mine)])
+lens = [len(seqs[g]) for g in mine]
+flags = [(1 if reset[i] else 0) | (2 if mode else 0) for i in range(len(lens))]
+all_hits, offsets = dist.allgather_hits(local_hits, len(lens))      # the all-gatherv
+all_lens, all_flags = dist.allgather_record_meta(lens, flags)
+assert offsets == [0, 3] and all_lens == [4000] * 5 and len(all_flags) == 5
+sc = engine.SimulationScratch(cp, host_only=True)
+got = eng.JoinHits(cp, sc, all_hits, all_lens, all_flags, ["rec%d" % r for r in range(5)])
+op = O.Panel(O.Config(max_mm=2, terminal_window=3, max_len=300, hit_cap=10000, seed_len=12),
+             [O.Pair(p.ID, p.Forward, p.Reverse, p.MinProduct, p.MaxProduct) for p in pairs])
+want = []
+for r, s in enumerate(seqs):
+    want += [("rec%d" % r,) + w.sig() for w in op.scan(s)]
+assert [(g.SequenceID,) + g.sig() for g in got] == want and len(want) >= 10
+tdist.barrier()
+print("RANK_OK", rank, len(got))
+'''
+
+
+def test_two_rank_gloo_allgather_and_join(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f"RANK_OK {rank}" in out, out

@@ -293,7 +293,10 @@ def test_lcg_device_matches_reference_generator(hip):
     n = 1_000_003
     t = torch.empty(n, dtype=torch.uint8, device="cuda:0")
     hip.engine.lcg_fill_device(t.data_ptr(), n, 0x5eed1234)
-    assert bytes(t.cpu().numpy().tobytes()) == O.bench_dna(n, 0x5eed1234)
+    want = O.bench_dna(n, 0x5eed1234)
+    assert bytes(t.cpu().numpy().tobytes()) == want
+    hip.engine.lcg_fill_device(t.data_ptr(), 1000, 0x5eed1234, 700_001)  # jump-ahead into the stream
+    assert bytes(t[:1000].cpu().numpy().tobytes()) == want[700_001:701_001]
 
 
 def test_resident_genome_multi_record(hip):

@@ -1,0 +1,221 @@
+"""CPU tests of the host side of the product: the C ABI surface, the panel compiler's
+seeded/unseeded decisions, and the hit -> match-list -> join logic (ordering, HitCap, 5' window
+filter, circular wrap) checked against the oracle with hits synthesised on the CPU.
+No device is touched: scans need a GPU and must fail loudly without one."""
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import ipcr_oracle as O
+from ipcr_amd import _lib, dist, engine, primer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ipcr_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ipcr_[a-z0-9_]+)\s*\(", hdr)) - {"ipcr_emit_fn"}
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    L = _lib.lib()  # resolves all of them or raises
+    assert L.ipcr_version().startswith(b"ipcr-hip")
+    import ctypes as C
+    assert C.sizeof(_lib.Hit) == 32 and C.sizeof(_lib.Product) == 24 + 7 * 4 + 32 + 4  # padded to 8
+
+
+def test_core_primer_helpers():  # core/primer/iupac_test.go, rc_test.go through the ABI
+    for g, p, want in [("A", "A", True), ("G", "R", True), ("C", "R", False), ("T", "N", True),
+                       ("A", "B", False), ("C", "B", True), ("T", "X", False), ("N", "N", False), ("a", "A", False)]:
+        assert primer.BaseMatch(g, p) is want
+    assert primer.RevComp("RYSWKMBDHVNACGT") == b"ACGTNBDHVKMWSRY"
+    assert primer.RevComp("") == b""
+    for bad in ("ACGX", "acgt"):
+        with pytest.raises(_lib.IpcrError):
+            primer.RevComp(bad)
+    assert primer.Validate(" ac'g\"t\n") == "ACGT"
+    with pytest.raises(ValueError):
+        primer.Validate("ACGU")
+
+
+def test_no_device_fails_loudly():
+    if _lib.lib().ipcr_device_count() > 0:
+        pytest.skip("a GPU is present")
+    cp = engine.New(engine.Config()).CompilePanel([primer.Pair("x", "ACGT", "ACGT")])
+    with pytest.raises(_lib.IpcrError) as e:
+        engine.SimulationScratch(cp)
+    assert e.value.status == _lib.ERR_DEVICE and "no CPU fallback" in e.value.message
+    with pytest.raises(_lib.IpcrError):
+        engine.New(engine.Config()).SimulateBatch("s", b"ACGTACGT", [primer.Pair("x", "ACGT", "ACGT")])
+    host = engine.SimulationScratch(cp, host_only=True)
+    import ctypes as C
+    st = _lib.lib().ipcr_scan_chunk(cp._h, host._h, b"ACGT", 4, None, None)
+    assert st == _lib.ERR_DEVICE
+
+
+def rand_primer(rng, lo=4, hi=30, amb=True):
+    L = rng.randint(lo, hi)
+    s = [rng.choice("ACGT") for _ in range(L)]
+    if amb:
+        for _ in range(rng.choice([0, 0, 1, 2, 6])):
+            s[rng.randrange(L)] = rng.choice("RYSWKMBDHVN")
+    return "".join(s)
+
+
+def test_have_matches_reference_seed_rules():  # core/engine/seed.go:152-367 via compiled.go:123-133
+    rng = random.Random(42)
+    for _ in range(300):
+        pairs = [primer.Pair("p%d" % i, rand_primer(rng), rand_primer(rng)) for i in range(rng.randint(1, 3))]
+        if rng.random() < 0.1:
+            pairs.append(primer.Pair("n", "N" * rng.randint(8, 14), rand_primer(rng)))
+        k, tw, sl = rng.choice([0, 1, 2, 3]), rng.choice([0, 1, 3, 5, 40]), rng.choice([0, 12, 6, 4, 33, -1])
+        cp = engine.New(engine.Config(MaxMM=k, TerminalWindow=tw, SeedLen=sl)).CompilePanel(pairs)
+        op = O.Panel(O.Config(max_mm=k, terminal_window=tw, seed_len=sl),
+                     [O.Pair(p.ID, p.Forward, p.Reverse) for p in pairs])
+        for i in range(len(pairs)):
+            for w in "ABab":
+                assert cp.have(i, w) == op.have(i, w), (pairs[i], w, k, tw, sl)
+        cp.close()
+        op.close()
+    # literal expectations of core/engine/performance_gate_test.go:25-49
+    cp = engine.New(engine.Config(MaxMM=2, SeedLen=12)).CompilePanel(
+        [primer.Pair("variant_cap", "NNNNNNNNNNNN", "ACGTACGTACGT"), primer.Pair("ordinary", "ACGTACGTACGT", "TGCATGCATGCA")])
+    assert [cp.have(0, w) for w in "ABab"] == [False, True, False, True]
+    assert all(cp.have(1, w) for w in "ABab")
+
+
+def synth_hits(cp, seq, k, record, mode):
+    """What the device would report for one record: every distinct scanned pattern's verified
+    matches (core/primer/match.go:30-90 semantics via the oracle), as ipcr_hit records."""
+    used = {cp.slot_pattern(i, w, mode) for i in range(len(cp.Pairs)) for w in "ABab"}
+    rows = []
+    for gid in sorted(used):
+        pat, left, tw_dev, soff, slen = cp.pattern_info(gid)
+        if not pat:
+            continue
+        if left:
+            ms = [m for m in O.find_matches(seq, pat, k, 0, 0) if all(j >= tw_dev for j in m.idx)]
+        else:
+            ms = O.find_matches(seq, pat, k, 0, tw_dev)
+        for m in ms:
+            flag = 0
+            if slen:
+                span = seq[m.pos + soff:m.pos + soff + slen]
+                flag = int(any(ch not in b"ACGTacgt" for ch in span))
+            m0 = sum(1 << j for j in m.idx if j < 64)
+            m1 = sum(1 << (j - 64) for j in m.idx if j >= 64)
+            rows.append((m.pos, record, gid | (flag << 31), m0, m1))
+    rng = random.Random(len(rows))
+    rng.shuffle(rows)  # the device appends in no particular order
+    return np.array(rows, dtype=dist.HIT_DTYPE) if rows else np.zeros(0, dtype=dist.HIT_DTYPE)
+
+
+def rand_seq(rng, n, junk):
+    s = [rng.choice("ACGT") for _ in range(n)]
+    if junk:
+        for _ in range(rng.randint(1, 5)):
+            p, run, ch = rng.randrange(n), rng.randint(1, 9), rng.choice("NNRacgtn")
+            for i in range(p, min(n, p + run)):
+                s[i] = ch
+    return s
+
+
+def plant(rng, seq, pat, pos, nmut):
+    conc = [rng.choice([b for b in "ACGT" if O.base_match(b, ch)]) for ch in pat]
+    for _ in range(nmut):
+        j = rng.randrange(len(conc))
+        conc[j] = O.different_base(conc[j])
+    seq[pos:pos + len(conc)] = conc
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_join_matches_reference_production_path(seed):
+    """ipcr_join_hits == Engine.ForEachCompiledProduct (core/engine/compiled.go:162-267), product
+    for product and in the same order, for random panels, junk bytes, caps and circular mode."""
+    rng = random.Random(900 + seed)
+    for _ in range(25):
+        n = rng.choice([80, 400, 3000])
+        nrec = rng.randint(1, 3)
+        pairs = [primer.Pair("p%d" % i, rand_primer(rng, 4 if n < 1000 else 8, 24), rand_primer(rng, 4 if n < 1000 else 8, 24),
+                             rng.choice([0, 0, 15]), rng.choice([0, 0, 300])) for i in range(rng.randint(1, 3))]
+        if rng.random() < 0.5:
+            pairs = primer.AddSelfPairs(pairs)
+        k = rng.choice([0, 1, 2, 3] if n < 1000 else [0, 1, 2])
+        cfg = engine.Config(MaxMM=k, TerminalWindow=rng.choice([0, 1, 3, 5]), MinLen=rng.choice([0, 8]),
+                            MaxLen=rng.choice([0, 150, 2000]), HitCap=rng.choice([0, 0, 1, 3, 10000]),
+                            SeedLen=rng.choice([0, 12, 5, -1]), Circular=rng.random() < 0.35)
+        seqs = []
+        for r in range(nrec):
+            s = rand_seq(rng, n, junk=rng.random() < 0.6)
+            for p in pairs:
+                for _ in range(rng.randint(0, 3)):
+                    a = rng.randrange(0, n - 60)
+                    ln = rng.randint(len(p.Forward) + len(p.Reverse), 58)
+                    plant(rng, s, p.Forward, a, rng.choice([0, 0, 1, 2]))
+                    rc = O.revcomp(p.Reverse).decode()
+                    plant(rng, s, rc, a + ln - len(rc), rng.choice([0, 0, 1]))
+            seqs.append("".join(s).encode())
+        eng = engine.New(cfg)
+        cp = eng.CompilePanel(pairs)
+        reset = [any(ch not in b"ACGTacgt" for ch in s) for s in seqs]
+        mode = 1 if any(reset) else 0          # what ipcr_scan_genome would pick for this genome
+        flags = [(1 if reset[r] else 0) | (2 if mode else 0) for r in range(nrec)]
+        hits = np.concatenate([synth_hits(cp, seqs[r], k, r, mode) for r in range(nrec)])
+        sc = engine.SimulationScratch(cp, host_only=True)
+        got = eng.JoinHits(cp, sc, hits, [len(s) for s in seqs], flags, ["rec%d" % r for r in range(nrec)])
+        op = O.Panel(O.Config(max_mm=cfg.MaxMM, terminal_window=cfg.TerminalWindow, min_len=cfg.MinLen,
+                              max_len=cfg.MaxLen, hit_cap=cfg.HitCap, seed_len=cfg.SeedLen, circular=cfg.Circular),
+                     [O.Pair(p.ID, p.Forward, p.Reverse, p.MinProduct, p.MaxProduct) for p in pairs])
+        want = []
+        for r, s in enumerate(seqs):
+            want += [("rec%d" % r,) + w.sig() for w in op.scan(s)]
+        assert [(g.SequenceID,) + g.sig() for g in got] == want, (cfg, pairs)
+        sc.close()
+        cp.close()
+        op.close()
+
+
+def test_join_known_answers():  # SURVEY appendix A.1-A.4 through the join alone
+    eng = engine.New(engine.Config())
+    cp = eng.CompilePanel([primer.Pair("test", "ACG", "ACG")])
+    seq = b"ACGTACGTACGT"
+    sc = engine.SimulationScratch(cp, host_only=True)
+    got = eng.JoinHits(cp, sc, synth_hits(cp, seq, 0, 0, 0), [len(seq)], [0])
+    six = [(0, 12, 12), (0, 8, 8), (0, 4, 4), (4, 12, 8), (4, 8, 4), (8, 12, 4)]
+    assert [(p.Type, p.Start, p.End, p.Length) for p in got] == [("forward",) + c for c in six] + [("revcomp",) + c for c in six]
+    eng = engine.New(engine.Config(Circular=True))
+    cp = eng.CompilePanel([primer.Pair("p1", "AG", "TC")])
+    sc = engine.SimulationScratch(cp, host_only=True)
+    got = eng.JoinHits(cp, sc, synth_hits(cp, b"TGACAAG", 0, 0, 0), [7], [0])
+    assert [(p.Type, p.Start, p.End, p.Length) for p in got] == [("forward", 5, 3, 5)]
+
+
+def test_panel_rejects_bad_input():
+    E, P = engine, primer.Pair
+    for cfg, pair, status in [(E.Config(MaxMM=-1), P("x", "ACGT", "ACGT"), _lib.ERR_INVALID),
+                              (E.Config(MaxMM=17), P("x", "ACGT", "ACGT"), _lib.ERR_UNSUPPORTED),
+                              (E.Config(), P("x", "ACGX", "ACGT"), _lib.ERR_PRIMER),
+                              (E.Config(), P("x", "acgt", "ACGT"), _lib.ERR_PRIMER),
+                              (E.Config(), P("x", "A" * 129, "ACGT"), _lib.ERR_UNSUPPORTED)]:
+        with pytest.raises(_lib.IpcrError) as e:
+            E.New(cfg).CompilePanel([pair])
+        assert e.value.status == status
+
+
+def test_filter_source_is_generated_for_the_headline_panels():
+    from ipcr_amd import workloads
+    cp = engine.New(engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12)).CompilePanel(workloads.c2_pairs())
+    assert cp.num_patterns == 4  # 3 pairs / 12 orientation slots / 4 distinct patterns
+    src = cp.filter_source(0)
+    assert "ipcr_filter" in src and src.count("// pattern 0 ") > 0
+    big = engine.New(engine.Config(MaxMM=2, TerminalWindow=3)).CompilePanel(workloads.c4_pairs(64))
+    assert big.filter_source(0) == ""  # > 48 patterns: table-driven filter (still on the device)
+
+
+def test_workload_primers_match_reference_generator():  # performance_benchmark_test.go:78-93
+    from ipcr_amd import workloads
+    for idx in (0, 1, 2, 3, 77, 2047):
+        assert workloads.bench_primer(idx) == O.bench_primer(idx, 20)
+    assert len(workloads.c4_pairs(1024)) == 1024 + 2048
