@@ -16,6 +16,14 @@ struct ipcr_dev_pattern {
     uint8_t mask[128];
 };
 
+// filter -> verifier queue: one surviving WORD: pattern (set-local index) in key bits 48..63,
+// padded position of strand bit 0 in bits 0..47; bit b of `bits` = strand b survived
+struct ipcr_queue_entry {
+    uint64_t key;
+    uint32_t bits;
+    uint32_t pad;
+};
+
 // layout-identical to ipcr_hit in include/ipcr_hip.h
 struct ipcr_hit_rec {
     uint64_t pos;

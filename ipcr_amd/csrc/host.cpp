@@ -598,14 +598,17 @@ struct ipcr_scratch {
     const ipcr_panel *panel = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    uint64_t *d_queue = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // filter start/stop, verify start/stop
+    ipcr_queue_entry *d_queue = nullptr;
     uint64_t qcap = 0;
+    uint64_t prefix_hint = 256; // hits copied back together with the counters
     ipcr_hit_rec *d_hits = nullptr;
     uint64_t hcap = 0;
-    unsigned long long *d_counts = nullptr; // [0] candidates, [1] hits
+    unsigned long long *d_counts = nullptr; // [0] queue entries, [1] hits, [2] candidate windows
     void *pinned = nullptr;                 // counts (16 B) + first PREFIX hits
-    std::vector<ipcr_hit> hits;
+    std::vector<ipcr_hit> hits;      // sorted by (record, pattern, pos)
+    std::vector<ipcr_hit> hits_raw;  // in device append order
+    std::vector<uint32_t> bucket;    // scratch of sort_hits
     std::vector<ipcr_product> products;
     std::vector<uint64_t> last_rec_len; // of the last scanned genome (for probe)
     std::vector<uint64_t> last_rec_start;
@@ -618,8 +621,8 @@ struct ipcr_scratch {
 
 namespace {
 
-constexpr uint64_t PREFIX_HITS = 4096;
-constexpr uint64_t QCAP_INIT = 1ull << 22;  // 4 Mi candidates (32 MiB)
+constexpr uint64_t PREFIX_HITS = 65536;
+constexpr uint64_t QCAP_INIT = 1ull << 21;  // 2 Mi surviving words (32 MiB)
 constexpr uint64_t HCAP_INIT = 1ull << 20;  // 1 Mi hits (32 MiB)
 constexpr uint64_t QCAP_MAX = 1ull << 30;
 constexpr uint64_t HCAP_MAX = 1ull << 28;
@@ -648,6 +651,34 @@ struct HitLess {
     }
 };
 
+// Hits come back in atomic-append order; the join wants them grouped by (record, pattern) and
+// ascending in position.  Counting sort over the (record, pattern) buckets, then each small
+// bucket by position -- O(n) instead of a comparison sort of 32-byte records.
+void sort_hits(const std::vector<ipcr_hit> &in, std::vector<ipcr_hit> &out, uint32_t nrec, uint32_t npat) {
+    const size_t n = in.size();
+    out.resize(n);
+    if (n == 0) return;
+    const uint64_t nb = (uint64_t)nrec * npat;
+    bool ok = nb > 0 && nb <= (1u << 22);
+    if (ok)
+        for (const ipcr_hit &h : in)
+            if (h.record >= nrec || (h.pattern & 0x7FFFFFFFu) >= npat) { ok = false; break; }
+    if (!ok) {
+        out = in;
+        std::sort(out.begin(), out.end(), HitLess());
+        return;
+    }
+    std::vector<uint32_t> cnt(nb + 1, 0);
+    for (const ipcr_hit &h : in) ++cnt[(uint64_t)h.record * npat + (h.pattern & 0x7FFFFFFFu) + 1];
+    for (uint64_t i = 0; i < nb; ++i) cnt[i + 1] += cnt[i];
+    std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+    for (const ipcr_hit &h : in) out[cur[(uint64_t)h.record * npat + (h.pattern & 0x7FFFFFFFu)]++] = h;
+    for (uint64_t i = 0; i < nb; ++i) {
+        const uint32_t b = cnt[i], e = cnt[i + 1];
+        if (e - b > 1) std::sort(out.begin() + b, out.begin() + e, [](const ipcr_hit &x, const ipcr_hit &y) { return x.pos < y.pos; });
+    }
+}
+
 ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     const auto t0 = std::chrono::steady_clock::now();
     s->hits.clear();
@@ -672,35 +703,32 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     const uint32_t check_rst = genome_any_reset(g) ? 1u : 0u;
 
     for (int attempt = 0; attempt < 8; ++attempt) {
-        HIPCHK(hipMemsetAsync(s->d_counts, 0, 16, s->stream));
-        HIPCHK(hipEventRecord(s->ev[0], s->stream));
+        HIPCHK(hipMemsetAsync(s->d_counts, 0, 32, s->stream));
         if (set.jit) {
-            HIPCHK(ipcr::jit_launch(set.jit, s->stream, g->planes, nblocks, s->d_queue, s->qcap, s->d_counts));
+            HIPCHK(ipcr::jit_launch(set.jit, s->stream, g->planes, nblocks, s->d_queue, s->qcap, s->d_counts, s->ev[0], s->ev[1]));
             s->stats.kernel_kind = 1;
         } else {
             HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)set.ids.size(),
-                                               (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, s->d_counts));
+                                               (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, s->d_counts, s->ev[0], s->ev[1]));
             s->stats.kernel_kind = 2;
         }
-        HIPCHK(hipEventRecord(s->ev[1], s->stream));
         HIPCHK(ipcr::launch_verify(s->stream, g->planes, g->rst, set.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
                                    g->d_rec_len, nrec, check_rst, s->d_queue, s->qcap, s->d_counts, s->d_hits,
-                                   s->hcap, s->d_counts + 1));
-        HIPCHK(hipEventRecord(s->ev[2], s->stream));
+                                   s->hcap, s->d_counts + 1, s->d_counts + 2, s->ev[2], s->ev[3]));
         unsigned long long *pc = static_cast<unsigned long long *>(s->pinned);
-        ipcr_hit *ph = reinterpret_cast<ipcr_hit *>(pc + 2);
-        HIPCHK(hipMemcpyAsync(pc, s->d_counts, 16, hipMemcpyDeviceToHost, s->stream));
-        const uint64_t pre = std::min<uint64_t>(PREFIX_HITS, s->hcap);
+        ipcr_hit *ph = reinterpret_cast<ipcr_hit *>(pc + 4);
+        HIPCHK(hipMemcpyAsync(pc, s->d_counts, 32, hipMemcpyDeviceToHost, s->stream));
+        const uint64_t pre = std::min<uint64_t>(std::min<uint64_t>(s->prefix_hint, PREFIX_HITS), s->hcap);
         HIPCHK(hipMemcpyAsync(ph, s->d_hits, pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
-        const uint64_t ncand = pc[0], nhit = pc[1];
-        if (ncand > s->qcap) { // candidate queue overflowed: regrow and rescan
+        const uint64_t nent = pc[0], nhit = pc[1], ncand = pc[2];
+        if (nent > s->qcap) { // candidate queue overflowed: regrow and rescan
             uint64_t want = s->qcap;
-            while (want < ncand) want *= 2;
-            if (want > QCAP_MAX) return fail(IPCR_ERR_CAPACITY, "%llu filter candidates exceed the device queue limit", (unsigned long long)ncand);
+            while (want < nent) want *= 2;
+            if (want > QCAP_MAX) return fail(IPCR_ERR_CAPACITY, "%llu filter survivors exceed the device queue limit", (unsigned long long)nent);
             HIPCHK(hipFree(s->d_queue));
             s->d_queue = nullptr;
-            HIPCHK(hipMalloc((void **)&s->d_queue, want * 8ull));
+            HIPCHK(hipMalloc((void **)&s->d_queue, want * sizeof(ipcr_queue_entry)));
             s->qcap = want;
             continue;
         }
@@ -714,18 +742,20 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             s->hcap = want;
             continue;
         }
-        s->hits.resize(nhit);
+        std::vector<ipcr_hit> &raw = s->hits_raw;
+        raw.resize(nhit);
         const uint64_t got = std::min<uint64_t>(nhit, pre);
-        if (got) memcpy(s->hits.data(), ph, got * sizeof(ipcr_hit));
-        if (nhit > got) HIPCHK(hipMemcpy(s->hits.data() + got, s->d_hits + got, (nhit - got) * sizeof(ipcr_hit), hipMemcpyDeviceToHost));
+        if (got) memcpy(raw.data(), ph, got * sizeof(ipcr_hit));
+        if (nhit > got) HIPCHK(hipMemcpy(raw.data() + got, s->d_hits + got, (nhit - got) * sizeof(ipcr_hit), hipMemcpyDeviceToHost));
+        s->prefix_hint = std::max<uint64_t>(256, nhit + nhit / 4 + 16);
         float fms = 0, vms = 0;
         HIPCHK(hipEventElapsedTime(&fms, s->ev[0], s->ev[1]));
-        HIPCHK(hipEventElapsedTime(&vms, s->ev[1], s->ev[2]));
+        HIPCHK(hipEventElapsedTime(&vms, s->ev[2], s->ev[3]));
         s->stats.filter_ms = fms;
         s->stats.verify_ms = vms;
         s->stats.candidates = ncand;
         s->stats.hits = nhit;
-        std::sort(s->hits.begin(), s->hits.end(), HitLess());
+        sort_hits(raw, s->hits, nrec, (uint32_t)p->defs.size());
         s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return IPCR_OK;
     }
@@ -951,10 +981,10 @@ ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out) {
         for (auto &e : raw->ev) HIPCHK(hipEventCreate(&e));
         raw->qcap = QCAP_INIT;
         raw->hcap = HCAP_INIT;
-        HIPCHK(hipMalloc((void **)&raw->d_queue, raw->qcap * 8ull));
+        HIPCHK(hipMalloc((void **)&raw->d_queue, raw->qcap * sizeof(ipcr_queue_entry)));
         HIPCHK(hipMalloc((void **)&raw->d_hits, raw->hcap * sizeof(ipcr_hit_rec)));
-        HIPCHK(hipMalloc((void **)&raw->d_counts, 16));
-        HIPCHK(hipHostMalloc(&raw->pinned, 16 + PREFIX_HITS * sizeof(ipcr_hit), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&raw->d_counts, 32));
+        HIPCHK(hipHostMalloc(&raw->pinned, 32 + PREFIX_HITS * sizeof(ipcr_hit), hipHostMallocDefault));
         return IPCR_OK;
     };
     ipcr_status st = build();
@@ -1032,8 +1062,8 @@ ipcr_status ipcr_join_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_hit 
     ipcr_status st = scratch_ready(p, s, false);
     if (st != IPCR_OK) return st;
     if ((n_hits > 0 && !hits) || (n_records > 0 && !record_len) || n_hits < 0) return fail(IPCR_ERR_INVALID, "ipcr_join_hits: null argument");
-    if (hits != s->hits.data()) s->hits.assign(hits, hits + n_hits);
-    std::sort(s->hits.begin(), s->hits.end(), HitLess());
+    s->hits_raw.assign(hits, hits + n_hits);
+    sort_hits(s->hits_raw, s->hits, n_records, (uint32_t)p->defs.size());
     s->products.clear();
     return join_sorted_hits(p, s, record_len, record_flags, n_records, emit, user);
 }

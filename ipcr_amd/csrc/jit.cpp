@@ -21,6 +21,7 @@
 // blocks); B only trades ALU work against how many false candidates reach the verifier.
 #include "jit.h"
 
+#include <hip/hip_ext.h>
 #include <hip/hiprtc.h>
 
 #include <cmath>
@@ -127,16 +128,18 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
         if (p.len == 0 || p.len > 32) return "";
         Lmax = std::max<int>(Lmax, p.len);
     }
-    const int W = (Lmax + 3) / 4 * 4; // window rows, multiple of the row-quad
-    const int QPI = W / 4;            // quads per unrolled iteration
-    const int LM1 = Lmax - 1;
-    const int QTOTAL = (128 + LM1 + 3) / 4;
-    const int NIT = (QTOTAL + QPI - 1) / QPI;
+    const int W = (Lmax + 3) / 4 * 4;        // window rows, multiple of the row-quad
+    const int QPI = W / 4;                   // quads per unrolled main-loop iteration
+    const int LM1 = Lmax - 1;                // rows of the next strand a window can reach
+    const int QTOTAL = (128 + LM1 + 3) / 4;  // quads streamed: 32 of the strand + the wrap rows
+    const int QM = (30 / QPI) * QPI;         // quads done by the rolled main loop (its prefetch stays < 32)
+    const int NFULL = QM / QPI;
+    const int QW = (LM1 + 3) / 4;            // head quads stashed for the wrap phase
 
     bool uses_n = false;
     std::vector<Plan> plans;
     for (const auto &p : pats) plans.push_back(choose_plan(p, k));
-    // evaluation code for one output row; slot of row r+j = (sr + j) % W with sr given per step
+    // evaluation of every pattern for the window that starts at slot sr
     auto eval_code = [&](int sr) {
         std::ostringstream o;
         for (size_t q = 0; q < pats.size(); ++q) {
@@ -150,113 +153,141 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
                 }
                 return e.empty() ? std::string("0u") : e;
             };
-            o << "        { // pattern " << q << " (len " << pl.L << ", " << pl.prot.size() << " protected, "
-              << pl.blocks.size() << " blocks)\n";
-            o << "          u32 f = " << orchain(pl.prot) << ";\n";
+            o << "          { // pattern " << q << ": len " << pl.L << ", " << pl.prot.size() << " protected, "
+              << pl.blocks.size() << " blocks\n";
+            o << "            u32 f = " << orchain(pl.prot) << ";\n";
             if (pl.counted) {
                 const int B = (int)pl.blocks.size();
-                // thermometer counter over block flags: u[t] = at least t bad blocks so far
-                for (int i = 0; i < B; ++i) {
-                    o << "          const u32 e" << i << " = " << orchain(pl.blocks[(size_t)i]) << ";\n";
-                }
+                for (int i = 0; i < B; ++i)
+                    o << "            const u32 e" << i << " = " << orchain(pl.blocks[(size_t)i]) << ";\n";
+                // thermometer counter over the block flags: u[t] = at least t bad blocks so far
                 std::vector<bool> live((size_t)k + 2, false);
                 for (int i = 0; i < B; ++i) {
                     for (int t = std::min(i + 1, k + 1); t >= 1; --t) {
                         const std::string prev = (t == 1) ? "" : "u" + std::to_string(t - 1) + " & ";
                         if (t >= 2 && !live[(size_t)t - 1]) continue;
                         if (!live[(size_t)t]) {
-                            o << "          u32 u" << t << " = " << prev << "e" << i << ";\n";
+                            o << "            u32 u" << t << " = " << prev << "e" << i << ";\n";
                             live[(size_t)t] = true;
                         } else {
-                            o << "          u" << t << " |= " << prev << "e" << i << ";\n";
+                            o << "            u" << t << " |= " << prev << "e" << i << ";\n";
                         }
                     }
                 }
-                o << "          f |= u" << (k + 1) << ";\n";
+                o << "            f |= u" << (k + 1) << ";\n";
             }
-            o << "          f" << q << " = f;\n        }\n";
+            o << "            f" << q << " = f;\n          }\n";
         }
         return o.str();
     };
+    // one row step: expand the row into mismatch planes at `slot`, then (if a window ends
+    // here) evaluate all patterns for the window starting LM1 rows earlier
+    auto row_code = [&](int slot, char comp, const std::string &xexpr, const std::string &guard) {
+        std::ostringstream b;
+        const std::string sl = std::to_string(slot);
+        b << "      { // window slot " << slot << "\n";
+        b << "        const u32 lo = clo." << comp << ", hi = chi." << comp << ", iv = civ." << comp << ";\n";
+        b << "        const u32 nlo = ~lo, nhi = ~hi;\n";
+        b << "        a" << sl << " = lo | hi | iv; c" << sl << " = nlo | hi | iv; g" << sl << " = lo | nhi | iv; t"
+          << sl << " = nlo | nhi | iv; n" << sl << " = iv;\n";
+        if (guard == "never") { b << "      }\n"; return b.str(); }
+        if (!guard.empty()) b << "        if (" << guard << ")\n";
+        b << "        {\n          u32 ";
+        for (size_t q = 0; q < pats.size(); ++q) b << (q ? ", f" : "f") << q;
+        b << ";\n";
+        b << eval_code(((slot - LM1) % W + W) % W);
+        b << "          u32 all = f0";
+        for (size_t q = 1; q < pats.size(); ++q) b << " & f" << q;
+        b << ";\n";
+        b << "          if (all != 0xFFFFFFFFu) { // rare: some window survived, hand the word to the verifier\n";
+        b << "            const u64 pos = posbase + (u64)(" << xexpr << " - " << LM1 << "u);\n";
+        for (size_t q = 0; q < pats.size(); ++q)
+            b << "            if (f" << q << " != 0xFFFFFFFFu) push(" << q << "ull, pos, ~f" << q << ", queue, qcap, qcount);\n";
+        b << "          }\n        }\n      }\n";
+        return b.str();
+    };
+    auto load_normal = [&](const std::string &q) {
+        return "p2lo = own[(" + q + ") * 192u]; p2hi = own[(" + q + ") * 192u + 64u]; p2iv = own[(" + q + ") * 192u + 128u];";
+    };
+    // rows past the strand end belong to the next strand: the same words shifted down one bit,
+    // bit 31 coming from the neighbour column (lane + 1, or lane 0 of the next block).  The head
+    // quads were stashed in LDS when first streamed (each wave its own slice, so no barrier), so
+    // nothing is fetched from HBM twice and the neighbour word is just the next lane's LDS slot.
+    auto load_wrap = [&](int kq) {
+        std::ostringstream b;
+        b << "{ v4 nlo = st[" << kq * 3 << "][(lane + 1u) & 63u], nhi = st[" << kq * 3 + 1 << "][(lane + 1u) & 63u], niv = st["
+          << kq * 3 + 2 << "][(lane + 1u) & 63u];\n";
+        b << "        if (lane == 63u) { nlo = nblk[" << kq * 192 << "]; nhi = nblk[" << kq * 192 + 64 << "]; niv = nblk["
+          << kq * 192 + 128 << "]; }\n";
+        b << "        p2lo = (st[" << kq * 3 << "][lane] >> 1) | (nlo << 31); p2hi = (st[" << kq * 3 + 1
+          << "][lane] >> 1) | (nhi << 31); p2iv = (st[" << kq * 3 + 2 << "][lane] >> 1) | (niv << 31); }";
+        return b.str();
+    };
+
+    std::ostringstream body; // rolled main loop: quads [0, QM)
+    for (int u4 = 0; u4 < QPI; ++u4) {
+        body << "    { // quad " << u4 << " of the iteration\n";
+        body << "      const u32 qi = it * " << QPI << "u + " << u4 << "u;\n";
+        body << "      const v4 clo = p1lo, chi = p1hi, civ = p1iv;\n";
+        body << "      p1lo = p2lo; p1hi = p2hi; p1iv = p2iv;\n";
+        body << "      " << load_normal("qi + 2u") << "\n";
+        if (u4 < QW)
+            body << "      if (it == 0u) { st[" << u4 * 3 << "][lane] = clo; st[" << u4 * 3 + 1 << "][lane] = chi; st[" << u4 * 3 + 2
+                 << "][lane] = civ; }\n";
+        for (int c = 0; c < 4; ++c) {
+            const int step = u4 * 4 + c;
+            body << row_code(step, "xyzw"[c], "(qi * 4u + " + std::to_string(c) + "u)", step < LM1 ? "it > 0u" : "");
+        }
+        body << "    }\n";
+    }
+    std::ostringstream epi; // static epilogue: quads [QM, QTOTAL)
+    for (int qi = QM; qi < QTOTAL; ++qi) {
+        epi << "  { // quad " << qi << "\n";
+        epi << "      const v4 clo = p1lo, chi = p1hi, civ = p1iv;\n";
+        epi << "      p1lo = p2lo; p1hi = p2hi; p1iv = p2iv;\n";
+        const int qn = qi + 2;
+        if (qn < 32) epi << "      " << load_normal(std::to_string(qn) + "u") << "\n";
+        else if (qn < QTOTAL) epi << "      " << load_wrap(qn - 32) << "\n";
+        for (int c = 0; c < 4; ++c) {
+            const int x = qi * 4 + c;
+            const int slot = (qi % QPI) * 4 + c;
+            const bool ev = x >= LM1 && x < 128 + LM1;
+            epi << row_code(slot, "xyzw"[c], std::to_string(x) + "u", ev ? "" : "never");
+        }
+        epi << "  }\n";
+    }
 
     std::ostringstream s;
     s << "// generated by ipcr_amd/csrc/jit.cpp for a panel of " << pats.size() << " patterns, k = " << k << "\n";
     s << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
     s << "typedef unsigned int u32;\ntypedef unsigned long long u64;\n";
     s << "typedef u32 v4 __attribute__((ext_vector_type(4)));\n";
-    s << "__device__ __forceinline__ void emit(u32 cand, u64 q, u64 pos, u64* queue, u64 qcap, u64* qcount) {\n"
-         "  while (cand) {\n"
-         "    const u32 b = (u32)__builtin_ctz(cand);\n"
-         "    cand &= cand - 1u;\n"
-         "    const u64 idx = atomicAdd(qcount, 1ull);\n"
-         "    if (idx < qcap) queue[idx] = (q << 48) | (pos + ((u64)b << 7));\n"
-         "  }\n}\n";
-    s << "extern \"C\" __global__ void __launch_bounds__(256) ipcr_filter(const v4* __restrict__ planes, u64 nblocks,\n"
-         "    u64* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {\n";
+    s << "struct qent { u64 key; u32 bits; u32 pad; };\n";
+    s << "__device__ __forceinline__ void push(u64 q, u64 pos, u32 bits, qent* queue, u64 qcap, u64* qcount) {\n"
+         "  const u64 idx = atomicAdd(qcount, 1ull);\n"
+         "  if (idx < qcap) { qent e; e.key = (q << 48) | pos; e.bits = bits; e.pad = 0u; queue[idx] = e; }\n"
+         "}\n";
+    s << "extern \"C\" __global__ void __launch_bounds__(256, 2) ipcr_filter(const v4* __restrict__ planes, u64 nblocks,\n"
+         "    qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {\n";
     s << "  const u32 lane = threadIdx.x & 63u;\n";
     s << "  const u64 block = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);\n";
     s << "  if (block >= nblocks) return;\n";
     s << "  const v4* own = planes + block * 6144ull + lane;\n";
-    s << "  const v4* nxt = (lane < 63u) ? own + 1 : planes + (block + 1ull) * 6144ull;\n";
+    s << "  const v4* nblk = planes + (block + 1ull) * 6144ull; // column 0 of the next block\n";
     s << "  const u64 posbase = ((block * 64ull + lane) * 32ull) << 7;\n";
-    // window registers
-    std::string body; // build iteration body first so uses_n is known
-    {
-        std::ostringstream b;
-        for (int u4 = 0; u4 < QPI; ++u4) {
-            b << "    { // quad " << u4 << " of the iteration\n";
-            b << "      const u32 qi = it * " << QPI << "u + " << u4 << "u;\n";
-            b << "      const v4 clo = plo, chi = phi, cinv = pinv;\n";
-            b << "      const u32 qn = qi + 1u;\n";
-            b << "      if (qn < 32u) {\n"
-                 "        plo = own[qn * 192u]; phi = own[qn * 192u + 64u]; pinv = own[qn * 192u + 128u];\n"
-                 "      } else if (qn < " << QTOTAL << "u) { // rows past the strand end: next strand = same words >> 1\n"
-                 "        const u32 w = (qn - 32u) * 192u;\n"
-                 "        plo = (own[w] >> 1) | (nxt[w] << 31);\n"
-                 "        phi = (own[w + 64u] >> 1) | (nxt[w + 64u] << 31);\n"
-                 "        pinv = (own[w + 128u] >> 1) | (nxt[w + 128u] << 31);\n"
-                 "      }\n";
-            for (int c = 0; c < 4; ++c) {
-                const int step = u4 * 4 + c;
-                const char comp = "xyzw"[c];
-                const std::string sl = std::to_string(step);
-                b << "      { // row step " << step << "\n";
-                b << "        const u32 lo = clo." << comp << ", hi = chi." << comp << ", iv = cinv." << comp << ";\n";
-                b << "        const u32 nlo = ~lo, nhi = ~hi;\n";
-                b << "        a" << sl << " = lo | hi | iv; c" << sl << " = nlo | hi | iv; g" << sl
-                  << " = lo | nhi | iv; t" << sl << " = nlo | nhi | iv; n" << sl << " = iv;\n";
-                b << "        const u32 x = qi * 4u + " << c << "u;\n";
-                b << "        if (x >= " << LM1 << "u && x < " << (128 + LM1) << "u) {\n";
-                b << "        u32 ";
-                for (size_t q = 0; q < pats.size(); ++q) b << (q ? ", f" : "f") << q;
-                b << ";\n";
-                const int sr = ((step - LM1) % W + W) % W;
-                b << eval_code(sr);
-                b << "          u32 all = f0";
-                for (size_t q = 1; q < pats.size(); ++q) b << " & f" << q;
-                b << ";\n";
-                b << "          if (all != 0xFFFFFFFFu) {\n";
-                b << "            const u64 pos = posbase + (u64)(x - " << LM1 << "u);\n";
-                for (size_t q = 0; q < pats.size(); ++q)
-                    b << "            emit(~f" << q << ", " << q << "ull, pos, queue, qcap, qcount);\n";
-                b << "          }\n";
-                b << "        }\n";
-                b << "      }\n";
-            }
-            b << "    }\n";
-        }
-        body = b.str();
-    }
     s << "  u32 ";
     for (int i = 0; i < W; ++i) {
         if (i) s << ", ";
         s << "a" << i << " = 0, c" << i << " = 0, g" << i << " = 0, t" << i << " = 0, n" << i << " = 0";
     }
     s << ";\n";
-    s << "  v4 plo = own[0], phi = own[64], pinv = own[128];\n";
-    s << "  for (u32 it = 0; it < " << NIT << "u; ++it) {\n";
-    s << body;
-    s << "  }\n}\n";
+    s << "  __shared__ v4 stash[4][" << QW * 3 << "][64]; // head quads of each wave's block, for the wrap rows\n";
+    s << "  v4 (*st)[64] = stash[threadIdx.x >> 6];\n";
+    s << "  v4 p1lo = own[0], p1hi = own[64], p1iv = own[128];\n";
+    s << "  v4 p2lo = own[192], p2hi = own[256], p2iv = own[320];\n";
+    s << "  for (u32 it = 0; it < " << NFULL << "u; ++it) {\n" << body.str() << "  }\n";
+    s << epi.str();
+    s << "}\n";
     (void)uses_n;
     return s.str();
 }
@@ -305,12 +336,13 @@ JitFilter *jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std:
     return f;
 }
 
-hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint64_t *queue,
-                      uint64_t qcap, unsigned long long *qcount) {
+hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,
+                      uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0) return hipSuccess;
     void *args[] = {(void *)&planes, (void *)&nblocks, (void *)&queue, (void *)&qcap, (void *)&qcount};
     const unsigned grid = (unsigned)((nblocks + 3) / 4);
-    return hipModuleLaunchKernel(f->fn, grid, 1, 1, 256, 1, 1, 0, st, args, nullptr);
+    // start/stop are attached to this dispatch itself (its begin/end timestamps)
+    return hipExtModuleLaunchKernel(f->fn, grid * 256u, 1, 1, 256, 1, 1, 0, st, args, nullptr, start, stop, 0);
 }
 
 void jit_destroy(JitFilter *f) {

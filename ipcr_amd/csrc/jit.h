@@ -17,8 +17,8 @@ struct JitFilter;
 std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int max_mm);
 // nullptr (and `err` set) when the panel cannot be specialised or hiprtc fails
 JitFilter *jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err);
-hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint64_t *queue,
-                      uint64_t qcap, unsigned long long *qcount);
+hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,
+                      uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop);
 void jit_destroy(JitFilter *f);
 
 } // namespace ipcr

@@ -10,6 +10,7 @@
 // The panel-specialised filter is generated and compiled at panel-compile time (jit.cpp);
 // it shares the queue format and the verifier below.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "device_types.h"
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void filter_generic_kernel(const uint32_t *__r
                                                              uint64_t nblocks,
                                                              const ipcr_dev_pattern *__restrict__ pats,
                                                              uint32_t npat, uint32_t max_mm,
-                                                             uint64_t *__restrict__ queue, uint64_t qcap,
+                                                             ipcr_queue_entry *__restrict__ queue, uint64_t qcap,
                                                              unsigned long long *__restrict__ qcount) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t tile = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); // (block, row)
@@ -194,21 +195,24 @@ __global__ __launch_bounds__(256) void filter_generic_kernel(const uint32_t *__r
 #pragma unroll
         for (int t = 1; t <= KMAX; ++t)
             if ((uint32_t)t == max_mm + 1u) over = u[t];
-        uint32_t alive = ~(dead | over);
-        while (alive) {
-            const uint32_t bit = (uint32_t)__builtin_ctz(alive);
-            alive &= alive - 1u;
-            const uint64_t P = ipcr_join_pos(block * 64u + lane, bit, row);
+        const uint32_t alive = ~(dead | over);
+        if (alive) { // one queue entry per surviving word: 32 strands of this row
             const unsigned long long idx = atomicAdd(qcount, 1ull);
-            if (idx < qcap) queue[idx] = ((uint64_t)q << 48) | P;
+            if (idx < qcap) {
+                ipcr_queue_entry e;
+                e.key = ((uint64_t)q << 48) | ipcr_join_pos(block * 64u + lane, 0, row);
+                e.bits = alive;
+                e.pad = 0;
+                queue[idx] = e;
+            }
         }
     }
 }
 
 template __global__ void filter_generic_kernel<4>(const uint32_t *, uint64_t, const ipcr_dev_pattern *, uint32_t,
-                                                  uint32_t, uint64_t *, uint64_t, unsigned long long *);
+                                                  uint32_t, ipcr_queue_entry *, uint64_t, unsigned long long *);
 template __global__ void filter_generic_kernel<17>(const uint32_t *, uint64_t, const ipcr_dev_pattern *, uint32_t,
-                                                   uint32_t, uint64_t *, uint64_t, unsigned long long *);
+                                                   uint32_t, ipcr_queue_entry *, uint64_t, unsigned long long *);
 
 // ------------------------------------------------------------------------------ verify
 // verifyAt (core/engine/ac.go:186-213) / the inner loop of FindMatches
@@ -237,17 +241,22 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint32_t *__restrict_
                                                      const uint64_t *__restrict__ rec_start,
                                                      const uint64_t *__restrict__ rec_len, uint32_t nrec,
                                                      uint32_t check_rst,
-                                                     const uint64_t *__restrict__ queue, uint64_t qcap,
+                                                     const ipcr_queue_entry *__restrict__ queue, uint64_t qcap,
                                                      const unsigned long long *__restrict__ qcount,
                                                      ipcr_hit_rec *__restrict__ hits, uint64_t hcap,
-                                                     unsigned long long *__restrict__ hcount) {
+                                                     unsigned long long *__restrict__ hcount,
+                                                     unsigned long long *__restrict__ ccount) {
     unsigned long long n = *qcount;
     if (n > qcap) n = qcap;
+    n *= 32ull; // one thread per (queue entry, strand bit)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t cand = queue[i];
-        const uint32_t q = (uint32_t)(cand >> 48);
-        const uint64_t P = cand & 0xFFFFFFFFFFFFull;
+        const ipcr_queue_entry ent = queue[i >> 5];
+        const uint32_t bit = (uint32_t)(i & 31u);
+        if (bit == 0u) atomicAdd(ccount, (unsigned long long)__builtin_popcount(ent.bits));
+        if (!((ent.bits >> bit) & 1u)) continue;
+        const uint32_t q = (uint32_t)(ent.key >> 48);
+        const uint64_t P = (ent.key & 0xFFFFFFFFFFFFull) + ((uint64_t)bit << IPCR_TILE_LOG_N);
         // record lookup: last record with start <= P
         uint32_t lo = 0, hi = nrec;
         while (hi - lo > 1u) {
@@ -403,25 +412,28 @@ hipError_t launch_lcg(hipStream_t st, uint8_t *out, uint64_t n, uint32_t seed, u
 
 hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_t nblocks,
                                  const ipcr_dev_pattern *pats, uint32_t npat, uint32_t max_mm,
-                                 uint64_t *queue, uint64_t qcap, unsigned long long *qcount) {
+                                 ipcr_queue_entry *queue, uint64_t qcap, unsigned long long *qcount,
+                                 hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0 || npat == 0) return hipSuccess;
     const uint64_t tiles = nblocks * 128u; // one wave per (block, row)
     const dim3 grid((uint32_t)((tiles + 3u) / 4u));
     if (max_mm <= 3u)
-        filter_generic_kernel<4><<<grid, dim3(256), 0, st>>>(planes, nblocks, pats, npat, max_mm, queue, qcap, qcount);
+        hipExtLaunchKernelGGL(filter_generic_kernel<4>, grid, dim3(256), 0, st, start, stop, 0, planes, nblocks, pats,
+                              npat, max_mm, queue, qcap, qcount);
     else
-        filter_generic_kernel<17><<<grid, dim3(256), 0, st>>>(planes, nblocks, pats, npat, max_mm, queue, qcap, qcount);
+        hipExtLaunchKernelGGL(filter_generic_kernel<17>, grid, dim3(256), 0, st, start, stop, 0, planes, nblocks, pats,
+                              npat, max_mm, queue, qcap, qcount);
     return hipGetLastError();
 }
 
 hipError_t launch_verify(hipStream_t st, const uint32_t *planes, const uint32_t *rst,
                          const ipcr_dev_pattern *pats, uint32_t max_mm, const uint64_t *rec_start,
-                         const uint64_t *rec_len, uint32_t nrec, uint32_t check_rst, const uint64_t *queue,
+                         const uint64_t *rec_len, uint32_t nrec, uint32_t check_rst, const ipcr_queue_entry *queue,
                          uint64_t qcap, const unsigned long long *qcount, ipcr_hit_rec *hits, uint64_t hcap,
-                         unsigned long long *hcount) {
+                         unsigned long long *hcount, unsigned long long *ccount, hipEvent_t start, hipEvent_t stop) {
     if (nrec == 0) return hipSuccess;
-    verify_kernel<<<dim3(1024), dim3(256), 0, st>>>(planes, rst, pats, max_mm, rec_start, rec_len, nrec, check_rst,
-                                                    queue, qcap, qcount, hits, hcap, hcount);
+    hipExtLaunchKernelGGL(verify_kernel, dim3(1024), dim3(256), 0, st, start, stop, 0, planes, rst, pats, max_mm,
+                          rec_start, rec_len, nrec, check_rst, queue, qcap, qcount, hits, hcap, hcount, ccount);
     return hipGetLastError();
 }
 

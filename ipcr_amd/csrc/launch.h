@@ -12,12 +12,13 @@ hipError_t launch_fill_pad(hipStream_t st, uint32_t *planes, uint32_t *rst, uint
 hipError_t launch_lcg(hipStream_t st, uint8_t *out, uint64_t n, uint32_t seed, uint64_t offset);
 hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_t nblocks,
                                  const ipcr_dev_pattern *pats, uint32_t npat, uint32_t max_mm,
-                                 uint64_t *queue, uint64_t qcap, unsigned long long *qcount);
+                                 ipcr_queue_entry *queue, uint64_t qcap, unsigned long long *qcount,
+                                 hipEvent_t start, hipEvent_t stop);
 hipError_t launch_verify(hipStream_t st, const uint32_t *planes, const uint32_t *rst,
                          const ipcr_dev_pattern *pats, uint32_t max_mm, const uint64_t *rec_start,
-                         const uint64_t *rec_len, uint32_t nrec, uint32_t check_rst, const uint64_t *queue,
+                         const uint64_t *rec_len, uint32_t nrec, uint32_t check_rst, const ipcr_queue_entry *queue,
                          uint64_t qcap, const unsigned long long *qcount, ipcr_hit_rec *hits, uint64_t hcap,
-                         unsigned long long *hcount);
+                         unsigned long long *hcount, unsigned long long *ccount, hipEvent_t start, hipEvent_t stop);
 hipError_t launch_unpack(hipStream_t st, const uint32_t *planes, const uint32_t *rst, uint64_t P0, uint64_t n,
                          uint8_t *out);
 hipError_t launch_gather(hipStream_t st, const uint32_t *planes, const uint32_t *rst, const ipcr_amp_seg *segs,

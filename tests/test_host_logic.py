@@ -209,7 +209,7 @@ def test_filter_source_is_generated_for_the_headline_panels():
     cp = engine.New(engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12)).CompilePanel(workloads.c2_pairs())
     assert cp.num_patterns == 4  # 3 pairs / 12 orientation slots / 4 distinct patterns
     src = cp.filter_source(0)
-    assert "ipcr_filter" in src and src.count("// pattern 0 ") > 0
+    assert "ipcr_filter" in src and src.count("// pattern 0:") > 0
     big = engine.New(engine.Config(MaxMM=2, TerminalWindow=3)).CompilePanel(workloads.c4_pairs(64))
     assert big.filter_source(0) == ""  # > 48 patterns: table-driven filter (still on the device)
 
