@@ -202,6 +202,8 @@ def main() -> None:
             "filter_candidates_rank0": int(sc.stats().candidates),
             "filter_kernel": "panel-specialised (hiprtc)" if sc.stats().kernel_kind == 1 else "table-driven",
             "pack_ms_per_genome": round(genome.pack_ms, 3),
+            "step_breakdown_ms_rank0": {k: round(getattr(sc.stats(), k), 4) for k in
+                                        ("filter_ms", "verify_ms", "enqueue_ms", "wait_ms", "sort_ms", "join_ms", "total_ms")},
             "parallelism": "1 genome per GPU, hit records all-gathered (RCCL)" if multi else "single GPU",
         },
         "roofline": {

@@ -109,6 +109,10 @@ typedef struct {
     uint64_t products;
     int32_t kernel_kind;  /* 1 = panel-specialised (runtime-compiled) filter, 2 = table-driven filter */
     int32_t n_patterns;
+    double enqueue_ms;    /* host time to enqueue memset + kernels + copies */
+    double wait_ms;       /* host time blocked in the stream synchronise */
+    double sort_ms;       /* host: hit records -> (record, pattern, pos) order */
+    double join_ms;       /* host: match lists + amplicon join */
 } ipcr_scan_stats;
 
 typedef struct ipcr_panel ipcr_panel;     /* engine.CompiledPanel + device tables */

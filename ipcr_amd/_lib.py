@@ -54,7 +54,8 @@ class ScanStats(C.Structure):
     _fields_ = [("pack_ms", C.c_double), ("filter_ms", C.c_double), ("verify_ms", C.c_double),
                 ("total_ms", C.c_double), ("bases", C.c_uint64), ("tile_bytes", C.c_uint64),
                 ("candidates", C.c_uint64), ("hits", C.c_uint64), ("products", C.c_uint64),
-                ("kernel_kind", C.c_int32), ("n_patterns", C.c_int32)]
+                ("kernel_kind", C.c_int32), ("n_patterns", C.c_int32), ("enqueue_ms", C.c_double),
+                ("wait_ms", C.c_double), ("sort_ms", C.c_double), ("join_ms", C.c_double)]
 
 
 EMIT_FN = C.CFUNCTYPE(C.c_int, C.POINTER(Product), C.c_void_p)

@@ -702,7 +702,11 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     if (nrec == 0 || set.ids.empty()) return IPCR_OK;
     const uint32_t check_rst = genome_any_reset(g) ? 1u : 0u;
 
+    auto ms_since = [](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
     for (int attempt = 0; attempt < 8; ++attempt) {
+        const auto te = std::chrono::steady_clock::now();
         HIPCHK(hipMemsetAsync(s->d_counts, 0, 32, s->stream));
         if (set.jit) {
             HIPCHK(ipcr::jit_launch(set.jit, s->stream, g->planes, nblocks, s->d_queue, s->qcap, s->d_counts, s->ev[0], s->ev[1]));
@@ -720,7 +724,10 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         HIPCHK(hipMemcpyAsync(pc, s->d_counts, 32, hipMemcpyDeviceToHost, s->stream));
         const uint64_t pre = std::min<uint64_t>(std::min<uint64_t>(s->prefix_hint, PREFIX_HITS), s->hcap);
         HIPCHK(hipMemcpyAsync(ph, s->d_hits, pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->stream));
+        s->stats.enqueue_ms = ms_since(te);
+        const auto tw = std::chrono::steady_clock::now();
         HIPCHK(hipStreamSynchronize(s->stream));
+        s->stats.wait_ms = ms_since(tw);
         const uint64_t nent = pc[0], nhit = pc[1], ncand = pc[2];
         if (nent > s->qcap) { // candidate queue overflowed: regrow and rescan
             uint64_t want = s->qcap;
@@ -755,7 +762,9 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         s->stats.verify_ms = vms;
         s->stats.candidates = ncand;
         s->stats.hits = nhit;
+        const auto ts = std::chrono::steady_clock::now();
         sort_hits(raw, s->hits, nrec, (uint32_t)p->defs.size());
+        s->stats.sort_ms = ms_since(ts);
         s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return IPCR_OK;
     }
@@ -1051,7 +1060,9 @@ ipcr_status ipcr_scan_genome(const ipcr_panel *p, ipcr_scratch *s, const ipcr_ge
     std::vector<uint8_t> fl(g->rec_start.size());
     const bool any = genome_any_reset(g);
     for (size_t r = 0; r < fl.size(); ++r) fl[r] = (uint8_t)((g->flags[r] & 1u) | (any ? 2u : 0u));
+    const auto tj = std::chrono::steady_clock::now();
     st = join_sorted_hits(p, s, g->rec_len.data(), fl.data(), (uint32_t)fl.size(), emit, user);
+    s->stats.join_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj).count();
     s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return st;
 }

@@ -360,3 +360,118 @@ def test_probe_random_vs_oracle(hip):
         w = O.best_hit(amp, prb, k)
         g = hip.oligo.BestHit(amp, prb, k)
         assert (g.Found, g.Strand, g.Pos, g.MM, g.Site) == (w.found, w.strand, w.pos, w.mm, w.site)
+
+
+# ---- BASELINE.json configurations at test scale (full-scale runs live in bench.py) -------------
+
+def build_planted_genome(hip, rng, nrec, reclen, pairs_to_plant, seed, junk_every=0, wrap=False):
+    """LCG records (reference benchDNA) with planted amplicons; returns (Genome, [bytes])."""
+    g = hip.engine.Genome(nrec * reclen, nrec)
+    seqs = []
+    stream = O.bench_dna(nrec * reclen, seed)
+    for r in range(nrec):
+        s = list(stream[r * reclen:(r + 1) * reclen].decode())
+        for t in range(6):
+            p = pairs_to_plant[(r + t) % len(pairs_to_plant)]
+            a = 1000 + t * ((reclen - 3000) // 6)
+            plant(rng, s, p.Forward, a, rng.choice([0, 1, 2]))
+            rc = O.revcomp(p.Reverse).decode()
+            plant(rng, s, rc, a + 180 - len(rc), rng.choice([0, 1]))
+        if wrap:  # reverse site near the record start, forward site near its end: origin-spanning amplicon
+            p = pairs_to_plant[0]
+            plant(rng, s, p.Forward, reclen - 120, 0)
+            rc = O.revcomp(p.Reverse).decode()
+            plant(rng, s, rc, 60, 0)
+        if junk_every and r % junk_every == 0:
+            for _ in range(4):
+                q = rng.randrange(reclen - 50)
+                s[q:q + rng.randint(1, 40)] = "N" * len(s[q:q + rng.randint(1, 40)])
+        b = "".join(s).encode()
+        seqs.append(b)
+        g.add_record("chr%d" % (r + 1), b)
+    return g, seqs
+
+
+def scan_and_compare(hip, cfg, pairs, g, seqs):
+    eng = hip.engine.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    sc = eng.NewSimulationScratch(cp)
+    got = eng.ScanGenome(g, cp, sc)
+    op = O.Panel(ocfg(cfg), opairs(pairs))
+    want = []
+    for r, s in enumerate(seqs):
+        want += [("chr%d" % (r + 1),) + w.sig() for w in op.scan(s)]
+    assert [(p.SequenceID,) + p.sig() for p in got] == want
+    return eng, cp, sc, got
+
+
+def test_config_c2_single_pair_k2_tw5(hip):
+    from ipcr_amd import workloads
+    rng = random.Random(21)
+    pairs = workloads.c2_pairs()
+    g, seqs = build_planted_genome(hip, rng, 6, 2_000_003, pairs[:1], 0x5eed1234, junk_every=0)
+    cfg = hip.engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12)
+    _, _, sc, got = scan_and_compare(hip, cfg, pairs, g, seqs)
+    assert sc.stats().kernel_kind == 1 and len(got) >= 20
+    g.close()
+
+
+def test_config_c2_with_reference_n(hip):
+    """the '+N' variant of SURVEY 8(d): non-ACGT runs force the reference onto its FindMatches path"""
+    from ipcr_amd import workloads
+    rng = random.Random(22)
+    pairs = workloads.c2_pairs()
+    g, seqs = build_planted_genome(hip, rng, 4, 1_500_000, pairs[:1], 0x5eed1235, junk_every=2)
+    cfg = hip.engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12)
+    scan_and_compare(hip, cfg, pairs, g, seqs)
+    scan_and_compare(hip, hip.engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=0, SeedLen=12), pairs, g, seqs)
+    g.close()
+
+
+def test_config_c3_iupac_k3_circular(hip):
+    from ipcr_amd import workloads
+    rng = random.Random(23)
+    pairs = workloads.c3_pairs()
+    g, seqs = build_planted_genome(hip, rng, 4, 1_000_000, pairs[:1], 0x5eed1236, wrap=True)
+    cfg = hip.engine.Config(MaxMM=3, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12, Circular=True)
+    _, _, sc, got = scan_and_compare(hip, cfg, pairs, g, seqs)
+    assert sc.stats().kernel_kind == 1
+    assert any(p.Start > p.End for p in got), "expected an origin-spanning product"
+    g.close()
+
+
+def test_config_c4_multiplex_panel(hip):
+    from ipcr_amd import workloads
+    rng = random.Random(24)
+    pairs = workloads.c4_pairs(24)  # 24 TSV rows -> 72 pairs, 96 distinct patterns: table-driven filter
+    g, seqs = build_planted_genome(hip, rng, 3, 300_000, pairs[:24], 0x5eed1237)
+    cfg = hip.engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)
+    _, cp, sc, got = scan_and_compare(hip, cfg, pairs, g, seqs)
+    assert sc.stats().kernel_kind == 2 and len(got) >= 18
+    small = workloads.c4_pairs(5)   # 15 pairs, 20 distinct patterns: specialised filter
+    _, _, sc2, _ = scan_and_compare(hip, cfg, small, g, seqs)
+    assert sc2.stats().kernel_kind == 1
+    g.close()
+
+
+def test_config_c5_probe_rescan(hip):
+    import ctypes as C
+    from ipcr_amd import workloads
+    rng = random.Random(25)
+    pairs = workloads.c2_pairs()
+    g, seqs = build_planted_genome(hip, rng, 3, 800_000, pairs[:1], 0x5eed1238)
+    cfg = hip.engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12, Circular=False)
+    eng, cp, sc, got = scan_and_compare(hip, cfg, pairs, g, seqs)
+    assert got
+    amp0 = seqs[got[0].Record][got[0].Start:got[0].End]
+    probe = amp0[70:91].decode()                      # 21-mer from the amplicon interior
+    probe_mut = probe[:9] + O.different_base(probe[9]) + probe[10:]
+    for prb, k in [(probe, 0), (probe_mut, 2), (O.revcomp(probe).decode(), 1), ("ACGTNNRYACGTACGTACGTT", 2)]:
+        out = (hip.lib.ProbeHit * len(got))()
+        hip.lib.check(hip.lib.lib().ipcr_probe_products(sc._h, g._h, prb.encode(), k, out, len(got)))
+        for i, p in enumerate(got):
+            amp = seqs[p.Record][p.Start:p.End]
+            w = O.best_hit(amp, prb, k)                # core/oligo/oligo.go:19-77 on Product.Seq
+            assert (bool(out[i].found), chr(out[i].strand) if out[i].found else "", out[i].pos, out[i].mm) == \
+                (w.found, w.strand, w.pos if w.found else 0, w.mm if w.found else 0)
+    g.close()
