@@ -84,18 +84,22 @@ def main() -> None:
     ap.add_argument("--record-len", type=int, default=RECORD_LEN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo to rehearse)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     from ipcr_amd import _lib, dist, engine, workloads
 
-    rank, world, local, backend = dist.init_process_group()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the ipcr_amd scan path has no CPU fallback")
+    if os.environ.get("IPCR_BENCH_ONE_DEVICE"):  # rehearsal: several ranks share GPU 0 (gloo collectives)
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local, backend = dist.init_process_group(args.backend)
     torch.cuda.set_device(local)
     _lib.check(_lib.lib().ipcr_set_device(local))
     dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective payloads live
     import torch.distributed as tdist
     multi = world > 1
 
@@ -114,20 +118,20 @@ def main() -> None:
     nrec = genome.num_records
     lens = [genome.record_len(r) for r in range(nrec)]
     flags = [genome.record_flags(r) for r in range(nrec)]
-    all_lens, all_flags = dist.allgather_record_meta(lens, flags, device=dev) if multi else (lens, flags)
+    all_lens, all_flags = dist.allgather_record_meta(lens, flags, device=cdev) if multi else (lens, flags)
     host_sc = engine.SimulationScratch(cp, host_only=True) if multi else None
+    xchg = dist.HitExchanger(device=cdev) if multi else None
 
     def step():
-        """one pass of the hot path; returns (#products on this rank's view, filter_ms)"""
+        """one pass of the hot path; returns (#products joined by this rank, filter_ms)"""
         if not multi:
             n = eng.ScanGenomeCount(genome, cp, sc)
             return n, sc.stats().filter_ms
         eng.ScanGenomeHits(genome, cp, sc)                      # filter + verify on this rank's genome
         fms = sc.stats().filter_ms
-        hits, _ = dist.allgather_hits(dist.hits_from_scratch(sc), nrec, device=dev)   # RCCL all-gatherv
-        n = 0
-        if rank == 0:                                            # join the whole job's hits
-            n = _join_count(eng, cp, host_sc, hits, all_lens, all_flags)
+        hits, ranges, _ = xchg.allgather(dist.hits_from_scratch(sc), nrec)   # all-gatherv of hit records (RCCL)
+        a, b = ranges[rank]                                      # the join is partitioned by record:
+        n = _join_count(eng, cp, host_sc, hits[a:b], all_lens, all_flags)   # each rank joins its records
         return n, fms
 
     for _ in range(max(args.warmup, 0)):
@@ -147,16 +151,21 @@ def main() -> None:
         tdist.barrier()
     elapsed = time.perf_counter() - t0
     if multi:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        ptot = torch.tensor([nprod], dtype=torch.int64, device=cdev)
+        tdist.all_reduce(ptot, op=tdist.ReduceOp.SUM)
+        nprod = int(ptot.item())
 
     # ---- correctness outside the timed region: every planted amplicon must come back exactly ----
     if not multi:
         prods = sc.products(genome.ids)
-    else:
-        prods = eng.JoinHits(cp, host_sc, dist.allgather_hits(dist.hits_from_scratch(sc), nrec, device=dev)[0],
-                             all_lens, all_flags) if rank == 0 else []
+    else:  # rank 0 joins the WHOLE job from the gathered hits and checks its own genome's plants
+        allhits, _, _ = xchg.allgather(dist.hits_from_scratch(sc), nrec)
+        prods = eng.JoinHits(cp, host_sc, allhits, all_lens, all_flags) if rank == 0 else []
+        if rank == 0:
+            assert len(prods) == nprod, f"whole-job join on rank 0 found {len(prods)} products, partitioned join {nprod}"
     if rank == 0:
         found = {(p.Record, p.Start): p for p in prods if p.ExperimentID == "bench_000" and p.Type == "forward" and p.Length == PRODUCT_LEN}
         for (r, start, nm) in plants:           # rank 0's own genome occupies records [0, nrec)
@@ -204,7 +213,8 @@ def main() -> None:
             "pack_ms_per_genome": round(genome.pack_ms, 3),
             "step_breakdown_ms_rank0": {k: round(getattr(sc.stats(), k), 4) for k in
                                         ("filter_ms", "verify_ms", "enqueue_ms", "wait_ms", "sort_ms", "join_ms", "total_ms")},
-            "parallelism": "1 genome per GPU, hit records all-gathered (RCCL)" if multi else "single GPU",
+            "parallelism": ("1 genome per GPU, one all-gatherv of hit records per step (%s), join partitioned by record" % backend)
+                           if multi else "single GPU",
         },
         "roofline": {
             "bound": "hbm",
@@ -249,7 +259,7 @@ def cpu_baseline(host0, budget_s: float, gpu_products):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ipcr_oracle as O
     from ipcr_amd import workloads
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     pairs = [O.Pair(p.ID, p.Forward, p.Reverse, p.MinProduct, p.MaxProduct) for p in workloads.c2_pairs()]
     panel = O.Panel(O.Config(max_mm=2, terminal_window=5, min_len=0, max_len=2000, hit_cap=10000, seed_len=12), pairs)
     n = int(host0.shape[0])
@@ -259,7 +269,7 @@ def cpu_baseline(host0, budget_s: float, gpu_products):
         nprod = panel.baseline_scan_mt(ptr, n, 4_000_000, 2000, cores)
         passes += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or passes >= 64:
+        if el >= budget_s or passes >= 4096:
             break
     gpu_rec0 = len([p for p in gpu_products if p.Record == 0])
     assert nprod == gpu_rec0, f"CPU baseline found {nprod} products in record 0, GPU path {gpu_rec0}"

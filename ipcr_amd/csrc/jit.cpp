@@ -26,6 +26,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -34,6 +35,7 @@ namespace ipcr {
 struct JitFilter {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
+    unsigned waves_per_group = 4;
 };
 
 namespace {
@@ -121,8 +123,19 @@ std::string plane_expr(uint8_t mask, int slot, bool &uses_n) {
 
 } // namespace
 
+static int env_int(const char *name, int dflt, int lo, int hi) {
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    const int x = atoi(v);
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+
 std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
     if (pats.empty() || pats.size() > 48) return "";
+    // tuning knobs (defaults are the measured best on MI355X for the C2 panel)
+    const int D = env_int("IPCR_JIT_DEPTH", 2, 1, 4);      // row-quads prefetched ahead
+    const int WPS = env_int("IPCR_JIT_WAVES", 2, 1, 4);    // __launch_bounds__ waves per SIMD
+    const int WPG = env_int("IPCR_JIT_WG", 4, 1, 4);       // waves per workgroup
     int Lmax = 0;
     for (const auto &p : pats) {
         if (p.len == 0 || p.len > 32) return "";
@@ -132,7 +145,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
     const int QPI = W / 4;                   // quads per unrolled main-loop iteration
     const int LM1 = Lmax - 1;                // rows of the next strand a window can reach
     const int QTOTAL = (128 + LM1 + 3) / 4;  // quads streamed: 32 of the strand + the wrap rows
-    const int QM = (30 / QPI) * QPI;         // quads done by the rolled main loop (its prefetch stays < 32)
+    const int QM = ((32 - D) / QPI) * QPI;   // quads done by the rolled main loop (its prefetch stays < 32)
     const int NFULL = QM / QPI;
     const int QW = (LM1 + 3) / 4;            // head quads stashed for the wrap phase
 
@@ -177,6 +190,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
                 o << "            f |= u" << (k + 1) << ";\n";
             }
             o << "            f" << q << " = f;\n          }\n";
+            if (env_int("IPCR_JIT_SCHEDBAR", 0, 0, 1)) o << "          __builtin_amdgcn_sched_barrier(0);\n";
         }
         return o.str();
     };
@@ -207,7 +221,8 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
         return b.str();
     };
     auto load_normal = [&](const std::string &q) {
-        return "p2lo = own[(" + q + ") * 192u]; p2hi = own[(" + q + ") * 192u + 64u]; p2iv = own[(" + q + ") * 192u + 128u];";
+        const std::string d = std::to_string(D);
+        return "p" + d + "lo = own[(" + q + ") * 192u]; p" + d + "hi = own[(" + q + ") * 192u + 64u]; p" + d + "iv = own[(" + q + ") * 192u + 128u];";
     };
     // rows past the strand end belong to the next strand: the same words shifted down one bit,
     // bit 31 coming from the neighbour column (lane + 1, or lane 0 of the next block).  The head
@@ -219,18 +234,23 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
           << kq * 3 + 2 << "][(lane + 1u) & 63u];\n";
         b << "        if (lane == 63u) { nlo = nblk[" << kq * 192 << "]; nhi = nblk[" << kq * 192 + 64 << "]; niv = nblk["
           << kq * 192 + 128 << "]; }\n";
-        b << "        p2lo = (st[" << kq * 3 << "][lane] >> 1) | (nlo << 31); p2hi = (st[" << kq * 3 + 1
-          << "][lane] >> 1) | (nhi << 31); p2iv = (st[" << kq * 3 + 2 << "][lane] >> 1) | (niv << 31); }";
+        b << "        p" << D << "lo = (st[" << kq * 3 << "][lane] >> 1) | (nlo << 31); p" << D << "hi = (st[" << kq * 3 + 1
+          << "][lane] >> 1) | (nhi << 31); p" << D << "iv = (st[" << kq * 3 + 2 << "][lane] >> 1) | (niv << 31); }";
         return b.str();
     };
 
+    std::string shift; // advance the prefetch ring by one quad
+    for (int i = 1; i < D; ++i) {
+        const std::string a = std::to_string(i), b2 = std::to_string(i + 1);
+        shift += "p" + a + "lo = p" + b2 + "lo; p" + a + "hi = p" + b2 + "hi; p" + a + "iv = p" + b2 + "iv; ";
+    }
     std::ostringstream body; // rolled main loop: quads [0, QM)
     for (int u4 = 0; u4 < QPI; ++u4) {
         body << "    { // quad " << u4 << " of the iteration\n";
         body << "      const u32 qi = it * " << QPI << "u + " << u4 << "u;\n";
         body << "      const v4 clo = p1lo, chi = p1hi, civ = p1iv;\n";
-        body << "      p1lo = p2lo; p1hi = p2hi; p1iv = p2iv;\n";
-        body << "      " << load_normal("qi + 2u") << "\n";
+        body << "      " << shift << "\n";
+        body << "      " << load_normal("qi + " + std::to_string(D) + "u") << "\n";
         if (u4 < QW)
             body << "      if (it == 0u) { st[" << u4 * 3 << "][lane] = clo; st[" << u4 * 3 + 1 << "][lane] = chi; st[" << u4 * 3 + 2
                  << "][lane] = civ; }\n";
@@ -244,8 +264,8 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
     for (int qi = QM; qi < QTOTAL; ++qi) {
         epi << "  { // quad " << qi << "\n";
         epi << "      const v4 clo = p1lo, chi = p1hi, civ = p1iv;\n";
-        epi << "      p1lo = p2lo; p1hi = p2hi; p1iv = p2iv;\n";
-        const int qn = qi + 2;
+        epi << "      " << shift << "\n";
+        const int qn = qi + D;
         if (qn < 32) epi << "      " << load_normal(std::to_string(qn) + "u") << "\n";
         else if (qn < QTOTAL) epi << "      " << load_wrap(qn - 32) << "\n";
         for (int c = 0; c < 4; ++c) {
@@ -267,10 +287,11 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
          "  const u64 idx = atomicAdd(qcount, 1ull);\n"
          "  if (idx < qcap) { qent e; e.key = (q << 48) | pos; e.bits = bits; e.pad = 0u; queue[idx] = e; }\n"
          "}\n";
-    s << "extern \"C\" __global__ void __launch_bounds__(256, 2) ipcr_filter(const v4* __restrict__ planes, u64 nblocks,\n"
+    s << "// IPCR_WAVES_PER_GROUP " << WPG << "\n";
+    s << "extern \"C\" __global__ void __launch_bounds__(" << WPG * 64 << ", " << WPS << ") ipcr_filter(const v4* __restrict__ planes, u64 nblocks,\n"
          "    qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {\n";
     s << "  const u32 lane = threadIdx.x & 63u;\n";
-    s << "  const u64 block = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);\n";
+    s << "  const u64 block = (u64)blockIdx.x * " << WPG << "u + (threadIdx.x >> 6);\n";
     s << "  if (block >= nblocks) return;\n";
     s << "  const v4* own = planes + block * 6144ull + lane;\n";
     s << "  const v4* nblk = planes + (block + 1ull) * 6144ull; // column 0 of the next block\n";
@@ -281,10 +302,11 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
         s << "a" << i << " = 0, c" << i << " = 0, g" << i << " = 0, t" << i << " = 0, n" << i << " = 0";
     }
     s << ";\n";
-    s << "  __shared__ v4 stash[4][" << QW * 3 << "][64]; // head quads of each wave's block, for the wrap rows\n";
+    s << "  __shared__ v4 stash[" << WPG << "][" << QW * 3 << "][64]; // head quads of each wave's block, for the wrap rows\n";
     s << "  v4 (*st)[64] = stash[threadIdx.x >> 6];\n";
-    s << "  v4 p1lo = own[0], p1hi = own[64], p1iv = own[128];\n";
-    s << "  v4 p2lo = own[192], p2hi = own[256], p2iv = own[320];\n";
+    for (int i = 1; i <= D; ++i)
+        s << "  v4 p" << i << "lo = own[" << (i - 1) * 192 << "], p" << i << "hi = own[" << (i - 1) * 192 + 64 << "], p" << i
+          << "iv = own[" << (i - 1) * 192 + 128 << "];\n";
     s << "  for (u32 it = 0; it < " << NFULL << "u; ++it) {\n" << body.str() << "  }\n";
     s << epi.str();
     s << "}\n";
@@ -327,6 +349,10 @@ JitFilter *jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std:
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
     JitFilter *f = new JitFilter;
+    {
+        const size_t at = src.find("// IPCR_WAVES_PER_GROUP ");
+        if (at != std::string::npos) f->waves_per_group = (unsigned)atoi(src.c_str() + at + 24);
+    }
     if (hipModuleLoadData(&f->module, code.data()) != hipSuccess ||
         hipModuleGetFunction(&f->fn, f->module, "ipcr_filter") != hipSuccess) {
         err = "hipModuleLoadData/GetFunction failed for the specialised filter";
@@ -340,9 +366,10 @@ hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint
                       uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0) return hipSuccess;
     void *args[] = {(void *)&planes, (void *)&nblocks, (void *)&queue, (void *)&qcap, (void *)&qcount};
-    const unsigned grid = (unsigned)((nblocks + 3) / 4);
+    const unsigned wpg = f->waves_per_group, threads = wpg * 64u;
+    const unsigned grid = (unsigned)((nblocks + wpg - 1) / wpg);
     // start/stop are attached to this dispatch itself (its begin/end timestamps)
-    return hipExtModuleLaunchKernel(f->fn, grid * 256u, 1, 1, 256, 1, 1, 0, st, args, nullptr, start, stop, 0);
+    return hipExtModuleLaunchKernel(f->fn, grid * threads, 1, 1, threads, 1, 1, 0, st, args, nullptr, start, stop, 0);
 }
 
 void jit_destroy(JitFilter *f) {

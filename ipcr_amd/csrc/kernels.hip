@@ -270,15 +270,25 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint32_t *__restrict_
         uint32_t mm = 0;
         uint64_t m0 = 0, m1 = 0;
         bool ok = true;
-        for (uint32_t j = 0; j < L; ++j) {
-            const uint32_t g = base_bits(planes, P + j);
-            const uint32_t onehot = (g & 4u) ? 0u : (1u << (g & 3u));
-            const uint32_t m = pp->mask[j];
-            if ((m & onehot) == 0u) {
-                if (m & 16u) { ok = false; break; }
-                if (++mm > max_mm) { ok = false; break; }
-                if (j < 64u) m0 |= 1ull << j; else m1 |= 1ull << (j - 64u);
+        // 8 positions per round: their 24 tile words are loaded back to back (independent
+        // addresses), then compared; the early exit is taken between rounds only
+        for (uint32_t j0 = 0; j0 < L && ok; j0 += 8u) {
+            uint32_t g[8];
+#pragma unroll
+            for (uint32_t t = 0; t < 8u; ++t) g[t] = (j0 + t < L) ? base_bits(planes, P + j0 + t) : 0u;
+#pragma unroll
+            for (uint32_t t = 0; t < 8u; ++t) {
+                const uint32_t j = j0 + t;
+                if (j >= L) break;
+                const uint32_t onehot = (g[t] & 4u) ? 0u : (1u << (g[t] & 3u));
+                const uint32_t m = pp->mask[j];
+                if ((m & onehot) == 0u) {
+                    if (m & 16u) ok = false;
+                    ++mm;
+                    if (j < 64u) m0 |= 1ull << j; else m1 |= 1ull << (j - 64u);
+                }
             }
+            if (mm > max_mm) ok = false;
         }
         if (!ok) continue;
         uint32_t flag = 0;

@@ -117,3 +117,73 @@ def allgather_record_meta(lens: Sequence[int], flags: Sequence[int], device=None
         all_lens += [int(v) for v in recv[r, 0, :ns[r]]]
         all_flags += [int(v) for v in recv[r, 1, :ns[r]]]
     return all_lens, all_flags
+
+
+class HitExchanger:
+    """Persistent buffers for the per-step all-gatherv of hit records: ONE collective per step
+    (a max-padded all-gather whose first 32-byte slot carries this rank's hit and record counts);
+    a second, larger round happens only when some rank overflows the current capacity, and every
+    rank takes that decision from the same gathered header, so they stay in lock step."""
+
+    def __init__(self, device=None, cap_hits: int = 4096, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.device = device if device is not None else torch.device("cpu")
+        self.cap = 0
+        self._alloc(cap_hits)
+
+    def _alloc(self, cap: int) -> None:
+        torch = self.torch
+        self.cap = cap
+        n = (cap + 1) * 32
+        pin = self.device.type == "cuda"
+        self.h_send = torch.zeros(n, dtype=torch.uint8, pin_memory=pin)
+        self.h_recv = torch.zeros(self.world * n, dtype=torch.uint8, pin_memory=pin)
+        if self.device.type == "cuda":
+            self.d_send = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            self.d_recv = torch.zeros(self.world * n, dtype=torch.uint8, device=self.device)
+        else:
+            self.d_send, self.d_recv = self.h_send, self.h_recv
+
+    def allgather(self, local: np.ndarray, n_local_records: int):
+        """-> (all hits with job-global record index, per-rank (hit_start, hit_end), record offsets)"""
+        assert local.dtype == HIT_DTYPE
+        if not self.active:
+            return local, [(0, len(local))], [0]
+        torch = self.torch
+        while True:
+            n = min(len(local), self.cap)
+            hs = self.h_send.numpy()
+            hs[:16].view(np.int64)[:] = (len(local), n_local_records)
+            if n:
+                hs[32:32 + n * 32] = local[:n].view(np.uint8).reshape(-1)
+            if self.d_send is not self.h_send:
+                self.d_send.copy_(self.h_send, non_blocking=True)
+            self.dist.all_gather_into_tensor(self.d_recv, self.d_send, group=self.group)
+            if self.d_recv is not self.h_recv:
+                self.h_recv.copy_(self.d_recv, non_blocking=True)
+                torch.cuda.current_stream(self.device).synchronize()
+            hr = self.h_recv.numpy().reshape(self.world, (self.cap + 1) * 32)
+            meta = hr[:, :16].copy().view(np.int64).reshape(self.world, 2)
+            need = int(meta[:, 0].max())
+            if need <= self.cap:
+                break
+            cap = self.cap
+            while cap < need:
+                cap *= 2
+            self._alloc(cap)  # identical on every rank: all saw the same header
+        parts, ranges, offsets, off, pos = [], [], [], 0, 0
+        for r in range(self.world):
+            cnt, nrec = int(meta[r, 0]), int(meta[r, 1])
+            part = hr[r, 32:32 + cnt * 32].copy().view(HIT_DTYPE)
+            part["record"] += np.uint32(off)
+            parts.append(part)
+            ranges.append((pos, pos + cnt))
+            offsets.append(off)
+            pos += cnt
+            off += nrec
+        return np.concatenate(parts), ranges, offsets

@@ -40,6 +40,13 @@ local_hits = np.concatenate([synth_hits(cp, seqs[g], cfg.MaxMM, i, mode) for i, 
 lens = [len(seqs[g]) for g in mine]
 flags = [(1 if reset[i] else 0) | (2 if mode else 0) for i in range(len(lens))]
 all_hits, offsets = dist.allgather_hits(local_hits, len(lens))      # the all-gatherv
+xchg = dist.HitExchanger(cap_hits=4)                       # tiny capacity: forces the agreed regrow round
+x_hits, x_ranges, x_offsets = xchg.allgather(local_hits, len(lens))
+assert x_offsets == offsets and np.array_equal(x_hits, all_hits) and xchg.cap >= max(b - a for a, b in x_ranges)
+a, b = x_ranges[rank]
+assert np.array_equal(x_hits[a:b]["pos"], local_hits["pos"])
+x2, _, _ = xchg.allgather(local_hits, len(lens))          # steady state: one collective
+assert np.array_equal(x2, all_hits)
 all_lens, all_flags = dist.allgather_record_meta(lens, flags)
 assert offsets == [0, 3] and all_lens == [4000] * 5 and len(all_flags) == 5
 sc = engine.SimulationScratch(cp, host_only=True)
@@ -50,6 +57,10 @@ want = []
 for r, s in enumerate(seqs):
     want += [("rec%d" % r,) + w.sig() for w in op.scan(s)]
 assert [(g.SequenceID,) + g.sig() for g in got] == want and len(want) >= 10
+# join partitioned by record: each rank joins its own slice of the gathered hits
+mine_got = eng.JoinHits(cp, sc, x_hits[a:b], all_lens, all_flags, ["rec%d" % r for r in range(5)])
+mine_want = [w for w in want if int(w[0][3:]) in mine]
+assert [(g.SequenceID,) + g.sig() for g in mine_got] == mine_want
 tdist.barrier()
 print("RANK_OK", rank, len(got))
 '''
