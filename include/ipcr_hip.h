@@ -143,7 +143,9 @@ int32_t ipcr_panel_have(const ipcr_panel *p, int32_t pair, char which);
 ipcr_status ipcr_panel_set_specialize(ipcr_panel *p, int32_t enable);
 /* HIP source of the panel-specialised filter kernel (what hiprtc compiles at first scan);
  * mode 0 = records without non-ACGT bytes, 1 = with.  Writes at most cap bytes (NUL-terminated),
- * *needed = full length + 1; an empty string means the panel is not specialisable. */
+ * *needed = full length + 1; an empty string means the panel is not specialisable (a primer
+ * longer than 32 nt).  Large panels are cut into groups of patterns, one kernel each; this
+ * returns the first group's source. */
 ipcr_status ipcr_panel_filter_source(const ipcr_panel *p, int32_t mode, char *out, size_t cap, size_t *needed);
 
 /* introspection of the compiled panel: the distinct patterns the device scans.

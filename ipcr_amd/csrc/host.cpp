@@ -160,7 +160,7 @@ struct PatternSet {
     std::vector<uint32_t> ids; // global pattern ids scanned in this mode
     std::vector<ipcr_dev_pattern> host;
     ipcr_dev_pattern *dev = nullptr;
-    ipcr::JitFilter *jit = nullptr;
+    std::vector<ipcr::JitFilter *> jit; // one kernel per pattern group
     bool jit_tried = false;
     std::string jit_error;
 };
@@ -319,7 +319,7 @@ void ipcr_panel_destroy(ipcr_panel *p) {
     if (!p) return;
     for (auto &s : p->set) {
         if (s.dev) (void)hipFree(s.dev);
-        if (s.jit) ipcr::jit_destroy(s.jit);
+        for (ipcr::JitFilter *f : s.jit) ipcr::jit_destroy(f);
     }
     delete p;
 }
@@ -363,7 +363,9 @@ int32_t ipcr_panel_slot_pattern(const ipcr_panel *p, int32_t pair, char which, i
 
 ipcr_status ipcr_panel_filter_source(const ipcr_panel *p, int32_t mode, char *out, size_t cap, size_t *needed) {
     if (!p || mode < 0 || mode > 1) return fail(IPCR_ERR_INVALID, "ipcr_panel_filter_source: bad argument");
-    const std::string src = ipcr::jit_source(p->set[mode].host, p->cfg.max_mm);
+    const std::vector<ipcr_dev_pattern> &all = p->set[mode].host;
+    const size_t G = ipcr::jit_group_size(all); // source of the first pattern group
+    const std::string src = G ? ipcr::jit_source(std::vector<ipcr_dev_pattern>(all.begin(), all.begin() + (long)std::min(G, all.size())), p->cfg.max_mm) : std::string();
     if (needed) *needed = src.size() + 1;
     if (out && cap) {
         const size_t n = std::min(cap - 1, src.size());
@@ -708,8 +710,10 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     for (int attempt = 0; attempt < 8; ++attempt) {
         const auto te = std::chrono::steady_clock::now();
         HIPCHK(hipMemsetAsync(s->d_counts, 0, 32, s->stream));
-        if (set.jit) {
-            HIPCHK(ipcr::jit_launch(set.jit, s->stream, g->planes, nblocks, s->d_queue, s->qcap, s->d_counts, s->ev[0], s->ev[1]));
+        if (!set.jit.empty()) {
+            for (size_t gi = 0; gi < set.jit.size(); ++gi) // every group streams the tiles once
+                HIPCHK(ipcr::jit_launch(set.jit[gi], s->stream, g->planes, nblocks, s->d_queue, s->qcap, s->d_counts,
+                                        gi == 0 ? s->ev[0] : nullptr, gi + 1 == set.jit.size() ? s->ev[1] : nullptr));
             s->stats.kernel_kind = 1;
         } else {
             HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)set.ids.size(),

@@ -26,9 +26,12 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
+#include <thread>
 
 namespace ipcr {
 
@@ -130,7 +133,7 @@ static int env_int(const char *name, int dflt, int lo, int hi) {
     return x < lo ? lo : (x > hi ? hi : x);
 }
 
-std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
+std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigned qbase) {
     if (pats.empty() || pats.size() > 48) return "";
     // tuning knobs (defaults are the measured best on MI355X for the C2 panel)
     const int D = env_int("IPCR_JIT_DEPTH", 2, 1, 4);      // row-quads prefetched ahead
@@ -216,7 +219,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
         b << "          if (all != 0xFFFFFFFFu) { // rare: some window survived, hand the word to the verifier\n";
         b << "            const u64 pos = posbase + (u64)(" << xexpr << " - " << LM1 << "u);\n";
         for (size_t q = 0; q < pats.size(); ++q)
-            b << "            if (f" << q << " != 0xFFFFFFFFu) push(" << q << "ull, pos, ~f" << q << ", queue, qcap, qcount);\n";
+            b << "            if (f" << q << " != 0xFFFFFFFFu) push(" << (qbase + q) << "ull, pos, ~f" << q << ", queue, qcap, qcount);\n";
         b << "          }\n        }\n      }\n";
         return b.str();
     };
@@ -314,22 +317,14 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k) {
     return s.str();
 }
 
-JitFilter *jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err) {
-    const std::string src = jit_source(pats, max_mm);
-    if (src.empty()) { err = "panel not specialisable (more than 48 patterns or a primer longer than 32 nt)"; return nullptr; }
+namespace {
+
+// hiprtc -> code object for one group (no device needed except for the arch name)
+bool compile_group(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &err) {
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "ipcr_filter.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         err = "hiprtcCreateProgram failed";
-        return nullptr;
-    }
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    hipDeviceProp_t prop;
-    std::string arch = "gfx950";
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0]) {
-        arch = prop.gcnArchName;
-        const size_t colon = arch.find(':');
-        if (colon != std::string::npos) arch = arch.substr(0, colon);
+        return false;
     }
     const std::string archopt = "--offload-arch=" + arch;
     const char *opts[] = {archopt.c_str(), "-O3"};
@@ -341,25 +336,90 @@ JitFilter *jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std:
         if (n) hiprtcGetProgramLog(prog, &log[0]);
         err = std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log;
         hiprtcDestroyProgram(&prog);
-        return nullptr;
+        return false;
     }
     size_t csize = 0;
     hiprtcGetCodeSize(prog, &csize);
-    std::vector<char> code(csize);
+    code.resize(csize);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
-    JitFilter *f = new JitFilter;
-    {
-        const size_t at = src.find("// IPCR_WAVES_PER_GROUP ");
-        if (at != std::string::npos) f->waves_per_group = (unsigned)atoi(src.c_str() + at + 24);
+    return true;
+}
+
+} // namespace
+
+size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats) {
+    for (const auto &p : pats)
+        if (p.len == 0 || p.len > 32) return 0; // not specialisable: table-driven filter
+    if (pats.empty()) return 0;
+    // the unrolled main loop of one kernel should stay inside the 64 KiB instruction cache:
+    // ~200 B of hot code per pattern per row step, W row steps
+    const size_t G = (size_t)env_int("IPCR_JIT_GROUP", 12, 1, 48);
+    const size_t ngroups = (pats.size() + G - 1) / G;
+    // every group is a separate hiprtc compile (seconds each, serialised inside hiprtc): beyond
+    // a few groups the table-driven filter is the better trade until the seed-index kernel for
+    // large panels exists
+    if (ngroups > (size_t)env_int("IPCR_JIT_MAX_GROUPS", 8, 1, 4096)) return 0;
+    return (pats.size() + ngroups - 1) / ngroups; // balanced
+}
+
+// Large panels are cut into groups of patterns; every group becomes its own kernel (each
+// streams the tiles once and appends to the same candidate queue).  Groups compile in parallel.
+std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err) {
+    std::vector<JitFilter *> out;
+    const size_t G = jit_group_size(pats);
+    if (G == 0) { err = "panel not specialised (a primer longer than 32 nt, or more pattern groups than IPCR_JIT_MAX_GROUPS)"; return out; }
+    const size_t ngroups = (pats.size() + G - 1) / G;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    std::string arch = "gfx950";
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0]) {
+        arch = prop.gcnArchName;
+        const size_t colon = arch.find(':');
+        if (colon != std::string::npos) arch = arch.substr(0, colon);
     }
-    if (hipModuleLoadData(&f->module, code.data()) != hipSuccess ||
-        hipModuleGetFunction(&f->fn, f->module, "ipcr_filter") != hipSuccess) {
-        err = "hipModuleLoadData/GetFunction failed for the specialised filter";
-        jit_destroy(f);
-        return nullptr;
+    std::vector<std::string> srcs(ngroups), errs(ngroups);
+    std::vector<std::vector<char>> codes(ngroups);
+    std::vector<char> ok(ngroups, 0);
+    for (size_t g = 0; g < ngroups; ++g) {
+        const size_t q0 = g * G, q1 = std::min(pats.size(), q0 + G);
+        srcs[g] = jit_source(std::vector<ipcr_dev_pattern>(pats.begin() + (long)q0, pats.begin() + (long)q1), max_mm, (unsigned)q0);
     }
-    return f;
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads == 0) nthreads = 4;
+    nthreads = (unsigned)std::min<size_t>({(size_t)nthreads, (size_t)16, ngroups});
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const size_t g = next.fetch_add(1);
+            if (g >= ngroups) break;
+            ok[g] = compile_group(srcs[g], arch, codes[g], errs[g]) ? 1 : 0;
+        }
+    };
+    if (nthreads <= 1) worker();
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthreads; ++t) th.emplace_back(worker);
+        for (auto &t : th) t.join();
+    }
+    for (size_t g = 0; g < ngroups; ++g)
+        if (!ok[g]) { err = errs[g]; return out; }
+    for (size_t g = 0; g < ngroups; ++g) {
+        JitFilter *f = new JitFilter;
+        const size_t at = srcs[g].find("// IPCR_WAVES_PER_GROUP ");
+        if (at != std::string::npos) f->waves_per_group = (unsigned)atoi(srcs[g].c_str() + at + 24);
+        if (hipModuleLoadData(&f->module, codes[g].data()) != hipSuccess ||
+            hipModuleGetFunction(&f->fn, f->module, "ipcr_filter") != hipSuccess) {
+            err = "hipModuleLoadData/GetFunction failed for the specialised filter";
+            jit_destroy(f);
+            for (JitFilter *o : out) jit_destroy(o);
+            out.clear();
+            return out;
+        }
+        out.push_back(f);
+    }
+    return out;
 }
 
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,

@@ -13,10 +13,14 @@ namespace ipcr {
 
 struct JitFilter;
 
-// HIP source of the specialised filter for these patterns (also used by the build check)
-std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int max_mm);
-// nullptr (and `err` set) when the panel cannot be specialised or hiprtc fails
-JitFilter *jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err);
+// HIP source of the specialised filter for one group of patterns (also used by the build
+// check); queue entries carry pattern index qbase + position in `pats`
+std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int max_mm, unsigned qbase = 0);
+// patterns per kernel for this panel; 0 = not specialisable (table-driven filter)
+size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats);
+// one kernel per pattern group, compiled in parallel; empty (and `err` set) when the panel
+// cannot be specialised or hiprtc fails
+std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err);
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,
                       uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop);
 void jit_destroy(JitFilter *f);

@@ -443,14 +443,16 @@ def test_config_c3_iupac_k3_circular(hip):
 def test_config_c4_multiplex_panel(hip):
     from ipcr_amd import workloads
     rng = random.Random(24)
-    pairs = workloads.c4_pairs(24)  # 24 TSV rows -> 72 pairs, 96 distinct patterns: table-driven filter
+    pairs = workloads.c4_pairs(24)  # 24 TSV rows -> 72 pairs, 96 distinct patterns: 8 kernel groups
     g, seqs = build_planted_genome(hip, rng, 3, 300_000, pairs[:24], 0x5eed1237)
     cfg = hip.engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)
-    _, cp, sc, got = scan_and_compare(hip, cfg, pairs, g, seqs)
-    assert sc.stats().kernel_kind == 2 and len(got) >= 10
-    small = workloads.c4_pairs(5)   # 15 pairs, 20 distinct patterns: specialised filter
-    _, _, sc2, _ = scan_and_compare(hip, cfg, small, g, seqs)
-    assert sc2.stats().kernel_kind == 1
+    eng, cp, sc, got = scan_and_compare(hip, cfg, pairs, g, seqs)
+    assert sc.stats().kernel_kind == 1 and sc.stats().n_patterns == 96 and len(got) >= 10
+    cp2 = eng.CompilePanel(pairs)
+    cp2.set_specialize(False)       # same panel on the table-driven filter
+    sc2 = eng.NewSimulationScratch(cp2)
+    got2 = eng.ScanGenome(g, cp2, sc2)
+    assert sc2.stats().kernel_kind == 2 and [p.sig() for p in got2] == [p.sig() for p in got]
     g.close()
 
 

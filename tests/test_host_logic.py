@@ -210,8 +210,12 @@ def test_filter_source_is_generated_for_the_headline_panels():
     assert cp.num_patterns == 4  # 3 pairs / 12 orientation slots / 4 distinct patterns
     src = cp.filter_source(0)
     assert "ipcr_filter" in src and src.count("// pattern 0:") > 0
+    mid = engine.New(engine.Config(MaxMM=2, TerminalWindow=3)).CompilePanel(workloads.c4_pairs(24))
+    assert "ipcr_filter" in mid.filter_source(0)  # 96 patterns: cut into 8 groups, one kernel each
     big = engine.New(engine.Config(MaxMM=2, TerminalWindow=3)).CompilePanel(workloads.c4_pairs(64))
-    assert big.filter_source(0) == ""  # > 48 patterns: table-driven filter (still on the device)
+    assert big.filter_source(0) == ""  # 256 patterns: too many kernels to compile, table-driven filter
+    long_p = "ACGT" * 9  # 36 nt > 32: table-driven filter (still on the device)
+    assert engine.New(engine.Config(MaxMM=1)).CompilePanel([primer.Pair("l", long_p, long_p)]).filter_source(0) == ""
 
 
 def test_workload_primers_match_reference_generator():  # performance_benchmark_test.go:78-93
