@@ -133,18 +133,101 @@ static int env_int(const char *name, int dflt, int lo, int hi) {
     return x < lo ? lo : (x > hi ? hi : x);
 }
 
+// "more than k of the B block flags e0..e{B-1} are set", OR-ed into f.  Two bit-sliced
+// counters; the cheaper one (in VALU ops) is emitted:
+//  * thermometer: u[t] = at least t bad blocks so far (one and-or per level per block);
+//  * carry-save adder tree: full adders (xor, xor, bitselect) compress the flags into binary
+//    weight planes; carries beyond the top bit of k only feed an overflow OR.
+std::string count_code(int B, int k) {
+    std::ostringstream th;
+    int th_cost = 0;
+    {
+        std::vector<bool> live((size_t)k + 2, false);
+        for (int i = 0; i < B; ++i) {
+            for (int t = std::min(i + 1, k + 1); t >= 1; --t) {
+                if (t < k + 1 - (B - 1 - i)) continue; // cannot reach level k+1 any more: dead
+                const std::string prev = (t == 1) ? "" : "u" + std::to_string(t - 1) + " & ";
+                if (t >= 2 && !live[(size_t)t - 1]) continue;
+                if (!live[(size_t)t]) {
+                    th << "            u32 u" << t << " = " << prev << "e" << i << ";\n";
+                    live[(size_t)t] = true;
+                } else {
+                    th << "            u" << t << " |= " << prev << "e" << i << ";\n";
+                }
+                ++th_cost;
+            }
+        }
+        th << "            f |= u" << (k + 1) << ";\n";
+        ++th_cost;
+    }
+    std::ostringstream cs;
+    int cs_cost = 0;
+    {
+        int wmax = 0;
+        while ((2 << wmax) <= k) ++wmax; // top weight whose bit can be set in a value <= k
+        std::vector<std::vector<std::string>> planes((size_t)wmax + 2);
+        for (int i = 0; i < B; ++i) planes[0].push_back("e" + std::to_string(i));
+        std::vector<std::string> ovf;
+        int tmp = 0;
+        for (int w = 0; w <= wmax; ++w) {
+            auto &pl = planes[(size_t)w];
+            while (pl.size() >= 2) {
+                const std::string a = pl[0], b = pl[1];
+                const std::string t = "x" + std::to_string(tmp++), sum = "x" + std::to_string(tmp++), cy = "x" + std::to_string(tmp++);
+                if (pl.size() >= 3) {
+                    const std::string c = pl[2];
+                    cs << "            const u32 " << t << " = " << a << " ^ " << b << ", " << sum << " = " << t << " ^ " << c << ", "
+                       << cy << " = (" << t << " & " << c << ") | (~" << t << " & " << a << ");\n";
+                    pl.erase(pl.begin(), pl.begin() + 3);
+                    cs_cost += 3;
+                } else {
+                    cs << "            const u32 " << sum << " = " << a << " ^ " << b << ", " << cy << " = " << a << " & " << b << ";\n";
+                    pl.erase(pl.begin(), pl.begin() + 2);
+                    cs_cost += 2;
+                }
+                pl.push_back(sum);
+                if (w == wmax) ovf.push_back(cy); else planes[(size_t)w + 1].push_back(cy);
+            }
+        }
+        // value = sum of planes[w][0] << w  (w <= wmax); fail = overflow | value > k
+        std::string gt, eq;
+        for (int w = wmax; w >= 0; --w) {
+            const std::string bw = planes[(size_t)w].empty() ? std::string("0u") : planes[(size_t)w][0];
+            if (((k >> w) & 1) == 0) {
+                const std::string term = eq.empty() ? bw : "(" + eq + " & " + bw + ")";
+                gt = gt.empty() ? term : gt + " | " + term;
+                eq = eq.empty() ? "~" + bw : eq + " & ~" + bw;
+                cs_cost += 2;
+            } else {
+                eq = eq.empty() ? bw : eq + " & " + bw;
+                cs_cost += 1;
+            }
+        }
+        cs << "            f |= ";
+        bool first = true;
+        for (const auto &o : ovf) { cs << (first ? "" : " | ") << o; first = false; ++cs_cost; }
+        if (!gt.empty()) { cs << (first ? "" : " | ") << gt; first = false; }
+        if (first) cs << "0u";
+        cs << ";\n";
+    }
+    const int force = env_int("IPCR_JIT_COUNTER", 0, 0, 2); // 1 = thermometer, 2 = adder tree
+    const bool use_cs = force == 2 || (force == 0 && cs_cost < th_cost);
+    return use_cs ? cs.str() : th.str();
+}
+
 std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigned qbase) {
     if (pats.empty() || pats.size() > 48) return "";
-    // tuning knobs (defaults are the measured best on MI355X for the C2 panel)
-    const int D = env_int("IPCR_JIT_DEPTH", 2, 1, 4);      // row-quads prefetched ahead
-    const int WPS = env_int("IPCR_JIT_WAVES", 2, 1, 4);    // __launch_bounds__ waves per SIMD
-    const int WPG = env_int("IPCR_JIT_WG", 4, 1, 4);       // waves per workgroup
     int Lmax = 0;
     for (const auto &p : pats) {
         if (p.len == 0 || p.len > 32) return "";
         Lmax = std::max<int>(Lmax, p.len);
     }
     const int W = (Lmax + 3) / 4 * 4;        // window rows, multiple of the row-quad
+    // tuning knobs; defaults = best of the sweeps on MI355X (tools/sweep_jit.py): windows up to
+    // 20 rows leave registers for two quads of prefetch, wider ones spill unless it is one
+    const int D = env_int("IPCR_JIT_DEPTH", W <= 20 ? 2 : 1, 1, 4);    // row-quads prefetched ahead
+    const int WPS = env_int("IPCR_JIT_WAVES", 2, 1, 4);                // __launch_bounds__ waves per SIMD
+    const int WPG = env_int("IPCR_JIT_WG", W <= 20 ? 2 : 4, 1, 4);     // waves per workgroup
     const int QPI = W / 4;                   // quads per unrolled main-loop iteration
     const int LM1 = Lmax - 1;                // rows of the next strand a window can reach
     const int QTOTAL = (128 + LM1 + 3) / 4;  // quads streamed: 32 of the strand + the wrap rows
@@ -176,21 +259,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
                 const int B = (int)pl.blocks.size();
                 for (int i = 0; i < B; ++i)
                     o << "            const u32 e" << i << " = " << orchain(pl.blocks[(size_t)i]) << ";\n";
-                // thermometer counter over the block flags: u[t] = at least t bad blocks so far
-                std::vector<bool> live((size_t)k + 2, false);
-                for (int i = 0; i < B; ++i) {
-                    for (int t = std::min(i + 1, k + 1); t >= 1; --t) {
-                        const std::string prev = (t == 1) ? "" : "u" + std::to_string(t - 1) + " & ";
-                        if (t >= 2 && !live[(size_t)t - 1]) continue;
-                        if (!live[(size_t)t]) {
-                            o << "            u32 u" << t << " = " << prev << "e" << i << ";\n";
-                            live[(size_t)t] = true;
-                        } else {
-                            o << "            u" << t << " |= " << prev << "e" << i << ";\n";
-                        }
-                    }
-                }
-                o << "            f |= u" << (k + 1) << ";\n";
+                o << count_code(B, k);
             }
             o << "            f" << q << " = f;\n          }\n";
             if (env_int("IPCR_JIT_SCHEDBAR", 0, 0, 1)) o << "          __builtin_amdgcn_sched_barrier(0);\n";

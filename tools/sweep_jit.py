@@ -18,7 +18,7 @@ if which == "c2":
 else:
     cfg, pairs = E.Config(MaxMM=3, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12, Circular=True), workloads.c3_pairs()
 eng = E.New(cfg)
-configs = [(2, 2, 4), (3, 2, 4), (1, 2, 4), (2, 2, 2), (3, 2, 2), (2, 3, 2), (3, 3, 2), (2, 3, 1), (4, 1, 4), (3, 1, 4), (2, 2, 1), (3, 2, 1)]
+configs = [tuple(int(x) for x in c.split(',')) for c in os.environ['SWEEP_CONFIGS'].split(';')] if os.environ.get('SWEEP_CONFIGS') else [(2, 2, 4), (3, 2, 4), (1, 2, 4), (2, 2, 2), (3, 2, 2), (2, 3, 2), (3, 3, 2), (2, 3, 1), (4, 1, 4), (3, 1, 4), (2, 2, 1), (3, 2, 1)]
 for (d, w, wg) in configs:
     os.environ["IPCR_JIT_DEPTH"], os.environ["IPCR_JIT_WAVES"], os.environ["IPCR_JIT_WG"] = str(d), str(w), str(wg)
     cp = eng.CompilePanel(pairs)
