@@ -197,6 +197,19 @@ uint64_t ipcr_genome_total_bases(const ipcr_genome *g);
 uint64_t ipcr_genome_tile_bytes(const ipcr_genome *g);
 double ipcr_genome_pack_ms(const ipcr_genome *g); /* accumulated pack-kernel time */
 
+/* ---- FASTA record / rolling-chunk stream -- core/fasta/path_ctx.go:19-179 ----
+ * open: gzip by content, "-" = stdin (open.go:29-50).  chunk_size <= 0 or chunk_size <= overlap
+ * streams whole records; else windows "id:start-end" advancing by chunk_size - overlap.
+ * Sequence is TrimSpace'd per line and a-z upper-cased (normalize.go:5-14). */
+typedef struct ipcr_fasta ipcr_fasta;
+ipcr_status ipcr_fasta_open(const char *path, int64_t chunk_size, int64_t overlap, ipcr_fasta **out);
+void ipcr_fasta_close(ipcr_fasta *f);
+/* next record/chunk; *got = 0 at end of input; *id and *seq stay valid until the next call */
+ipcr_status ipcr_fasta_next(ipcr_fasta *f, const char **id, const uint8_t **seq, uint64_t *len, int32_t *got);
+/* pack every record of a FASTA file into a resident genome; record IDs come back '\n'-joined */
+ipcr_status ipcr_genome_add_fasta(ipcr_genome *g, const char *path, uint32_t *n_added, char *ids_out, size_t cap,
+                                  size_t *ids_needed);
+
 /* scan every record of a resident genome with one launch; products carry `record` */
 ipcr_status ipcr_scan_genome(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g,
                              ipcr_emit_fn emit, void *user);

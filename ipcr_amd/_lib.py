@@ -99,6 +99,10 @@ SYMBOLS = {
     "ipcr_genome_tile_bytes": (C.c_uint64, [C.c_void_p]),
     "ipcr_genome_pack_ms": (C.c_double, [C.c_void_p]),
     "ipcr_genome_record_flags": (C.c_uint8, [C.c_void_p, C.c_uint32]),
+    "ipcr_fasta_open": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
+    "ipcr_fasta_close": (None, [C.c_void_p]),
+    "ipcr_fasta_next": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
+    "ipcr_genome_add_fasta": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ipcr_scan_genome": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipcr_scan_genome_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipcr_join_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_uint64),

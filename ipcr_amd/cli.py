@@ -1,0 +1,192 @@
+"""Minimal `ipcr` / `ipcr-probe` / `ipcr-multiplex` driver over the HIP engine.
+
+Only what sits directly either side of the scan path ("next" 1 and 2):
+FASTA -> resident tiles, the collector's total product order, and the text/TSV rows -- with the
+reference's flag names and defaults (internal/clibase/common.go:61-110) so outputs can be
+diffed against `ipcr`.  Thermo scoring, pretty blocks, JSON and nested PCR are out of scope.
+
+    python -m ipcr_amd.cli -f AGAGTTTGATCMTGGCTCAG -r TACGGYTACCTTGTTAYGACTT --mismatches 0 demo.fa
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import functools
+import os
+import sys
+from typing import List, Optional, Sequence
+
+from . import _lib, engine, primer
+
+TSV_HEADER = ("source_file\tsequence_id\texperiment_id\tstart\tend\tlength\ttype\tfwd_mm\trev_mm"
+              "\tfwd_mm_i\trev_mm_i")                                   # internal/output/common.go:5
+TSV_HEADER_PROBE = TSV_HEADER + ("\tprobe_name\tprobe_seq\tprobe_found\tprobe_strand\tprobe_pos"
+                                 "\tprobe_mm\tprobe_site")              # internal/probeoutput/types.go:24-26
+
+
+def load_tsv(path: str) -> List[primer.Pair]:
+    """primer.LoadTSV -- core/primer/loader.go:11-61"""
+    out = []
+    with open(path) as fh:
+        for ln, line in enumerate(fh, 1):
+            line = line.strip()
+            if not line or line[0] == "#":
+                continue
+            f = line.split()
+            if len(f) < 3 or len(f) > 5:
+                raise ValueError(f"{path}:{ln} bad field count")
+            p = primer.Pair(f[0], primer.Validate(f[1]), primer.Validate(f[2]))
+            if len(f) >= 4:
+                p.MinProduct = int(f[3])
+            if len(f) == 5:
+                p.MaxProduct = int(f[4])
+            out.append(p)
+    return out
+
+
+def ints_csv(a: Sequence[int]) -> str:  # internal/output/rows.go:10-19
+    return ",".join(str(v) for v in a)
+
+
+def split_chunk_suffix(seq_id: str):
+    """common.SplitChunkSuffix -- internal/common/ids.go:11-27"""
+    colon = seq_id.rfind(":")
+    if colon == -1 or colon == len(seq_id) - 1:
+        return seq_id, 0, False
+    suffix = seq_id[colon + 1:]
+    dash = suffix.find("-")
+    if dash == -1:
+        return seq_id, 0, False
+    try:
+        start = int(suffix[:dash])
+    except ValueError:
+        return seq_id, 0, False
+    return seq_id[:colon], start, True
+
+
+def product_sort_key(source_file: str, p: engine.Product):
+    """common.LessProduct -- internal/common/sort.go:34-78 as a sort key."""
+    base, off, ok = split_chunk_suffix(p.SequenceID)
+    if not ok:
+        base, off = p.SequenceID, 0
+    return (source_file, base, p.Start + off, p.End + off, p.Length, p.Type, p.ExperimentID, p.FwdMM, p.RevMM,
+            ints_csv(p.FwdMismatchIdx), ints_csv(p.RevMismatchIdx), p.SequenceID)
+
+
+def format_row(source_file: str, p: engine.Product) -> str:
+    """output.FormatBaseRowTSV -- internal/output/rows.go:21-29"""
+    return "\t".join([source_file, p.SequenceID, p.ExperimentID, str(p.Start), str(p.End), str(p.Length), p.Type,
+                      str(p.FwdMM), str(p.RevMM), ints_csv(p.FwdMismatchIdx), ints_csv(p.RevMismatchIdx)])
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="ipcr-hip", add_help=True)
+    ap.add_argument("--primers", "-p", default="")
+    ap.add_argument("--forward", "-f", default="")
+    ap.add_argument("--reverse", "-r", default="")
+    ap.add_argument("--sequences", "-s", action="append", default=[])
+    ap.add_argument("--mismatches", "-m", type=int, default=0)
+    ap.add_argument("--min-length", type=int, default=0)
+    ap.add_argument("--max-length", type=int, default=2000)
+    ap.add_argument("--hit-cap", type=int, default=10000)
+    ap.add_argument("--terminal-window", type=int, default=3)
+    ap.add_argument("--self", dest="self_", action=argparse.BooleanOptionalAction, default=True)
+    ap.add_argument("--seed-length", type=int, default=12)
+    ap.add_argument("--circular", "-c", action="store_true")
+    ap.add_argument("--sort", action="store_true")
+    ap.add_argument("--no-header", action="store_true")
+    ap.add_argument("--multiplex", action="store_true", help="ipcr-multiplex self-pair rule (unique oligos)")
+    ap.add_argument("--probe", "-P", default="")
+    ap.add_argument("--probe-name", default="probe")
+    ap.add_argument("--probe-max-mm", "-M", type=int, default=0)
+    ap.add_argument("--require-probe", action=argparse.BooleanOptionalAction, default=True)
+    ap.add_argument("--no-match-exit-code", type=int, default=0)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("fasta", nargs="*")
+    return ap
+
+
+def run(argv: Optional[Sequence[str]] = None, stdout=None, stderr=None) -> int:
+    """app.RunContext -- internal/app/app.go:23-114 (scan-relevant part)."""
+    stdout = stdout or sys.stdout
+    stderr = stderr or sys.stderr
+    o = build_parser().parse_args(argv)
+    seq_files = list(o.sequences) + list(o.fasta)
+    try:
+        if o.primers:
+            pairs = load_tsv(o.primers)
+        else:
+            if not o.forward or not o.reverse:
+                print("error: --forward and --reverse (or --primers) are required", file=stderr)
+                return 2
+            pairs = [primer.Pair("manual", primer.Validate(o.forward), primer.Validate(o.reverse),
+                                 o.min_length, o.max_length)]              # app.go:98
+        if o.self_:
+            pairs = primer.AddSelfPairsUnique(pairs) if o.multiplex else primer.AddSelfPairs(pairs)
+    except (ValueError, OSError) as e:
+        print(f"error: {e}", file=stderr)
+        return 2
+    if not seq_files:
+        print("error: no FASTA input", file=stderr)
+        return 2
+    tw = o.terminal_window if o.terminal_window >= 1 else 0            # runutil.EffectiveTerminalWindow
+    cfg = engine.Config(MaxMM=o.mismatches, TerminalWindow=tw, MinLen=o.min_length, MaxLen=o.max_length,
+                        HitCap=o.hit_cap, SeedLen=o.seed_length, Circular=o.circular)
+    _lib.check(_lib.lib().ipcr_set_device(o.device))
+    eng = engine.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    sc = eng.NewSimulationScratch(cp)
+    rows = []
+    for path in seq_files:
+        size = os.path.getsize(path) if path != "-" and os.path.exists(path) else (1 << 28)
+        factor = 8 if path.endswith(".gz") else 1
+        g = engine.Genome(max(size * factor, 1 << 20), max_records=1 << 16)
+        n = C.c_uint32()
+        need = C.c_size_t()
+        try:
+            _lib.check(_lib.lib().ipcr_genome_add_fasta(g._h, path.encode(), C.byref(n), None, 0, C.byref(need)))
+        except _lib.IpcrError as e:
+            print(f"error: {e}", file=stderr)       # pipeline.go:174-182: record the error, go on
+            continue
+        # the IDs of what was just packed (second pass over the file is cheap next to the scan)
+        from . import fasta
+        g.ids = [r.ID for r in fasta.StreamChunks(path)] if path != "-" else ["%d" % i for i in range(n.value)]
+        prods = eng.ScanGenome(g, cp, sc)
+        probe_hits = None
+        if o.probe:
+            out = (_lib.ProbeHit * max(len(prods), 1))()
+            _lib.check(_lib.lib().ipcr_probe_products(sc._h, g._h, o.probe.encode(), o.probe_max_mm, out, len(prods)))
+            probe_hits = [out[i] for i in range(len(prods))]
+        for i, p in enumerate(prods):
+            if probe_hits is None:
+                rows.append((path, p, None))
+                continue
+            h = probe_hits[i]
+            if o.require_probe and not h.found:                         # internal/visitors/probe.go:20-22
+                continue
+            site = ""
+            if h.found:
+                amp = (g.read(p.Record, p.Start, p.End - p.Start) if p.Start <= p.End else
+                       g.read(p.Record, p.Start, g.record_len(p.Record) - p.Start) + g.read(p.Record, 0, p.End))
+                site = amp.upper()[h.pos:h.pos + len(primer.Normalize(o.probe))].decode()
+            rows.append((path, p, (h, site)))
+        g.close()
+    if o.sort:
+        rows.sort(key=lambda t: product_sort_key(t[0], t[1]))
+    if not o.no_header:
+        print(TSV_HEADER_PROBE if o.probe else TSV_HEADER, file=stdout)
+    for path, p, ph in rows:
+        line = format_row(path, p)
+        if o.probe:                                                      # probeoutput/text.go:11-28
+            h, site = ph
+            line += "\t" + "\t".join([o.probe_name, o.probe.upper(), "true" if h.found else "false",
+                                      chr(h.strand) if h.found else "", str(h.pos) if h.found else "",
+                                      str(h.mm) if h.found else "", site])
+        print(line, file=stdout)
+    if not rows and o.no_match_exit_code:
+        return o.no_match_exit_code
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(run())

@@ -47,6 +47,18 @@ ipcr_status fail(ipcr_status st, const char *fmt, ...) {
     return st;
 }
 
+} // namespace
+ipcr_status ipcr_internal_fail(ipcr_status st, const char *fmt, ...) { // for the other translation units
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+namespace {
+
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \

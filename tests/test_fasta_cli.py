@@ -1,0 +1,143 @@
+"""FASTA record/rolling-chunk stream (core/fasta) and the CLI-side formatting helpers: CPU tests;
+the end-to-end CLI runs (config C1 and friends) need a GPU."""
+import gzip
+import io
+import os
+
+import pytest
+
+import ipcr_oracle as O
+from ipcr_amd import cli, fasta, engine
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def chunks(path, cs=0, ov=0):
+    return [(r.ID, r.Seq) for r in fasta.StreamChunks(path, cs, ov)]
+
+
+def test_rolling_overlap(tmp_path):  # core/fasta/reader_test.go:91-116
+    p = tmp_path / "chunk.fa"
+    p.write_text(">s\nACGTACGTACGT\n")
+    assert chunks(str(p), 5, 2) == [("s:0-5", b"ACGTA"), ("s:3-8", b"TACGT"), ("s:6-11", b"GTACG"), ("s:9-12", b"CGT")]
+
+
+def test_short_record_keeps_base_id(tmp_path):  # reader_test.go:118-135
+    p = tmp_path / "short.fa"
+    p.write_text(">s\nACGTA\n")
+    assert chunks(str(p), 5, 2) == [("s", b"ACGTA")]
+
+
+def test_gzip_and_normalisation(tmp_path):  # reader_test.go:15-66, normalize.go:5-14
+    p = tmp_path / "t.fa.gz"
+    with gzip.open(p, "wt") as fh:
+        fh.write(">seq1\nACGT\n>seq2\nNNnn\n")
+    assert chunks(str(p)) == [("seq1", b"ACGT"), ("seq2", b"NNNN")]
+    q = tmp_path / "noext"  # gzip detected by magic, not by suffix (open.go:40-42)
+    q.write_bytes(p.read_bytes())
+    assert chunks(str(q)) == [("seq1", b"ACGT"), ("seq2", b"NNNN")]
+
+
+def test_header_id_and_stray_lines(tmp_path):  # stream.go:125-131, path_ctx.go:142-144
+    p = tmp_path / "w.fa"
+    p.write_bytes(b"ACGT\n>a\tb c\n ac gt \r\nAC\n\n>empty\n>  lead trail  \nGG")
+    assert chunks(str(p)) == [("a", b"AC GTAC"), ("empty", b""), ("lead", b"GG")]
+
+
+def test_chunk_schedule_matches_reference_rule(tmp_path):  # path_ctx.go:146-163 on many shapes
+    import random
+    rng = random.Random(3)
+    for _ in range(40):
+        n, cs, ov, width = rng.randint(0, 400), rng.randint(1, 60), rng.randint(0, 70), rng.choice([7, 60, 1000])
+        seq = "".join(rng.choice("ACGTN") for _ in range(n))
+        p = tmp_path / "r.fa"
+        p.write_text(">id x\n" + "\n".join(seq[i:i + width] for i in range(0, n, width)) + ("\n" if n else ""))
+        got = chunks(str(p), cs, ov)
+        step = cs - ov
+        if step <= 0 or n <= cs:
+            want = [("id", seq.encode())]
+        else:
+            want, ws, last = [], 0, 0
+            while n - ws > cs:
+                want.append(("id:%d-%d" % (ws, ws + cs), seq[ws:ws + cs].encode()))
+                last = ws + cs
+                ws += step
+            if last < n:
+                want.append(("id:%d-%d" % (ws, n), seq[ws:n].encode()))
+        assert got == want, (n, cs, ov, width)
+
+
+def test_split_chunk_suffix():  # internal/common/ids.go:11-27
+    assert cli.split_chunk_suffix("chr1:100-200") == ("chr1", 100, True)
+    assert cli.split_chunk_suffix("chr1") == ("chr1", 0, False)
+    assert cli.split_chunk_suffix("a:b:7-9") == ("a:b", 7, True)
+    assert cli.split_chunk_suffix("x:") == ("x:", 0, False)
+    assert cli.split_chunk_suffix("x:ab-3") == ("x:ab-3", 0, False)
+
+
+def test_row_format_and_order():  # internal/output/rows.go:21-29, internal/common/sort.go:34-78
+    P = engine.Product
+    a = P("e", "chr1", 10, 30, 20, "forward", 1, 0, (3,), ())
+    b = P("e", "chr1", 10, 30, 20, "revcomp", 0, 2, (), (9, 4))
+    c = P("e", "chr0:5-100", 2, 22, 20, "forward", 0, 0, (), ())
+    assert cli.format_row("g.fa", b) == "g.fa\tchr1\te\t10\t30\t20\trevcomp\t0\t2\t\t9,4"
+    rows = sorted([b, a, c], key=lambda p: cli.product_sort_key("g.fa", p))
+    assert rows == [c, a, b]  # base id, then global start; 'forward' < 'revcomp'
+
+
+def test_primer_tsv_loader(tmp_path):  # core/primer/loader.go:11-61
+    p = tmp_path / "p.tsv"
+    p.write_text("# comment\n\nid1 acgt TTGA\nid2\tACGT\tGGCC\t100\nid3 ACGT GGCC 100 200\n")
+    got = cli.load_tsv(str(p))
+    assert [(x.ID, x.Forward, x.Reverse, x.MinProduct, x.MaxProduct) for x in got] == [
+        ("id1", "ACGT", "TTGA", 0, 0), ("id2", "ACGT", "GGCC", 100, 0), ("id3", "ACGT", "GGCC", 100, 200)]
+    p.write_text("only two\n")
+    with pytest.raises(ValueError):
+        cli.load_tsv(str(p))
+
+
+@pytest.mark.gpu
+def test_config_c1_demo_fa_header_only():
+    """BASELINE.json configs[0]: ipcr 27F/1492R --mismatches 0 on demo.fa -> header only, exit 0."""
+    out = io.StringIO()
+    rc = cli.run(["-f", "AGAGTTTGATCMTGGCTCAG", "-r", "TACGGYTACCTTGTTAYGACTT", "--mismatches", "0",
+                  os.path.join(GOLDEN, "demo.fa")], stdout=out)
+    assert rc == 0 and out.getvalue() == cli.TSV_HEADER + "\n"
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_matches_oracle(tmp_path):
+    import random
+    rng = random.Random(8)
+    recs = []
+    fwd, rev = "ACGTTGCATGCAAGCT", "GGCCTTAAGGCCATAT"
+    for r in range(3):
+        s = list(O.bench_dna(20000, 77 + r).decode())
+        for t in range(3):
+            a = 500 + t * 5000
+            s[a:a + len(fwd)] = fwd
+            rc = O.revcomp(rev).decode()
+            s[a + 200:a + 200 + len(rc)] = rc
+        recs.append(("ctg%d" % r, "".join(s)))
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(">%s some description\n%s\n" % (i, "\n".join(s[j:j + 70].lower() for j in range(0, len(s), 70))) for i, s in recs))
+    out = io.StringIO()
+    rc = cli.run(["-f", fwd, "-r", rev, "-m", "1", "--sort", str(fa)], stdout=out)
+    assert rc == 0
+    lines = out.getvalue().splitlines()
+    assert lines[0] == cli.TSV_HEADER
+    cfg = O.Config(max_mm=1, terminal_window=3, max_len=2000, hit_cap=10000, seed_len=12)
+    pairs = [O.Pair("manual", fwd, rev, 0, 2000), O.Pair("manual+A:self", fwd, fwd), O.Pair("manual+B:self", rev, rev)]
+    want = []
+    for i, s in recs:
+        for w in O.simulate_batch(cfg, s, pairs):
+            want.append(engine.Product(w.experiment_id, i, w.start, w.end, w.length, w.type, w.fwd_mm, w.rev_mm, w.fwd_idx, w.rev_idx))
+    want.sort(key=lambda p: cli.product_sort_key(str(fa), p))
+    assert lines[1:] == [cli.format_row(str(fa), p) for p in want] and len(want) >= 9
+    # ipcr-probe overlay
+    out = io.StringIO()
+    probe = recs[0][1][600:621]
+    rc = cli.run(["-f", fwd, "-r", rev, "-m", "1", "--sort", "--probe", probe, str(fa)], stdout=out)
+    lines = out.getvalue().splitlines()
+    assert rc == 0 and lines[0] == cli.TSV_HEADER_PROBE and len(lines) >= 2
+    assert all(l.split("\t")[13] == "true" for l in lines[1:])
