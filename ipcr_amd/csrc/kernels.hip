@@ -35,43 +35,30 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
     const uint64_t base = (pairidx * 64u + lane) * IPCR_TILE_N; // record-local first base of my strand
     uint32_t saw_rst = 0;
 
-    // the whole 128-byte strand first: 8 independent 16-B loads per lane, so every 128-B line
-    // is fetched exactly once even though neighbouring lanes sit 128 B apart
-    uint32_t w[32];
-    uint32_t realmask[4]; // bit t of realmask[t/32]: byte t of the strand is inside the record
-    if (base + IPCR_TILE_N <= len) {
-#pragma unroll
-        for (uint32_t rg = 0; rg < 8; ++rg) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(seq + base + rg * 16u);
-            w[rg * 4 + 0] = v.x; w[rg * 4 + 1] = v.y; w[rg * 4 + 2] = v.z; w[rg * 4 + 3] = v.w;
-        }
-        realmask[0] = realmask[1] = realmask[2] = realmask[3] = 0xFFFFFFFFu;
-    } else {
-#pragma unroll
-        for (uint32_t i = 0; i < 32; ++i) w[i] = 0;
-        realmask[0] = realmask[1] = realmask[2] = realmask[3] = 0;
-        for (uint32_t t = 0; t < IPCR_TILE_N; ++t) {
-            if (base + t < len) {
-                const uint32_t by = seq[base + t];
-#pragma unroll
-                for (uint32_t i = 0; i < 32; ++i)
-                    if (i == (t >> 2)) w[i] |= by << ((t & 3u) * 8u);
-#pragma unroll
-                for (uint32_t i = 0; i < 4; ++i)
-                    if (i == (t >> 5)) realmask[i] |= 1u << (t & 31u);
+    for (uint32_t rg = 0; rg < 8; ++rg) {
+        const uint64_t p0 = base + rg * 16u;
+        uint32_t w[4] = {0, 0, 0, 0};
+        uint32_t realmask; // bit t: byte t is inside the record
+        if (p0 + 16u <= len) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(seq + p0);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            realmask = 0xFFFFu;
+        } else {
+            realmask = 0;
+            for (uint32_t t = 0; t < 16; ++t) {
+                if (p0 + t < len) {
+                    w[t >> 2] |= (uint32_t)seq[p0 + t] << ((t & 3u) * 8u);
+                    realmask |= 1u << t;
+                }
             }
         }
-    }
-#pragma unroll
-    for (uint32_t rg = 0; rg < 8; ++rg) {
 #pragma unroll
         for (uint32_t q = 0; q < 4; ++q) {
             uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0; // lanes 0..7 collect rows 4q..4q+3
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
-                const uint32_t t = rg * 16u + q * 4u + k;
-                const uint32_t b = (w[rg * 4 + q] >> (k * 8u)) & 0xFFu;
-                const bool real = (realmask[t >> 5] >> (t & 31u)) & 1u;
+                const uint32_t b = (w[q] >> (k * 8u)) & 0xFFu;
+                const bool real = (realmask >> (q * 4u + k)) & 1u;
                 const uint32_t u = b & 0xDFu;
                 const bool isacgt = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
                 const bool valid = isacgt & (b == u) & real;
