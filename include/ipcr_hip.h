@@ -107,7 +107,7 @@ typedef struct {
     uint64_t candidates;  /* filter survivors handed to the verifier */
     uint64_t hits;        /* verified primer.Match records */
     uint64_t products;
-    int32_t kernel_kind;  /* 1 = panel-specialised (runtime-compiled) filter, 2 = table-driven filter */
+    int32_t kernel_kind;  /* 1 = panel-specialised (runtime-compiled) filter, 2 = table-driven filter, 3 = seed-index filter */
     int32_t n_patterns;
     double enqueue_ms;    /* host time to enqueue memset + kernels + copies */
     double wait_ms;       /* host time blocked in the stream synchronise */

@@ -39,3 +39,34 @@ struct ipcr_amp_seg { // amplicon = [pa, pa+len_a) ++ [pb, pb+len_b) in padded c
 struct ipcr_probe_rec { // layout-identical to ipcr_probe_hit
     int32_t found, strand, pos, mm;
 };
+
+// ---- seed-index filter for large panels (kernels.hip: filter_index_kernel) ----
+// One shape = one exact "key" every window of a pattern group must contain if it is to match
+// with <= k mismatches: the protected terminal bases plus one of k+1 pigeonhole blocks, both
+// relative to the anchored end of the window.  Keys are read out of a rolling 2-bit k-mer.
+struct ipcr_index_shape {
+    uint8_t left;       // 1: anchored at the window start (rc orientations), 0: at its end
+    uint8_t tw_shift;   // k-mer bit offset of the protected part
+    uint8_t blk_shift;  // k-mer bit offset of the block part
+    uint8_t tw_bits;    // 2 * bases of the protected part used in the key
+    uint32_t tw_mask;   // (1 << tw_bits) - 1
+    uint32_t blk_mask;  // (1 << 2*b) - 1
+    uint32_t reserved;
+    uint64_t valid_mask; // even bits of the k-mer positions the key reads (must all be valid bases)
+};
+
+struct ipcr_index_entry { // open-addressing hash table slot
+    uint32_t tag;     // shape << 16 | key ; 0xFFFFFFFF = empty
+    uint32_t pattern; // set-local pattern index
+    uint64_t code;    // the pattern's 2-bit string, last base in the lowest bits
+};
+
+struct ipcr_index_meta { // per pattern
+    uint64_t prot2; // even bit 2*(L-1-j) set when position j is protected
+    uint8_t len;
+    uint8_t left;
+    uint8_t pad[6];
+};
+
+#define IPCR_INDEX_MAX_SHAPES 16
+#define IPCR_INDEX_BITMAP_WORDS 2048u // 65536 bits per shape

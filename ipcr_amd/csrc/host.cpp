@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -168,8 +169,25 @@ struct PatternDef {
     bool seeded;
 };
 
+// seed index over the pure-ACGT patterns of a set (large panels; kernels.hip: filter_index_kernel)
+struct IndexPlan {
+    bool built = false, usable = false;
+    std::vector<ipcr_index_shape> shapes;
+    std::vector<uint32_t> bitmaps;
+    std::vector<ipcr_index_entry> table;
+    uint32_t table_mask = 0;
+    std::vector<ipcr_index_meta> meta;
+    std::vector<uint32_t> leftover; // set-local patterns the index cannot serve (IUPAC, > 32 nt, ...)
+    ipcr_index_shape *d_shapes = nullptr;
+    uint32_t *d_bitmaps = nullptr;
+    ipcr_index_entry *d_table = nullptr;
+    ipcr_index_meta *d_meta = nullptr;
+    uint32_t *d_leftover = nullptr;
+};
+
 struct PatternSet {
     std::vector<uint32_t> ids; // global pattern ids scanned in this mode
+    IndexPlan index;
     std::vector<ipcr_dev_pattern> host;
     ipcr_dev_pattern *dev = nullptr;
     std::vector<ipcr::JitFilter *> jit; // one kernel per pattern group
@@ -195,6 +213,106 @@ struct ipcr_panel {
 };
 
 namespace {
+
+// Pigeonhole keys for the seed-index filter.  Patterns are grouped by (anchored end, protected
+// length t); a group with shortest pattern Lmin uses blocks of bf = (Lmin - t) / (k+1) bases laid
+// next to the protected bases, so any window with <= k mismatches (none protected) has the
+// protected bases and at least one whole block exact.  A key = protected part + (a prefix of) one
+// block, at most 8 bases = 16 bits.
+void build_index(const ipcr_panel &p, PatternSet &set) {
+    IndexPlan &ix = set.index;
+    ix.built = true;
+    const int k = p.cfg.max_mm;
+    const size_t P = set.host.size();
+    ix.meta.assign(P, ipcr_index_meta{});
+    struct Group { bool left; int t; int lmin; std::vector<uint32_t> members; };
+    std::vector<Group> groups;
+    std::vector<uint64_t> codes(P, 0);
+    for (uint32_t q = 0; q < P; ++q) {
+        const ipcr_dev_pattern &dp = set.host[q];
+        const PatternDef &d = p.defs[set.ids[q]];
+        const int L = dp.len;
+        bool pure = L >= 1 && L <= 32;
+        uint64_t code = 0, prot2 = 0;
+        for (int j = 0; j < L && pure; ++j) {
+            const uint8_t m = dp.mask[j] & 15u;
+            int b = -1;
+            if (m == 1) b = 0; else if (m == 2) b = 1; else if (m == 4) b = 2; else if (m == 8) b = 3;
+            if (b < 0) { pure = false; break; }
+            code |= (uint64_t)b << (2 * (L - 1 - j));
+            if (dp.mask[j] & 16u) prot2 |= 1ull << (2 * (L - 1 - j));
+        }
+        if (!pure) { ix.leftover.push_back(q); continue; }
+        codes[q] = code;
+        ix.meta[q].prot2 = prot2;
+        ix.meta[q].len = (uint8_t)L;
+        ix.meta[q].left = d.left ? 1 : 0;
+        int t = k == 0 ? L : std::min(d.tw_dev, L);
+        if (t < 0) t = 0;
+        bool found = false;
+        for (Group &g : groups)
+            if (g.left == d.left && g.t == std::min(t, 32)) { g.members.push_back(q); g.lmin = std::min(g.lmin, L); found = true; break; }
+        if (!found) groups.push_back(Group{d.left, std::min(t, 32), L, {q}});
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> ents; // (tag, pattern)
+    for (Group &g : groups) {
+        const int t = std::min(g.t, g.lmin), tu = std::min(t, 8);
+        const int bf = (t >= g.lmin) ? 0 : (g.lmin - t) / (k + 1);
+        const int b = (tu >= 8) ? 0 : std::min(8 - tu, bf);
+        if (tu == 0 && b == 0) { // nothing exact to key on
+            for (uint32_t q : g.members) ix.leftover.push_back(q);
+            continue;
+        }
+        const int ns = b > 0 ? k + 1 : 1;
+        if (ix.shapes.size() + (size_t)ns > IPCR_INDEX_MAX_SHAPES) {
+            for (uint32_t q : g.members) ix.leftover.push_back(q);
+            continue;
+        }
+        for (int j = 0; j < ns; ++j) {
+            ipcr_index_shape sh{};
+            sh.left = g.left ? 1 : 0;
+            sh.tw_bits = (uint8_t)(2 * tu);
+            sh.tw_mask = tu ? (uint32_t)((1ull << (2 * tu)) - 1ull) : 0u;
+            sh.blk_mask = b ? (uint32_t)((1ull << (2 * b)) - 1ull) : 0u;
+            uint64_t vm = 0;
+            if (!g.left) { // anchored at the window end = lowest bits of the k-mer
+                sh.tw_shift = 0;
+                sh.blk_shift = (uint8_t)(2 * (t + j * bf));
+                for (int u = 0; u < tu; ++u) vm |= 1ull << (2 * u);
+                for (int u = 0; u < b; ++u) vm |= 1ull << (2 * (t + j * bf + u));
+            } else {       // anchored at the window start = top of the 32-base k-mer
+                sh.tw_shift = (uint8_t)(tu ? 64 - 2 * tu : 0);
+                sh.blk_shift = (uint8_t)(b ? 64 - 2 * (t + j * bf + b) : 0);
+                for (int u = 0; u < tu; ++u) vm |= 1ull << (2 * (31 - u));
+                for (int u = 0; u < b; ++u) vm |= 1ull << (2 * (31 - (t + j * bf + u)));
+            }
+            sh.valid_mask = vm;
+            const uint32_t s = (uint32_t)ix.shapes.size();
+            ix.shapes.push_back(sh);
+            for (uint32_t q : g.members) {
+                const int L = ix.meta[q].len;
+                const uint64_t km = g.left ? (L >= 32 ? codes[q] : codes[q] << (64 - 2 * L)) : codes[q];
+                const uint32_t key = ((uint32_t)(km >> sh.tw_shift) & sh.tw_mask) |
+                                     (((uint32_t)(km >> sh.blk_shift) & sh.blk_mask) << sh.tw_bits);
+                ents.emplace_back((s << 16) | key, q);
+            }
+        }
+    }
+    ix.bitmaps.assign(std::max<size_t>(1, ix.shapes.size()) * IPCR_INDEX_BITMAP_WORDS, 0u);
+    uint32_t slots = 1024;
+    while (slots < ents.size() * 4) slots *= 2;
+    ix.table.assign(slots, ipcr_index_entry{0xFFFFFFFFu, 0u, 0ull});
+    ix.table_mask = slots - 1;
+    for (auto &e : ents) {
+        const uint32_t s = e.first >> 16, key = e.first & 0xFFFFu;
+        ix.bitmaps[s * IPCR_INDEX_BITMAP_WORDS + (key >> 5)] |= 1u << (key & 31u);
+        uint32_t h = (e.first * 2654435761u) & ix.table_mask;
+        while (ix.table[h].tag != 0xFFFFFFFFu) h = (h + 1) & ix.table_mask;
+        ix.table[h] = ipcr_index_entry{e.first, e.second, codes[e.second]};
+    }
+    std::sort(ix.leftover.begin(), ix.leftover.end());
+    ix.usable = !ix.shapes.empty();
+}
 
 void build_dev_pattern(const ipcr_panel &p, const PatternDef &d, uint32_t gid, ipcr_dev_pattern &o) {
     memset(&o, 0, sizeof o);
@@ -330,6 +448,11 @@ ipcr_status ipcr_panel_create(const ipcr_config *cfg, const ipcr_pair *pairs, in
 void ipcr_panel_destroy(ipcr_panel *p) {
     if (!p) return;
     for (auto &s : p->set) {
+        if (s.index.d_shapes) (void)hipFree(s.index.d_shapes);
+        if (s.index.d_bitmaps) (void)hipFree(s.index.d_bitmaps);
+        if (s.index.d_table) (void)hipFree(s.index.d_table);
+        if (s.index.d_meta) (void)hipFree(s.index.d_meta);
+        if (s.index.d_leftover) (void)hipFree(s.index.d_leftover);
         if (s.dev) (void)hipFree(s.dev);
         for (ipcr::JitFilter *f : s.jit) ipcr::jit_destroy(f);
     }
@@ -649,9 +772,29 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode) {
         HIPCHK(hipMalloc((void **)&s.dev, s.host.size() * sizeof(ipcr_dev_pattern)));
         HIPCHK(hipMemcpy(s.dev, s.host.data(), s.host.size() * sizeof(ipcr_dev_pattern), hipMemcpyHostToDevice));
     }
+    const bool force_index = getenv("IPCR_FORCE_INDEX") && atoi(getenv("IPCR_FORCE_INDEX")) != 0;
     if (p->specialize && !s.jit_tried && !s.host.empty()) {
         s.jit_tried = true;
-        s.jit = ipcr::jit_build(s.host, p->cfg.max_mm, s.jit_error);
+        if (!force_index) s.jit = ipcr::jit_build(s.host, p->cfg.max_mm, s.jit_error);
+    }
+    // panels too large to specialise: seed-index filter (+ table-driven kernel for what it cannot key)
+    if (p->specialize && s.jit.empty() && !s.index.built && !s.host.empty() && p->cfg.max_mm <= 3) {
+        build_index(*p, s);
+        IndexPlan &ix = s.index;
+        if (ix.usable) {
+            HIPCHK(hipMalloc((void **)&ix.d_shapes, ix.shapes.size() * sizeof(ipcr_index_shape)));
+            HIPCHK(hipMemcpy(ix.d_shapes, ix.shapes.data(), ix.shapes.size() * sizeof(ipcr_index_shape), hipMemcpyHostToDevice));
+            HIPCHK(hipMalloc((void **)&ix.d_bitmaps, ix.bitmaps.size() * 4));
+            HIPCHK(hipMemcpy(ix.d_bitmaps, ix.bitmaps.data(), ix.bitmaps.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMalloc((void **)&ix.d_table, ix.table.size() * sizeof(ipcr_index_entry)));
+            HIPCHK(hipMemcpy(ix.d_table, ix.table.data(), ix.table.size() * sizeof(ipcr_index_entry), hipMemcpyHostToDevice));
+            HIPCHK(hipMalloc((void **)&ix.d_meta, ix.meta.size() * sizeof(ipcr_index_meta)));
+            HIPCHK(hipMemcpy(ix.d_meta, ix.meta.data(), ix.meta.size() * sizeof(ipcr_index_meta), hipMemcpyHostToDevice));
+            if (!ix.leftover.empty()) {
+                HIPCHK(hipMalloc((void **)&ix.d_leftover, ix.leftover.size() * 4));
+                HIPCHK(hipMemcpy(ix.d_leftover, ix.leftover.data(), ix.leftover.size() * 4, hipMemcpyHostToDevice));
+            }
+        }
     }
     return IPCR_OK;
 }
@@ -664,6 +807,19 @@ struct HitLess {
         return a.pos < b.pos;
     }
 };
+
+// The seed-index filter can report one window through several of its keys: keep one hit per
+// (record, pattern, position).
+void dedup_sorted_hits(std::vector<ipcr_hit> &v) {
+    size_t w = 0;
+    for (size_t i = 0; i < v.size(); ++i) {
+        if (w && v[w - 1].record == v[i].record && v[w - 1].pos == v[i].pos &&
+            (v[w - 1].pattern & 0x7FFFFFFFu) == (v[i].pattern & 0x7FFFFFFFu))
+            continue;
+        v[w++] = v[i];
+    }
+    v.resize(w);
+}
 
 // Hits come back in atomic-append order; the join wants them grouped by (record, pattern) and
 // ascending in position.  Counting sort over the (record, pattern) buckets, then each small
@@ -680,6 +836,7 @@ void sort_hits(const std::vector<ipcr_hit> &in, std::vector<ipcr_hit> &out, uint
     if (!ok) {
         out = in;
         std::sort(out.begin(), out.end(), HitLess());
+        dedup_sorted_hits(out);
         return;
     }
     std::vector<uint32_t> cnt(nb + 1, 0);
@@ -691,6 +848,7 @@ void sort_hits(const std::vector<ipcr_hit> &in, std::vector<ipcr_hit> &out, uint
         const uint32_t b = cnt[i], e = cnt[i + 1];
         if (e - b > 1) std::sort(out.begin() + b, out.begin() + e, [](const ipcr_hit &x, const ipcr_hit &y) { return x.pos < y.pos; });
     }
+    dedup_sorted_hits(out);
 }
 
 ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
@@ -727,9 +885,20 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
                 HIPCHK(ipcr::jit_launch(set.jit[gi], s->stream, g->planes, nblocks, s->d_queue, s->qcap, s->d_counts,
                                         gi == 0 ? s->ev[0] : nullptr, gi + 1 == set.jit.size() ? s->ev[1] : nullptr));
             s->stats.kernel_kind = 1;
+        } else if (set.index.usable) {
+            const IndexPlan &ix = set.index;
+            const bool more = !ix.leftover.empty();
+            HIPCHK(ipcr::launch_filter_index(s->stream, g->planes, nblocks, ix.d_shapes, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
+                                             ix.d_table, ix.table_mask, ix.d_meta, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
+                                             s->d_counts, s->ev[0], more ? nullptr : s->ev[1]));
+            if (more) // IUPAC / long patterns the index cannot key
+                HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)ix.leftover.size(),
+                                                   (uint32_t)p->cfg.max_mm, ix.d_leftover, s->d_queue, s->qcap, s->d_counts,
+                                                   nullptr, s->ev[1]));
+            s->stats.kernel_kind = 3;
         } else {
             HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)set.ids.size(),
-                                               (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, s->d_counts, s->ev[0], s->ev[1]));
+                                               (uint32_t)p->cfg.max_mm, nullptr, s->d_queue, s->qcap, s->d_counts, s->ev[0], s->ev[1]));
             s->stats.kernel_kind = 2;
         }
         HIPCHK(ipcr::launch_verify(s->stream, g->planes, g->rst, set.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void filter_generic_kernel(const uint32_t *__r
                                                              uint64_t nblocks,
                                                              const ipcr_dev_pattern *__restrict__ pats,
                                                              uint32_t npat, uint32_t max_mm,
+                                                             const uint32_t *__restrict__ sel, // pattern subset or null
                                                              ipcr_queue_entry *__restrict__ queue, uint64_t qcap,
                                                              unsigned long long *__restrict__ qcount) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(256) void filter_generic_kernel(const uint32_t *__r
     const uint32_t row = (uint32_t)(tile & 127u);
     if (block >= nblocks) return;
 
-    for (uint32_t q = 0; q < npat; ++q) {
+    for (uint32_t qi = 0; qi < npat; ++qi) {
+        const uint32_t q = sel ? sel[qi] : qi;
         const ipcr_dev_pattern *pp = pats + q;
         const uint32_t L = pp->len;
         uint32_t u[KMAX + 1];
@@ -210,9 +212,99 @@ __global__ __launch_bounds__(256) void filter_generic_kernel(const uint32_t *__r
 }
 
 template __global__ void filter_generic_kernel<4>(const uint32_t *, uint64_t, const ipcr_dev_pattern *, uint32_t,
-                                                  uint32_t, ipcr_queue_entry *, uint64_t, unsigned long long *);
+                                                  uint32_t, const uint32_t *, ipcr_queue_entry *, uint64_t,
+                                                  unsigned long long *);
 template __global__ void filter_generic_kernel<17>(const uint32_t *, uint64_t, const ipcr_dev_pattern *, uint32_t,
-                                                   uint32_t, ipcr_queue_entry *, uint64_t, unsigned long long *);
+                                                   uint32_t, const uint32_t *, ipcr_queue_entry *, uint64_t,
+                                                   unsigned long long *);
+
+// ------------------------------------------------------------------ seed-index filter
+// For panels too large to unroll into code (thousands of patterns): cost per genome base is
+// independent of the panel size.  One THREAD walks one strand (bit `bit` of column `col`) down
+// its 128 rows plus 32 rows of the next strand, keeping the last 32 bases as a rolling 2-bit
+// k-mer (and an invalid-base mask).  At every base, each shape's key is cut out of the k-mer and
+// looked up in a 64-Kbit bitmap in LDS; on a hit the (shape,key) -> patterns hash table in
+// global memory (L2-resident) is probed and each listed pattern is checked exactly with a 2-bit
+// XOR/popcount against the k-mer (pure-ACGT patterns only; others go to the table-driven
+// kernel).  Survivors are queued for the verifier like every other filter's.
+__global__ __launch_bounds__(256) void filter_index_kernel(const uint32_t *__restrict__ planes, uint64_t ncolpairs,
+                                                           const ipcr_index_shape *__restrict__ shapes, uint32_t nshapes,
+                                                           const uint32_t *__restrict__ bitmaps,
+                                                           const ipcr_index_entry *__restrict__ table, uint32_t table_mask,
+                                                           const ipcr_index_meta *__restrict__ meta, uint32_t max_mm,
+                                                           ipcr_queue_entry *__restrict__ queue, uint64_t qcap,
+                                                           unsigned long long *__restrict__ qcount) {
+    extern __shared__ uint32_t lds_bitmaps[]; // nshapes * 2048 words
+    for (uint32_t i = threadIdx.x; i < nshapes * IPCR_INDEX_BITMAP_WORDS; i += blockDim.x) lds_bitmaps[i] = bitmaps[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t half = lane >> 5, bit = lane & 31u;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t cp = wave0; cp < ncolpairs; cp += nwaves) {
+        const uint64_t col = cp * 2u + half;
+        // successor strand for the wrap rows: next bit of the same column, or bit 0 of the next column
+        const uint64_t ncol = (bit == 31u) ? col + 1u : col;
+        const uint32_t nbit = (bit + 1u) & 31u;
+        const uint64_t strand_base = ((col << 5) + bit) << IPCR_TILE_LOG_N;
+        uint64_t km = 0, im = 0x5555555555555555ull; // nothing seen yet = all invalid
+        for (uint32_t rq = 0; rq < 40u; ++rq) { // 32 row quads of the strand + 8 of the next
+            const bool wrap = rq >= 32u;
+            const uint64_t c = wrap ? ncol : col;
+            const uint32_t b = wrap ? nbit : bit;
+            const uint32_t r0 = (rq & 31u) * 4u;
+            const uint64_t w = ipcr_plane_word(c >> 6, r0, 0, (uint32_t)(c & 63u));
+            const uint4 qlo = *reinterpret_cast<const uint4 *>(planes + w);
+            const uint4 qhi = *reinterpret_cast<const uint4 *>(planes + w + 256u);
+            const uint4 qiv = *reinterpret_cast<const uint4 *>(planes + w + 512u);
+            const uint32_t alo[4] = {qlo.x, qlo.y, qlo.z, qlo.w};
+            const uint32_t ahi[4] = {qhi.x, qhi.y, qhi.z, qhi.w};
+            const uint32_t aiv[4] = {qiv.x, qiv.y, qiv.z, qiv.w};
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; ++t) {
+                const uint32_t code = ((alo[t] >> b) & 1u) | (((ahi[t] >> b) & 1u) << 1);
+                km = (km << 2) | code;
+                im = (im << 2) | ((aiv[t] >> b) & 1u);
+                const int32_t erow = (int32_t)(rq * 4u + t); // row of the newest base, own-strand coordinates
+                for (uint32_t s = 0; s < nshapes; ++s) {
+                    const ipcr_index_shape sh = shapes[s]; // wave-uniform
+                    if (im & sh.valid_mask) continue;      // an invalid base inside the key: cannot be exact
+                    const uint32_t key = ((uint32_t)(km >> sh.tw_shift) & sh.tw_mask) |
+                                         (((uint32_t)(km >> sh.blk_shift) & sh.blk_mask) << sh.tw_bits);
+                    if (!((lds_bitmaps[s * IPCR_INDEX_BITMAP_WORDS + (key >> 5)] >> (key & 31u)) & 1u)) continue;
+                    const uint32_t tag = (s << 16) | key;
+                    uint32_t h = (tag * 2654435761u) & table_mask;
+                    for (;;) {
+                        const ipcr_index_entry e = table[h];
+                        if (e.tag == 0xFFFFFFFFu) break;
+                        if (e.tag == tag) {
+                            const ipcr_index_meta m = meta[e.pattern];
+                            const uint32_t L = m.len;
+                            const uint32_t sft = m.left ? 64u - 2u * L : 0u;
+                            const uint64_t x = km >> sft, iv = im >> sft;
+                            const uint64_t wm = (L >= 32u) ? ~0ull : ((1ull << (2u * L)) - 1ull);
+                            const uint64_t d = x ^ e.code;
+                            const uint64_t mm2 = (((d | (d >> 1)) & 0x5555555555555555ull) | iv) & wm;
+                            const int32_t srow = m.left ? erow - 31 : erow - (int32_t)L + 1;
+                            if ((mm2 & m.prot2) == 0ull && (uint32_t)__popcll(mm2) <= max_mm && srow >= 0 &&
+                                srow < (int32_t)IPCR_TILE_N) {
+                                const unsigned long long idx = atomicAdd(qcount, 1ull);
+                                if (idx < qcap) {
+                                    ipcr_queue_entry qe;
+                                    qe.key = ((uint64_t)e.pattern << 48) | (strand_base + (uint64_t)srow);
+                                    qe.bits = 1u;
+                                    qe.pad = 0;
+                                    queue[idx] = qe;
+                                }
+                            }
+                        }
+                        h = (h + 1u) & table_mask;
+                    }
+                }
+            }
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------ verify
 // verifyAt (core/engine/ac.go:186-213) / the inner loop of FindMatches
@@ -421,7 +513,7 @@ hipError_t launch_lcg(hipStream_t st, uint8_t *out, uint64_t n, uint32_t seed, u
 }
 
 hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_t nblocks,
-                                 const ipcr_dev_pattern *pats, uint32_t npat, uint32_t max_mm,
+                                 const ipcr_dev_pattern *pats, uint32_t npat, uint32_t max_mm, const uint32_t *sel,
                                  ipcr_queue_entry *queue, uint64_t qcap, unsigned long long *qcount,
                                  hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0 || npat == 0) return hipSuccess;
@@ -429,10 +521,32 @@ hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_
     const dim3 grid((uint32_t)((tiles + 3u) / 4u));
     if (max_mm <= 3u)
         hipExtLaunchKernelGGL(filter_generic_kernel<4>, grid, dim3(256), 0, st, start, stop, 0, planes, nblocks, pats,
-                              npat, max_mm, queue, qcap, qcount);
+                              npat, max_mm, sel, queue, qcap, qcount);
     else
         hipExtLaunchKernelGGL(filter_generic_kernel<17>, grid, dim3(256), 0, st, start, stop, 0, planes, nblocks, pats,
-                              npat, max_mm, queue, qcap, qcount);
+                              npat, max_mm, sel, queue, qcap, qcount);
+    return hipGetLastError();
+}
+
+hipError_t launch_filter_index(hipStream_t st, const uint32_t *planes, uint64_t nblocks,
+                               const ipcr_index_shape *shapes, uint32_t nshapes, const uint32_t *bitmaps,
+                               const ipcr_index_entry *table, uint32_t table_mask, const ipcr_index_meta *meta,
+                               uint32_t max_mm, ipcr_queue_entry *queue, uint64_t qcap, unsigned long long *qcount,
+                               hipEvent_t start, hipEvent_t stop) {
+    if (nblocks == 0 || nshapes == 0) return hipSuccess;
+    const uint64_t ncolpairs = nblocks * 32u;
+    const uint32_t lds = nshapes * IPCR_INDEX_BITMAP_WORDS * 4u;
+    // persistent workgroups: the bitmaps are staged into LDS once per workgroup
+    uint32_t per_cu = lds > 80u * 1024u ? 1u : 2u;
+    uint64_t grid = 256ull * per_cu;
+    if (grid * 4u > ncolpairs) grid = (ncolpairs + 3u) / 4u;
+    if (lds > 48u * 1024u) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(filter_index_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipExtLaunchKernelGGL(filter_index_kernel, dim3((uint32_t)grid), dim3(256), lds, st, start, stop, 0, planes, ncolpairs,
+                          shapes, nshapes, bitmaps, table, table_mask, meta, max_mm, queue, qcap, qcount);
     return hipGetLastError();
 }
 

@@ -477,3 +477,66 @@ def test_config_c5_probe_rescan(hip):
             assert (bool(out[i].found), chr(out[i].strand) if out[i].found else "", out[i].pos, out[i].mm) == \
                 (w.found, w.strand, w.pos if w.found else 0, w.mm if w.found else 0)
     g.close()
+
+
+# ---- seed-index filter (large panels) ------------------------------------------------------------
+
+@pytest.fixture
+def force_index(monkeypatch):
+    monkeypatch.setenv("IPCR_FORCE_INDEX", "1")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_index_filter_random(hip, force_index, seed):
+    """same differential test as above, every panel pushed through the seed-index filter
+    (IUPAC primers take its table-driven side path)"""
+    rng = random.Random(4321 + seed)
+    E, P = hip.engine, hip.primer.Pair
+    kinds = set()
+    for it in range(8):
+        n = rng.choice([300, 5000, 70000])
+        seq = rand_case(rng, n, with_junk=rng.random() < 0.5)
+        lmin = 6 if n <= 300 else (9 if n <= 5000 else 14)
+        pairs = []
+        for i in range(rng.randint(1, 5)):
+            def mk():
+                L = rng.randint(lmin, 30)
+                s = [rng.choice("ACGT") for _ in range(L)]
+                if rng.random() < 0.2:
+                    s[rng.randrange(L)] = rng.choice("RYSWKMBDHVN")
+                return "".join(s)
+            pairs.append(P("p%d" % i, mk(), mk(), rng.choice([0, 0, 20]), rng.choice([0, 0, 400])))
+        for p in pairs:
+            for _ in range(rng.randint(1, 3)):
+                a = rng.randrange(0, max(1, n - 200))
+                ln = rng.randint(len(p.Forward) + len(p.Reverse), 150)
+                if a + ln > n:
+                    continue
+                plant(rng, seq, p.Forward, a, rng.choice([0, 0, 1, 2]))
+                rc = O.revcomp(p.Reverse).decode()
+                plant(rng, seq, rc, a + ln - len(rc), rng.choice([0, 0, 1]))
+        cfg = E.Config(MaxMM=rng.choice([0, 1, 2, 3] if n <= 5000 else [0, 1, 2]), TerminalWindow=rng.choice([0, 1, 3, 5, 9]),
+                       MinLen=rng.choice([0, 10]), MaxLen=rng.choice([0, 200, 2000]),
+                       HitCap=rng.choice([0, 0, 3, 10000]), SeedLen=rng.choice([0, 12, -1]), Circular=rng.random() < 0.3)
+        if rng.random() < 0.5:
+            pairs = hip.primer.AddSelfPairs(pairs)
+        eng = E.New(cfg)
+        cp = eng.CompilePanel(pairs)
+        sc = eng.NewSimulationScratch(cp)
+        got = eng.SimulateCompiledWithScratch("seq", "".join(seq).encode(), cp, sc)
+        kinds.add(sc.stats().kernel_kind)
+        want = O.simulate_batch(ocfg(cfg), "".join(seq).encode(), opairs(pairs))
+        assert [g.sig() for g in got] == [w.sig() for w in want], (cfg, pairs)
+    assert 3 in kinds
+
+
+def test_config_c4_large_panel_index(hip):
+    """256 TSV rows -> 768 pairs / 1024 distinct patterns: seed-index filter, vs the oracle"""
+    from ipcr_amd import workloads
+    rng = random.Random(26)
+    pairs = workloads.c4_pairs(256)
+    g, seqs = build_planted_genome(hip, rng, 3, 400_000, pairs[:256], 0x5eed1239)
+    cfg = hip.engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)
+    _, cp, sc, got = scan_and_compare(hip, cfg, pairs, g, seqs)
+    assert sc.stats().kernel_kind == 3 and sc.stats().n_patterns == 1024 and len(got) >= 10
+    g.close()
