@@ -55,10 +55,13 @@ struct ipcr_index_shape {
     uint64_t valid_mask; // even bits of the k-mer positions the key reads (must all be valid bases)
 };
 
-struct ipcr_index_entry { // open-addressing hash table slot
+struct ipcr_index_entry { // open-addressing hash table slot (32 B: one load per probe)
     uint32_t tag;     // shape << 16 | key ; 0xFFFFFFFF = empty
     uint32_t pattern; // set-local pattern index
     uint64_t code;    // the pattern's 2-bit string, last base in the lowest bits
+    uint64_t prot2;   // even bit 2*(L-1-j) set when position j is protected
+    uint32_t len;
+    uint32_t left;
 };
 
 struct ipcr_index_meta { // per pattern

@@ -301,14 +301,14 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     ix.bitmaps.assign(std::max<size_t>(1, ix.shapes.size()) * IPCR_INDEX_BITMAP_WORDS, 0u);
     uint32_t slots = 1024;
     while (slots < ents.size() * 4) slots *= 2;
-    ix.table.assign(slots, ipcr_index_entry{0xFFFFFFFFu, 0u, 0ull});
+    ix.table.assign(slots, ipcr_index_entry{0xFFFFFFFFu, 0u, 0ull, 0ull, 0u, 0u});
     ix.table_mask = slots - 1;
     for (auto &e : ents) {
         const uint32_t s = e.first >> 16, key = e.first & 0xFFFFu;
         ix.bitmaps[s * IPCR_INDEX_BITMAP_WORDS + (key >> 5)] |= 1u << (key & 31u);
         uint32_t h = (e.first * 2654435761u) & ix.table_mask;
         while (ix.table[h].tag != 0xFFFFFFFFu) h = (h + 1) & ix.table_mask;
-        ix.table[h] = ipcr_index_entry{e.first, e.second, codes[e.second]};
+        ix.table[h] = ipcr_index_entry{e.first, e.second, codes[e.second], ix.meta[e.second].prot2, ix.meta[e.second].len, ix.meta[e.second].left};
     }
     std::sort(ix.leftover.begin(), ix.leftover.end());
     ix.usable = !ix.shapes.empty();
