@@ -204,6 +204,7 @@ struct ipcr_panel {
     std::vector<uint8_t> have;                   // orientationMask compiled.go:6-37
     std::vector<PatternDef> defs;                // global pattern table
     std::vector<std::array<std::array<uint32_t, 2>, 4>> slot; // [pair][which][mode] -> global id
+    std::vector<std::vector<uint32_t>> users[2]; // [mode][global pattern] -> pairs scanning it (ascending)
     PatternSet set[2];                           // mode 0: no record holds a reset byte; mode 1: some do
     bool modes_equal = true;
     int max_len = 0;
@@ -441,6 +442,14 @@ ipcr_status ipcr_panel_create(const ipcr_config *cfg, const ipcr_pair *pairs, in
             }
     }
     p->modes_equal = p->set[0].ids == p->set[1].ids;
+    for (int mode = 0; mode < 2; ++mode) {
+        p->users[mode].assign(p->defs.size(), {});
+        for (uint32_t i = 0; i < p->slot.size(); ++i)
+            for (int w = 0; w < 4; ++w) {
+                auto &u = p->users[mode][p->slot[i][(size_t)w][(size_t)mode]];
+                if (u.empty() || u.back() != i) u.push_back(i);
+            }
+    }
     *out = p.release();
     return IPCR_OK;
 }
@@ -1102,6 +1111,7 @@ ipcr_status join_sorted_hits(const ipcr_panel *p, ipcr_scratch *s, const uint64_
     const size_t npairs = p->id.size();
     std::vector<MatchRef> m[4];
     std::vector<MatchRef> sorted_right;
+    std::vector<uint32_t> touched;
     size_t i = 0;
     while (i < H.size()) {
         const uint32_t rec = H[i].record;
@@ -1111,7 +1121,19 @@ ipcr_status join_sorted_hits(const ipcr_panel *p, ipcr_scratch *s, const uint64_
         const uint8_t fl = rec_flags ? rec_flags[rec] : 0;
         const bool rec_reset = fl & 1u;
         const int mode = (!p->modes_equal && (fl & 2u)) ? 1 : 0;
-        for (size_t pi = 0; pi < npairs; ++pi) {
+        // only pairs that scan a pattern with hits in this record can yield products
+        touched.clear();
+        for (size_t h = i; h < j;) {
+            const uint32_t gid = H[h].pattern & 0x7FFFFFFFu;
+            if (gid < p->users[mode].size())
+                touched.insert(touched.end(), p->users[mode][gid].begin(), p->users[mode][gid].end());
+            while (h < j && (H[h].pattern & 0x7FFFFFFFu) == gid) ++h;
+        }
+        std::sort(touched.begin(), touched.end());
+        touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+        for (const uint32_t pi32 : touched) {
+            const size_t pi = pi32;
+            if (pi >= npairs) continue;
             bool any = false;
             for (int w = 0; w < 4; ++w) {
                 const ipcr_hit *b = nullptr, *e = nullptr;
