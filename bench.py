@@ -121,6 +121,11 @@ def main() -> None:
     all_lens, all_flags = dist.allgather_record_meta(lens, flags, device=cdev) if multi else (lens, flags)
     host_sc = engine.SimulationScratch(cp, host_only=True) if multi else None
     xchg = dist.HitExchanger(device=cdev) if multi else None
+    rec_off = 0
+    if multi:  # one synchronous exchange: sizes the buffers on every rank, yields this rank's record offset
+        eng.ScanGenomeHits(genome, cp, sc)
+        _, _, offs = xchg.allgather(dist.hits_from_scratch(sc), nrec)
+        rec_off = offs[rank]
 
     def step():
         """one pass of the hot path; returns (#products joined by this rank, filter_ms)"""
@@ -129,9 +134,11 @@ def main() -> None:
             return n, sc.stats().filter_ms
         eng.ScanGenomeHits(genome, cp, sc)                      # filter + verify on this rank's genome
         fms = sc.stats().filter_ms
-        hits, ranges, _ = xchg.allgather(dist.hits_from_scratch(sc), nrec)   # all-gatherv of hit records (RCCL)
-        a, b = ranges[rank]                                      # the join is partitioned by record:
-        n = _join_count(eng, cp, host_sc, hits[a:b], all_lens, all_flags)   # each rank joins its records
+        mine = dist.hits_from_scratch(sc)
+        work = xchg.start(mine, nrec)                            # all-gatherv of hit records (RCCL), async:
+        mine["record"] += np.uint32(rec_off)                     # (job-global record index for the join)
+        n = _join_count(eng, cp, host_sc, mine, all_lens, all_flags)   # ... overlapped with the join of this
+        xchg.finish(work)                                        # rank's partition (its own records)
         return n, fms
 
     for _ in range(max(args.warmup, 0)):
@@ -162,7 +169,7 @@ def main() -> None:
     if not multi:
         prods = sc.products(genome.ids)
     else:  # rank 0 joins the WHOLE job from the gathered hits and checks its own genome's plants
-        allhits, _, _ = xchg.allgather(dist.hits_from_scratch(sc), nrec)
+        allhits, _, _ = xchg.gathered()                     # what the last step's all-gatherv left on every rank
         prods = eng.JoinHits(cp, host_sc, allhits, all_lens, all_flags) if rank == 0 else []
         if rank == 0:
             assert len(prods) == nprod, f"whole-job join on rank 0 found {len(prods)} products, partitioned join {nprod}"

@@ -142,7 +142,8 @@ int32_t ipcr_panel_have(const ipcr_panel *p, int32_t pair, char which);
 /* 0 = table-driven filter only, 1 = allow the panel-specialised filter (default) */
 ipcr_status ipcr_panel_set_specialize(ipcr_panel *p, int32_t enable);
 /* HIP source of the panel-specialised filter kernel (what hiprtc compiles at first scan);
- * mode 0 = records without non-ACGT bytes, 1 = with.  Writes at most cap bytes (NUL-terminated),
+ * mode 0 = records without non-ACGT bytes, 1 = with; 2 / 3 = the seed-index filter's source (the
+ * kernel large panels use) for mode 0 / 1.  Writes at most cap bytes (NUL-terminated),
  * *needed = full length + 1; an empty string means the panel is not specialisable (a primer
  * longer than 32 nt).  Large panels are cut into groups of patterns, one kernel each; this
  * returns the first group's source. */

@@ -183,6 +183,7 @@ struct IndexPlan {
     ipcr_index_entry *d_table = nullptr;
     ipcr_index_meta *d_meta = nullptr;
     uint32_t *d_leftover = nullptr;
+    ipcr::JitFilter *jit = nullptr; // the same kernel with the key shapes baked in (hiprtc)
 };
 
 struct PatternSet {
@@ -457,6 +458,7 @@ ipcr_status ipcr_panel_create(const ipcr_config *cfg, const ipcr_pair *pairs, in
 void ipcr_panel_destroy(ipcr_panel *p) {
     if (!p) return;
     for (auto &s : p->set) {
+        if (s.index.jit) ipcr::jit_destroy(s.index.jit);
         if (s.index.d_shapes) (void)hipFree(s.index.d_shapes);
         if (s.index.d_bitmaps) (void)hipFree(s.index.d_bitmaps);
         if (s.index.d_table) (void)hipFree(s.index.d_table);
@@ -506,7 +508,21 @@ int32_t ipcr_panel_slot_pattern(const ipcr_panel *p, int32_t pair, char which, i
 }
 
 ipcr_status ipcr_panel_filter_source(const ipcr_panel *p, int32_t mode, char *out, size_t cap, size_t *needed) {
-    if (!p || mode < 0 || mode > 1) return fail(IPCR_ERR_INVALID, "ipcr_panel_filter_source: bad argument");
+    if (!p || mode < 0 || mode > 3) return fail(IPCR_ERR_INVALID, "ipcr_panel_filter_source: bad argument");
+    if (mode >= 2) { // the seed-index filter's source for mode - 2
+        ipcr_panel *mp = const_cast<ipcr_panel *>(p);
+        std::lock_guard<std::mutex> lock(mp->mu);
+        PatternSet &ps = mp->set[mode - 2];
+        if (!ps.index.built) build_index(*mp, ps);
+        const std::string isrc = ps.index.usable ? ipcr::jit_index_source(ps.index.shapes) : std::string();
+        if (needed) *needed = isrc.size() + 1;
+        if (out && cap) {
+            const size_t n = std::min(cap - 1, isrc.size());
+            memcpy(out, isrc.data(), n);
+            out[n] = 0;
+        }
+        return IPCR_OK;
+    }
     const std::vector<ipcr_dev_pattern> &all = p->set[mode].host;
     const size_t G = ipcr::jit_group_size(all); // source of the first pattern group
     const std::string src = G ? ipcr::jit_source(std::vector<ipcr_dev_pattern>(all.begin(), all.begin() + (long)std::min(G, all.size())), p->cfg.max_mm) : std::string();
@@ -787,8 +803,8 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode) {
         if (!force_index) s.jit = ipcr::jit_build(s.host, p->cfg.max_mm, s.jit_error);
     }
     // panels too large to specialise: seed-index filter (+ table-driven kernel for what it cannot key)
-    if (p->specialize && s.jit.empty() && !s.index.built && !s.host.empty() && p->cfg.max_mm <= 3) {
-        build_index(*p, s);
+    if (p->specialize && s.jit.empty() && !s.index.d_table && !s.host.empty() && p->cfg.max_mm <= 3) {
+        if (!s.index.built) build_index(*p, s);
         IndexPlan &ix = s.index;
         if (ix.usable) {
             HIPCHK(hipMalloc((void **)&ix.d_shapes, ix.shapes.size() * sizeof(ipcr_index_shape)));
@@ -799,6 +815,10 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode) {
             HIPCHK(hipMemcpy(ix.d_table, ix.table.data(), ix.table.size() * sizeof(ipcr_index_entry), hipMemcpyHostToDevice));
             HIPCHK(hipMalloc((void **)&ix.d_meta, ix.meta.size() * sizeof(ipcr_index_meta)));
             HIPCHK(hipMemcpy(ix.d_meta, ix.meta.data(), ix.meta.size() * sizeof(ipcr_index_meta), hipMemcpyHostToDevice));
+            if (!(getenv("IPCR_INDEX_NOJIT") && atoi(getenv("IPCR_INDEX_NOJIT")))) {
+                std::string jerr;
+                ix.jit = ipcr::jit_build_index(ix.shapes, jerr); // nullptr: the precompiled kernel serves
+            }
             if (!ix.leftover.empty()) {
                 HIPCHK(hipMalloc((void **)&ix.d_leftover, ix.leftover.size() * 4));
                 HIPCHK(hipMemcpy(ix.d_leftover, ix.leftover.data(), ix.leftover.size() * 4, hipMemcpyHostToDevice));
@@ -897,9 +917,14 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         } else if (set.index.usable) {
             const IndexPlan &ix = set.index;
             const bool more = !ix.leftover.empty();
-            HIPCHK(ipcr::launch_filter_index(s->stream, g->planes, nblocks, ix.d_shapes, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
-                                             ix.d_table, ix.table_mask, ix.d_meta, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
-                                             s->d_counts, s->ev[0], more ? nullptr : s->ev[1]));
+            if (ix.jit)
+                HIPCHK(ipcr::jit_launch_index(ix.jit, s->stream, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
+                                              ix.d_table, ix.table_mask, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
+                                              s->d_counts, s->ev[0], more ? nullptr : s->ev[1]));
+            else
+                HIPCHK(ipcr::launch_filter_index(s->stream, g->planes, nblocks, ix.d_shapes, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
+                                                 ix.d_table, ix.table_mask, ix.d_meta, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
+                                                 s->d_counts, s->ev[0], more ? nullptr : s->ev[1]));
             if (more) // IUPAC / long patterns the index cannot key
                 HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)ix.leftover.size(),
                                                    (uint32_t)p->cfg.max_mm, ix.d_leftover, s->d_queue, s->qcap, s->d_counts,

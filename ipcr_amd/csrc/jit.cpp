@@ -491,6 +491,154 @@ std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, in
     return out;
 }
 
+// ---- seed-index filter with the panel's key shapes baked in (same algorithm as
+// kernels.hip: filter_index_kernel; constants let the compiler turn every variable 64-bit shift
+// and mask into a 32-bit bitfield extract)
+std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes) {
+    const size_t NS = shapes.size();
+    std::ostringstream s;
+    s << "// generated by ipcr_amd/csrc/jit.cpp: seed-index filter, " << NS << " key shapes\n";
+    s << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
+    s << "typedef unsigned int u32;\ntypedef unsigned long long u64;\n";
+    s << "typedef u32 v4 __attribute__((ext_vector_type(4)));\n";
+    s << "struct qent { u64 key; u32 bits; u32 pad; };\n";
+    s << "#define NS " << NS << "\n";
+    auto arr = [&](const char *type, const char *name, auto get) {
+        s << "__device__ constexpr " << type << " " << name << "[NS] = {";
+        for (size_t i = 0; i < NS; ++i) s << (i ? ", " : "") << get(shapes[i]);
+        s << "};\n";
+    };
+    arr("u32", "TW_SHIFT", [](const ipcr_index_shape &x) { return std::to_string(x.tw_shift) + "u"; });
+    arr("u32", "BLK_SHIFT", [](const ipcr_index_shape &x) { return std::to_string(x.blk_shift) + "u"; });
+    arr("u32", "TW_BITS", [](const ipcr_index_shape &x) { return std::to_string(x.tw_bits) + "u"; });
+    arr("u32", "TW_MASK", [](const ipcr_index_shape &x) { return std::to_string(x.tw_mask) + "u"; });
+    arr("u32", "BLK_MASK", [](const ipcr_index_shape &x) { return std::to_string(x.blk_mask) + "u"; });
+    arr("u64", "VALID", [](const ipcr_index_shape &x) { return std::to_string(x.valid_mask) + "ull"; });
+    s << R"SRC(
+template <int S> struct key_of {
+  static __device__ __forceinline__ u32 get(u64 km) {
+    return ((u32)(km >> TW_SHIFT[S]) & TW_MASK[S]) | (((u32)(km >> BLK_SHIFT[S]) & BLK_MASK[S]) << TW_BITS[S]);
+  }
+};
+template <int S> __device__ __forceinline__ void probe_all(u64 km, u64 im, const u32* lds, u32* keys, u32& hitmask) {
+  if constexpr (S < NS) {
+    const u32 k = key_of<S>::get(km);
+    keys[S] = k;
+    const u32 w = lds[S * 2048 + (k >> 5)];
+    if ((im & VALID[S]) == 0ull && ((w >> (k & 31u)) & 1u)) hitmask |= 1u << S;
+    probe_all<S + 1>(km, im, lds, keys, hitmask);
+  }
+}
+extern "C" __global__ void __launch_bounds__(512) ipcr_index_filter(const u32* __restrict__ planes, u64 ncolpairs,
+    const u32* __restrict__ bitmaps, const v4* __restrict__ table, u32 table_mask, u32 max_mm,
+    qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {
+  extern __shared__ u32 lds[];
+  for (u32 i = threadIdx.x; i < NS * 2048u; i += blockDim.x) lds[i] = bitmaps[i];
+  __syncthreads();
+  const u32 lane = threadIdx.x & 63u, half = lane >> 5, bit = lane & 31u;
+  const u64 wave0 = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);
+  for (u64 cp = wave0; cp < ncolpairs; cp += nwaves) {
+    const u64 col = cp * 2u + half;
+    const u64 ncol = (bit == 31u) ? col + 1u : col;
+    const u32 nbit = (bit + 1u) & 31u;
+    const u64 strand_base = ((col << 5) + bit) << 7;
+    u64 km = 0, im = 0x5555555555555555ull;
+    for (u32 rq = 0; rq < 40u; ++rq) {
+      const bool wrap = rq >= 32u;
+      const u64 c = wrap ? ncol : col;
+      const u32 b = wrap ? nbit : bit;
+      const u64 w = (((c >> 6) * 32u + (rq & 31u)) * 3u * 64u + (u32)(c & 63u)) << 2; // tile_layout.h: ipcr_plane_word
+      const v4 qlo = *reinterpret_cast<const v4*>(planes + w);
+      const v4 qhi = *reinterpret_cast<const v4*>(planes + w + 256u);
+      const v4 qiv = *reinterpret_cast<const v4*>(planes + w + 512u);
+#pragma unroll
+      for (u32 t = 0; t < 4u; ++t) {
+        const u32 code = ((qlo[t] >> b) & 1u) | (((qhi[t] >> b) & 1u) << 1);
+        km = (km << 2) | code;
+        im = (im << 2) | ((qiv[t] >> b) & 1u);
+        const int erow = (int)(rq * 4u + t);
+        u32 keys[NS];
+        u32 hitmask = 0;
+        probe_all<0>(km, im, lds, keys, hitmask);
+        while (hitmask) {
+          const u32 s = (u32)__builtin_ctz(hitmask);
+          hitmask &= hitmask - 1u;
+          u32 key = 0;
+#pragma unroll
+          for (int u = 0; u < NS; ++u) key = ((u32)u == s) ? keys[u] : key;
+          const u32 tag = (s << 16) | key;
+          u32 h = (tag * 2654435761u) & table_mask;
+          for (;;) {
+            const v4 e0 = table[h * 2u];
+            if (e0.x == 0xFFFFFFFFu) break;
+            if (e0.x == tag) {
+              const v4 e1 = table[h * 2u + 1u];
+              const u64 ecode = ((u64)e0.w << 32) | e0.z, prot2 = ((u64)e1.y << 32) | e1.x;
+              const u32 L = e1.z, left = e1.w;
+              const u32 sft = left ? 64u - 2u * L : 0u;
+              const u64 x = km >> sft, iv = im >> sft;
+              const u64 wm = (L >= 32u) ? ~0ull : ((1ull << (2u * L)) - 1ull);
+              const u64 d = x ^ ecode;
+              const u64 mm2 = (((d | (d >> 1)) & 0x5555555555555555ull) | iv) & wm;
+              const int srow = left ? erow - 31 : erow - (int)L + 1;
+              if ((mm2 & prot2) == 0ull && (u32)__popcll(mm2) <= max_mm && srow >= 0 && srow < 128) {
+                const u64 idx = atomicAdd(qcount, 1ull);
+                if (idx < qcap) { qent qe; qe.key = ((u64)e0.y << 48) | (strand_base + (u64)srow); qe.bits = 1u; qe.pad = 0u; queue[idx] = qe; }
+              }
+            }
+            h = (h + 1u) & table_mask;
+          }
+        }
+      }
+    }
+  }
+}
+)SRC";
+    return s.str();
+}
+
+JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, std::string &err) {
+    if (shapes.empty() || shapes.size() > IPCR_INDEX_MAX_SHAPES) { err = "no index shapes"; return nullptr; }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    std::string arch = "gfx950";
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0]) {
+        arch = prop.gcnArchName;
+        const size_t colon = arch.find(':');
+        if (colon != std::string::npos) arch = arch.substr(0, colon);
+    }
+    std::vector<char> code;
+    if (!compile_group(jit_index_source(shapes), arch, code, err)) return nullptr;
+    JitFilter *f = new JitFilter;
+    f->waves_per_group = 8;
+    if (hipModuleLoadData(&f->module, code.data()) != hipSuccess ||
+        hipModuleGetFunction(&f->fn, f->module, "ipcr_index_filter") != hipSuccess) {
+        err = "hipModuleLoadData/GetFunction failed for the specialised index filter";
+        jit_destroy(f);
+        return nullptr;
+    }
+    const unsigned lds = (unsigned)shapes.size() * 8192u;
+    if (lds > 48u * 1024u) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(f->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return f;
+}
+
+hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint32_t nshapes,
+                            const uint32_t *bitmaps, const void *table, uint32_t table_mask, uint32_t max_mm, void *queue,
+                            uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop) {
+    if (nblocks == 0) return hipSuccess;
+    uint64_t ncolpairs = nblocks * 32u;
+    const unsigned lds = nshapes * 8192u;
+    unsigned per_cu = (160u * 1024u) / (lds ? lds : 1u);
+    per_cu = per_cu < 1u ? 1u : (per_cu > 4u ? 4u : per_cu);
+    uint64_t grid = 256ull * per_cu;
+    if (grid * 8u > ncolpairs) grid = (ncolpairs + 7u) / 8u;
+    void *args[] = {(void *)&planes, (void *)&ncolpairs, (void *)&bitmaps, (void *)&table, (void *)&table_mask,
+                    (void *)&max_mm, (void *)&queue, (void *)&qcap, (void *)&qcount};
+    return hipExtModuleLaunchKernel(f->fn, (unsigned)grid * 512u, 1, 1, 512, 1, 1, lds, st, args, nullptr, start, stop, 0);
+}
+
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,
                       uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0) return hipSuccess;

@@ -23,6 +23,12 @@ size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats);
 std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err);
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,
                       uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop);
+// seed-index filter specialised on the panel's key shapes (same results as kernels.hip's)
+std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes);
+JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, std::string &err);
+hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint32_t nshapes,
+                            const uint32_t *bitmaps, const void *table, uint32_t table_mask, uint32_t max_mm, void *queue,
+                            uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop);
 void jit_destroy(JitFilter *f);
 
 } // namespace ipcr

@@ -28,6 +28,17 @@ def main() -> None:
             subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-c", path,
                                    "-o", path[:-4] + ".o"])
         cp.close()
+    # seed-index filter of a large panel (config C4)
+    from ipcr_amd.workloads import c4_pairs
+    cp = engine.New(engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)).CompilePanel(c4_pairs(64))
+    for mode in (2, 3):
+        src = cp.filter_source(mode)
+        assert "ipcr_index_filter" in src
+        path = os.path.join(outdir, f"index_c4_m{mode - 2}.hip")
+        with open(path, "w") as f:
+            f.write(src)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-c", path, "-o", path[:-4] + ".o"])
+    cp.close()
     print("jit_check: specialised filter sources compile for gfx950")
 
 

@@ -149,6 +149,58 @@ class HitExchanger:
         else:
             self.d_send, self.d_recv = self.h_send, self.h_recv
 
+    # -- overlapped form: the collective runs while the host joins this rank's own records --------
+    def start(self, local: np.ndarray, n_local_records: int):
+        """Enqueue the all-gatherv of this step's hit records (H2D of the local records + one
+        RCCL all-gather) and return at once.  Capacity must already fit (it does after one
+        synchronous `allgather`, which regrows it on every rank consistently)."""
+        assert local.dtype == HIT_DTYPE
+        if not self.active:
+            return None
+        if len(local) > self.cap:
+            raise RuntimeError(f"{len(local)} hit records exceed the exchange capacity {self.cap}; "
+                               "call allgather() once first so every rank regrows it together")
+        n = len(local)
+        hs = self.h_send.numpy()
+        hs[:16].view(np.int64)[:] = (n, n_local_records)
+        if n:
+            hs[32:32 + n * 32] = local.view(np.uint8).reshape(-1)
+        if self.d_send is not self.h_send:
+            self.d_send.copy_(self.h_send, non_blocking=True)
+        return self.dist.all_gather_into_tensor(self.d_recv, self.d_send, group=self.group, async_op=True)
+
+    def finish(self, work) -> None:
+        """Wait until every rank's hit records of this step are resident in this rank's memory
+        (`d_recv`: world x (header + cap records)); `gathered()` brings them to the host."""
+        if work is None:
+            return
+        work.wait()
+        if self.device.type == "cuda":
+            self.torch.cuda.current_stream(self.device).synchronize()
+
+    def gathered(self):
+        """Host copy of the last gathered buffer -> same triple as allgather()."""
+        if not self.active:
+            raise RuntimeError("no exchange in a single-process job")
+        if self.d_recv is not self.h_recv:
+            self.h_recv.copy_(self.d_recv)
+        return self._unpack()
+
+    def _unpack(self):
+        hr = self.h_recv.numpy().reshape(self.world, (self.cap + 1) * 32)
+        meta = hr[:, :16].copy().view(np.int64).reshape(self.world, 2)
+        parts, ranges, offsets, off, pos = [], [], [], 0, 0
+        for r in range(self.world):
+            cnt, nrec = int(meta[r, 0]), int(meta[r, 1])
+            part = hr[r, 32:32 + cnt * 32].copy().view(HIT_DTYPE)
+            part["record"] += np.uint32(off)
+            parts.append(part)
+            ranges.append((pos, pos + cnt))
+            offsets.append(off)
+            pos += cnt
+            off += nrec
+        return np.concatenate(parts), ranges, offsets
+
     def allgather(self, local: np.ndarray, n_local_records: int):
         """-> (all hits with job-global record index, per-rank (hit_start, hit_end), record offsets)"""
         assert local.dtype == HIT_DTYPE

@@ -47,6 +47,10 @@ a, b = x_ranges[rank]
 assert np.array_equal(x_hits[a:b]["pos"], local_hits["pos"])
 x2, _, _ = xchg.allgather(local_hits, len(lens))          # steady state: one collective
 assert np.array_equal(x2, all_hits)
+work = xchg.start(local_hits, len(lens))                   # overlapped form: enqueue, join own records, wait
+xchg.finish(work)
+x3, r3, o3 = xchg.gathered()
+assert np.array_equal(x3, all_hits) and r3 == x_ranges and o3 == offsets
 all_lens, all_flags = dist.allgather_record_meta(lens, flags)
 assert offsets == [0, 3] and all_lens == [4000] * 5 and len(all_flags) == 5
 sc = engine.SimulationScratch(cp, host_only=True)
