@@ -540,3 +540,21 @@ def test_config_c4_large_panel_index(hip):
     _, cp, sc, got = scan_and_compare(hip, cfg, pairs, g, seqs)
     assert sc.stats().kernel_kind == 3 and sc.stats().n_patterns == 1024 and len(got) >= 10
     g.close()
+
+
+def test_buffer_regrowth_on_dense_hits(hip):
+    """millions of hits: the device hit buffer (1 Mi records) and candidate queue must regrow and the
+    scan re-run transparently; HitCap still keeps only the first matches per orientation"""
+    E, P = hip.engine, hip.primer.Pair
+    n = 2_500_000
+    seq = b"A" * n
+    cfg = E.Config(MaxMM=0, TerminalWindow=3, MaxLen=40, HitCap=4)
+    eng = E.New(cfg)
+    cp = eng.CompilePanel([P("polyA", "AAAAAAAAAAAA", "TTTTTTTTTTTT")])
+    sc = eng.NewSimulationScratch(cp)
+    got = eng.SimulateCompiledWithScratch("s", seq, cp, sc)
+    assert sc.stats().hits >= 2 * (n - 11)          # A and rc(B)=A...A both match everywhere
+    want = O.simulate_batch(ocfg(cfg), seq[:200000], opairs(cp.Pairs))  # capped lists: a prefix decides
+    assert [g.sig() for g in got] == [w.sig() for w in want] and len(got) > 0
+    # and the scratch is still healthy afterwards
+    assert len(eng.SimulateCompiledWithScratch("seq1", b"AAAAAAAAAAAAGAAAAAAAAAAAA", cp, sc)) >= 1
