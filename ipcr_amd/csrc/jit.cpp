@@ -294,6 +294,9 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
     };
     auto load_normal = [&](const std::string &q) {
         const std::string d = std::to_string(D);
+        if (env_int("IPCR_JIT_NT", 1, 0, 1)) // every tile byte is read once: non-temporal loads
+            return "p" + d + "lo = __builtin_nontemporal_load(own + (" + q + ") * 192u); p" + d + "hi = __builtin_nontemporal_load(own + (" + q +
+                   ") * 192u + 64u); p" + d + "iv = __builtin_nontemporal_load(own + (" + q + ") * 192u + 128u);";
         return "p" + d + "lo = own[(" + q + ") * 192u]; p" + d + "hi = own[(" + q + ") * 192u + 64u]; p" + d + "iv = own[(" + q + ") * 192u + 128u];";
     };
     // rows past the strand end belong to the next strand: the same words shifted down one bit,

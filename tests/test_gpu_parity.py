@@ -558,3 +558,43 @@ def test_buffer_regrowth_on_dense_hits(hip):
     assert [g.sig() for g in got] == [w.sig() for w in want] and len(got) > 0
     # and the scratch is still healthy afterwards
     assert len(eng.SimulateCompiledWithScratch("seq1", b"AAAAAAAAAAAAGAAAAAAAAAAAA", cp, sc)) >= 1
+
+
+def test_concurrent_workers_share_one_panel(hip):
+    """the pipeline's threading contract (internal/pipeline/pipeline.go:60-125): CompilePanel once,
+    one scratch per worker, ForEachCompiledProduct concurrently from several workers"""
+    import threading
+    E, P = hip.engine, hip.primer.Pair
+    cfg = E.Config(MaxMM=1, TerminalWindow=3, MaxLen=400, HitCap=10000, SeedLen=12)
+    pairs = hip.primer.AddSelfPairs([P("p", "ACGTTGCATGCAAGCT", "GGCCTTAAGGCCATAT")])
+    eng = E.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    rng = random.Random(77)
+    jobs = []
+    for j in range(24):
+        n = rng.choice([3000, 50000, 300000])
+        s = rand_case(rng, n, with_junk=(j % 4 == 0))
+        for _ in range(4):
+            a = rng.randrange(0, n - 400)
+            plant(rng, s, pairs[0].Forward, a, rng.choice([0, 1]))
+            plant(rng, s, O.revcomp(pairs[0].Reverse).decode(), a + rng.randint(40, 300), 0)
+        jobs.append("".join(s).encode())
+    want = [[w.sig() for w in O.simulate_batch(ocfg(cfg), s, opairs(pairs))] for s in jobs]
+    got = [None] * len(jobs)
+    errors = []
+
+    def worker(wid):
+        try:
+            sc = eng.NewSimulationScratch(cp)
+            for j in range(wid, len(jobs), 4):
+                got[j] = [p.sig() for p in eng.SimulateCompiledWithScratch("job%d" % j, jobs[j], cp, sc)]
+            sc.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and got == want
