@@ -766,7 +766,12 @@ struct ipcr_scratch {
     uint64_t prefix_hint = 256; // hits copied back together with the counters
     ipcr_hit_rec *d_hits = nullptr;
     uint64_t hcap = 0;
-    unsigned long long *d_counts = nullptr; // [0] queue entries, [1] hits, [2] candidate windows
+    // two alternating counter sets ([0] queue entries, [1] hits, [2] candidate windows) live in the
+    // 64 bytes in FRONT of the hit records (d_hitbuf): one D2H copy brings counters + first hits
+    // back, and each scan's verify kernel clears the set of the next scan (no memset launch)
+    unsigned long long *d_counts = nullptr; // set 0; set 1 = d_counts + 4
+    void *d_hitbuf = nullptr;
+    uint32_t cset = 0;
     void *pinned = nullptr;                 // counts (16 B) + first PREFIX hits
     std::vector<ipcr_hit> hits;      // sorted by (record, pattern, pos)
     std::vector<ipcr_hit> hits_raw;  // in device append order
@@ -908,10 +913,12 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     };
     for (int attempt = 0; attempt < 8; ++attempt) {
         const auto te = std::chrono::steady_clock::now();
-        HIPCHK(hipMemsetAsync(s->d_counts, 0, 32, s->stream));
+        unsigned long long *cnt = s->d_counts + 4u * s->cset, *cnt_next = s->d_counts + 4u * (s->cset ^ 1u);
+        const uint32_t cset_used = s->cset;
+        s->cset ^= 1u;
         if (!set.jit.empty()) {
             for (size_t gi = 0; gi < set.jit.size(); ++gi) // every group streams the tiles once
-                HIPCHK(ipcr::jit_launch(set.jit[gi], s->stream, g->planes, nblocks, s->d_queue, s->qcap, s->d_counts,
+                HIPCHK(ipcr::jit_launch(set.jit[gi], s->stream, g->planes, nblocks, s->d_queue, s->qcap, cnt,
                                         gi == 0 ? s->ev[0] : nullptr, gi + 1 == set.jit.size() ? s->ev[1] : nullptr));
             s->stats.kernel_kind = 1;
         } else if (set.index.usable) {
@@ -920,29 +927,28 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             if (ix.jit)
                 HIPCHK(ipcr::jit_launch_index(ix.jit, s->stream, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
                                               ix.d_table, ix.table_mask, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
-                                              s->d_counts, s->ev[0], more ? nullptr : s->ev[1]));
+                                              cnt, s->ev[0], more ? nullptr : s->ev[1]));
             else
                 HIPCHK(ipcr::launch_filter_index(s->stream, g->planes, nblocks, ix.d_shapes, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
                                                  ix.d_table, ix.table_mask, ix.d_meta, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
-                                                 s->d_counts, s->ev[0], more ? nullptr : s->ev[1]));
+                                                 cnt, s->ev[0], more ? nullptr : s->ev[1]));
             if (more) // IUPAC / long patterns the index cannot key
                 HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)ix.leftover.size(),
-                                                   (uint32_t)p->cfg.max_mm, ix.d_leftover, s->d_queue, s->qcap, s->d_counts,
+                                                   (uint32_t)p->cfg.max_mm, ix.d_leftover, s->d_queue, s->qcap, cnt,
                                                    nullptr, s->ev[1]));
             s->stats.kernel_kind = 3;
         } else {
             HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)set.ids.size(),
-                                               (uint32_t)p->cfg.max_mm, nullptr, s->d_queue, s->qcap, s->d_counts, s->ev[0], s->ev[1]));
+                                               (uint32_t)p->cfg.max_mm, nullptr, s->d_queue, s->qcap, cnt, s->ev[0], s->ev[1]));
             s->stats.kernel_kind = 2;
         }
         HIPCHK(ipcr::launch_verify(s->stream, g->planes, g->rst, set.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
-                                   g->d_rec_len, nrec, check_rst, s->d_queue, s->qcap, s->d_counts, s->d_hits,
-                                   s->hcap, s->d_counts + 1, s->d_counts + 2, s->ev[2], s->ev[3]));
-        unsigned long long *pc = static_cast<unsigned long long *>(s->pinned);
-        ipcr_hit *ph = reinterpret_cast<ipcr_hit *>(pc + 4);
-        HIPCHK(hipMemcpyAsync(pc, s->d_counts, 32, hipMemcpyDeviceToHost, s->stream));
+                                   g->d_rec_len, nrec, check_rst, s->d_queue, s->qcap, cnt, s->d_hits,
+                                   s->hcap, cnt + 1, cnt + 2, cnt_next, s->ev[2], s->ev[3]));
+        unsigned long long *pc = static_cast<unsigned long long *>(s->pinned) + 4u * cset_used;
+        ipcr_hit *ph = reinterpret_cast<ipcr_hit *>(static_cast<unsigned long long *>(s->pinned) + 8);
         const uint64_t pre = std::min<uint64_t>(std::min<uint64_t>(s->prefix_hint, PREFIX_HITS), s->hcap);
-        HIPCHK(hipMemcpyAsync(ph, s->d_hits, pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(s->pinned, s->d_hitbuf, 64 + pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->stream)); // counters + hits
         s->stats.enqueue_ms = ms_since(te);
         const auto tw = std::chrono::steady_clock::now();
         HIPCHK(hipStreamSynchronize(s->stream));
@@ -962,9 +968,14 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             uint64_t want = s->hcap;
             while (want < nhit) want *= 2;
             if (want > HCAP_MAX) return fail(IPCR_ERR_CAPACITY, "%llu hits exceed the device hit-buffer limit", (unsigned long long)nhit);
-            HIPCHK(hipFree(s->d_hits));
+            HIPCHK(hipFree(s->d_hitbuf));
+            s->d_hitbuf = nullptr;
             s->d_hits = nullptr;
-            HIPCHK(hipMalloc((void **)&s->d_hits, want * sizeof(ipcr_hit_rec)));
+            s->d_counts = nullptr;
+            HIPCHK(hipMalloc(&s->d_hitbuf, (want + 2) * sizeof(ipcr_hit_rec)));
+            HIPCHK(hipMemset(s->d_hitbuf, 0, 64));
+            s->d_counts = static_cast<unsigned long long *>(s->d_hitbuf);
+            s->d_hits = static_cast<ipcr_hit_rec *>(s->d_hitbuf) + 2;
             s->hcap = want;
             continue;
         }
@@ -1223,9 +1234,11 @@ ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out) {
         raw->qcap = QCAP_INIT;
         raw->hcap = HCAP_INIT;
         HIPCHK(hipMalloc((void **)&raw->d_queue, raw->qcap * sizeof(ipcr_queue_entry)));
-        HIPCHK(hipMalloc((void **)&raw->d_hits, raw->hcap * sizeof(ipcr_hit_rec)));
-        HIPCHK(hipMalloc((void **)&raw->d_counts, 32));
-        HIPCHK(hipHostMalloc(&raw->pinned, 32 + PREFIX_HITS * sizeof(ipcr_hit), hipHostMallocDefault));
+        HIPCHK(hipMalloc(&raw->d_hitbuf, (raw->hcap + 2) * sizeof(ipcr_hit_rec)));
+        HIPCHK(hipMemset(raw->d_hitbuf, 0, 64));
+        raw->d_counts = static_cast<unsigned long long *>(raw->d_hitbuf);
+        raw->d_hits = static_cast<ipcr_hit_rec *>(raw->d_hitbuf) + 2;
+        HIPCHK(hipHostMalloc(&raw->pinned, 64 + PREFIX_HITS * sizeof(ipcr_hit), hipHostMallocDefault));
         return IPCR_OK;
     };
     ipcr_status st = build();
@@ -1246,8 +1259,7 @@ void ipcr_scratch_destroy(ipcr_scratch *s) {
     if (!s) return;
     if (s->chunk) ipcr_genome_destroy(s->chunk);
     if (s->d_queue) (void)hipFree(s->d_queue);
-    if (s->d_hits) (void)hipFree(s->d_hits);
-    if (s->d_counts) (void)hipFree(s->d_counts);
+    if (s->d_hitbuf) (void)hipFree(s->d_hitbuf);
     if (s->d_amps) (void)hipFree(s->d_amps);
     if (s->d_probe_misc) (void)hipFree(s->d_probe_misc);
     if (s->pinned) (void)hipHostFree(s->pinned);

@@ -367,7 +367,11 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint32_t *__restrict_
                                                      const unsigned long long *__restrict__ qcount,
                                                      ipcr_hit_rec *__restrict__ hits, uint64_t hcap,
                                                      unsigned long long *__restrict__ hcount,
-                                                     unsigned long long *__restrict__ ccount) {
+                                                     unsigned long long *__restrict__ ccount,
+                                                     unsigned long long *__restrict__ next_counters) {
+    // the counters alternate between two sets; this launch clears the set the NEXT scan will use
+    // (its values were copied to the host before this scan was enqueued), so no memset launch
+    if (blockIdx.x == 0 && threadIdx.x < 4u) next_counters[threadIdx.x] = 0ull;
     unsigned long long n = *qcount;
     if (n > qcap) n = qcap;
     n *= 32ull; // one thread per (queue entry, strand bit)
@@ -598,10 +602,12 @@ hipError_t launch_verify(hipStream_t st, const uint32_t *planes, const uint32_t 
                          const ipcr_dev_pattern *pats, uint32_t max_mm, const uint64_t *rec_start,
                          const uint64_t *rec_len, uint32_t nrec, uint32_t check_rst, const ipcr_queue_entry *queue,
                          uint64_t qcap, const unsigned long long *qcount, ipcr_hit_rec *hits, uint64_t hcap,
-                         unsigned long long *hcount, unsigned long long *ccount, hipEvent_t start, hipEvent_t stop) {
+                         unsigned long long *hcount, unsigned long long *ccount, unsigned long long *next_counters,
+                         hipEvent_t start, hipEvent_t stop) {
     if (nrec == 0) return hipSuccess;
     hipExtLaunchKernelGGL(verify_kernel, dim3(1024), dim3(256), 0, st, start, stop, 0, planes, rst, pats, max_mm,
-                          rec_start, rec_len, nrec, check_rst, queue, qcap, qcount, hits, hcap, hcount, ccount);
+                          rec_start, rec_len, nrec, check_rst, queue, qcap, qcount, hits, hcap, hcount, ccount,
+                          next_counters);
     return hipGetLastError();
 }
 
