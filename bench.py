@@ -218,6 +218,7 @@ def main() -> None:
             "filter_candidates_rank0": int(sc.stats().candidates),
             "filter_kernel": "panel-specialised (hiprtc)" if sc.stats().kernel_kind == 1 else "table-driven",
             "pack_ms_per_genome": round(genome.pack_ms, 3),
+            "gbases_per_s_incl_pack": round(genome.total_bases * world / ((genome.pack_ms + ms_per_step) * 1e-3) / 1e9, 1),
             "step_breakdown_ms_rank0": {k: round(getattr(sc.stats(), k), 4) for k in
                                         ("filter_ms", "verify_ms", "enqueue_ms", "wait_ms", "sort_ms", "join_ms", "total_ms")},
             "parallelism": ("1 genome per GPU, one all-gatherv of hit records per step (%s), join partitioned by record" % backend)

@@ -372,65 +372,80 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint32_t *__restrict_
     // the counters alternate between two sets; this launch clears the set the NEXT scan will use
     // (its values were copied to the host before this scan was enqueued), so no memset launch
     if (blockIdx.x == 0 && threadIdx.x < 4u) next_counters[threadIdx.x] = 0ull;
+    // hit slots and the candidate count are aggregated per workgroup in LDS: thousands of
+    // same-address global atomics would serialise at ~12 ns each (MI355X_MICROARCH.md, fanin)
+    __shared__ uint32_t s_hits, s_cands;
+    __shared__ unsigned long long s_base;
     unsigned long long n = *qcount;
     if (n > qcap) n = qcap;
     n *= 32ull; // one thread per (queue entry, strand bit)
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        const ipcr_queue_entry ent = queue[i >> 5];
-        const uint32_t bit = (uint32_t)(i & 31u);
-        if (bit == 0u) atomicAdd(ccount, (unsigned long long)__builtin_popcount(ent.bits));
-        if (!((ent.bits >> bit) & 1u)) continue;
-        const uint32_t q = (uint32_t)(ent.key >> 48);
-        const uint64_t P = (ent.key & 0xFFFFFFFFFFFFull) + ((uint64_t)bit << IPCR_TILE_LOG_N);
-        // record lookup: last record with start <= P
-        uint32_t lo = 0, hi = nrec;
-        while (hi - lo > 1u) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (rec_start[mid] <= P) lo = mid; else hi = mid;
-        }
-        const uint64_t local = P - rec_start[lo];
-        const ipcr_dev_pattern *pp = pats + q;
-        const uint32_t L = pp->len;
-        if (local + L > rec_len[lo]) continue; // window leaves the record (ac.go:188-190)
-        uint32_t mm = 0;
-        uint64_t m0 = 0, m1 = 0;
-        bool ok = true;
-        // 8 positions per round: their 24 tile words are loaded back to back (independent
-        // addresses), then compared; the early exit is taken between rounds only
-        for (uint32_t j0 = 0; j0 < L && ok; j0 += 8u) {
-            uint32_t g[8];
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
+        if (threadIdx.x == 0) { s_hits = 0; s_cands = 0; }
+        __syncthreads();
+        const uint64_t i = base + threadIdx.x;
+        bool hit = false;
+        ipcr_hit_rec h;
+        if (i < n) {
+            const ipcr_queue_entry ent = queue[i >> 5];
+            const uint32_t bit = (uint32_t)(i & 31u);
+            if (bit == 0u) atomicAdd(&s_cands, (uint32_t)__builtin_popcount(ent.bits));
+            if ((ent.bits >> bit) & 1u) {
+                const uint32_t q = (uint32_t)(ent.key >> 48);
+                const uint64_t P = (ent.key & 0xFFFFFFFFFFFFull) + ((uint64_t)bit << IPCR_TILE_LOG_N);
+                // record lookup: last record with start <= P
+                uint32_t lo = 0, hi = nrec;
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (rec_start[mid] <= P) lo = mid; else hi = mid;
+                }
+                const uint64_t local = P - rec_start[lo];
+                const ipcr_dev_pattern *pp = pats + q;
+                const uint32_t L = pp->len;
+                bool ok = local + L <= rec_len[lo]; // window must stay inside the record (ac.go:188-190)
+                uint32_t mm = 0;
+                uint64_t m0 = 0, m1 = 0;
+                // 8 positions per round: their 24 tile words are loaded back to back (independent
+                // addresses), then compared; the early exit is taken between rounds only
+                for (uint32_t j0 = 0; j0 < L && ok; j0 += 8u) {
+                    uint32_t g[8];
 #pragma unroll
-            for (uint32_t t = 0; t < 8u; ++t) g[t] = (j0 + t < L) ? base_bits(planes, P + j0 + t) : 0u;
+                    for (uint32_t t = 0; t < 8u; ++t) g[t] = (j0 + t < L) ? base_bits(planes, P + j0 + t) : 0u;
 #pragma unroll
-            for (uint32_t t = 0; t < 8u; ++t) {
-                const uint32_t j = j0 + t;
-                if (j >= L) break;
-                const uint32_t onehot = (g[t] & 4u) ? 0u : (1u << (g[t] & 3u));
-                const uint32_t m = pp->mask[j];
-                if ((m & onehot) == 0u) {
-                    if (m & 16u) ok = false;
-                    ++mm;
-                    if (j < 64u) m0 |= 1ull << j; else m1 |= 1ull << (j - 64u);
+                    for (uint32_t t = 0; t < 8u; ++t) {
+                        const uint32_t j = j0 + t;
+                        if (j >= L) break;
+                        const uint32_t onehot = (g[t] & 4u) ? 0u : (1u << (g[t] & 3u));
+                        const uint32_t m = pp->mask[j];
+                        if ((m & onehot) == 0u) {
+                            if (m & 16u) ok = false;
+                            ++mm;
+                            if (j < 64u) m0 |= 1ull << j; else m1 |= 1ull << (j - 64u);
+                        }
+                    }
+                    if (mm > max_mm) ok = false;
+                }
+                if (ok) {
+                    uint32_t flag = 0;
+                    if (check_rst && pp->seed_len)
+                        for (uint32_t j = 0; j < pp->seed_len; ++j) flag |= rst_bit(rst, P + pp->seed_off + j);
+                    hit = true;
+                    h.pos = local;
+                    h.record = lo;
+                    h.pattern = pp->global_id | (flag << 31);
+                    h.mm_mask[0] = m0;
+                    h.mm_mask[1] = m1;
                 }
             }
-            if (mm > max_mm) ok = false;
         }
-        if (!ok) continue;
-        uint32_t flag = 0;
-        if (check_rst && pp->seed_len) {
-            for (uint32_t j = 0; j < pp->seed_len; ++j) flag |= rst_bit(rst, P + pp->seed_off + j);
+        const uint32_t slot = hit ? atomicAdd(&s_hits, 1u) : 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_base = s_hits ? atomicAdd(hcount, (unsigned long long)s_hits) : 0ull;
+            if (s_cands) atomicAdd(ccount, (unsigned long long)s_cands);
         }
-        const unsigned long long idx = atomicAdd(hcount, 1ull);
-        if (idx < hcap) {
-            ipcr_hit_rec h;
-            h.pos = local;
-            h.record = lo;
-            h.pattern = pp->global_id | (flag << 31);
-            h.mm_mask[0] = m0;
-            h.mm_mask[1] = m1;
-            hits[idx] = h;
-        }
+        __syncthreads();
+        if (hit && s_base + slot < hcap) hits[s_base + slot] = h;
+        __syncthreads();
     }
 }
 
