@@ -24,6 +24,10 @@ struct ipcr_queue_entry {
     uint32_t pad;
 };
 
+// the queue is cut into segments, one push counter each, 128 B apart
+#define IPCR_QUEUE_SHARDS 256u
+#define IPCR_QUEUE_COUNTER_STRIDE 16u // in 8-byte words
+
 // layout-identical to ipcr_hit in include/ipcr_hip.h
 struct ipcr_hit_rec {
     uint64_t pos;

@@ -761,8 +761,9 @@ struct ipcr_scratch {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // filter start/stop, verify start/stop
-    ipcr_queue_entry *d_queue = nullptr;
-    uint64_t qcap = 0;
+    ipcr_queue_entry *d_queue = nullptr; // IPCR_QUEUE_SHARDS segments of qcap entries
+    uint64_t qcap = 0;                   // capacity of ONE segment
+    unsigned long long *d_qcounts = nullptr; // 2 sets x IPCR_QUEUE_SHARDS counters, 128 B apart
     uint64_t prefix_hint = 256; // hits copied back together with the counters
     ipcr_hit_rec *d_hits = nullptr;
     uint64_t hcap = 0;
@@ -789,9 +790,9 @@ struct ipcr_scratch {
 namespace {
 
 constexpr uint64_t PREFIX_HITS = 65536;
-constexpr uint64_t QCAP_INIT = 1ull << 21;  // 2 Mi surviving words (32 MiB)
+constexpr uint64_t QCAP_INIT = 1ull << 13;  // per segment: 256 x 8 Ki surviving words (32 MiB)
 constexpr uint64_t HCAP_INIT = 1ull << 20;  // 1 Mi hits (32 MiB)
-constexpr uint64_t QCAP_MAX = 1ull << 30;
+constexpr uint64_t QCAP_MAX = 1ull << 23;   // per segment (2 Gi words in all)
 constexpr uint64_t HCAP_MAX = 1ull << 28;
 
 ipcr_status panel_upload(const ipcr_panel *cp, int mode) {
@@ -914,11 +915,13 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     for (int attempt = 0; attempt < 8; ++attempt) {
         const auto te = std::chrono::steady_clock::now();
         unsigned long long *cnt = s->d_counts + 4u * s->cset, *cnt_next = s->d_counts + 4u * (s->cset ^ 1u);
+        const uint64_t qset = (uint64_t)IPCR_QUEUE_SHARDS * IPCR_QUEUE_COUNTER_STRIDE;
+        unsigned long long *qc = s->d_qcounts + qset * s->cset, *qc_next = s->d_qcounts + qset * (s->cset ^ 1u);
         const uint32_t cset_used = s->cset;
         s->cset ^= 1u;
         if (!set.jit.empty()) {
             for (size_t gi = 0; gi < set.jit.size(); ++gi) // every group streams the tiles once
-                HIPCHK(ipcr::jit_launch(set.jit[gi], s->stream, g->planes, nblocks, s->d_queue, s->qcap, cnt,
+                HIPCHK(ipcr::jit_launch(set.jit[gi], s->stream, g->planes, nblocks, s->d_queue, s->qcap, qc,
                                         gi == 0 ? s->ev[0] : nullptr, gi + 1 == set.jit.size() ? s->ev[1] : nullptr));
             s->stats.kernel_kind = 1;
         } else if (set.index.usable) {
@@ -927,24 +930,24 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             if (ix.jit)
                 HIPCHK(ipcr::jit_launch_index(ix.jit, s->stream, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
                                               ix.d_table, ix.table_mask, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
-                                              cnt, s->ev[0], more ? nullptr : s->ev[1]));
+                                              qc, s->ev[0], more ? nullptr : s->ev[1]));
             else
                 HIPCHK(ipcr::launch_filter_index(s->stream, g->planes, nblocks, ix.d_shapes, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
                                                  ix.d_table, ix.table_mask, ix.d_meta, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
-                                                 cnt, s->ev[0], more ? nullptr : s->ev[1]));
+                                                 qc, s->ev[0], more ? nullptr : s->ev[1]));
             if (more) // IUPAC / long patterns the index cannot key
                 HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)ix.leftover.size(),
-                                                   (uint32_t)p->cfg.max_mm, ix.d_leftover, s->d_queue, s->qcap, cnt,
+                                                   (uint32_t)p->cfg.max_mm, ix.d_leftover, s->d_queue, s->qcap, qc,
                                                    nullptr, s->ev[1]));
             s->stats.kernel_kind = 3;
         } else {
             HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)set.ids.size(),
-                                               (uint32_t)p->cfg.max_mm, nullptr, s->d_queue, s->qcap, cnt, s->ev[0], s->ev[1]));
+                                               (uint32_t)p->cfg.max_mm, nullptr, s->d_queue, s->qcap, qc, s->ev[0], s->ev[1]));
             s->stats.kernel_kind = 2;
         }
         HIPCHK(ipcr::launch_verify(s->stream, g->planes, g->rst, set.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
-                                   g->d_rec_len, nrec, check_rst, s->d_queue, s->qcap, cnt, s->d_hits,
-                                   s->hcap, cnt + 1, cnt + 2, cnt_next, s->ev[2], s->ev[3]));
+                                   g->d_rec_len, nrec, check_rst, s->d_queue, s->qcap, qc, s->d_hits,
+                                   s->hcap, cnt + 1, cnt + 2, cnt_next, qc_next, s->ev[2], s->ev[3]));
         unsigned long long *pc = static_cast<unsigned long long *>(s->pinned) + 4u * cset_used;
         ipcr_hit *ph = reinterpret_cast<ipcr_hit *>(static_cast<unsigned long long *>(s->pinned) + 8);
         const uint64_t pre = std::min<uint64_t>(std::min<uint64_t>(s->prefix_hint, PREFIX_HITS), s->hcap);
@@ -953,14 +956,14 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         const auto tw = std::chrono::steady_clock::now();
         HIPCHK(hipStreamSynchronize(s->stream));
         s->stats.wait_ms = ms_since(tw);
-        const uint64_t nent = pc[0], nhit = pc[1], ncand = pc[2];
-        if (nent > s->qcap) { // candidate queue overflowed: regrow and rescan
+        const uint64_t nhit = pc[1], ncand = pc[2], fullest = pc[3];
+        if (fullest > s->qcap) { // a queue segment overflowed: regrow all segments and rescan
             uint64_t want = s->qcap;
-            while (want < nent) want *= 2;
-            if (want > QCAP_MAX) return fail(IPCR_ERR_CAPACITY, "%llu filter survivors exceed the device queue limit", (unsigned long long)nent);
+            while (want < fullest) want *= 2;
+            if (want > QCAP_MAX) return fail(IPCR_ERR_CAPACITY, "%llu filter survivors in one queue segment exceed the device queue limit", (unsigned long long)fullest);
             HIPCHK(hipFree(s->d_queue));
             s->d_queue = nullptr;
-            HIPCHK(hipMalloc((void **)&s->d_queue, want * sizeof(ipcr_queue_entry)));
+            HIPCHK(hipMalloc((void **)&s->d_queue, want * IPCR_QUEUE_SHARDS * sizeof(ipcr_queue_entry)));
             s->qcap = want;
             continue;
         }
@@ -1233,7 +1236,9 @@ ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out) {
         for (auto &e : raw->ev) HIPCHK(hipEventCreate(&e));
         raw->qcap = QCAP_INIT;
         raw->hcap = HCAP_INIT;
-        HIPCHK(hipMalloc((void **)&raw->d_queue, raw->qcap * sizeof(ipcr_queue_entry)));
+        HIPCHK(hipMalloc((void **)&raw->d_queue, raw->qcap * IPCR_QUEUE_SHARDS * sizeof(ipcr_queue_entry)));
+        HIPCHK(hipMalloc((void **)&raw->d_qcounts, 2ull * IPCR_QUEUE_SHARDS * IPCR_QUEUE_COUNTER_STRIDE * 8ull));
+        HIPCHK(hipMemset(raw->d_qcounts, 0, 2ull * IPCR_QUEUE_SHARDS * IPCR_QUEUE_COUNTER_STRIDE * 8ull));
         HIPCHK(hipMalloc(&raw->d_hitbuf, (raw->hcap + 2) * sizeof(ipcr_hit_rec)));
         HIPCHK(hipMemset(raw->d_hitbuf, 0, 64));
         raw->d_counts = static_cast<unsigned long long *>(raw->d_hitbuf);
@@ -1259,6 +1264,7 @@ void ipcr_scratch_destroy(ipcr_scratch *s) {
     if (!s) return;
     if (s->chunk) ipcr_genome_destroy(s->chunk);
     if (s->d_queue) (void)hipFree(s->d_queue);
+    if (s->d_qcounts) (void)hipFree(s->d_qcounts);
     if (s->d_hitbuf) (void)hipFree(s->d_hitbuf);
     if (s->d_amps) (void)hipFree(s->d_amps);
     if (s->d_probe_misc) (void)hipFree(s->d_probe_misc);

@@ -199,13 +199,14 @@ __global__ __launch_bounds__(256) void filter_generic_kernel(const uint32_t *__r
             if ((uint32_t)t == max_mm + 1u) over = u[t];
         const uint32_t alive = ~(dead | over);
         if (alive) { // one queue entry per surviving word: 32 strands of this row
-            const unsigned long long idx = atomicAdd(qcount, 1ull);
-            if (idx < qcap) {
+            const uint32_t shard = (uint32_t)block & (IPCR_QUEUE_SHARDS - 1u);
+            const unsigned long long idx = atomicAdd(qcount + shard * IPCR_QUEUE_COUNTER_STRIDE, 1ull);
+            if (idx < qcap) { // qcap = capacity of one shard's segment
                 ipcr_queue_entry e;
                 e.key = ((uint64_t)q << 48) | ipcr_join_pos(block * 64u + lane, 0, row);
                 e.bits = alive;
                 e.pad = 0;
-                queue[idx] = e;
+                queue[(uint64_t)shard * qcap + idx] = e;
             }
         }
     }
@@ -318,13 +319,14 @@ __global__ __launch_bounds__(512) void filter_index_kernel(const uint32_t *__res
                             const int32_t srow = e.left ? erow - 31 : erow - (int32_t)L + 1;
                             if ((mm2 & e.prot2) == 0ull && (uint32_t)__popcll(mm2) <= max_mm && srow >= 0 &&
                                 srow < (int32_t)IPCR_TILE_N) {
-                                const unsigned long long idx = atomicAdd(qcount, 1ull);
+                                const uint32_t shard = (uint32_t)cp & (IPCR_QUEUE_SHARDS - 1u);
+                                const unsigned long long idx = atomicAdd(qcount + shard * IPCR_QUEUE_COUNTER_STRIDE, 1ull);
                                 if (idx < qcap) {
                                     ipcr_queue_entry qe;
                                     qe.key = ((uint64_t)e.pattern << 48) | (strand_base + (uint64_t)srow);
                                     qe.bits = 1u;
                                     qe.pad = 0;
-                                    queue[idx] = qe;
+                                    queue[(uint64_t)shard * qcap + idx] = qe;
                                 }
                             }
                         }
@@ -368,17 +370,37 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint32_t *__restrict_
                                                      ipcr_hit_rec *__restrict__ hits, uint64_t hcap,
                                                      unsigned long long *__restrict__ hcount,
                                                      unsigned long long *__restrict__ ccount,
-                                                     unsigned long long *__restrict__ next_counters) {
-    // the counters alternate between two sets; this launch clears the set the NEXT scan will use
-    // (its values were copied to the host before this scan was enqueued), so no memset launch
-    if (blockIdx.x == 0 && threadIdx.x < 4u) next_counters[threadIdx.x] = 0ull;
-    // hit slots and the candidate count are aggregated per workgroup in LDS: thousands of
-    // same-address global atomics would serialise at ~12 ns each (MI355X_MICROARCH.md, fanin)
+                                                     unsigned long long *__restrict__ next_counters,
+                                                     unsigned long long *__restrict__ next_qcount) {
+    // The candidate queue is cut into IPCR_QUEUE_SHARDS segments with a counter each (a single
+    // counter serialises the filters' pushes at ~12 ns apiece, MI355X_MICROARCH.md "dequeue").
+    // qcount = this scan's shard counters, qcap = capacity of one segment.
+    // The counters alternate between two sets; this launch clears the set the NEXT scan will use
+    // (its values were copied to the host before this scan was enqueued), so no memset launch.
+    __shared__ uint32_t s_pref[IPCR_QUEUE_SHARDS]; // inclusive prefix of the (clamped) shard counts
     __shared__ uint32_t s_hits, s_cands;
     __shared__ unsigned long long s_base;
-    unsigned long long n = *qcount;
-    if (n > qcap) n = qcap;
-    n *= 32ull; // one thread per (queue entry, strand bit)
+    {
+        const uint32_t t = threadIdx.x; // blockDim.x == IPCR_QUEUE_SHARDS == 256
+        const unsigned long long raw = qcount[t * IPCR_QUEUE_COUNTER_STRIDE];
+        s_pref[t] = (uint32_t)(raw > qcap ? qcap : raw);
+        if (blockIdx.x == 0) {
+            next_qcount[t * IPCR_QUEUE_COUNTER_STRIDE] = 0ull;
+            if (t < 4u) next_counters[t] = 0ull;
+            atomicAdd(ccount - 2, raw);           // header[0]: total queue entries pushed
+            atomicMax(ccount + 1, raw);           // header[3]: fullest shard (overflow check on the host)
+        }
+        __syncthreads();
+        for (uint32_t d = 1; d < IPCR_QUEUE_SHARDS; d <<= 1) { // Hillis-Steele scan
+            const uint32_t v = (t >= d) ? s_pref[t - d] : 0u;
+            __syncthreads();
+            s_pref[t] += v;
+            __syncthreads();
+        }
+    }
+    // hit slots and the candidate count are aggregated per workgroup in LDS: thousands of
+    // same-address global atomics would serialise (see above)
+    unsigned long long n = (unsigned long long)s_pref[IPCR_QUEUE_SHARDS - 1u] * 32ull; // one thread per (entry, strand bit)
     for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
         if (threadIdx.x == 0) { s_hits = 0; s_cands = 0; }
         __syncthreads();
@@ -386,7 +408,14 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint32_t *__restrict_
         bool hit = false;
         ipcr_hit_rec h;
         if (i < n) {
-            const ipcr_queue_entry ent = queue[i >> 5];
+            const uint32_t eidx = (uint32_t)(i >> 5);
+            uint32_t slo = 0, shi = IPCR_QUEUE_SHARDS - 1u; // first shard whose inclusive prefix exceeds eidx
+            while (slo < shi) {
+                const uint32_t mid = (slo + shi) >> 1;
+                if (s_pref[mid] > eidx) shi = mid; else slo = mid + 1u;
+            }
+            const uint32_t within = eidx - (slo ? s_pref[slo - 1u] : 0u);
+            const ipcr_queue_entry ent = queue[(uint64_t)slo * qcap + within];
             const uint32_t bit = (uint32_t)(i & 31u);
             if (bit == 0u) atomicAdd(&s_cands, (uint32_t)__builtin_popcount(ent.bits));
             if ((ent.bits >> bit) & 1u) {
@@ -618,11 +647,11 @@ hipError_t launch_verify(hipStream_t st, const uint32_t *planes, const uint32_t 
                          const uint64_t *rec_len, uint32_t nrec, uint32_t check_rst, const ipcr_queue_entry *queue,
                          uint64_t qcap, const unsigned long long *qcount, ipcr_hit_rec *hits, uint64_t hcap,
                          unsigned long long *hcount, unsigned long long *ccount, unsigned long long *next_counters,
-                         hipEvent_t start, hipEvent_t stop) {
+                         unsigned long long *next_qcount, hipEvent_t start, hipEvent_t stop) {
     if (nrec == 0) return hipSuccess;
     hipExtLaunchKernelGGL(verify_kernel, dim3(1024), dim3(256), 0, st, start, stop, 0, planes, rst, pats, max_mm,
                           rec_start, rec_len, nrec, check_rst, queue, qcap, qcount, hits, hcap, hcount, ccount,
-                          next_counters);
+                          next_counters, next_qcount);
     return hipGetLastError();
 }
 
