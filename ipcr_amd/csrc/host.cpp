@@ -860,6 +860,7 @@ void dedup_sorted_hits(std::vector<ipcr_hit> &v) {
 // ascending in position.  Counting sort over the (record, pattern) buckets, then each small
 // bucket by position -- O(n) instead of a comparison sort of 32-byte records.
 void sort_hits(const std::vector<ipcr_hit> &in, std::vector<ipcr_hit> &out, uint32_t nrec, uint32_t npat) {
+    static thread_local std::vector<uint32_t> cnt, cur;
     const size_t n = in.size();
     out.resize(n);
     if (n == 0) return;
@@ -874,10 +875,10 @@ void sort_hits(const std::vector<ipcr_hit> &in, std::vector<ipcr_hit> &out, uint
         dedup_sorted_hits(out);
         return;
     }
-    std::vector<uint32_t> cnt(nb + 1, 0);
+    cnt.assign(nb + 1, 0);
     for (const ipcr_hit &h : in) ++cnt[(uint64_t)h.record * npat + (h.pattern & 0x7FFFFFFFu) + 1];
     for (uint64_t i = 0; i < nb; ++i) cnt[i + 1] += cnt[i];
-    std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+    cur.assign(cnt.begin(), cnt.end() - 1);
     for (const ipcr_hit &h : in) out[cur[(uint64_t)h.record * npat + (h.pattern & 0x7FFFFFFFu)]++] = h;
     for (uint64_t i = 0; i < nb; ++i) {
         const uint32_t b = cnt[i], e = cnt[i + 1];
@@ -1045,16 +1046,16 @@ struct JoinCtx {
 
 bool push_product(JoinCtx &c, int pair, uint32_t rec, int64_t start, int64_t end, int64_t length, int type,
                   const MatchRef &mf, const MatchRef &mr, int rlen) {
-    ipcr_product pr;
-    memset(&pr, 0, sizeof pr);
+    c.out->emplace_back();
+    ipcr_product &pr = c.out->back();
     pr.start = start; pr.end = end; pr.length = length;
     pr.pair = pair; pr.record = (int32_t)rec; pr.type = type;
+    memset(pr.fwd_idx, 0, sizeof pr.fwd_idx + sizeof pr.rev_idx);
     pr.fwd_mm = hit_mm(mf.h);
     pr.rev_mm = hit_mm(mr.h);
-    pr.n_fwd_idx = fill_idx(mf.h, pr.fwd_idx, false, 0);
-    pr.n_rev_idx = fill_idx(mr.h, pr.rev_idx, true, rlen);
-    c.out->push_back(pr);
-    if (c.emit && c.emit(&c.out->back(), c.user) != 0) { c.aborted = true; return false; }
+    pr.n_fwd_idx = pr.fwd_mm ? fill_idx(mf.h, pr.fwd_idx, false, 0) : 0;
+    pr.n_rev_idx = pr.rev_mm ? fill_idx(mr.h, pr.rev_idx, true, rlen) : 0;
+    if (c.emit && c.emit(&pr, c.user) != 0) { c.aborted = true; return false; }
     return true;
 }
 
@@ -1195,14 +1196,24 @@ ipcr_status join_sorted_hits(const ipcr_panel *p, ipcr_scratch *s, const uint64_
             const int alen = (int)p->fwd[pi].size(), blen = (int)p->rev[pi].size();
             const int64_t seqlen = (int64_t)rec_len[rec];
             auto by_pos = [](const MatchRef &a, const MatchRef &b) { return a.pos < b.pos; };
-            // "forward": A x rc(B)   (rc list sorted by position, engine.go:144)
-            sorted_right = m[3];
-            std::stable_sort(sorted_right.begin(), sorted_right.end(), by_pos);
-            if (!join_direction(c, (int)pi, rec, seqlen, minL, maxL, m[0], sorted_right, blen, 0)) return fail(IPCR_ERR_ABORTED, "emit callback aborted the scan");
+            // "forward": A x rc(B)   (rc list sorted by position unless it already is, engine.go:70-85,144)
+            const std::vector<MatchRef> *right = &m[3];
+            if (!std::is_sorted(m[3].begin(), m[3].end(), by_pos)) {
+                sorted_right = m[3];
+                std::stable_sort(sorted_right.begin(), sorted_right.end(), by_pos);
+                right = &sorted_right;
+            }
+            if (!m[0].empty() && !right->empty() &&
+                !join_direction(c, (int)pi, rec, seqlen, minL, maxL, m[0], *right, blen, 0)) return fail(IPCR_ERR_ABORTED, "emit callback aborted the scan");
             // "revcomp": B x rc(A)   (engine.go:275)
-            sorted_right = m[2];
-            std::stable_sort(sorted_right.begin(), sorted_right.end(), by_pos);
-            if (!join_direction(c, (int)pi, rec, seqlen, minL, maxL, m[1], sorted_right, alen, 1)) return fail(IPCR_ERR_ABORTED, "emit callback aborted the scan");
+            right = &m[2];
+            if (!std::is_sorted(m[2].begin(), m[2].end(), by_pos)) {
+                sorted_right = m[2];
+                std::stable_sort(sorted_right.begin(), sorted_right.end(), by_pos);
+                right = &sorted_right;
+            }
+            if (!m[1].empty() && !right->empty() &&
+                !join_direction(c, (int)pi, rec, seqlen, minL, maxL, m[1], *right, alen, 1)) return fail(IPCR_ERR_ABORTED, "emit callback aborted the scan");
         }
         i = j;
     }
