@@ -59,14 +59,17 @@ struct ipcr_index_shape {
     uint64_t valid_mask; // even bits of the k-mer positions the key reads (must all be valid bases)
 };
 
-struct ipcr_index_entry { // open-addressing hash table slot (32 B: one load per probe)
+struct ipcr_index_entry { // open-addressing hash table slot, 64 B
     uint32_t tag;     // shape << 16 | key ; 0xFFFFFFFF = empty
     uint32_t pattern; // set-local pattern index
-    uint64_t code;    // the pattern's 2-bit string, last base in the lowest bits
+    uint64_t ok[4];   // IUPAC masks as four position sets: even bit 2*(L-1-j) of ok[b] set when base b
+                      // (A,C,G,T) is allowed at pattern position j -- pure ACGT primers are the one-hot case
     uint64_t prot2;   // even bit 2*(L-1-j) set when position j is protected
     uint32_t len;
     uint32_t left;
+    uint64_t pad;
 };
+static_assert(sizeof(ipcr_index_entry) == 64, "index entries are read as four 16-byte loads");
 
 struct ipcr_index_meta { // per pattern
     uint64_t prot2; // even bit 2*(L-1-j) set when position j is protected

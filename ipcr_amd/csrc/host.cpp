@@ -229,24 +229,26 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     ix.meta.assign(P, ipcr_index_meta{});
     struct Group { bool left; int t; int lmin; std::vector<uint32_t> members; };
     std::vector<Group> groups;
-    std::vector<uint64_t> codes(P, 0);
+    struct Pat { uint64_t ok[4]; uint64_t prot2; int len; bool left; };
+    std::vector<Pat> pats(P);
     for (uint32_t q = 0; q < P; ++q) {
         const ipcr_dev_pattern &dp = set.host[q];
         const PatternDef &d = p.defs[set.ids[q]];
         const int L = dp.len;
-        bool pure = L >= 1 && L <= 32;
-        uint64_t code = 0, prot2 = 0;
-        for (int j = 0; j < L && pure; ++j) {
+        bool usable = L >= 1 && L <= 32;
+        Pat &pt = pats[q];
+        memset(&pt, 0, sizeof pt);
+        for (int j = 0; j < L && usable; ++j) {
             const uint8_t m = dp.mask[j] & 15u;
-            int b = -1;
-            if (m == 1) b = 0; else if (m == 2) b = 1; else if (m == 4) b = 2; else if (m == 8) b = 3;
-            if (b < 0) { pure = false; break; }
-            code |= (uint64_t)b << (2 * (L - 1 - j));
-            if (dp.mask[j] & 16u) prot2 |= 1ull << (2 * (L - 1 - j));
+            if (m == 0) { usable = false; break; } // matches nothing: leave it to the table-driven kernel
+            for (int b = 0; b < 4; ++b)
+                if (m & (1u << b)) pt.ok[b] |= 1ull << (2 * (L - 1 - j));
+            if (dp.mask[j] & 16u) pt.prot2 |= 1ull << (2 * (L - 1 - j));
         }
-        if (!pure) { ix.leftover.push_back(q); continue; }
-        codes[q] = code;
-        ix.meta[q].prot2 = prot2;
+        if (!usable) { ix.leftover.push_back(q); continue; }
+        pt.len = L;
+        pt.left = d.left;
+        ix.meta[q].prot2 = pt.prot2;
         ix.meta[q].len = (uint8_t)L;
         ix.meta[q].left = d.left ? 1 : 0;
         int t = k == 0 ? L : std::min(d.tw_dev, L);
@@ -257,19 +259,18 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         if (!found) groups.push_back(Group{d.left, std::min(t, 32), L, {q}});
     }
     std::vector<std::pair<uint32_t, uint32_t>> ents; // (tag, pattern)
+    std::vector<char> dropped(P, 0);
     for (Group &g : groups) {
         const int t = std::min(g.t, g.lmin), tu = std::min(t, 8);
         const int bf = (t >= g.lmin) ? 0 : (g.lmin - t) / (k + 1);
         const int b = (tu >= 8) ? 0 : std::min(8 - tu, bf);
-        if (tu == 0 && b == 0) { // nothing exact to key on
-            for (uint32_t q : g.members) ix.leftover.push_back(q);
-            continue;
-        }
         const int ns = b > 0 ? k + 1 : 1;
-        if (ix.shapes.size() + (size_t)ns > IPCR_INDEX_MAX_SHAPES) {
-            for (uint32_t q : g.members) ix.leftover.push_back(q);
+        if ((tu == 0 && b == 0) || ix.shapes.size() + (size_t)ns > IPCR_INDEX_MAX_SHAPES) { // nothing exact to key on
+            for (uint32_t q : g.members) dropped[q] = 1;
             continue;
         }
+        const size_t ents_before = ents.size();
+        const size_t shapes_before = ix.shapes.size();
         for (int j = 0; j < ns; ++j) {
             ipcr_index_shape sh{};
             sh.left = g.left ? 1 : 0;
@@ -292,28 +293,76 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
             const uint32_t s = (uint32_t)ix.shapes.size();
             ix.shapes.push_back(sh);
             for (uint32_t q : g.members) {
-                const int L = ix.meta[q].len;
-                const uint64_t km = g.left ? (L >= 32 ? codes[q] : codes[q] << (64 - 2 * L)) : codes[q];
-                const uint32_t key = ((uint32_t)(km >> sh.tw_shift) & sh.tw_mask) |
-                                     (((uint32_t)(km >> sh.blk_shift) & sh.blk_mask) << sh.tw_bits);
-                ents.emplace_back((s << 16) | key, q);
+                if (dropped[q]) continue;
+                const Pat &pt = pats[q];
+                const int L = pt.len;
+                const int up = g.left ? 64 - 2 * L : 0; // pattern bit -> k-mer bit
+                // key positions of this shape, in pattern (right-aligned) bit coordinates, and the
+                // bases each may take: IUPAC codes expand into every concrete key (capped)
+                std::vector<int> kb;
+                for (int bit = 0; bit < 64; bit += 2)
+                    if (vm & (1ull << bit)) kb.push_back(bit - up);
+                uint64_t combos = 1;
+                for (int pb : kb) {
+                    int n = 0;
+                    for (int bb = 0; bb < 4; ++bb) n += (pt.ok[bb] >> pb) & 1;
+                    combos *= (uint64_t)n;
+                    if (combos > 64) break;
+                }
+                if (combos == 0 || combos > 64) { dropped[q] = 1; continue; } // too degenerate to key
+                std::vector<int> choice(kb.size(), 0);
+                for (uint64_t it = 0; it < combos; ++it) {
+                    uint64_t km = 0, rem = it;
+                    for (size_t z = 0; z < kb.size(); ++z) {
+                        int opts[4], n = 0;
+                        for (int bb = 0; bb < 4; ++bb)
+                            if ((pt.ok[bb] >> kb[z]) & 1) opts[n++] = bb;
+                        const int pick = opts[rem % (uint64_t)n];
+                        rem /= (uint64_t)n;
+                        km |= (uint64_t)pick << (kb[z] + up);
+                    }
+                    const uint32_t key = ((uint32_t)(km >> sh.tw_shift) & sh.tw_mask) |
+                                         (((uint32_t)(km >> sh.blk_shift) & sh.blk_mask) << sh.tw_bits);
+                    ents.emplace_back((s << 16) | key, q);
+                }
             }
         }
+        // a pattern dropped in a later shape must lose the keys of the earlier ones too
+        size_t w = ents_before;
+        for (size_t i = ents_before; i < ents.size(); ++i)
+            if (!dropped[ents[i].second]) ents[w++] = ents[i];
+        ents.resize(w);
+        bool any = false;
+        for (uint32_t q : g.members) any |= !dropped[q];
+        if (!any) ix.shapes.resize(shapes_before);
     }
+    for (uint32_t q = 0; q < P; ++q)
+        if (dropped[q]) ix.leftover.push_back(q);
+    std::sort(ents.begin(), ents.end());
+    ents.erase(std::unique(ents.begin(), ents.end()), ents.end());
     ix.bitmaps.assign(std::max<size_t>(1, ix.shapes.size()) * IPCR_INDEX_BITMAP_WORDS, 0u);
     uint32_t slots = 1024;
     while (slots < ents.size() * 4) slots *= 2;
-    ix.table.assign(slots, ipcr_index_entry{0xFFFFFFFFu, 0u, 0ull, 0ull, 0u, 0u});
+    ipcr_index_entry empty{};
+    empty.tag = 0xFFFFFFFFu;
+    ix.table.assign(slots, empty);
     ix.table_mask = slots - 1;
     for (auto &e : ents) {
         const uint32_t s = e.first >> 16, key = e.first & 0xFFFFu;
         ix.bitmaps[s * IPCR_INDEX_BITMAP_WORDS + (key >> 5)] |= 1u << (key & 31u);
         uint32_t h = (e.first * 2654435761u) & ix.table_mask;
         while (ix.table[h].tag != 0xFFFFFFFFu) h = (h + 1) & ix.table_mask;
-        ix.table[h] = ipcr_index_entry{e.first, e.second, codes[e.second], ix.meta[e.second].prot2, ix.meta[e.second].len, ix.meta[e.second].left};
+        ipcr_index_entry en{};
+        en.tag = e.first;
+        en.pattern = e.second;
+        for (int bb = 0; bb < 4; ++bb) en.ok[bb] = pats[e.second].ok[bb];
+        en.prot2 = pats[e.second].prot2;
+        en.len = (uint32_t)pats[e.second].len;
+        en.left = pats[e.second].left ? 1u : 0u;
+        ix.table[h] = en;
     }
     std::sort(ix.leftover.begin(), ix.leftover.end());
-    ix.usable = !ix.shapes.empty();
+    ix.usable = !ix.shapes.empty() && !ents.empty();
 }
 
 void build_dev_pattern(const ipcr_panel &p, const PatternDef &d, uint32_t gid, ipcr_dev_pattern &o) {

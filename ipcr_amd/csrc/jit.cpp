@@ -580,17 +580,21 @@ extern "C" __global__ void __launch_bounds__(512) ipcr_index_filter(const u32* _
           const u32 tag = (s << 16) | key;
           u32 h = (tag * 2654435761u) & table_mask;
           for (;;) {
-            const v4 e0 = table[h * 2u];
+            const v4 e0 = table[h * 4u];
             if (e0.x == 0xFFFFFFFFu) break;
             if (e0.x == tag) {
-              const v4 e1 = table[h * 2u + 1u];
-              const u64 ecode = ((u64)e0.w << 32) | e0.z, prot2 = ((u64)e1.y << 32) | e1.x;
-              const u32 L = e1.z, left = e1.w;
+              const v4 e1 = table[h * 4u + 1u], e2 = table[h * 4u + 2u], e3 = table[h * 4u + 3u];
+              const u64 okA = ((u64)e0.w << 32) | e0.z, okC = ((u64)e1.y << 32) | e1.x;
+              const u64 okG = ((u64)e1.w << 32) | e1.z, okT = ((u64)e2.y << 32) | e2.x;
+              const u64 prot2 = ((u64)e2.w << 32) | e2.z;
+              const u32 L = e3.x, left = e3.y;
               const u32 sft = left ? 64u - 2u * L : 0u;
               const u64 x = km >> sft, iv = im >> sft;
               const u64 wm = (L >= 32u) ? ~0ull : ((1ull << (2u * L)) - 1ull);
-              const u64 d = x ^ ecode;
-              const u64 mm2 = (((d | (d >> 1)) & 0x5555555555555555ull) | iv) & wm;
+              const u64 E = 0x5555555555555555ull;
+              const u64 lo = x & E, hi = (x >> 1) & E;
+              const u64 match = (~lo & ~hi & okA) | (lo & ~hi & okC) | (~lo & hi & okG) | (lo & hi & okT);
+              const u64 mm2 = ((~match & E) | iv) & wm;
               const int srow = left ? erow - 31 : erow - (int)L + 1;
               if ((mm2 & prot2) == 0ull && (u32)__popcll(mm2) <= max_mm && srow >= 0 && srow < 128) {
                 const u32 shard = (u32)cp & 255u;

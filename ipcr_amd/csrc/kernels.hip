@@ -303,19 +303,28 @@ __global__ __launch_bounds__(512) void filter_index_kernel(const uint32_t *__res
                     const uint32_t tag = (s << 16) | key;
                     uint32_t h = (tag * 2654435761u) & table_mask;
                     for (;;) {
-                        const uint4 e0 = reinterpret_cast<const uint4 *>(table)[h * 2u];
+                        const uint4 e0 = reinterpret_cast<const uint4 *>(table)[h * 4u];
                         if (e0.x == 0xFFFFFFFFu) break;
-                        const uint4 e1 = reinterpret_cast<const uint4 *>(table)[h * 2u + 1u];
                         ipcr_index_entry e;
-                        e.tag = e0.x; e.pattern = e0.y; e.code = ((uint64_t)e0.w << 32) | e0.z;
-                        e.prot2 = ((uint64_t)e1.y << 32) | e1.x; e.len = e1.z; e.left = e1.w;
+                        e.tag = e0.x; e.pattern = e0.y;
                         if (e.tag == tag) {
+                            const uint4 e1 = reinterpret_cast<const uint4 *>(table)[h * 4u + 1u];
+                            const uint4 e2 = reinterpret_cast<const uint4 *>(table)[h * 4u + 2u];
+                            const uint4 e3 = reinterpret_cast<const uint4 *>(table)[h * 4u + 3u];
+                            e.ok[0] = ((uint64_t)e0.w << 32) | e0.z;
+                            e.ok[1] = ((uint64_t)e1.y << 32) | e1.x;
+                            e.ok[2] = ((uint64_t)e1.w << 32) | e1.z;
+                            e.ok[3] = ((uint64_t)e2.y << 32) | e2.x;
+                            e.prot2 = ((uint64_t)e2.w << 32) | e2.z;
+                            e.len = e3.x; e.left = e3.y;
                             const uint32_t L = e.len;
                             const uint32_t sft = e.left ? 64u - 2u * L : 0u;
                             const uint64_t x = km >> sft, iv = im >> sft;
                             const uint64_t wm = (L >= 32u) ? ~0ull : ((1ull << (2u * L)) - 1ull);
-                            const uint64_t d = x ^ e.code;
-                            const uint64_t mm2 = (((d | (d >> 1)) & 0x5555555555555555ull) | iv) & wm;
+                            const uint64_t E = 0x5555555555555555ull;
+                            const uint64_t lo = x & E, hi = (x >> 1) & E;
+                            const uint64_t match = (~lo & ~hi & e.ok[0]) | (lo & ~hi & e.ok[1]) | (~lo & hi & e.ok[2]) | (lo & hi & e.ok[3]);
+                            const uint64_t mm2 = ((~match & E) | iv) & wm;
                             const int32_t srow = e.left ? erow - 31 : erow - (int32_t)L + 1;
                             if ((mm2 & e.prot2) == 0ull && (uint32_t)__popcll(mm2) <= max_mm && srow >= 0 &&
                                 srow < (int32_t)IPCR_TILE_N) {

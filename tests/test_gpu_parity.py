@@ -598,3 +598,26 @@ def test_concurrent_workers_share_one_panel(hip):
     for t in threads:
         t.join()
     assert not errors and got == want
+
+
+def test_index_large_iupac_panel(hip):
+    """a 150-row panel where a third of the primers carry IUPAC codes: the seed index expands them
+    into concrete keys and checks them with per-base masks; vs the oracle"""
+    rng = random.Random(27)
+    P = hip.primer.Pair
+    rows = []
+    for i in range(150):
+        def mk():
+            L = rng.randint(18, 25)
+            s = [rng.choice("ACGT") for _ in range(L)]
+            if rng.random() < 0.33:
+                for _ in range(rng.randint(1, 3)):
+                    s[rng.randrange(L)] = rng.choice("RYSWKMBDHVN")
+            return "".join(s)
+        rows.append(P("row%03d" % i, mk(), mk(), 0, 0))
+    pairs = hip.primer.AddSelfPairsUnique(rows)
+    g, seqs = build_planted_genome(hip, rng, 2, 300_000, rows, 0x5eed123a, junk_every=2)
+    cfg = hip.engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)
+    _, cp, sc, got = scan_and_compare(hip, cfg, pairs, g, seqs)
+    assert sc.stats().kernel_kind == 3 and sc.stats().n_patterns >= 590 and len(got) >= 4
+    g.close()
