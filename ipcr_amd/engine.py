@@ -51,6 +51,8 @@ class Product:
     RevMismatchIdx: Tuple[int, ...]
     FwdPrimer: str = ""
     RevPrimer: str = ""
+    FwdSite: str = ""
+    RevSite: str = ""
     Record: int = 0
 
     def sig(self):
@@ -202,6 +204,18 @@ class SimulationScratch:
         return [_product(self._cp, ptr[i], seq_ids) for i in range(n.value)]
 
 
+def _fill_sites(pr: Product, seq: bytes) -> None:
+    """FwdSite / RevSite as core/engine/engine.go:175-183 slices them (NeedSites, pretty text only):
+    the target under the left primer, and the reverse complement of the target under the right one."""
+    from .primer import RevComp
+    flen, rlen = len(pr.FwdPrimer), len(pr.RevPrimer)
+    if pr.Start + flen <= len(seq):
+        pr.FwdSite = seq[pr.Start:pr.Start + flen].decode("latin-1")
+    b = pr.End - rlen
+    if 0 <= b and pr.End <= len(seq):
+        pr.RevSite = RevComp(seq[b:pr.End]).decode("latin-1")   # raises where the reference panics (rc.go:27-34)
+
+
 def _product(cp: CompiledPanel, p: _lib.Product, seq_ids: Sequence[str]) -> Product:
     pair = cp.Pairs[p.pair]
     fwd = p.type == 0
@@ -314,7 +328,10 @@ class Engine:
         err_box = []
 
         def _cb(pp, _user):
-            r = emit(_product(cp, pp.contents, [seqID]))
+            pr = _product(cp, pp.contents, [seqID])
+            if cp.Cfg.NeedSites:
+                _fill_sites(pr, bytes(b))
+            r = emit(pr)
             if r:
                 err_box.append(r)
                 return 1
@@ -340,6 +357,9 @@ class Engine:
         b = seq if isinstance(seq, (bytes, bytearray)) else seq.encode()
         _lib.check(_lib.lib().ipcr_scan_chunk(cp._h, scratch._h, bytes(b), len(b), None, None))
         out = scratch.products([seqID])
+        if cp.Cfg.NeedSites:
+            for pr in out:
+                _fill_sites(pr, bytes(b))
         if own:
             scratch.close()
         return out

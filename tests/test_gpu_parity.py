@@ -621,3 +621,17 @@ def test_index_large_iupac_panel(hip):
     _, cp, sc, got = scan_and_compare(hip, cfg, pairs, g, seqs)
     assert sc.stats().kernel_kind == 3 and sc.stats().n_patterns >= 590 and len(got) >= 4
     g.close()
+
+
+def test_need_sites(hip):  # core/engine/engine.go:175-183 (FwdSite / RevSite for pretty text)
+    E, P = hip.engine, hip.primer.Pair
+    seq = b"TTTTCGTACAAAAGGTACCTTT"
+    eng = E.New(E.Config(MaxMM=1, TerminalWindow=3, MinLen=1, MaxLen=100, SeedLen=12, NeedSites=True))
+    got = eng.SimulateBatch("seq", seq, [P("x", "ACGTAC", "GGTACC")])
+    by = {(p.Type, p.Start): p for p in got}
+    f = by[("forward", 3)]
+    assert (f.FwdPrimer, f.RevPrimer, f.FwdSite, f.RevSite) == ("ACGTAC", "GGTACC", "TCGTAC", "GGTACC")
+    r = by[("revcomp", 13)]
+    assert (r.FwdPrimer, r.RevPrimer, r.FwdSite, r.RevSite) == ("GGTACC", "ACGTAC", "GGTACC", "AGGTAC")
+    plain = E.New(E.Config(MaxMM=1, TerminalWindow=3, MinLen=1, MaxLen=100)).SimulateBatch("seq", seq, [P("x", "ACGTAC", "GGTACC")])
+    assert all(p.FwdSite == "" and p.RevSite == "" for p in plain)
