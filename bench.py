@@ -85,6 +85,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo to rehearse)")
+    ap.add_argument("--no-pipeline", action="store_true", help="finish every pass before the next one is enqueued")
     args = ap.parse_args()
 
     import numpy as np
@@ -127,32 +128,45 @@ def main() -> None:
         _, _, offs = xchg.allgather(dist.hits_from_scratch(sc), nrec)
         rec_off = offs[rank]
 
-    def step():
-        """one pass of the hot path; returns (#products joined by this rank, filter_ms)"""
-        if not multi:
-            n = eng.ScanGenomeCount(genome, cp, sc)
-            return n, sc.stats().filter_ms
-        eng.ScanGenomeHits(genome, cp, sc)                      # filter + verify on this rank's genome
-        fms = sc.stats().filter_ms
-        mine = dist.hits_from_scratch(sc)
-        work = xchg.start(mine, nrec)                            # all-gatherv of hit records (RCCL), async:
-        mine["record"] += np.uint32(rec_off)                     # (job-global record index for the join)
-        n = _join_count(eng, cp, host_sc, mine, all_lens, all_flags)   # ... overlapped with the join of this
-        xchg.finish(work)                                        # rank's partition (its own records)
-        return n, fms
+    sc2 = eng.NewSimulationScratch(cp)
+    scs = [sc, sc2]
+    for s_ in scs:  # untimed set-up: kernel specialisation (hiprtc) and buffer sizing happen here
+        eng.ScanGenomeCount(genome, cp, s_)
 
-    for _ in range(max(args.warmup, 0)):
-        step()
+    def run_steps(k):
+        """k passes of the hot path, pipelined the way the reference's worker pool + collector are
+        (internal/pipeline/pipeline.go:60-161): while the host waits for / joins pass i, the kernels of
+        pass i+1 are already enqueued on the other scratch's stream; with several GPUs the all-gatherv
+        of pass i's hit records (RCCL) runs under pass i+1 too.  Every pass is complete (filter ->
+        verify -> hits -> match lists -> join -> products, hits exchanged) when run_steps returns."""
+        fms, n, work = [], 0, None
+        if k <= 0:
+            return fms, n
+        eng.ScanGenomeBegin(genome, cp, scs[0])
+        for i in range(k):
+            cur = scs[i & 1]
+            if i + 1 < k and not args.no_pipeline:
+                scs[(i + 1) & 1].chain_after(cur)               # device: pass i+1's kernels after pass i's
+                eng.ScanGenomeBegin(genome, cp, scs[(i + 1) & 1])
+            n = eng.ScanGenomeEndCount(genome, cp, cur)          # this rank's partition of the join: its records
+            if i + 1 < k and args.no_pipeline:
+                eng.ScanGenomeBegin(genome, cp, scs[(i + 1) & 1])
+            fms.append(cur.stats().filter_ms)
+            if multi:
+                if work is not None:
+                    xchg.finish(work)
+                work = xchg.start(dist.hits_from_scratch(cur), nrec)   # all-gatherv of hit records, async
+        if multi and work is not None:
+            xchg.finish(work)
+        return fms, n
+
+    run_steps(max(args.warmup, 0))
 
     if multi:
         tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    filter_ms = []
-    nprod = 0
-    for _ in range(args.steps):
-        nprod, fms = step()
-        filter_ms.append(fms)
+    filter_ms, nprod = run_steps(args.steps)
     torch.cuda.synchronize()
     if multi:
         tdist.barrier()
@@ -164,10 +178,11 @@ def main() -> None:
         ptot = torch.tensor([nprod], dtype=torch.int64, device=cdev)
         tdist.all_reduce(ptot, op=tdist.ReduceOp.SUM)
         nprod = int(ptot.item())
+    last = scs[(args.steps - 1) & 1]   # scratch holding the last pass
 
     # ---- correctness outside the timed region: every planted amplicon must come back exactly ----
     if not multi:
-        prods = sc.products(genome.ids)
+        prods = last.products(genome.ids)
     else:  # rank 0 joins the WHOLE job from the gathered hits and checks its own genome's plants
         allhits, _, _ = xchg.gathered()                     # what the last step's all-gatherv left on every rank
         prods = eng.JoinHits(cp, host_sc, allhits, all_lens, all_flags) if rank == 0 else []
@@ -214,12 +229,15 @@ def main() -> None:
                         "(%d x %d b LCG records, %d planted amplicons)" % (genome.total_bases / 1e9, nrec, args.record_len, len(plants)),
             "input": "2-bit + invalid-bit tiles resident in HBM (0.375 B/base); pack kernel timed separately",
             "products_per_step": int(nprod),
-            "hits_per_step_rank0": int(sc.stats().hits),
-            "filter_candidates_rank0": int(sc.stats().candidates),
-            "filter_kernel": "panel-specialised (hiprtc)" if sc.stats().kernel_kind == 1 else "table-driven",
+            "hits_per_step_rank0": int(last.stats().hits),
+            "filter_candidates_rank0": int(last.stats().candidates),
+            "filter_kernel": "panel-specialised (hiprtc)" if last.stats().kernel_kind == 1 else "table-driven",
+            "pipelining": "off" if args.no_pipeline else
+                          "pass i+1's kernels are enqueued (second scratch/stream, started after pass i's kernels) while "
+                          "the host waits for and joins pass i",
             "pack_ms_per_genome": round(genome.pack_ms, 3),
             "gbases_per_s_incl_pack": round(genome.total_bases * world / ((genome.pack_ms + ms_per_step) * 1e-3) / 1e9, 1),
-            "step_breakdown_ms_rank0": {k: round(getattr(sc.stats(), k), 4) for k in
+            "step_breakdown_ms_rank0": {k: round(getattr(last.stats(), k), 4) for k in
                                         ("filter_ms", "verify_ms", "enqueue_ms", "wait_ms", "sort_ms", "join_ms", "total_ms")},
             "parallelism": ("1 genome per GPU, one all-gatherv of hit records per step (%s), join partitioned by record" % backend)
                            if multi else "single GPU",

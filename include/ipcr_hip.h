@@ -214,6 +214,17 @@ ipcr_status ipcr_genome_add_fasta(ipcr_genome *g, const char *path, uint32_t *n_
 /* scan every record of a resident genome with one launch; products carry `record` */
 ipcr_status ipcr_scan_genome(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g,
                              ipcr_emit_fn emit, void *user);
+/* split form of ipcr_scan_genome, for pipelining as the reference's worker pool + collector do
+ * (internal/pipeline/pipeline.go:60-161): begin() enqueues the kernels and the read-back on the
+ * scratch's stream and returns at once; end() waits, rebuilds the match lists and joins.  The
+ * scratch must not be used in between; other scratches may scan (and be joined) meanwhile. */
+ipcr_status ipcr_scan_genome_begin(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g);
+/* order two pipelined scans on the device: the next scan begun on `s` starts its kernels only
+ * after the kernels of the scan most recently begun on `prev` have finished (prev's read-back and
+ * host-side join still overlap).  Call after prev's begin() and before s's begin(). */
+ipcr_status ipcr_scratch_chain_after(ipcr_scratch *s, const ipcr_scratch *prev);
+ipcr_status ipcr_scan_genome_end(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g,
+                                 ipcr_emit_fn emit, void *user);
 /* scan only (rows 10-15 of SURVEY section 8a): verified hits, no join */
 ipcr_status ipcr_scan_genome_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g);
 /* join step alone (core/engine/engine.go:108-404) over an arbitrary hit list, e.g. the

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libipcr_hip.so")
+SO_PATH = os.environ.get("IPCR_HIP_LIBRARY") or os.path.join(_HERE, "libipcr_hip.so")  # override: A/B builds
 
 IPCR_MAX_MM = 16
 IPCR_MAX_PRIMER_LEN = 128
@@ -105,6 +105,9 @@ SYMBOLS = {
     "ipcr_genome_add_fasta": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ipcr_scan_genome": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipcr_scan_genome_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ipcr_scan_genome_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ipcr_scratch_chain_after": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ipcr_scan_genome_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipcr_join_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_uint64),
                                  C.POINTER(C.c_uint8), C.c_uint32, C.c_void_p, C.c_void_p]),
     "ipcr_probe_best_hit": (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_int32, C.POINTER(ProbeHit)]),

@@ -822,6 +822,14 @@ struct ipcr_scratch {
     unsigned long long *d_counts = nullptr; // set 0; set 1 = d_counts + 4
     void *d_hitbuf = nullptr;
     uint32_t cset = 0;
+    hipEvent_t chain_after = nullptr; // next filter launch waits for this event (ipcr_scratch_chain_after)
+    struct Pending { // a scan enqueued by scan_enqueue and not yet collected
+        bool active = false, empty = false;
+        int mode = 0;
+        uint32_t nrec = 0, check_rst = 0, cset_used = 0;
+        uint64_t nblocks = 0, pre = 0;
+        std::chrono::steady_clock::time_point t0;
+    } pend;
     void *pinned = nullptr;                 // counts (16 B) + first PREFIX hits
     std::vector<ipcr_hit> hits;      // sorted by (record, pattern, pos)
     std::vector<ipcr_hit> hits_raw;  // in device append order
@@ -936,8 +944,66 @@ void sort_hits(const std::vector<ipcr_hit> &in, std::vector<ipcr_hit> &out, uint
     dedup_sorted_hits(out);
 }
 
-ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
-    const auto t0 = std::chrono::steady_clock::now();
+double ms_since(std::chrono::steady_clock::time_point a) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+}
+
+// enqueue one attempt: filter kernel(s), verify kernel, read-back of counters + first hits
+ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
+    ipcr_scratch::Pending &pd = s->pend;
+    const PatternSet &set = p->set[pd.mode];
+    const auto te = std::chrono::steady_clock::now();
+    unsigned long long *cnt = s->d_counts + 4u * s->cset, *cnt_next = s->d_counts + 4u * (s->cset ^ 1u);
+    const uint64_t qset = (uint64_t)IPCR_QUEUE_SHARDS * IPCR_QUEUE_COUNTER_STRIDE;
+    unsigned long long *qc = s->d_qcounts + qset * s->cset, *qc_next = s->d_qcounts + qset * (s->cset ^ 1u);
+    pd.cset_used = s->cset;
+    s->cset ^= 1u;
+    const uint64_t nblocks = pd.nblocks;
+    if (s->chain_after) { // pipelined scans: kernels of two passes must not share the device (they would only
+                          // slow each other down); the previous pass's read-back and join still overlap
+        HIPCHK(hipStreamWaitEvent(s->stream, s->chain_after, 0));
+        s->chain_after = nullptr;
+    }
+    if (!set.jit.empty()) {
+        for (size_t gi = 0; gi < set.jit.size(); ++gi) // every group streams the tiles once
+            HIPCHK(ipcr::jit_launch(set.jit[gi], s->stream, g->planes, nblocks, s->d_queue, s->qcap, qc,
+                                    gi == 0 ? s->ev[0] : nullptr, gi + 1 == set.jit.size() ? s->ev[1] : nullptr));
+        s->stats.kernel_kind = 1;
+    } else if (set.index.usable) {
+        const IndexPlan &ix = set.index;
+        const bool more = !ix.leftover.empty();
+        if (ix.jit)
+            HIPCHK(ipcr::jit_launch_index(ix.jit, s->stream, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
+                                          ix.d_table, ix.table_mask, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
+                                          qc, s->ev[0], more ? nullptr : s->ev[1]));
+        else
+            HIPCHK(ipcr::launch_filter_index(s->stream, g->planes, nblocks, ix.d_shapes, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
+                                             ix.d_table, ix.table_mask, ix.d_meta, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
+                                             qc, s->ev[0], more ? nullptr : s->ev[1]));
+        if (more) // patterns the index cannot key
+            HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)ix.leftover.size(),
+                                               (uint32_t)p->cfg.max_mm, ix.d_leftover, s->d_queue, s->qcap, qc,
+                                               nullptr, s->ev[1]));
+        s->stats.kernel_kind = 3;
+    } else {
+        HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)set.ids.size(),
+                                           (uint32_t)p->cfg.max_mm, nullptr, s->d_queue, s->qcap, qc, s->ev[0], s->ev[1]));
+        s->stats.kernel_kind = 2;
+    }
+    HIPCHK(ipcr::launch_verify(s->stream, g->planes, g->rst, set.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
+                               g->d_rec_len, pd.nrec, pd.check_rst, s->d_queue, s->qcap, qc, s->d_hits,
+                               s->hcap, cnt + 1, cnt + 2, cnt_next, qc_next, s->ev[2], s->ev[3]));
+    pd.pre = std::min<uint64_t>(std::min<uint64_t>(s->prefix_hint, PREFIX_HITS), s->hcap);
+    HIPCHK(hipMemcpyAsync(s->pinned, s->d_hitbuf, 64 + pd.pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->stream)); // counters + hits
+    s->stats.enqueue_ms = ms_since(te);
+    return IPCR_OK;
+}
+
+// first half of a scan: everything up to (and including) the enqueue; returns without waiting
+ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
+    ipcr_scratch::Pending &pd = s->pend;
+    pd.active = false;
+    pd.t0 = std::chrono::steady_clock::now();
     s->hits.clear();
     s->products.clear();
     const double pack_ms_keep = s->stats.pack_ms;
@@ -947,65 +1013,34 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     if (st != IPCR_OK) return st;
     s->last_rec_len = g->rec_len;
     s->last_rec_start = g->rec_start;
-    const int mode = (!p->modes_equal && genome_any_reset(g)) ? 1 : 0;
-    st = panel_upload(p, mode);
+    pd.mode = (!p->modes_equal && genome_any_reset(g)) ? 1 : 0;
+    st = panel_upload(p, pd.mode);
     if (st != IPCR_OK) return st;
-    const PatternSet &set = p->set[mode];
-    const uint32_t nrec = (uint32_t)g->rec_start.size();
-    const uint64_t nblocks = (g->next_col + 63) / 64;
+    const PatternSet &set = p->set[pd.mode];
+    pd.nrec = (uint32_t)g->rec_start.size();
+    pd.nblocks = (g->next_col + 63) / 64;
+    pd.check_rst = genome_any_reset(g) ? 1u : 0u;
     s->stats.bases = g->total_bases;
-    s->stats.tile_bytes = nblocks * IPCR_BLOCK_PLANE_WORDS * 4ull;
+    s->stats.tile_bytes = pd.nblocks * IPCR_BLOCK_PLANE_WORDS * 4ull;
     s->stats.n_patterns = (int32_t)set.ids.size();
-    if (nrec == 0 || set.ids.empty()) return IPCR_OK;
-    const uint32_t check_rst = genome_any_reset(g) ? 1u : 0u;
+    pd.empty = pd.nrec == 0 || set.ids.empty();
+    pd.active = true;
+    if (pd.empty) return IPCR_OK;
+    return scan_launch(p, s, g);
+}
 
-    auto ms_since = [](std::chrono::steady_clock::time_point a) {
-        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
-    };
+// second half: wait, regrow + rescan if a buffer overflowed, bring the hits into join order
+ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
+    ipcr_scratch::Pending &pd = s->pend;
+    if (!pd.active) return fail(IPCR_ERR_INVALID, "no scan in flight on this scratch");
+    pd.active = false;
+    if (pd.empty) return IPCR_OK;
     for (int attempt = 0; attempt < 8; ++attempt) {
-        const auto te = std::chrono::steady_clock::now();
-        unsigned long long *cnt = s->d_counts + 4u * s->cset, *cnt_next = s->d_counts + 4u * (s->cset ^ 1u);
-        const uint64_t qset = (uint64_t)IPCR_QUEUE_SHARDS * IPCR_QUEUE_COUNTER_STRIDE;
-        unsigned long long *qc = s->d_qcounts + qset * s->cset, *qc_next = s->d_qcounts + qset * (s->cset ^ 1u);
-        const uint32_t cset_used = s->cset;
-        s->cset ^= 1u;
-        if (!set.jit.empty()) {
-            for (size_t gi = 0; gi < set.jit.size(); ++gi) // every group streams the tiles once
-                HIPCHK(ipcr::jit_launch(set.jit[gi], s->stream, g->planes, nblocks, s->d_queue, s->qcap, qc,
-                                        gi == 0 ? s->ev[0] : nullptr, gi + 1 == set.jit.size() ? s->ev[1] : nullptr));
-            s->stats.kernel_kind = 1;
-        } else if (set.index.usable) {
-            const IndexPlan &ix = set.index;
-            const bool more = !ix.leftover.empty();
-            if (ix.jit)
-                HIPCHK(ipcr::jit_launch_index(ix.jit, s->stream, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
-                                              ix.d_table, ix.table_mask, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
-                                              qc, s->ev[0], more ? nullptr : s->ev[1]));
-            else
-                HIPCHK(ipcr::launch_filter_index(s->stream, g->planes, nblocks, ix.d_shapes, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
-                                                 ix.d_table, ix.table_mask, ix.d_meta, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
-                                                 qc, s->ev[0], more ? nullptr : s->ev[1]));
-            if (more) // IUPAC / long patterns the index cannot key
-                HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)ix.leftover.size(),
-                                                   (uint32_t)p->cfg.max_mm, ix.d_leftover, s->d_queue, s->qcap, qc,
-                                                   nullptr, s->ev[1]));
-            s->stats.kernel_kind = 3;
-        } else {
-            HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)set.ids.size(),
-                                               (uint32_t)p->cfg.max_mm, nullptr, s->d_queue, s->qcap, qc, s->ev[0], s->ev[1]));
-            s->stats.kernel_kind = 2;
-        }
-        HIPCHK(ipcr::launch_verify(s->stream, g->planes, g->rst, set.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
-                                   g->d_rec_len, nrec, check_rst, s->d_queue, s->qcap, qc, s->d_hits,
-                                   s->hcap, cnt + 1, cnt + 2, cnt_next, qc_next, s->ev[2], s->ev[3]));
-        unsigned long long *pc = static_cast<unsigned long long *>(s->pinned) + 4u * cset_used;
-        ipcr_hit *ph = reinterpret_cast<ipcr_hit *>(static_cast<unsigned long long *>(s->pinned) + 8);
-        const uint64_t pre = std::min<uint64_t>(std::min<uint64_t>(s->prefix_hint, PREFIX_HITS), s->hcap);
-        HIPCHK(hipMemcpyAsync(s->pinned, s->d_hitbuf, 64 + pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->stream)); // counters + hits
-        s->stats.enqueue_ms = ms_since(te);
         const auto tw = std::chrono::steady_clock::now();
         HIPCHK(hipStreamSynchronize(s->stream));
         s->stats.wait_ms = ms_since(tw);
+        const unsigned long long *pc = static_cast<unsigned long long *>(s->pinned) + 4u * pd.cset_used;
+        const ipcr_hit *ph = reinterpret_cast<ipcr_hit *>(static_cast<unsigned long long *>(s->pinned) + 8);
         const uint64_t nhit = pc[1], ncand = pc[2], fullest = pc[3];
         if (fullest > s->qcap) { // a queue segment overflowed: regrow all segments and rescan
             uint64_t want = s->qcap;
@@ -1015,6 +1050,8 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             s->d_queue = nullptr;
             HIPCHK(hipMalloc((void **)&s->d_queue, want * IPCR_QUEUE_SHARDS * sizeof(ipcr_queue_entry)));
             s->qcap = want;
+            ipcr_status st = scan_launch(p, s, g);
+            if (st != IPCR_OK) return st;
             continue;
         }
         if (nhit > s->hcap) {
@@ -1030,11 +1067,13 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             s->d_counts = static_cast<unsigned long long *>(s->d_hitbuf);
             s->d_hits = static_cast<ipcr_hit_rec *>(s->d_hitbuf) + 2;
             s->hcap = want;
+            ipcr_status st = scan_launch(p, s, g);
+            if (st != IPCR_OK) return st;
             continue;
         }
         std::vector<ipcr_hit> &raw = s->hits_raw;
         raw.resize(nhit);
-        const uint64_t got = std::min<uint64_t>(nhit, pre);
+        const uint64_t got = std::min<uint64_t>(nhit, pd.pre);
         if (got) memcpy(raw.data(), ph, got * sizeof(ipcr_hit));
         if (nhit > got) HIPCHK(hipMemcpy(raw.data() + got, s->d_hits + got, (nhit - got) * sizeof(ipcr_hit), hipMemcpyDeviceToHost));
         s->prefix_hint = std::max<uint64_t>(256, nhit + nhit / 4 + 16);
@@ -1046,12 +1085,18 @@ ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         s->stats.candidates = ncand;
         s->stats.hits = nhit;
         const auto ts = std::chrono::steady_clock::now();
-        sort_hits(raw, s->hits, nrec, (uint32_t)p->defs.size());
+        sort_hits(raw, s->hits, pd.nrec, (uint32_t)p->defs.size());
         s->stats.sort_ms = ms_since(ts);
-        s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        s->stats.total_ms = ms_since(pd.t0);
         return IPCR_OK;
     }
     return fail(IPCR_ERR_CAPACITY, "scan buffers kept overflowing");
+}
+
+ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
+    ipcr_status st = scan_enqueue(p, s, g);
+    if (st != IPCR_OK) return st;
+    return scan_collect(p, s, g);
 }
 
 // ---------------------------------------------------------------------------- join
@@ -1374,6 +1419,38 @@ ipcr_status ipcr_scan_genome(const ipcr_panel *p, ipcr_scratch *s, const ipcr_ge
     st = join_sorted_hits(p, s, g->rec_len.data(), fl.data(), (uint32_t)fl.size(), emit, user);
     s->stats.join_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj).count();
     s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+}
+
+ipcr_status ipcr_scratch_chain_after(ipcr_scratch *s, const ipcr_scratch *prev) {
+    if (!s || !prev) return fail(IPCR_ERR_INVALID, "ipcr_scratch_chain_after: null argument");
+    if (!s->stream || !prev->stream) return fail(IPCR_ERR_DEVICE, "host-only scratch cannot scan");
+    s->chain_after = prev->ev[3]; // stop event of prev's verify dispatch: its kernels are done, only
+                                  // the read-back and the host-side join overlap the next sweep
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_scan_genome_begin(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g) {
+    ipcr_status st = scratch_ready(p, s);
+    if (st != IPCR_OK) return st;
+    if (!g) return fail(IPCR_ERR_INVALID, "null genome");
+    s->stats.pack_ms = 0;
+    return scan_enqueue(p, s, const_cast<ipcr_genome *>(g));
+}
+
+ipcr_status ipcr_scan_genome_end(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g, ipcr_emit_fn emit, void *user) {
+    ipcr_status st = scratch_ready(p, s);
+    if (st != IPCR_OK) return st;
+    if (!g) return fail(IPCR_ERR_INVALID, "null genome");
+    st = scan_collect(p, s, const_cast<ipcr_genome *>(g));
+    if (st != IPCR_OK) return st;
+    std::vector<uint8_t> fl(g->rec_start.size());
+    const bool any = genome_any_reset(g);
+    for (size_t r = 0; r < fl.size(); ++r) fl[r] = (uint8_t)((g->flags[r] & 1u) | (any ? 2u : 0u));
+    const auto tj = std::chrono::steady_clock::now();
+    st = join_sorted_hits(p, s, g->rec_len.data(), fl.data(), (uint32_t)fl.size(), emit, user);
+    s->stats.join_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj).count();
+    s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s->pend.t0).count();
     return st;
 }
 

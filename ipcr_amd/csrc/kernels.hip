@@ -15,6 +15,7 @@
 
 #include "device_types.h"
 #include "tile_layout.h"
+#define IPCR_VERIFY_BLOCKS 1024 // more blocks do not help (latency floor ~30 us), fewer are slower
 
 // ------------------------------------------------------------------------------- pack
 // One wavefront packs 64 consecutive strands (two columns).  Lane = strand: it walks its
@@ -658,7 +659,7 @@ hipError_t launch_verify(hipStream_t st, const uint32_t *planes, const uint32_t 
                          unsigned long long *hcount, unsigned long long *ccount, unsigned long long *next_counters,
                          unsigned long long *next_qcount, hipEvent_t start, hipEvent_t stop) {
     if (nrec == 0) return hipSuccess;
-    hipExtLaunchKernelGGL(verify_kernel, dim3(1024), dim3(256), 0, st, start, stop, 0, planes, rst, pats, max_mm,
+    hipExtLaunchKernelGGL(verify_kernel, dim3(IPCR_VERIFY_BLOCKS), dim3(256), 0, st, start, stop, 0, planes, rst, pats, max_mm,
                           rec_start, rec_len, nrec, check_rst, queue, qcap, qcount, hits, hcap, hcount, ccount,
                           next_counters, next_qcount);
     return hipGetLastError();

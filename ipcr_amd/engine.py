@@ -168,6 +168,10 @@ class SimulationScratch:
         except Exception:
             pass
 
+    def chain_after(self, prev: "SimulationScratch") -> None:
+        """The next scan begun on this scratch sweeps the tiles only after `prev`'s current sweep."""
+        _lib.check(_lib.lib().ipcr_scratch_chain_after(self._h, prev._h))
+
     def stats(self) -> _lib.ScanStats:
         st = _lib.ScanStats()
         _lib.check(_lib.lib().ipcr_scratch_stats(self._h, C.byref(st)))
@@ -409,6 +413,15 @@ class Engine:
         _lib.check(_lib.lib().ipcr_join_hits(cp._h, scratch._h, ptr, n, lens, flags, nrec, None, None))
         ids = list(seq_ids) if seq_ids is not None else [str(r) for r in range(nrec)]
         return scratch.products(ids)
+
+    def ScanGenomeBegin(self, genome: Genome, cp: CompiledPanel, scratch: SimulationScratch) -> None:
+        """Enqueue a scan of the resident genome on `scratch` and return at once (pipelining)."""
+        _lib.check(_lib.lib().ipcr_scan_genome_begin(cp._h, scratch._h, genome._h))
+
+    def ScanGenomeEndCount(self, genome: Genome, cp: CompiledPanel, scratch: SimulationScratch) -> int:
+        """Wait for the scan begun on `scratch`, join; products stay in the scratch."""
+        _lib.check(_lib.lib().ipcr_scan_genome_end(cp._h, scratch._h, genome._h, None, None))
+        return scratch.num_products()
 
     def ScanGenomeHits(self, genome: Genome, cp: CompiledPanel, scratch: SimulationScratch) -> List[Hit]:
         _lib.check(_lib.lib().ipcr_scan_genome_hits(cp._h, scratch._h, genome._h))
