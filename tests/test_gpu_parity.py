@@ -635,3 +635,29 @@ def test_need_sites(hip):  # core/engine/engine.go:175-183 (FwdSite / RevSite fo
     assert (r.FwdPrimer, r.RevPrimer, r.FwdSite, r.RevSite) == ("GGTACC", "ACGTAC", "GGTACC", "AGGTAC")
     plain = E.New(E.Config(MaxMM=1, TerminalWindow=3, MinLen=1, MaxLen=100)).SimulateBatch("seq", seq, [P("x", "ACGTAC", "GGTACC")])
     assert all(p.FwdSite == "" and p.RevSite == "" for p in plain)
+
+
+def test_pipelined_begin_end(hip):
+    """ipcr_scan_genome_begin / _end on two alternating scratches (the bench's pipelining) give the
+    same products as the one-call scan, pass after pass"""
+    from ipcr_amd import workloads
+    rng = random.Random(31)
+    pairs = workloads.c2_pairs()
+    g, seqs = build_planted_genome(hip, rng, 3, 700_000, pairs[:1], 0x5eed123b, junk_every=3)
+    cfg = hip.engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12)
+    eng = hip.engine.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    a, b = eng.NewSimulationScratch(cp), eng.NewSimulationScratch(cp)
+    want = [p.sig() for p in eng.ScanGenome(g, cp, a)]
+    assert want
+    scs = [a, b]
+    eng.ScanGenomeBegin(g, cp, scs[0])
+    for i in range(6):
+        if i + 1 < 6:
+            scs[(i + 1) & 1].chain_after(scs[i & 1])
+            eng.ScanGenomeBegin(g, cp, scs[(i + 1) & 1])
+        n = eng.ScanGenomeEndCount(g, cp, scs[i & 1])
+        assert n == len(want) and [p.sig() for p in scs[i & 1].products(g.ids)] == want
+    with pytest.raises(hip.lib.IpcrError):  # nothing in flight any more
+        eng.ScanGenomeEndCount(g, cp, a)
+    g.close()
