@@ -219,9 +219,11 @@ ipcr_status ipcr_scan_genome(const ipcr_panel *p, ipcr_scratch *s, const ipcr_ge
  * scratch's stream and returns at once; end() waits, rebuilds the match lists and joins.  The
  * scratch must not be used in between; other scratches may scan (and be joined) meanwhile. */
 ipcr_status ipcr_scan_genome_begin(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g);
-/* order two pipelined scans on the device: the next scan begun on `s` starts its kernels only
- * after the kernels of the scan most recently begun on `prev` have finished (prev's read-back and
- * host-side join still overlap).  Call after prev's begin() and before s's begin(). */
+/* order two pipelined scans on the device: the next scan begun on `s` runs its filter sweep
+ * directly after the filter sweep of the scan most recently begun on `prev` (the two sweeps share
+ * one in-order stream, so they never compete for HBM); prev's verify kernel, read-back and
+ * host-side join overlap it.  Call after prev's begin() and before s's begin(); scratches of a
+ * chain should be destroyed only after their scans have ended. */
 ipcr_status ipcr_scratch_chain_after(ipcr_scratch *s, const ipcr_scratch *prev);
 ipcr_status ipcr_scan_genome_end(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g,
                                  ipcr_emit_fn emit, void *user);

@@ -822,10 +822,24 @@ struct ipcr_scratch {
     unsigned long long *d_counts = nullptr; // set 0; set 1 = d_counts + 4
     void *d_hitbuf = nullptr;
     uint32_t cset = 0;
-    hipEvent_t chain_after = nullptr; // next filter launch waits for this event (ipcr_scratch_chain_after)
+    // pipelined scans (ipcr_scratch_chain_after): the scans of a chain of scratches are enqueued on ONE
+    // in-order stream (the "lane" = the stream of the chain's first scratch), so scan i+1's sweep starts
+    // the moment scan i's kernels and read-back are done, with no cross-stream dependency (tens of
+    // microseconds each on this runtime) in front of the bandwidth-bound kernel
+    struct Lane {
+        hipStream_t s = nullptr;
+        ~Lane() { if (s) (void)hipStreamDestroy(s); }
+    };
+    std::shared_ptr<Lane> own_lane;   // holds `stream`
+    std::shared_ptr<Lane> lane_next;  // lane of the next scan (null: own)
+    std::shared_ptr<Lane> lane_used;  // lane the last scan ran on
+    hipEvent_t ev_done = nullptr;     // recorded behind a scan's read-back when it runs on a shared lane
     struct Pending { // a scan enqueued by scan_enqueue and not yet collected
         bool active = false, empty = false;
         int mode = 0;
+        bool fused = false;    // the filter verified its own survivors (specialised kernel)
+        bool verified = false; // the stand-alone verifier has run over the queue
+        bool on_lane = false;  // wait for ev_done (false: a follow-up on the private stream, wait for the stream)
         uint32_t nrec = 0, check_rst = 0, cset_used = 0;
         uint64_t nblocks = 0, pre = 0;
         std::chrono::steady_clock::time_point t0;
@@ -944,6 +958,13 @@ void sort_hits(const std::vector<ipcr_hit> &in, std::vector<ipcr_hit> &out, uint
     dedup_sorted_hits(out);
 }
 
+// IPCR_DEBUG_TIMES=1: host-side timeline of the scan calls on stderr
+void trace(const char *what, const void *s) {
+    static const bool on = getenv("IPCR_DEBUG_TIMES") != nullptr;
+    static const auto t0 = std::chrono::steady_clock::now();
+    if (on) fprintf(stderr, "[t %10.1f us] %p %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), s, what);
+}
+
 double ms_since(std::chrono::steady_clock::time_point a) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
 }
@@ -959,50 +980,76 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     pd.cset_used = s->cset;
     s->cset ^= 1u;
     const uint64_t nblocks = pd.nblocks;
-    if (s->chain_after) { // pipelined scans: kernels of two passes must not share the device (they would only
-                          // slow each other down); the previous pass's read-back and join still overlap
-        HIPCHK(hipStreamWaitEvent(s->stream, s->chain_after, 0));
-        s->chain_after = nullptr;
-    }
+    trace("launch>", s);
+    const hipStream_t own = s->stream;
+    const hipStream_t lane = s->lane_next ? s->lane_next->s : own;
+    s->lane_used = s->lane_next ? std::move(s->lane_next) : s->own_lane;
+    s->lane_next.reset();
+    pd.fused = false;
+    pd.verified = false;
     if (!set.jit.empty()) {
-        for (size_t gi = 0; gi < set.jit.size(); ++gi) // every group streams the tiles once
-            HIPCHK(ipcr::jit_launch(set.jit[gi], s->stream, g->planes, nblocks, s->d_queue, s->qcap, qc,
+        ipcr::JitVerify v;
+        v.rst = g->rst;
+        v.pats = set.dev;
+        v.rec_start = g->d_rec_start;
+        v.rec_len = g->d_rec_len;
+        v.nrec = pd.nrec;
+        v.max_mm = (uint32_t)p->cfg.max_mm;
+        v.check_rst = pd.check_rst;
+        v.hits = s->d_hits;
+        v.hcap = s->hcap;
+        v.counts = cnt;
+        for (size_t gi = 0; gi < set.jit.size(); ++gi) { // every group streams the tiles once
+            v.next_counts = gi == 0 ? cnt_next : nullptr;
+            v.next_qcount = gi == 0 ? qc_next : nullptr;
+            HIPCHK(ipcr::jit_launch(set.jit[gi], lane, g->planes, nblocks, s->d_queue, s->qcap, qc, v,
                                     gi == 0 ? s->ev[0] : nullptr, gi + 1 == set.jit.size() ? s->ev[1] : nullptr));
+        }
         s->stats.kernel_kind = 1;
+        pd.fused = true;
     } else if (set.index.usable) {
         const IndexPlan &ix = set.index;
         const bool more = !ix.leftover.empty();
         if (ix.jit)
-            HIPCHK(ipcr::jit_launch_index(ix.jit, s->stream, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
+            HIPCHK(ipcr::jit_launch_index(ix.jit, lane, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
                                           ix.d_table, ix.table_mask, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
                                           qc, s->ev[0], more ? nullptr : s->ev[1]));
         else
-            HIPCHK(ipcr::launch_filter_index(s->stream, g->planes, nblocks, ix.d_shapes, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
+            HIPCHK(ipcr::launch_filter_index(lane, g->planes, nblocks, ix.d_shapes, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
                                              ix.d_table, ix.table_mask, ix.d_meta, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
                                              qc, s->ev[0], more ? nullptr : s->ev[1]));
         if (more) // patterns the index cannot key
-            HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)ix.leftover.size(),
+            HIPCHK(ipcr::launch_filter_generic(lane, g->planes, nblocks, set.dev, (uint32_t)ix.leftover.size(),
                                                (uint32_t)p->cfg.max_mm, ix.d_leftover, s->d_queue, s->qcap, qc,
                                                nullptr, s->ev[1]));
         s->stats.kernel_kind = 3;
     } else {
-        HIPCHK(ipcr::launch_filter_generic(s->stream, g->planes, nblocks, set.dev, (uint32_t)set.ids.size(),
+        HIPCHK(ipcr::launch_filter_generic(lane, g->planes, nblocks, set.dev, (uint32_t)set.ids.size(),
                                            (uint32_t)p->cfg.max_mm, nullptr, s->d_queue, s->qcap, qc, s->ev[0], s->ev[1]));
         s->stats.kernel_kind = 2;
     }
-    HIPCHK(ipcr::launch_verify(s->stream, g->planes, g->rst, set.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
-                               g->d_rec_len, pd.nrec, pd.check_rst, s->d_queue, s->qcap, qc, s->d_hits,
-                               s->hcap, cnt + 1, cnt + 2, cnt_next, qc_next, s->ev[2], s->ev[3]));
+    if (!pd.fused) {
+        HIPCHK(ipcr::launch_verify(lane, g->planes, g->rst, set.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
+                                   g->d_rec_len, pd.nrec, pd.check_rst, s->d_queue, s->qcap, qc, s->d_hits,
+                                   s->hcap, cnt + 1, cnt + 2, cnt_next, qc_next, s->ev[2], s->ev[3]));
+        pd.verified = true;
+    }
     pd.pre = std::min<uint64_t>(std::min<uint64_t>(s->prefix_hint, PREFIX_HITS), s->hcap);
-    HIPCHK(hipMemcpyAsync(s->pinned, s->d_hitbuf, 64 + pd.pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->stream)); // counters + hits
+    HIPCHK(hipMemcpyAsync(s->pinned, s->d_hitbuf, 64 + pd.pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, lane)); // counters + hits
+    // the host waits for this marker, not for the stream: a scan chained after this one may already
+    // be queued behind it on the same stream (ipcr_scratch_chain_after)
+    if (!s->ev_done) HIPCHK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(s->ev_done, lane));
+    pd.on_lane = true;
     s->stats.enqueue_ms = ms_since(te);
+    trace("launch<", s);
     return IPCR_OK;
 }
 
 // first half of a scan: everything up to (and including) the enqueue; returns without waiting
 ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     ipcr_scratch::Pending &pd = s->pend;
-    pd.active = false;
+    if (pd.active) return fail(IPCR_ERR_INVALID, "a scan is already in flight on this scratch (ipcr_scan_genome_end not called)");
     pd.t0 = std::chrono::steady_clock::now();
     s->hits.clear();
     s->products.clear();
@@ -1026,7 +1073,9 @@ ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     pd.empty = pd.nrec == 0 || set.ids.empty();
     pd.active = true;
     if (pd.empty) return IPCR_OK;
-    return scan_launch(p, s, g);
+    st = scan_launch(p, s, g);
+    if (st != IPCR_OK) pd.active = false;
+    return st;
 }
 
 // second half: wait, regrow + rescan if a buffer overflowed, bring the hits into join order
@@ -1035,12 +1084,30 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     if (!pd.active) return fail(IPCR_ERR_INVALID, "no scan in flight on this scratch");
     pd.active = false;
     if (pd.empty) return IPCR_OK;
-    for (int attempt = 0; attempt < 8; ++attempt) {
+    for (int attempt = 0; attempt < 12; ++attempt) {
         const auto tw = std::chrono::steady_clock::now();
-        HIPCHK(hipStreamSynchronize(s->stream));
-        s->stats.wait_ms = ms_since(tw);
+        trace("wait>", s);
+        if (pd.on_lane) HIPCHK(hipEventSynchronize(s->ev_done)); // the lane already carries the next scan
+        else HIPCHK(hipStreamSynchronize(s->stream));
+        s->stats.wait_ms += ms_since(tw);
+        trace("wait<", s);
         const unsigned long long *pc = static_cast<unsigned long long *>(s->pinned) + 4u * pd.cset_used;
         const ipcr_hit *ph = reinterpret_cast<ipcr_hit *>(static_cast<unsigned long long *>(s->pinned) + 8);
+        if (!pd.verified && pc[0] > 0) {
+            // some wave's survivor list was full and spilled to the queue (dense matches): run the
+            // stand-alone verifier over the spilled words; it appends to the same hit buffer
+            const PatternSet &set = p->set[pd.mode];
+            const uint64_t qset = (uint64_t)IPCR_QUEUE_SHARDS * IPCR_QUEUE_COUNTER_STRIDE;
+            unsigned long long *cnt = s->d_counts + 4u * pd.cset_used, *cnt_next = s->d_counts + 4u * (pd.cset_used ^ 1u);
+            unsigned long long *qc = s->d_qcounts + qset * pd.cset_used, *qc_next = s->d_qcounts + qset * (pd.cset_used ^ 1u);
+            HIPCHK(ipcr::launch_verify(s->stream, g->planes, g->rst, set.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
+                                       g->d_rec_len, pd.nrec, pd.check_rst, s->d_queue, s->qcap, qc, s->d_hits,
+                                       s->hcap, cnt + 1, cnt + 2, cnt_next, qc_next, s->ev[2], s->ev[3]));
+            HIPCHK(hipMemcpyAsync(s->pinned, s->d_hitbuf, 64 + pd.pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->stream));
+            pd.verified = true;
+            pd.on_lane = false;
+            continue;
+        }
         const uint64_t nhit = pc[1], ncand = pc[2], fullest = pc[3];
         if (fullest > s->qcap) { // a queue segment overflowed: regrow all segments and rescan
             uint64_t want = s->qcap;
@@ -1079,7 +1146,7 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         s->prefix_hint = std::max<uint64_t>(256, nhit + nhit / 4 + 16);
         float fms = 0, vms = 0;
         HIPCHK(hipEventElapsedTime(&fms, s->ev[0], s->ev[1]));
-        HIPCHK(hipEventElapsedTime(&vms, s->ev[2], s->ev[3]));
+        if (pd.verified) HIPCHK(hipEventElapsedTime(&vms, s->ev[2], s->ev[3]));
         s->stats.filter_ms = fms;
         s->stats.verify_ms = vms;
         s->stats.candidates = ncand;
@@ -1088,6 +1155,7 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         sort_hits(raw, s->hits, pd.nrec, (uint32_t)p->defs.size());
         s->stats.sort_ms = ms_since(ts);
         s->stats.total_ms = ms_since(pd.t0);
+        trace("sorted", s);
         return IPCR_OK;
     }
     return fail(IPCR_ERR_CAPACITY, "scan buffers kept overflowing");
@@ -1337,7 +1405,9 @@ ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out) {
     ipcr_scratch *raw = s.get();
     auto build = [&]() -> ipcr_status {
         HIPCHK(hipGetDevice(&raw->device));
-        HIPCHK(hipStreamCreateWithFlags(&raw->stream, hipStreamNonBlocking));
+        raw->own_lane = std::make_shared<ipcr_scratch::Lane>();
+        HIPCHK(hipStreamCreateWithFlags(&raw->own_lane->s, hipStreamNonBlocking));
+        raw->stream = raw->own_lane->s;
         for (auto &e : raw->ev) HIPCHK(hipEventCreate(&e));
         raw->qcap = QCAP_INIT;
         raw->hcap = HCAP_INIT;
@@ -1367,6 +1437,10 @@ ipcr_status ipcr_scratch_create_host(const ipcr_panel *p, ipcr_scratch **out) {
 
 void ipcr_scratch_destroy(ipcr_scratch *s) {
     if (!s) return;
+    if (s->stream) { // a scan left in flight still reads and writes the buffers freed below
+        if (s->pend.active && s->lane_used) (void)hipStreamSynchronize(s->lane_used->s);
+        (void)hipStreamSynchronize(s->stream);
+    }
     if (s->chunk) ipcr_genome_destroy(s->chunk);
     if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->d_qcounts) (void)hipFree(s->d_qcounts);
@@ -1376,7 +1450,8 @@ void ipcr_scratch_destroy(ipcr_scratch *s) {
     if (s->pinned) (void)hipHostFree(s->pinned);
     for (auto &e : s->ev)
         if (e) (void)hipEventDestroy(e);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->ev_done) (void)hipEventDestroy(s->ev_done);
+    // the stream goes with the last scratch that shares it (own_lane / lane_used references)
     delete s;
 }
 
@@ -1425,8 +1500,10 @@ ipcr_status ipcr_scan_genome(const ipcr_panel *p, ipcr_scratch *s, const ipcr_ge
 ipcr_status ipcr_scratch_chain_after(ipcr_scratch *s, const ipcr_scratch *prev) {
     if (!s || !prev) return fail(IPCR_ERR_INVALID, "ipcr_scratch_chain_after: null argument");
     if (!s->stream || !prev->stream) return fail(IPCR_ERR_DEVICE, "host-only scratch cannot scan");
-    s->chain_after = prev->ev[3]; // stop event of prev's verify dispatch: its kernels are done, only
-                                  // the read-back and the host-side join overlap the next sweep
+    if (s == prev) return fail(IPCR_ERR_INVALID, "ipcr_scratch_chain_after: a scratch cannot follow itself");
+    if (s->pend.active) return fail(IPCR_ERR_INVALID, "ipcr_scratch_chain_after: a scan is in flight on this scratch");
+    if (s->device != prev->device) return fail(IPCR_ERR_INVALID, "ipcr_scratch_chain_after: scratches of different devices");
+    s->lane_next = prev->lane_used ? prev->lane_used : prev->own_lane; // stream order is the dependency
     return IPCR_OK;
 }
 
@@ -1451,6 +1528,7 @@ ipcr_status ipcr_scan_genome_end(const ipcr_panel *p, ipcr_scratch *s, const ipc
     st = join_sorted_hits(p, s, g->rec_len.data(), fl.data(), (uint32_t)fl.size(), emit, user);
     s->stats.join_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj).count();
     s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s->pend.t0).count();
+    trace("joined", s);
     return st;
 }
 

@@ -237,6 +237,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
     const int QM = ((32 - D) / QPI) * QPI;   // quads done by the rolled main loop (its prefetch stays < 32)
     const int NFULL = QM / QPI;
     const int QW = (LM1 + 3) / 4;            // head quads stashed for the wrap phase
+    const int LIST_CAP = env_int("IPCR_JIT_LIST", 48, 1, 1024); // survivor words a wave keeps for its own verify pass
 
     bool uses_n = false;
     std::vector<Plan> plans;
@@ -291,7 +292,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
         b << "          if (all != 0xFFFFFFFFu) { // rare: some window survived, hand the word to the verifier\n";
         b << "            const u64 pos = posbase + (u64)(" << xexpr << " - " << LM1 << "u);\n";
         for (size_t q = 0; q < pats.size(); ++q)
-            b << "            if (f" << q << " != 0xFFFFFFFFu) push(" << (qbase + q) << "ull, pos, ~f" << q << ", queue, qcap, qcount);\n";
+            b << "            if (f" << q << " != 0xFFFFFFFFu) push(" << (qbase + q) << "ull, pos, ~f" << q << ", lcnt, lkey, lbits, queue, qcap, qcount, counts);\n";
         b << "          }\n        }\n      }\n";
         return b.str();
     };
@@ -361,17 +362,54 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
     s << "typedef unsigned int u32;\ntypedef unsigned long long u64;\n";
     s << "typedef u32 v4 __attribute__((ext_vector_type(4)));\n";
     s << "struct qent { u64 key; u32 bits; u32 pad; };\n";
+    s << "struct hitrec { u64 pos; u32 record; u32 pattern; u64 m0, m1; };\n";
+    s << "struct dpat { unsigned short len, seed_off, seed_len, reserved; u32 global_id; unsigned char mask[128]; };\n";
+    s << "#define LIST_CAP " << LIST_CAP << "u\n";
+    // position -> (block, row, lane, bit) of the strand-major tiles (tile_layout.h)
+    s << "__device__ __forceinline__ u32 base_bits(const u32* __restrict__ planes, u64 P) {\n"
+         "  const u64 strand = P >> 7, col = strand >> 5;\n"
+         "  const u32 row = (u32)P & 127u, bit = (u32)strand & 31u;\n"
+         "  const u64 w = (((((col >> 6) * 32u + (row >> 2)) * 3u) * 64u + (col & 63u)) << 2) + (row & 3u);\n"
+         "  return ((planes[w] >> bit) & 1u) | (((planes[w + 256u] >> bit) & 1u) << 1) | (((planes[w + 512u] >> bit) & 1u) << 2);\n"
+         "}\n"
+         "__device__ __forceinline__ u32 rst_bit(const u32* __restrict__ rst, u64 P) {\n"
+         "  const u64 strand = P >> 7, col = strand >> 5;\n"
+         "  const u32 row = (u32)P & 127u, bit = (u32)strand & 31u;\n"
+         "  return (rst[((((col >> 6) * 32u + (row >> 2)) * 64u + (col & 63u)) << 2) + (row & 3u)] >> bit) & 1u;\n"
+         "}\n";
+    // A surviving word goes to this wave's list in LDS and is verified by the wave itself once its
+    // block is done; only when the list is full (dense matches: low-complexity genome against a
+    // low-complexity primer) does it spill to the global queue of the stand-alone verifier, and
+    // counts[0] tells the host that that kernel has to run.
     // qcount: this wave's shard counter, queue: its segment, qcap: capacity of one segment
-    s << "__device__ __forceinline__ void push(u64 q, u64 pos, u32 bits, qent* queue, u64 qcap, u64* qcount) {\n"
+    s << "__device__ __forceinline__ void push(u64 q, u64 pos, u32 bits, u32* lcnt, u64* lkey, u32* lbits,\n"
+         "    qent* queue, u64 qcap, u64* qcount, u64* counts) {\n"
+         "  const u32 i = atomicAdd(lcnt, 1u);\n"
+         "  if (i < LIST_CAP) { lkey[i] = (q << 48) | pos; lbits[i] = bits; return; }\n"
+         "  atomicAdd(counts, 1ull);\n"
          "  const u64 idx = atomicAdd(qcount, 1ull);\n"
          "  if (idx < qcap) { qent e; e.key = (q << 48) | pos; e.bits = bits; e.pad = 0u; queue[idx] = e; }\n"
          "}\n";
     s << "// IPCR_WAVES_PER_GROUP " << WPG << "\n";
     s << "extern \"C\" __global__ void __launch_bounds__(" << WPG * 64 << ", " << WPS << ") ipcr_filter(const v4* __restrict__ planes, u64 nblocks,\n"
-         "    qent* __restrict__ queue_all, u64 qcap, u64* __restrict__ qcount_all) {\n";
+         "    qent* __restrict__ queue_all, u64 qcap, u64* __restrict__ qcount_all,\n"
+         "    const u32* __restrict__ rst, const dpat* __restrict__ pats, const u64* __restrict__ rec_start,\n"
+         "    const u64* __restrict__ rec_len, u32 nrec, u32 max_mm, u32 check_rst, hitrec* __restrict__ hits, u64 hcap,\n"
+         "    u64* __restrict__ counts, u64* __restrict__ next_counts, u64* __restrict__ next_qcount) {\n";
     s << "  const u32 lane = threadIdx.x & 63u;\n";
-    s << "  const u64 block = (u64)blockIdx.x * " << WPG << "u + (threadIdx.x >> 6);\n";
+    s << "  const u32 wv = threadIdx.x >> 6;\n";
+    s << "  const u64 block = (u64)blockIdx.x * " << WPG << "u + wv;\n";
+    // the counters alternate between two sets; workgroup 0 clears the set the NEXT scan will use
+    s << "  if (blockIdx.x == 0u && next_counts) {\n"
+         "    if (threadIdx.x < 4u) next_counts[threadIdx.x] = 0ull;\n"
+         "    for (u32 t = threadIdx.x; t < 256u; t += " << WPG * 64 << "u) next_qcount[t * 16u] = 0ull;\n"
+         "  }\n";
     s << "  if (block >= nblocks) return;\n";
+    s << "  __shared__ u64 lkey_all[" << WPG << "][LIST_CAP];\n";
+    s << "  __shared__ u32 lbits_all[" << WPG << "][LIST_CAP];\n";
+    s << "  __shared__ u32 lcnt_all[" << WPG << "];\n";
+    s << "  u64* lkey = lkey_all[wv]; u32* lbits = lbits_all[wv]; u32* lcnt = lcnt_all + wv;\n";
+    s << "  if (lane == 0u) *lcnt = 0u;\n";
     s << "  const u32 shard = (u32)block & 255u; // candidate queue: 256 segments, one push counter each\n";
     s << "  qent* queue = queue_all + (u64)shard * qcap;\n";
     s << "  u64* qcount = qcount_all + shard * 16u;\n";
@@ -385,12 +423,55 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
     }
     s << ";\n";
     s << "  __shared__ v4 stash[" << WPG << "][" << QW * 3 << "][64]; // head quads of each wave's block, for the wrap rows\n";
-    s << "  v4 (*st)[64] = stash[threadIdx.x >> 6];\n";
+    s << "  v4 (*st)[64] = stash[wv];\n";
     for (int i = 1; i <= D; ++i)
         s << "  v4 p" << i << "lo = own[" << (i - 1) * 192 << "], p" << i << "hi = own[" << (i - 1) * 192 + 64 << "], p" << i
           << "iv = own[" << (i - 1) * 192 + 128 << "];\n";
     s << "  for (u32 it = 0; it < " << NFULL << "u; ++it) {\n" << body.str() << "  }\n";
     s << epi.str();
+    // ---- exact verification of this wave's survivors (verifyAt, core/engine/ac.go:186-213 / the
+    // inner loop of FindMatches, core/primer/match.go:67-84): lane j compares window position j
+    s << "  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\");\n"
+         "  u32 nl = (u32)__builtin_amdgcn_readfirstlane(*lcnt);\n"
+         "  if (nl == 0u) return;\n"
+         "  if (nl > LIST_CAP) nl = LIST_CAP;\n"
+         "  const u32* planes32 = (const u32*)planes;\n"
+         "  u32 ncand = 0u;\n"
+         "  for (u32 e = 0u; e < nl; ++e) {\n"
+         "    const u64 key = lkey[e];\n"
+         "    u32 bits = (u32)__builtin_amdgcn_readfirstlane(lbits[e]);\n"
+         "    const u32 q = (u32)__builtin_amdgcn_readfirstlane((u32)(key >> 48));\n"
+         "    const u64 P0 = ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(key >> 32) & 0xFFFFu) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((u32)key); // the builtin returns int\n"
+         "    ncand += (u32)__builtin_popcount(bits);\n"
+         "    const dpat* pp = pats + q;\n"
+         "    const u32 L = pp->len, slen = pp->seed_len, soff = pp->seed_off, gid = pp->global_id;\n"
+         "    const u32 m = lane < L ? pp->mask[lane] : 0u;\n"
+         "    while (bits) {\n"
+         "      const u32 bit = (u32)__builtin_ctz(bits);\n"
+         "      bits &= bits - 1u;\n"
+         "      const u64 P = P0 + ((u64)bit << 7);\n"
+         "      u32 lo = 0u, hi = nrec; // last record with start <= P\n"
+         "      while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (rec_start[mid] <= P) lo = mid; else hi = mid; }\n"
+         "      const u64 local = P - rec_start[lo];\n"
+         "      if (local + L > rec_len[lo]) continue; // window must stay inside the record (ac.go:188-190)\n"
+         "      bool mis = false, prot = false;\n"
+         "      if (lane < L) {\n"
+         "        const u32 g = base_bits(planes32, P + lane);\n"
+         "        const u32 onehot = (g & 4u) ? 0u : (1u << (g & 3u));\n"
+         "        mis = (m & onehot) == 0u;\n"
+         "        prot = mis && (m & 16u);\n"
+         "      }\n"
+         "      const u64 mm = __ballot(mis);\n"
+         "      if (__ballot(prot) != 0ull || (u32)__popcll(mm) > max_mm) continue;\n"
+         "      u32 flag = 0u;\n"
+         "      if (check_rst && slen) flag = __ballot(lane < slen && rst_bit(rst, P + soff + lane)) != 0ull ? 1u : 0u;\n"
+         "      if (lane == 0u) {\n"
+         "        const u64 slot = atomicAdd(counts + 1, 1ull);\n"
+         "        if (slot < hcap) { hitrec h; h.pos = local; h.record = lo; h.pattern = gid | (flag << 31); h.m0 = mm; h.m1 = 0ull; hits[slot] = h; }\n"
+         "      }\n"
+         "    }\n"
+         "  }\n"
+         "  if (lane == 0u && ncand) atomicAdd(counts + 2, (u64)ncand);\n";
     s << "}\n";
     (void)uses_n;
     return s.str();
@@ -655,9 +736,13 @@ hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes
 }
 
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,
-                      uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop) {
+                      uint64_t qcap, unsigned long long *qcount, const JitVerify &v, hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0) return hipSuccess;
-    void *args[] = {(void *)&planes, (void *)&nblocks, (void *)&queue, (void *)&qcap, (void *)&qcount};
+    JitVerify a = v;
+    void *args[] = {(void *)&planes, (void *)&nblocks, (void *)&queue, (void *)&qcap, (void *)&qcount,
+                    (void *)&a.rst, (void *)&a.pats, (void *)&a.rec_start, (void *)&a.rec_len, (void *)&a.nrec,
+                    (void *)&a.max_mm, (void *)&a.check_rst, (void *)&a.hits, (void *)&a.hcap, (void *)&a.counts,
+                    (void *)&a.next_counts, (void *)&a.next_qcount};
     const unsigned wpg = f->waves_per_group, threads = wpg * 64u;
     const unsigned grid = (unsigned)((nblocks + wpg - 1) / wpg);
     // start/stop are attached to this dispatch itself (its begin/end timestamps)

@@ -21,8 +21,22 @@ size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats);
 // one kernel per pattern group, compiled in parallel; empty (and `err` set) when the panel
 // cannot be specialised or hiprtc fails
 std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err);
+// The specialised filter verifies its own survivors (each wave, when its block is done) and appends
+// the hit records itself: these are the exact verifier's operands.  counts = this scan's counter
+// set ([0] survivor words spilled to the queue because a wave's list was full -> the stand-alone
+// verifier must run over the queue, [1] hits, [2] candidate windows); next_* = the sets of the next
+// scan, cleared by workgroup 0 (null for every kernel of a scan but the first).
+struct JitVerify {
+    const uint32_t *rst = nullptr;
+    const ipcr_dev_pattern *pats = nullptr;
+    const uint64_t *rec_start = nullptr, *rec_len = nullptr;
+    uint32_t nrec = 0, max_mm = 0, check_rst = 0;
+    ipcr_hit_rec *hits = nullptr;
+    uint64_t hcap = 0;
+    unsigned long long *counts = nullptr, *next_counts = nullptr, *next_qcount = nullptr;
+};
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,
-                      uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop);
+                      uint64_t qcap, unsigned long long *qcount, const JitVerify &v, hipEvent_t start, hipEvent_t stop);
 // seed-index filter specialised on the panel's key shapes (same results as kernels.hip's)
 std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes);
 JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, std::string &err);

@@ -554,6 +554,9 @@ def test_buffer_regrowth_on_dense_hits(hip):
     sc = eng.NewSimulationScratch(cp)
     got = eng.SimulateCompiledWithScratch("s", seq, cp, sc)
     assert sc.stats().hits >= 2 * (n - 11)          # A and rc(B)=A...A both match everywhere
+    # dense survivors overflow the waves' own verify lists: the spilled words went through the queue and
+    # the stand-alone verifier (sparse scans never launch it, see test_pipelined_begin_end)
+    assert sc.stats().kernel_kind == 1 and sc.stats().verify_ms > 0
     want = O.simulate_batch(ocfg(cfg), seq[:200000], opairs(cp.Pairs))  # capped lists: a prefix decides
     assert [g.sig() for g in got] == [w.sig() for w in want] and len(got) > 0
     # and the scratch is still healthy afterwards
@@ -650,6 +653,8 @@ def test_pipelined_begin_end(hip):
     a, b = eng.NewSimulationScratch(cp), eng.NewSimulationScratch(cp)
     want = [p.sig() for p in eng.ScanGenome(g, cp, a)]
     assert want
+    st = a.stats()  # specialised filter, survivors verified by the filter's own waves: one kernel per scan
+    assert st.kernel_kind == 1 and st.verify_ms == 0 and st.hits > 0 and st.candidates >= st.hits
     scs = [a, b]
     eng.ScanGenomeBegin(g, cp, scs[0])
     for i in range(6):
