@@ -840,11 +840,15 @@ struct ipcr_scratch {
         bool fused = false;    // the filter verified its own survivors (specialised kernel)
         bool verified = false; // the stand-alone verifier has run over the queue
         bool on_lane = false;  // wait for ev_done (false: a follow-up on the private stream, wait for the stream)
+        bool published = false; // the filter's last wave writes counters + sequence word to pinned memory: poll
+        bool times_pending = false;
         uint32_t nrec = 0, check_rst = 0, cset_used = 0;
         uint64_t nblocks = 0, pre = 0;
         std::chrono::steady_clock::time_point t0;
     } pend;
-    void *pinned = nullptr;                 // counts (16 B) + first PREFIX hits
+    void *pinned = nullptr;                 // two counter sets (64 B) + first PREFIX hits + the sequence word
+    uint32_t *d_tickets = nullptr;          // 65 counters, 128 B apart (specialised filter: last wave publishes)
+    uint32_t seq = 0;                       // id of the last scan launched on this scratch
     std::vector<ipcr_hit> hits;      // sorted by (record, pattern, pos)
     std::vector<ipcr_hit> hits_raw;  // in device append order
     std::vector<uint32_t> bucket;    // scratch of sort_hits
@@ -969,6 +973,43 @@ double ms_since(std::chrono::steady_clock::time_point a) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
 }
 
+bool env_flag(const char *name, bool dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) != 0 : dflt;
+}
+
+uint32_t *pinned_seq(const ipcr_scratch *s) {
+    return reinterpret_cast<uint32_t *>(static_cast<char *>(s->pinned) + 64 + PREFIX_HITS * sizeof(ipcr_hit));
+}
+
+bool publish_enabled() { // IPCR_PUBLISH=0: read-back by a copy operation behind the kernel instead
+    static const bool on = env_flag("IPCR_PUBLISH", true);
+    return on;
+}
+
+// the specialised filter's last wave has written counters, first hits and finally the scan's
+// sequence word into pinned memory: spin on that word (microseconds after the kernel's last wave,
+// no marker packet between two chained sweeps)
+ipcr_status wait_published(ipcr_scratch *s) {
+    volatile uint32_t *w = pinned_seq(s);
+    const uint32_t want = s->seq;
+    const hipStream_t lane = s->lane_used ? s->lane_used->s : s->stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 1;; ++spin) {
+        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == want) return IPCR_OK;
+        __builtin_ia32_pause();
+        if ((spin & 0xFFFFu) == 0) { // a fault on the stream would otherwise spin for ever
+            const hipError_t q = hipStreamQuery(lane);
+            if (q == hipSuccess) { // stream drained: the word is there, or the kernel died
+                if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == want) return IPCR_OK;
+                return fail(IPCR_ERR_DEVICE, "specialised filter finished without publishing its results");
+            }
+            if (q != hipErrorNotReady) return fail(IPCR_ERR_DEVICE, "HIP: %s", hipGetErrorString(q));
+            if (ms_since(t0) > 120000.0) return fail(IPCR_ERR_DEVICE, "scan did not finish within 120 s");
+        }
+    }
+}
+
 // enqueue one attempt: filter kernel(s), verify kernel, read-back of counters + first hits
 ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     ipcr_scratch::Pending &pd = s->pend;
@@ -987,6 +1028,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     s->lane_next.reset();
     pd.fused = false;
     pd.verified = false;
+    pd.published = false;
     if (!set.jit.empty()) {
         ipcr::JitVerify v;
         v.rst = g->rst;
@@ -999,9 +1041,22 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         v.hits = s->d_hits;
         v.hcap = s->hcap;
         v.counts = cnt;
+        pd.pre = std::min<uint64_t>(PREFIX_HITS, s->hcap);
+        ++s->seq;
         for (size_t gi = 0; gi < set.jit.size(); ++gi) { // every group streams the tiles once
             v.next_counts = gi == 0 ? cnt_next : nullptr;
             v.next_qcount = gi == 0 ? qc_next : nullptr;
+            if (publish_enabled()) { // every kernel of the scan writes its first hits to the pinned buffer too
+                v.pub_hits = reinterpret_cast<ipcr_hit_rec *>(static_cast<unsigned long long *>(s->pinned) + 8);
+                v.pre = (uint32_t)pd.pre;
+            }
+            if (gi + 1 == set.jit.size() && publish_enabled()) { // the scan's last kernel hands the results over itself
+                v.tickets = s->d_tickets;
+                v.pub = static_cast<unsigned long long *>(s->pinned) + 4u * pd.cset_used;
+                v.pub_seq = pinned_seq(s);
+                v.seq = s->seq;
+                pd.published = true;
+            }
             HIPCHK(ipcr::jit_launch(set.jit[gi], lane, g->planes, nblocks, s->d_queue, s->qcap, qc, v,
                                     gi == 0 ? s->ev[0] : nullptr, gi + 1 == set.jit.size() ? s->ev[1] : nullptr));
         }
@@ -1034,12 +1089,14 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
                                    s->hcap, cnt + 1, cnt + 2, cnt_next, qc_next, s->ev[2], s->ev[3]));
         pd.verified = true;
     }
-    pd.pre = std::min<uint64_t>(std::min<uint64_t>(s->prefix_hint, PREFIX_HITS), s->hcap);
-    HIPCHK(hipMemcpyAsync(s->pinned, s->d_hitbuf, 64 + pd.pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, lane)); // counters + hits
-    // the host waits for this marker, not for the stream: a scan chained after this one may already
-    // be queued behind it on the same stream (ipcr_scratch_chain_after)
-    if (!s->ev_done) HIPCHK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(s->ev_done, lane));
+    if (!pd.published) {
+        pd.pre = std::min<uint64_t>(std::min<uint64_t>(s->prefix_hint, PREFIX_HITS), s->hcap);
+        HIPCHK(hipMemcpyAsync(s->pinned, s->d_hitbuf, 64 + pd.pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, lane)); // counters + hits
+        // the host waits for this marker, not for the stream: a scan chained after this one may already
+        // be queued behind it on the same stream (ipcr_scratch_chain_after)
+        if (!s->ev_done) HIPCHK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(s->ev_done, lane));
+    }
     pd.on_lane = true;
     s->stats.enqueue_ms = ms_since(te);
     trace("launch<", s);
@@ -1087,7 +1144,10 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     for (int attempt = 0; attempt < 12; ++attempt) {
         const auto tw = std::chrono::steady_clock::now();
         trace("wait>", s);
-        if (pd.on_lane) HIPCHK(hipEventSynchronize(s->ev_done)); // the lane already carries the next scan
+        if (pd.published) {
+            const ipcr_status ws = wait_published(s);
+            if (ws != IPCR_OK) return ws;
+        } else if (pd.on_lane) HIPCHK(hipEventSynchronize(s->ev_done)); // the lane already carries the next scan
         else HIPCHK(hipStreamSynchronize(s->stream));
         s->stats.wait_ms += ms_since(tw);
         trace("wait<", s);
@@ -1106,6 +1166,7 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             HIPCHK(hipMemcpyAsync(s->pinned, s->d_hitbuf, 64 + pd.pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->stream));
             pd.verified = true;
             pd.on_lane = false;
+            pd.published = false;
             continue;
         }
         const uint64_t nhit = pc[1], ncand = pc[2], fullest = pc[3];
@@ -1145,6 +1206,8 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         if (nhit > got) HIPCHK(hipMemcpy(raw.data() + got, s->d_hits + got, (nhit - got) * sizeof(ipcr_hit), hipMemcpyDeviceToHost));
         s->prefix_hint = std::max<uint64_t>(256, nhit + nhit / 4 + 16);
         float fms = 0, vms = 0;
+        if (pd.published) HIPCHK(hipEventSynchronize(s->ev[1])); // the kernel retires a moment after its last wave
+        trace("retired", s);
         HIPCHK(hipEventElapsedTime(&fms, s->ev[0], s->ev[1]));
         if (pd.verified) HIPCHK(hipEventElapsedTime(&vms, s->ev[2], s->ev[3]));
         s->stats.filter_ms = fms;
@@ -1418,7 +1481,10 @@ ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out) {
         HIPCHK(hipMemset(raw->d_hitbuf, 0, 64));
         raw->d_counts = static_cast<unsigned long long *>(raw->d_hitbuf);
         raw->d_hits = static_cast<ipcr_hit_rec *>(raw->d_hitbuf) + 2;
-        HIPCHK(hipHostMalloc(&raw->pinned, 64 + PREFIX_HITS * sizeof(ipcr_hit), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&raw->pinned, 64 + PREFIX_HITS * sizeof(ipcr_hit) + 64, hipHostMallocDefault));
+        memset(raw->pinned, 0, 64 + PREFIX_HITS * sizeof(ipcr_hit) + 64);
+        HIPCHK(hipMalloc((void **)&raw->d_tickets, 65 * 128));
+        HIPCHK(hipMemset(raw->d_tickets, 0, 65 * 128));
         return IPCR_OK;
     };
     ipcr_status st = build();
@@ -1448,6 +1514,7 @@ void ipcr_scratch_destroy(ipcr_scratch *s) {
     if (s->d_amps) (void)hipFree(s->d_amps);
     if (s->d_probe_misc) (void)hipFree(s->d_probe_misc);
     if (s->pinned) (void)hipHostFree(s->pinned);
+    if (s->d_tickets) (void)hipFree(s->d_tickets);
     for (auto &e : s->ev)
         if (e) (void)hipEventDestroy(e);
     if (s->ev_done) (void)hipEventDestroy(s->ev_done);

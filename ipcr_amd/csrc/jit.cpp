@@ -395,7 +395,8 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
          "    qent* __restrict__ queue_all, u64 qcap, u64* __restrict__ qcount_all,\n"
          "    const u32* __restrict__ rst, const dpat* __restrict__ pats, const u64* __restrict__ rec_start,\n"
          "    const u64* __restrict__ rec_len, u32 nrec, u32 max_mm, u32 check_rst, hitrec* __restrict__ hits, u64 hcap,\n"
-         "    u64* __restrict__ counts, u64* __restrict__ next_counts, u64* __restrict__ next_qcount) {\n";
+         "    u64* __restrict__ counts, u64* __restrict__ next_counts, u64* __restrict__ next_qcount,\n"
+         "    u32* __restrict__ tickets, u64* __restrict__ pub, hitrec* __restrict__ pub_hits, u32 pre, u32* __restrict__ pub_seq, u32 seq) {\n";
     s << "  const u32 lane = threadIdx.x & 63u;\n";
     s << "  const u32 wv = threadIdx.x >> 6;\n";
     s << "  const u64 block = (u64)blockIdx.x * " << WPG << "u + wv;\n";
@@ -433,10 +434,10 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
     // inner loop of FindMatches, core/primer/match.go:67-84): lane j compares window position j
     s << "  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\");\n"
          "  u32 nl = (u32)__builtin_amdgcn_readfirstlane(*lcnt);\n"
-         "  if (nl == 0u) return;\n"
          "  if (nl > LIST_CAP) nl = LIST_CAP;\n"
          "  const u32* planes32 = (const u32*)planes;\n"
          "  u32 ncand = 0u;\n"
+         "  bool wrote = false;\n"
          "  for (u32 e = 0u; e < nl; ++e) {\n"
          "    const u64 key = lkey[e];\n"
          "    u32 bits = (u32)__builtin_amdgcn_readfirstlane(lbits[e]);\n"
@@ -465,13 +466,43 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
          "      if (__ballot(prot) != 0ull || (u32)__popcll(mm) > max_mm) continue;\n"
          "      u32 flag = 0u;\n"
          "      if (check_rst && slen) flag = __ballot(lane < slen && rst_bit(rst, P + soff + lane)) != 0ull ? 1u : 0u;\n"
+         "      wrote = true;\n"
          "      if (lane == 0u) {\n"
          "        const u64 slot = atomicAdd(counts + 1, 1ull);\n"
-         "        if (slot < hcap) { hitrec h; h.pos = local; h.record = lo; h.pattern = gid | (flag << 31); h.m0 = mm; h.m1 = 0ull; hits[slot] = h; }\n"
+         "        hitrec h; h.pos = local; h.record = lo; h.pattern = gid | (flag << 31); h.m0 = mm; h.m1 = 0ull;\n"
+         "        if (slot < hcap) hits[slot] = h;\n"
+         "        if (pub_hits && slot < pre) pub_hits[slot] = h; // the first hits also go straight to the host's pinned buffer\n"
          "      }\n"
          "    }\n"
          "  }\n"
          "  if (lane == 0u && ncand) atomicAdd(counts + 2, (u64)ncand);\n";
+    // ---- the last wave of the scan hands the counters to the host (no copy operation behind the
+    // kernel): two-level ticket, 64 first-level counters 128 B apart so that the ~12 ns same-address
+    // atomics of thousands of finishing waves do not queue up behind one another
+    s << "  if (pub) {\n"
+         "    // my counter atomics and my records in the host's (uncached) buffer must have been performed before\n"
+         "    // my ticket; nothing of mine sits dirty in this XCD's L2 that the last wave reads, so no L2 write-back\n"
+         "    // (thousands of waves issuing one cost half the kernel time again)\n"
+         "    if (wrote || ncand) asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
+         "    const u32 sh = (u32)block & 63u;\n"
+         "    const u32 expect = (u32)((nblocks - sh + 63ull) >> 6); // waves of this ticket shard\n"
+         "    u32 t = 0u;\n"
+         "    if (lane == 0u) t = atomicAdd(tickets + sh * 32u, 1u);\n"
+         "    t = (u32)__builtin_amdgcn_readfirstlane(t);\n"
+         "    if (t + 1u == expect) {\n"
+         "      u32 t2 = 0u;\n"
+         "      if (lane == 0u) { tickets[sh * 32u] = 0u; t2 = atomicAdd(tickets + 2048u, 1u); }\n"
+         "      t2 = (u32)__builtin_amdgcn_readfirstlane(t2);\n"
+         "      const u32 nsh = nblocks < 64ull ? (u32)nblocks : 64u;\n"
+         "      if (t2 + 1u == nsh) { // every other wave of the scan has finished\n"
+         "        __threadfence();\n"
+         "        if (lane < 4u) pub[lane] = __hip_atomic_load(counts + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+         "        if (lane == 0u) tickets[2048u] = 0u;\n"
+         "        __threadfence_system();\n"
+         "        if (lane == 0u) __hip_atomic_store(pub_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);\n"
+         "      }\n"
+         "    }\n"
+         "  }\n";
     s << "}\n";
     (void)uses_n;
     return s.str();
@@ -742,7 +773,8 @@ hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint
     void *args[] = {(void *)&planes, (void *)&nblocks, (void *)&queue, (void *)&qcap, (void *)&qcount,
                     (void *)&a.rst, (void *)&a.pats, (void *)&a.rec_start, (void *)&a.rec_len, (void *)&a.nrec,
                     (void *)&a.max_mm, (void *)&a.check_rst, (void *)&a.hits, (void *)&a.hcap, (void *)&a.counts,
-                    (void *)&a.next_counts, (void *)&a.next_qcount};
+                    (void *)&a.next_counts, (void *)&a.next_qcount, (void *)&a.tickets, (void *)&a.pub,
+                    (void *)&a.pub_hits, (void *)&a.pre, (void *)&a.pub_seq, (void *)&a.seq};
     const unsigned wpg = f->waves_per_group, threads = wpg * 64u;
     const unsigned grid = (unsigned)((nblocks + wpg - 1) / wpg);
     // start/stop are attached to this dispatch itself (its begin/end timestamps)

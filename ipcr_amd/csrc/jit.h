@@ -34,6 +34,16 @@ struct JitVerify {
     ipcr_hit_rec *hits = nullptr;
     uint64_t hcap = 0;
     unsigned long long *counts = nullptr, *next_counts = nullptr, *next_qcount = nullptr;
+    // publishing: every kernel writes the first `pre` hit records to pub_hits (pinned host memory) as
+    // they are found; in the last kernel of a scan (pub != null) the last wave to finish writes the
+    // counter set to pub[0..3] and then `seq` to *pub_seq, both in pinned host memory.
+    // tickets: 65 zeroed counters, 32 words apart, left zeroed again.
+    uint32_t *tickets = nullptr;
+    unsigned long long *pub = nullptr;
+    ipcr_hit_rec *pub_hits = nullptr;
+    uint32_t pre = 0;
+    uint32_t *pub_seq = nullptr;
+    uint32_t seq = 0;
 };
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,
                       uint64_t qcap, unsigned long long *qcount, const JitVerify &v, hipEvent_t start, hipEvent_t stop);

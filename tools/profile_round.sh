@@ -13,7 +13,7 @@ python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || { tail -5 "$out/benc
 tail -1 "$out/bench.json"
 python3 bench.py --no-pipeline --no-cpu-baseline > "$out/bench_serial.json" 2> "$out/bench_serial.err" || exit 1
 tail -1 "$out/bench_serial.json"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$out/stats.log" 2>&1 || { tail -5 "$out/stats.log"; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 400 --warmup 50 --no-cpu-baseline > "$out/stats.log" 2>&1 || { tail -5 "$out/stats.log"; exit 1; }
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1 || { tail -5 "$out/pmc_fetch.log"; exit 1; }
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > "$out/pmc_write.log" 2>&1 || { tail -5 "$out/pmc_write.log"; exit 1; }
 # keep the merge-back small: the per-dispatch traces are not needed, the summaries are
