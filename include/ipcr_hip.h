@@ -194,6 +194,9 @@ ipcr_status ipcr_lcg_fill_device(void *dev_out, uint64_t len, uint32_t seed, uin
 ipcr_status ipcr_genome_read(const ipcr_genome *g, uint32_t record, uint64_t pos, uint8_t *out, uint64_t len);
 uint32_t ipcr_genome_num_records(const ipcr_genome *g);
 uint64_t ipcr_genome_record_len(const ipcr_genome *g, uint32_t record);
+/* ID of a record loaded by ipcr_genome_add_fasta (header text up to the first blank,
+ * core/fasta/stream.go:125-131); "" for records added as bytes.  Valid until the genome changes. */
+const char *ipcr_genome_record_id(const ipcr_genome *g, uint32_t record);
 uint64_t ipcr_genome_total_bases(const ipcr_genome *g);
 uint64_t ipcr_genome_tile_bytes(const ipcr_genome *g);
 double ipcr_genome_pack_ms(const ipcr_genome *g); /* accumulated pack-kernel time */
@@ -207,7 +210,9 @@ ipcr_status ipcr_fasta_open(const char *path, int64_t chunk_size, int64_t overla
 void ipcr_fasta_close(ipcr_fasta *f);
 /* next record/chunk; *got = 0 at end of input; *id and *seq stay valid until the next call */
 ipcr_status ipcr_fasta_next(ipcr_fasta *f, const char **id, const uint8_t **seq, uint64_t *len, int32_t *got);
-/* pack every record of a FASTA file into a resident genome; record IDs come back '\n'-joined */
+/* pack every record of a FASTA file (plain or gzip, "-" = stdin) into a resident genome: raw
+ * slabs go to the device, which strips line ends / white space and folds case itself (same record
+ * semantics as the stream above); record IDs come back '\n'-joined and via ipcr_genome_record_id */
 ipcr_status ipcr_genome_add_fasta(ipcr_genome *g, const char *path, uint32_t *n_added, char *ids_out, size_t cap,
                                   size_t *ids_needed);
 

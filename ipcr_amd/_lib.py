@@ -95,6 +95,7 @@ SYMBOLS = {
     "ipcr_genome_read": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_char_p, C.c_uint64]),
     "ipcr_genome_num_records": (C.c_uint32, [C.c_void_p]),
     "ipcr_genome_record_len": (C.c_uint64, [C.c_void_p, C.c_uint32]),
+    "ipcr_genome_record_id": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "ipcr_genome_total_bases": (C.c_uint64, [C.c_void_p]),
     "ipcr_genome_tile_bytes": (C.c_uint64, [C.c_void_p]),
     "ipcr_genome_pack_ms": (C.c_double, [C.c_void_p]),

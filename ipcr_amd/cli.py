@@ -141,16 +141,11 @@ def run(argv: Optional[Sequence[str]] = None, stdout=None, stderr=None) -> int:
         size = os.path.getsize(path) if path != "-" and os.path.exists(path) else (1 << 28)
         factor = 8 if path.endswith(".gz") else 1
         g = engine.Genome(max(size * factor, 1 << 20), max_records=1 << 16)
-        n = C.c_uint32()
-        need = C.c_size_t()
         try:
-            _lib.check(_lib.lib().ipcr_genome_add_fasta(g._h, path.encode(), C.byref(n), None, 0, C.byref(need)))
+            g.add_fasta(path)
         except _lib.IpcrError as e:
             print(f"error: {e}", file=stderr)       # pipeline.go:174-182: record the error, go on
             continue
-        # the IDs of what was just packed (second pass over the file is cheap next to the scan)
-        from . import fasta
-        g.ids = [r.ID for r in fasta.StreamChunks(path)] if path != "-" else ["%d" % i for i in range(n.value)]
         prods = eng.ScanGenome(g, cp, sc)
         probe_hits = None
         if o.probe:

@@ -80,3 +80,8 @@ struct ipcr_index_meta { // per pattern
 
 #define IPCR_INDEX_MAX_SHAPES 16
 #define IPCR_INDEX_BITMAP_WORDS 2048u // 65536 bits per shape
+
+// raw byte range [start, end) of one FASTA header line (its '\n' included) inside a slab
+struct ipcr_fasta_range {
+    uint64_t start, end;
+};

@@ -7,17 +7,24 @@
 //   sequence lines: TrimSpace, a-z -> A-Z                core/fasta/normalize.go:5-14
 //   sequence lines before the first header are ignored   core/fasta/path_ctx.go:142-144
 //   rolling chunks "id:start-end", step = chunk-overlap  core/fasta/path_ctx.go:83-179
-// The parse runs on the host (zlib inflate is serial anyway); records go to HBM through
-// ipcr_genome_add_record's staging copy + pack kernel.
+// Two consumers: the streaming reader (ipcr_fasta_next: host parse, what a worker of the drop-in
+// pipeline or the CLI's chunked mode pulls from) and the resident-genome loader
+// (ipcr_genome_add_fasta: raw slabs to the device, normalisation in fasta_kernels.hip).
+#include <fcntl.h>
+#include <hip/hip_runtime_api.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
 
+#include "device_types.h"
 #include "ipcr_hip.h"
+#include "launch.h"
 
 struct ipcr_fasta {
     gzFile fh = nullptr;
@@ -42,12 +49,15 @@ struct ipcr_fasta {
 };
 
 extern ipcr_status ipcr_internal_fail(ipcr_status st, const char *fmt, ...);
+// host.cpp: pack a record that already lies in device memory (16-byte aligned) and remember its ID
+extern ipcr_status ipcr_internal_genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len, const char *id);
+extern hipStream_t ipcr_internal_genome_stream(ipcr_genome *g);
 
 namespace {
 
-bool is_space(uint8_t c) { // bytes.TrimSpace's ASCII set plus the two Latin-1 spaces it knows
-    return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f' || c == 0x85 || c == 0xA0;
-}
+// bytes.TrimSpace's ASCII set.  (Go also trims multi-byte Unicode spaces such as U+0085 / U+00A0 in
+// their UTF-8 form; FASTA is ASCII, those stay sequence bytes here -- and are non-ACGT either way.)
+bool is_space(uint8_t c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
 
 void trim(const std::string &s, size_t &a, size_t &b) {
     a = 0;
@@ -122,6 +132,202 @@ void start_record(ipcr_fasta *f, const std::string &header) { // path_ctx.go:100
     f->emitted_chunk = false;
 }
 
+
+// ---------------------------------------------------------------- device-side FASTA decode driver
+#define FHIP(call)                                                                                         \
+    do {                                                                                                   \
+        const hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return ipcr_internal_fail(IPCR_ERR_DEVICE, "HIP: %s (%s)", hipGetErrorString(e_), #call); \
+    } while (0)
+
+struct FastaLoader {
+    ipcr_genome *g = nullptr;
+    int fd = -1;
+    gzFile gz = nullptr; // gzip input (or stdin); plain files are read with read(2) straight into pinned memory
+    bool eof = false;
+    size_t slab = 0;
+    hipStream_t st = nullptr;
+    uint8_t *pin = nullptr, *d_raw = nullptr, *d_out = nullptr, *d_rec = nullptr;
+    uint32_t *d_counts = nullptr, *d_hdr_off = nullptr, *h_small = nullptr; // h_small: pinned, hdr_off[nh] + total
+    ipcr_fasta_range *d_hdr = nullptr;
+    size_t hdr_cap = 0;
+    uint64_t rec_cap = 0, rec_len = 0;
+    std::vector<uint8_t> carry;
+    std::vector<ipcr_fasta_range> ranges;
+    bool at_line_start = true, lead_open = true;
+    bool have_id = false;
+    std::string id, ids;
+    uint32_t n_added = 0;
+
+    ~FastaLoader() {
+        if (gz) gzclose(gz);
+        else if (fd >= 0) close(fd);
+        if (pin) (void)hipHostFree(pin);
+        if (h_small) (void)hipHostFree(h_small);
+        if (d_raw) (void)hipFree(d_raw);
+        if (d_out) (void)hipFree(d_out);
+        if (d_rec) (void)hipFree(d_rec);
+        if (d_counts) (void)hipFree(d_counts);
+        if (d_hdr_off) (void)hipFree(d_hdr_off);
+        if (d_hdr) (void)hipFree(d_hdr);
+    }
+
+    ipcr_status open(ipcr_genome *genome, const char *path) {
+        g = genome;
+        st = ipcr_internal_genome_stream(g);
+        const char *es = getenv("IPCR_FASTA_SLAB");
+        slab = es && *es ? (size_t)strtoull(es, nullptr, 10) : ((size_t)64 << 20);
+        if (slab < 64) slab = 64;
+        slab = (slab + 15) & ~(size_t)15;
+        if (strcmp(path, "-") == 0) {
+            gz = gzdopen(0, "rb");
+        } else {
+            fd = ::open(path, O_RDONLY);
+            if (fd < 0) return ipcr_internal_fail(IPCR_ERR_INVALID, "cannot open %s", path);
+            unsigned char magic[2] = {0, 0};
+            const ssize_t m = pread(fd, magic, 2, 0);
+            const size_t pl = strlen(path);
+            if ((m == 2 && magic[0] == 0x1f && magic[1] == 0x8b) || (pl > 3 && strcmp(path + pl - 3, ".gz") == 0)) { // open.go:29-50
+                gz = gzdopen(fd, "rb");
+                if (gz) gzbuffer(gz, 1 << 20);
+            }
+        }
+        if (fd < 0 && !gz) return ipcr_internal_fail(IPCR_ERR_INVALID, "cannot open %s", path);
+        FHIP(hipHostMalloc((void **)&pin, slab, hipHostMallocDefault));
+        FHIP(hipMalloc((void **)&d_raw, slab));
+        FHIP(hipMalloc((void **)&d_out, slab));
+        FHIP(hipMalloc((void **)&d_counts, (slab / 4096 + 2) * 4));
+        return IPCR_OK;
+    }
+
+    // fill pin[have, slab) from the file; returns bytes now in the buffer
+    ipcr_status fill(size_t have, size_t *n) {
+        while (have < slab && !eof) {
+            long r;
+            if (gz) r = gzread(gz, pin + have, (unsigned)std::min<size_t>(slab - have, 1u << 30));
+            else r = (long)::read(fd, pin + have, slab - have);
+            if (r < 0) return ipcr_internal_fail(IPCR_ERR_INVALID, "read error in FASTA input");
+            if (r == 0) eof = true;
+            have += (size_t)r;
+        }
+        *n = have;
+        return IPCR_OK;
+    }
+
+    ipcr_status finish_record() {
+        if (!have_id) return IPCR_OK;
+        const ipcr_status s = ipcr_internal_genome_add_device(g, d_rec ? d_rec : d_out, rec_len, id.c_str());
+        if (s != IPCR_OK) return s;
+        if (n_added) ids.push_back('\n');
+        ids += id;
+        ++n_added;
+        have_id = false;
+        rec_len = 0;
+        return IPCR_OK;
+    }
+
+    ipcr_status append(uint64_t a, uint64_t b) { // compacted bytes [a, b) of this slab belong to the open record
+        if (!have_id || b <= a) return IPCR_OK;
+        const uint64_t need = rec_len + (b - a);
+        if (need > rec_cap) {
+            uint64_t want = std::max<uint64_t>(need + (need >> 2), (uint64_t)1 << 20);
+            want = (want + 255) & ~(uint64_t)255;
+            uint8_t *nb = nullptr;
+            FHIP(hipMalloc((void **)&nb, want));
+            if (rec_len) FHIP(hipMemcpyAsync(nb, d_rec, rec_len, hipMemcpyDeviceToDevice, st));
+            FHIP(hipStreamSynchronize(st));
+            if (d_rec) (void)hipFree(d_rec);
+            d_rec = nb;
+            rec_cap = want;
+        }
+        FHIP(hipMemcpyAsync(d_rec + rec_len, d_out + a, b - a, hipMemcpyDeviceToDevice, st));
+        rec_len = need;
+        return IPCR_OK;
+    }
+
+    ipcr_status run() {
+        size_t have = 0;
+        for (;;) {
+            if (!carry.empty()) memcpy(pin, carry.data(), carry.size());
+            have = carry.size();
+            carry.clear();
+            size_t n = 0;
+            ipcr_status s = fill(have, &n);
+            if (s != IPCR_OK) return s;
+            if (n == 0) break;
+            // where to cut: behind the last line end; a slab without one is cut in front of its trailing
+            // white space (whether that is kept depends on what follows)
+            size_t cut = n;
+            if (!eof) {
+                const void *nl = memrchr(pin, '\n', n);
+                if (nl) cut = (size_t)((const uint8_t *)nl - pin) + 1;
+                else {
+                    while (cut > 0 && is_space(pin[cut - 1])) --cut;
+                    if (cut == 0 && n == slab) return ipcr_internal_fail(IPCR_ERR_UNSUPPORTED, "FASTA: a run of white space longer than the %zu-byte slab", slab);
+                }
+            }
+            // header lines of [0, cut)
+            ranges.clear();
+            for (size_t pos = 0; pos < cut;) {
+                const void *p = memchr(pin + pos, '>', cut - pos);
+                if (!p) break;
+                const size_t i = (size_t)((const uint8_t *)p - pin);
+                const bool ls = i == 0 ? at_line_start : pin[i - 1] == '\n';
+                if (!ls) { pos = i + 1; continue; }
+                const void *e = memchr(pin + i, '\n', cut - i);
+                if (!e && !eof) return ipcr_internal_fail(IPCR_ERR_UNSUPPORTED, "FASTA: a header line longer than the %zu-byte slab", slab);
+                const size_t end = e ? (size_t)((const uint8_t *)e - pin) + 1 : cut;
+                ranges.push_back({(uint64_t)i, (uint64_t)end});
+                pos = end;
+            }
+            const uint32_t nh = (uint32_t)ranges.size();
+            if (nh + 1 > hdr_cap) {
+                if (d_hdr) (void)hipFree(d_hdr);
+                if (d_hdr_off) (void)hipFree(d_hdr_off);
+                if (h_small) (void)hipHostFree(h_small);
+                d_hdr = nullptr; d_hdr_off = nullptr; h_small = nullptr;
+                hdr_cap = (size_t)nh * 2 + 64;
+                FHIP(hipMalloc((void **)&d_hdr, hdr_cap * sizeof(ipcr_fasta_range)));
+                FHIP(hipMalloc((void **)&d_hdr_off, hdr_cap * 4));
+                FHIP(hipHostMalloc((void **)&h_small, (hdr_cap + 1) * 4, hipHostMallocDefault));
+            }
+            uint32_t total = 0;
+            if (cut) {
+                const uint32_t nb = (uint32_t)((cut + 4095) / 4096);
+                FHIP(hipMemcpyAsync(d_raw, pin, cut, hipMemcpyHostToDevice, st));
+                if (nh) FHIP(hipMemcpyAsync(d_hdr, ranges.data(), (size_t)nh * sizeof(ipcr_fasta_range), hipMemcpyHostToDevice, st));
+                FHIP(ipcr::launch_fasta_decode(st, d_raw, cut, d_hdr, nh, (at_line_start || lead_open) ? 1u : 0u, d_counts, d_out, d_hdr_off));
+                if (nh) FHIP(hipMemcpyAsync(h_small, d_hdr_off, (size_t)nh * 4, hipMemcpyDeviceToHost, st));
+                FHIP(hipMemcpyAsync(h_small + nh, d_counts + nb, 4, hipMemcpyDeviceToHost, st));
+                FHIP(hipStreamSynchronize(st));
+                total = h_small[nh];
+            }
+            // hand the compacted bytes to the records
+            uint64_t a = 0;
+            for (uint32_t k = 0; k < nh; ++k) {
+                s = append(a, h_small[k]);
+                if (s == IPCR_OK) s = finish_record(); // path_ctx.go:164-170: a header flushes the open record
+                if (s != IPCR_OK) return s;
+                a = h_small[k];
+                const std::string hdr((const char *)pin + ranges[k].start + 1, (size_t)(ranges[k].end - ranges[k].start - 1));
+                id = parse_header_id(hdr);
+                have_id = !id.empty(); // a header without an ID drops its record
+                rec_len = 0;
+            }
+            s = append(a, total);
+            if (s != IPCR_OK) return s;
+            FHIP(hipStreamSynchronize(st)); // d_out and the pinned slab are reused by the next slab
+            // state for the next slab
+            if (cut < n) carry.assign(pin + cut, pin + n);
+            if (cut > 0) {
+                at_line_start = pin[cut - 1] == '\n';
+                lead_open = at_line_start; // a cut inside a line is behind one of its non-blank bytes
+            }
+            if (eof) break; // cut == n: everything has been consumed
+        }
+        return finish_record();
+    }
+};
 } // namespace
 
 extern "C" {
@@ -202,35 +408,26 @@ ipcr_status ipcr_fasta_next(ipcr_fasta *f, const char **id, const uint8_t **seq,
 }
 
 // Load every record of a FASTA file into a resident genome (whole records, no chunking: one
-// launch scans them all).  ids: '\n'-joined record IDs written to ids_out (NUL-terminated,
-// truncated to cap); *n_added = records appended.
+// launch scans them all).  The file is read in slabs into pinned memory and copied to the device as
+// it is; the host only finds the header lines and parses their IDs, the device strips line ends /
+// white space, folds case and compacts (fasta_kernels.hip), and every finished record goes through
+// the pack kernel.  Same record semantics as the streaming reader above (and as the reference):
+// header ID up to the first blank, sequence before the first header ignored, a header without an
+// ID drops its record, empty records are kept.
+// ids: '\n'-joined record IDs written to ids_out (NUL-terminated, truncated to cap);
+// *n_added = records appended.  IPCR_FASTA_SLAB = slab bytes (default 64 MiB, tests use tiny ones).
 ipcr_status ipcr_genome_add_fasta(ipcr_genome *g, const char *path, uint32_t *n_added, char *ids_out, size_t cap,
                                   size_t *ids_needed) {
     if (!g || !path) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_genome_add_fasta: null argument");
-    ipcr_fasta *f = nullptr;
-    ipcr_status st = ipcr_fasta_open(path, 0, 0, &f);
-    if (st != IPCR_OK) return st;
-    std::string ids;
-    uint32_t n = 0;
-    for (;;) {
-        const char *id;
-        const uint8_t *seq;
-        uint64_t len;
-        int32_t got;
-        st = ipcr_fasta_next(f, &id, &seq, &len, &got);
-        if (st != IPCR_OK || !got) break;
-        st = ipcr_genome_add_record(g, seq, len);
-        if (st != IPCR_OK) break;
-        if (n) ids.push_back('\n');
-        ids += id;
-        ++n;
-    }
-    ipcr_fasta_close(f);
-    if (n_added) *n_added = n;
-    if (ids_needed) *ids_needed = ids.size() + 1;
+    if (n_added) *n_added = 0;
+    FastaLoader L;
+    ipcr_status st = L.open(g, path);
+    if (st == IPCR_OK) st = L.run();
+    if (n_added) *n_added = L.n_added;
+    if (ids_needed) *ids_needed = L.ids.size() + 1;
     if (ids_out && cap) {
-        const size_t m = ids.size() < cap - 1 ? ids.size() : cap - 1;
-        memcpy(ids_out, ids.data(), m);
+        const size_t m = L.ids.size() < cap - 1 ? L.ids.size() : cap - 1;
+        memcpy(ids_out, L.ids.data(), m);
         ids_out[m] = 0;
     }
     return st;

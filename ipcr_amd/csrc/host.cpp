@@ -603,6 +603,7 @@ struct ipcr_genome {
     uint32_t *d_flags = nullptr; // per record, bit0 = holds a non-ACGTacgt byte
     uint64_t *d_rec_start = nullptr, *d_rec_len = nullptr;
     std::vector<uint64_t> rec_start, rec_len; // padded start, length
+    std::vector<std::string> ids;             // record IDs (FASTA loader; empty for records added as bytes)
     mutable std::vector<uint8_t> flags;
     mutable bool flags_valid = false;
     bool tables_dirty = true;
@@ -650,6 +651,7 @@ void genome_clear(ipcr_genome *g) { // forget the records, keep the buffers
     if (!g->rec_start.empty() && g->d_flags) (void)hipMemsetAsync(g->d_flags, 0, g->rec_start.size() * 4ull, g->stream);
     g->rec_start.clear();
     g->rec_len.clear();
+    g->ids.clear();
     g->flags.clear();
     g->flags_valid = false;
     g->tables_dirty = true;
@@ -675,6 +677,7 @@ ipcr_status genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len)
     g->pack_ms += ms;
     g->rec_start.push_back(g->next_col * IPCR_COLUMN_BASES);
     g->rec_len.push_back(len);
+    g->ids.emplace_back();
     g->next_col += cols;
     if (g->padded_until < g->next_col) g->padded_until = g->next_col;
     g->total_bases += len;
@@ -764,6 +767,18 @@ ipcr_status ipcr_genome_add_record_device(ipcr_genome *g, const void *dev_seq, u
     return genome_add_device(g, static_cast<const uint8_t *>(dev_seq), len);
 }
 
+} // extern "C"
+
+// hooks for fasta.cpp (the FASTA loader packs records it has normalised on the device)
+ipcr_status ipcr_internal_genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len, const char *id) {
+    const ipcr_status st = genome_add_device(g, dseq, len);
+    if (st == IPCR_OK && id) g->ids.back() = id;
+    return st;
+}
+hipStream_t ipcr_internal_genome_stream(ipcr_genome *g) { return g->stream; }
+
+extern "C" {
+
 ipcr_status ipcr_lcg_fill_device(void *dev_out, uint64_t len, uint32_t seed, uint64_t stream_offset) {
     if (!dev_out && len) return fail(IPCR_ERR_INVALID, "ipcr_lcg_fill_device: null argument");
     HIPCHK(ipcr::launch_lcg(nullptr, static_cast<uint8_t *>(dev_out), len, seed, stream_offset));
@@ -787,6 +802,7 @@ ipcr_status ipcr_genome_read(const ipcr_genome *g, uint32_t record, uint64_t pos
 
 uint32_t ipcr_genome_num_records(const ipcr_genome *g) { return g ? (uint32_t)g->rec_start.size() : 0; }
 uint64_t ipcr_genome_record_len(const ipcr_genome *g, uint32_t r) { return (g && r < g->rec_len.size()) ? g->rec_len[r] : 0; }
+const char *ipcr_genome_record_id(const ipcr_genome *g, uint32_t r) { return (g && r < g->ids.size()) ? g->ids[r].c_str() : ""; }
 uint64_t ipcr_genome_total_bases(const ipcr_genome *g) { return g ? g->total_bases : 0; }
 uint64_t ipcr_genome_tile_bytes(const ipcr_genome *g) { // bytes the filter kernel streams: whole blocks of lo/hi/inv
     return g ? ((g->next_col + 63) / 64) * IPCR_BLOCK_PLANE_WORDS * 4ull : 0;

@@ -266,6 +266,16 @@ class Genome:
         _lib.check(_lib.lib().ipcr_genome_add_record_device(self._h, C.c_void_p(dev_ptr), length))
         self.ids.append(seq_id)
 
+    def add_fasta(self, path: str) -> int:
+        """Pack every record of a FASTA file (plain / gzip); the device normalises the raw text
+        (core/fasta/scan.go:10-69, normalize.go:5-14).  Returns the number of records added."""
+        n = C.c_uint32()
+        first = self.num_records
+        _lib.check(_lib.lib().ipcr_genome_add_fasta(self._h, path.encode(), C.byref(n), None, 0, None))
+        for r in range(first, first + n.value):
+            self.ids.append(_lib.lib().ipcr_genome_record_id(self._h, r).decode())
+        return n.value
+
     def read(self, record: int, pos: int, length: int) -> bytes:
         buf = C.create_string_buffer(max(length, 1))
         _lib.check(_lib.lib().ipcr_genome_read(self._h, record, pos, buf, length))

@@ -1,0 +1,118 @@
+"""Device-side FASTA normalisation (ipcr_genome_add_fasta: raw slabs -> fasta_kernels.hip -> pack kernel)
+against the line-by-line host reader, which restates core/fasta (scan.go:10-69, normalize.go:5-14,
+stream.go:125-131, path_ctx.go:142-144) and is itself pinned by tests/test_fasta_cli.py."""
+import gzip
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def as_tiles(seq: bytes) -> bytes:
+    """what ipcr_genome_read returns for a normalised record: ACGT stay, everything else reads back as N"""
+    return bytes(c if c in b"ACGT" else ord("N") for c in seq)
+
+
+def load_and_compare(path, slab=None):
+    from ipcr_amd import engine, fasta
+    want = [(r.ID, r.Seq) for r in fasta.StreamChunks(path)]
+    old = os.environ.pop("IPCR_FASTA_SLAB", None)
+    if slab is not None:
+        os.environ["IPCR_FASTA_SLAB"] = str(slab)
+    try:
+        g = engine.Genome(max(sum(len(s) for _, s in want) * 2, 1 << 16) + 8192 * (len(want) + 2), max_records=len(want) + 4)
+        n = g.add_fasta(path)
+    finally:
+        os.environ.pop("IPCR_FASTA_SLAB", None)
+        if old is not None:
+            os.environ["IPCR_FASTA_SLAB"] = old
+    assert n == len(want) == g.num_records
+    assert g.ids == [i for i, _ in want]
+    for r, (_, seq) in enumerate(want):
+        assert g.record_len(r) == len(seq)
+        assert g.read(r, 0, len(seq)) == as_tiles(seq), (r, slab)
+        has_reset = any(c not in b"ACGTacgt" for c in seq)
+        assert (g.record_flags(r) & 1) == int(has_reset)
+    g.close()
+    return want
+
+
+TRICKY = (
+    b"stray line before any header\nACGT\n"
+    b">r1 first record\tdesc\nACGTacgtNNnn\n  ACG T  \r\n\n\t\nTTTT\r\n"
+    b">  r2   padded header id\n\n\n"
+    b">r3\nA\nC\nG\nT\n>\nAAAA dropped: header without id\n>r4|x more\n"
+    b"acgtRYKMswbdhvn-*.\nGG>GG not a header\n \x0b\x0c \nCCCC"
+    b"\n>r5\nTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTT"
+)
+
+
+@pytest.mark.parametrize("slab", [None, 64, 80, 96, 128, 4096])
+def test_tricky_file_every_slab_size(tmp_path, slab):
+    p = tmp_path / "tricky.fa"
+    p.write_bytes(TRICKY)
+    want = load_and_compare(str(p), slab)
+    assert [i for i, _ in want] == ["r1", "r2", "r3", "r4|x", "r5"]
+    assert want[0][1] == b"ACGTACGTNNNNACG TTTTT" and want[1][1] == b"" and want[2][1] == b"ACGT"
+
+
+def test_no_final_newline_header_last_and_empty_file(tmp_path):
+    p = tmp_path / "a.fa"
+    p.write_bytes(b">x\nACGT\n>y")            # header is the last line, no line end: empty record y
+    assert load_and_compare(str(p), 64) == [("x", b"ACGT"), ("y", b"")]
+    q = tmp_path / "empty.fa"
+    q.write_bytes(b"")
+    assert load_and_compare(str(q)) == []
+    w = tmp_path / "ws.fa"
+    w.write_bytes(b">z\nAC\n   \n \t \n\n")
+    assert load_and_compare(str(w), 64) == [("z", b"AC")]
+
+
+def test_long_lines_span_slabs(tmp_path):
+    """one sequence line much longer than the slab, with blanks inside and at both ends"""
+    rng = random.Random(5)
+    body = bytes(rng.choice(b"ACGTacgtN") for _ in range(3000))
+    line = b"  \t" + body[:1000] + b" " + body[1000:2000] + b"\t \t" + body[2000:] + b"   \r\n"
+    p = tmp_path / "long.fa"
+    p.write_bytes(b">long\n" + line + b">next\nACGT\n")
+    for slab in (64, 256, 1024, None):
+        want = load_and_compare(str(p), slab)
+        assert len(want[0][1]) == 3004 and want[1] == ("next", b"ACGT")
+
+
+def test_random_files_gzip_and_plain(tmp_path):
+    rng = random.Random(11)
+    for case in range(6):
+        parts = []
+        for r in range(rng.randint(1, 12)):
+            parts.append(b">rec%d some text\n" % r if rng.random() < 0.9 else b">\n")
+            n = rng.choice([0, 1, 59, 60, 61, 500, 5000, 70000])
+            seq = bytes(rng.choice(b"ACGTACGTACGTacgtNnRY") for _ in range(n))
+            width = rng.choice([1, 7, 60, 80, 10 ** 9])
+            eol = rng.choice([b"\n", b"\r\n"])
+            for i in range(0, n, width):
+                parts.append(seq[i:i + width] + eol)
+            if rng.random() < 0.3:
+                parts.append(eol)
+        raw = b"".join(parts)
+        p = tmp_path / ("r%d.fa" % case)
+        p.write_bytes(raw)
+        load_and_compare(str(p), rng.choice([64, 1024, 65536, None]))
+        z = tmp_path / ("r%d.fa.gz" % case)
+        with gzip.open(z, "wb") as fh:
+            fh.write(raw)
+        load_and_compare(str(z), 4096)
+
+
+def test_cli_uses_record_ids_from_loader(tmp_path):
+    import io
+    from ipcr_amd import cli
+    p = tmp_path / "g.fa"
+    p.write_text(">chrA desc\nTTTTACGTACGTACGTTTTTGGGGCCCCAAAATTTT\n>chrB\nacgtacgtaaaa\n")
+    out = io.StringIO()
+    rc = cli.run(["-f", "ACGTACGT", "-r", "GGGGCCCC", "--mismatches", "0", "--max-length", "100", str(p)], stdout=out)
+    rows = out.getvalue().splitlines()
+    assert rc == 0 and rows[0] == cli.TSV_HEADER
+    assert any(row.split("\t")[1] == "chrA" for row in rows[1:])
