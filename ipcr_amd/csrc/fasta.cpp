@@ -11,15 +11,19 @@
 // pipeline or the CLI's chunked mode pulls from) and the resident-genome loader
 // (ipcr_genome_add_fasta: raw slabs to the device, normalisation in fasta_kernels.hip).
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <hip/hip_runtime_api.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "device_types.h"
@@ -145,24 +149,27 @@ struct FastaLoader {
     int fd = -1;
     gzFile gz = nullptr; // gzip input (or stdin); plain files are read with read(2) straight into pinned memory
     bool eof = false;
+    int64_t fsize = -1; // regular plain file: its size (read with pread at foff)
+    uint64_t foff = 0;
     size_t slab = 0;
     hipStream_t st = nullptr;
-    uint8_t *pin = nullptr, *d_raw = nullptr, *d_out = nullptr, *d_rec = nullptr;
+    uint8_t *pin = nullptr, *pin2 = nullptr, *d_raw = nullptr, *d_out = nullptr, *d_rec = nullptr;
     uint32_t *d_counts = nullptr, *d_hdr_off = nullptr, *h_small = nullptr; // h_small: pinned, hdr_off[nh] + total
     ipcr_fasta_range *d_hdr = nullptr;
     size_t hdr_cap = 0;
     uint64_t rec_cap = 0, rec_len = 0;
-    std::vector<uint8_t> carry;
     std::vector<ipcr_fasta_range> ranges;
     bool at_line_start = true, lead_open = true;
     bool have_id = false;
     std::string id, ids;
     uint32_t n_added = 0;
+    double t_read = 0, t_host = 0, t_decode = 0, t_pack = 0;
 
     ~FastaLoader() {
         if (gz) gzclose(gz);
         else if (fd >= 0) close(fd);
         if (pin) (void)hipHostFree(pin);
+        if (pin2) (void)hipHostFree(pin2);
         if (h_small) (void)hipHostFree(h_small);
         if (d_raw) (void)hipFree(d_raw);
         if (d_out) (void)hipFree(d_out);
@@ -190,22 +197,56 @@ struct FastaLoader {
             if ((m == 2 && magic[0] == 0x1f && magic[1] == 0x8b) || (pl > 3 && strcmp(path + pl - 3, ".gz") == 0)) { // open.go:29-50
                 gz = gzdopen(fd, "rb");
                 if (gz) gzbuffer(gz, 1 << 20);
+            } else {
+                struct stat sb;
+                if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) fsize = (int64_t)sb.st_size;
             }
         }
         if (fd < 0 && !gz) return ipcr_internal_fail(IPCR_ERR_INVALID, "cannot open %s", path);
         FHIP(hipHostMalloc((void **)&pin, slab, hipHostMallocDefault));
+        FHIP(hipHostMalloc((void **)&pin2, slab, hipHostMallocDefault));
         FHIP(hipMalloc((void **)&d_raw, slab));
         FHIP(hipMalloc((void **)&d_out, slab));
         FHIP(hipMalloc((void **)&d_counts, (slab / 4096 + 2) * 4));
         return IPCR_OK;
     }
 
-    // fill pin[have, slab) from the file; returns bytes now in the buffer
-    ipcr_status fill(size_t have, size_t *n) {
+    // fill buf[have, slab) from the file; returns bytes now in the buffer.  Plain files are read by a
+    // few threads at once (one pread stream copies from the page cache at ~8 GB/s, less than PCIe takes)
+    ipcr_status fill(uint8_t *buf, size_t have, size_t *n) {
+        if (!gz && fsize >= 0) {
+            const size_t want = (size_t)std::min<uint64_t>(slab - have, (uint64_t)fsize - foff);
+            const size_t piece = (size_t)4 << 20;
+            const unsigned nt = (unsigned)std::min<size_t>(8, (want + piece - 1) / piece);
+            std::atomic<bool> bad{false};
+            auto reader = [&](size_t a, size_t b) {
+                while (a < b) {
+                    const ssize_t r = pread(fd, buf + have + a, b - a, (off_t)(foff + a));
+                    if (r <= 0) { bad = true; return; }
+                    a += (size_t)r;
+                }
+            };
+            if (nt <= 1) reader(0, want);
+            else {
+                std::vector<std::thread> th;
+                const size_t per = ((want + nt - 1) / nt + 4095) & ~(size_t)4095;
+                for (unsigned t = 0; t < nt; ++t) {
+                    const size_t a = std::min(want, (size_t)t * per), b = std::min(want, a + per);
+                    if (a < b) th.emplace_back(reader, a, b);
+                }
+                for (auto &t : th) t.join();
+            }
+            if (bad) return ipcr_internal_fail(IPCR_ERR_INVALID, "read error in FASTA input");
+            foff += want;
+            have += want;
+            if (foff >= (uint64_t)fsize) eof = true;
+            *n = have;
+            return IPCR_OK;
+        }
         while (have < slab && !eof) {
             long r;
-            if (gz) r = gzread(gz, pin + have, (unsigned)std::min<size_t>(slab - have, 1u << 30));
-            else r = (long)::read(fd, pin + have, slab - have);
+            if (gz) r = gzread(gz, buf + have, (unsigned)std::min<size_t>(slab - have, 1u << 30));
+            else r = (long)::read(fd, buf + have, slab - have);
             if (r < 0) return ipcr_internal_fail(IPCR_ERR_INVALID, "read error in FASTA input");
             if (r == 0) eof = true;
             have += (size_t)r;
@@ -245,41 +286,64 @@ struct FastaLoader {
         return IPCR_OK;
     }
 
+    // header lines of buf[0, cut): '>' at a line start (scan.go:27).  A few threads search their piece
+    // of the slab (memchr runs at ~35 GB/s, the slab arrives faster than that)
+    ipcr_status find_headers(const uint8_t *buf, size_t cut) {
+        ranges.clear();
+        const size_t piece = (size_t)8 << 20;
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(8, cut / piece));
+        std::vector<std::vector<size_t>> found(nt);
+        auto search = [&](unsigned t) {
+            const size_t a = cut * t / nt, b = cut * (t + 1) / nt;
+            for (size_t pos = a; pos < b;) {
+                const void *p = memchr(buf + pos, '>', b - pos);
+                if (!p) break;
+                const size_t i = (size_t)((const uint8_t *)p - buf);
+                if (i == 0 ? at_line_start : buf[i - 1] == '\n') found[t].push_back(i);
+                pos = i + 1;
+            }
+        };
+        if (nt == 1) search(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(search, t);
+            for (auto &t : th) t.join();
+        }
+        for (unsigned t = 0; t < nt; ++t)
+            for (const size_t i : found[t]) {
+                const void *e = memchr(buf + i, '\n', cut - i);
+                if (!e && !eof) return ipcr_internal_fail(IPCR_ERR_UNSUPPORTED, "FASTA: a header line longer than the %zu-byte slab", slab);
+                ranges.push_back({(uint64_t)i, (uint64_t)(e ? (size_t)((const uint8_t *)e - buf) + 1 : cut)});
+            }
+        return IPCR_OK;
+    }
+
     ipcr_status run() {
-        size_t have = 0;
-        for (;;) {
-            if (!carry.empty()) memcpy(pin, carry.data(), carry.size());
-            have = carry.size();
-            carry.clear();
-            size_t n = 0;
-            ipcr_status s = fill(have, &n);
-            if (s != IPCR_OK) return s;
-            if (n == 0) break;
+        uint8_t *buf[2] = {pin, pin2};
+        int cur = 0;
+        size_t n = 0;
+        auto tr0 = std::chrono::steady_clock::now();
+        ipcr_status s = fill(buf[0], 0, &n);
+        t_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+        if (s != IPCR_OK) return s;
+        while (n > 0) {
+            const uint8_t *raw = buf[cur];
+            const auto th0 = std::chrono::steady_clock::now();
             // where to cut: behind the last line end; a slab without one is cut in front of its trailing
             // white space (whether that is kept depends on what follows)
             size_t cut = n;
-            if (!eof) {
-                const void *nl = memrchr(pin, '\n', n);
-                if (nl) cut = (size_t)((const uint8_t *)nl - pin) + 1;
+            const bool last = eof;
+            if (!last) {
+                const void *nl = memrchr(raw, '\n', n);
+                if (nl) cut = (size_t)((const uint8_t *)nl - raw) + 1;
                 else {
-                    while (cut > 0 && is_space(pin[cut - 1])) --cut;
+                    while (cut > 0 && is_space(raw[cut - 1])) --cut;
                     if (cut == 0 && n == slab) return ipcr_internal_fail(IPCR_ERR_UNSUPPORTED, "FASTA: a run of white space longer than the %zu-byte slab", slab);
                 }
             }
-            // header lines of [0, cut)
-            ranges.clear();
-            for (size_t pos = 0; pos < cut;) {
-                const void *p = memchr(pin + pos, '>', cut - pos);
-                if (!p) break;
-                const size_t i = (size_t)((const uint8_t *)p - pin);
-                const bool ls = i == 0 ? at_line_start : pin[i - 1] == '\n';
-                if (!ls) { pos = i + 1; continue; }
-                const void *e = memchr(pin + i, '\n', cut - i);
-                if (!e && !eof) return ipcr_internal_fail(IPCR_ERR_UNSUPPORTED, "FASTA: a header line longer than the %zu-byte slab", slab);
-                const size_t end = e ? (size_t)((const uint8_t *)e - pin) + 1 : cut;
-                ranges.push_back({(uint64_t)i, (uint64_t)end});
-                pos = end;
-            }
+            if (cut) FHIP(hipMemcpyAsync(d_raw, raw, cut, hipMemcpyHostToDevice, st)); // in flight during the header search
+            s = find_headers(raw, cut);
+            if (s != IPCR_OK) return s;
             const uint32_t nh = (uint32_t)ranges.size();
             if (nh + 1 > hdr_cap) {
                 if (d_hdr) (void)hipFree(d_hdr);
@@ -291,10 +355,25 @@ struct FastaLoader {
                 FHIP(hipMalloc((void **)&d_hdr_off, hdr_cap * 4));
                 FHIP(hipHostMalloc((void **)&h_small, (hdr_cap + 1) * 4, hipHostMallocDefault));
             }
+            // the next slab is read (behind the bytes carried over) while the device works on this one
+            size_t n_next = 0;
+            ipcr_status s_next = IPCR_OK;
+            std::thread reader;
+            const size_t ncarry = n - cut;
+            if (!last) {
+                memcpy(buf[cur ^ 1], raw + cut, ncarry);
+                reader = std::thread([&, ncarry]() {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    s_next = fill(buf[cur ^ 1], ncarry, &n_next);
+                    t_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                });
+            }
+            struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{reader};
             uint32_t total = 0;
+            const auto td0 = std::chrono::steady_clock::now();
+            t_host += std::chrono::duration<double>(td0 - th0).count();
             if (cut) {
                 const uint32_t nb = (uint32_t)((cut + 4095) / 4096);
-                FHIP(hipMemcpyAsync(d_raw, pin, cut, hipMemcpyHostToDevice, st));
                 if (nh) FHIP(hipMemcpyAsync(d_hdr, ranges.data(), (size_t)nh * sizeof(ipcr_fasta_range), hipMemcpyHostToDevice, st));
                 FHIP(ipcr::launch_fasta_decode(st, d_raw, cut, d_hdr, nh, (at_line_start || lead_open) ? 1u : 0u, d_counts, d_out, d_hdr_off));
                 if (nh) FHIP(hipMemcpyAsync(h_small, d_hdr_off, (size_t)nh * 4, hipMemcpyDeviceToHost, st));
@@ -302,6 +381,8 @@ struct FastaLoader {
                 FHIP(hipStreamSynchronize(st));
                 total = h_small[nh];
             }
+            const auto tp0 = std::chrono::steady_clock::now();
+            t_decode += std::chrono::duration<double>(tp0 - td0).count();
             // hand the compacted bytes to the records
             uint64_t a = 0;
             for (uint32_t k = 0; k < nh; ++k) {
@@ -309,23 +390,30 @@ struct FastaLoader {
                 if (s == IPCR_OK) s = finish_record(); // path_ctx.go:164-170: a header flushes the open record
                 if (s != IPCR_OK) return s;
                 a = h_small[k];
-                const std::string hdr((const char *)pin + ranges[k].start + 1, (size_t)(ranges[k].end - ranges[k].start - 1));
+                const std::string hdr((const char *)raw + ranges[k].start + 1, (size_t)(ranges[k].end - ranges[k].start - 1));
                 id = parse_header_id(hdr);
                 have_id = !id.empty(); // a header without an ID drops its record
                 rec_len = 0;
             }
             s = append(a, total);
             if (s != IPCR_OK) return s;
-            FHIP(hipStreamSynchronize(st)); // d_out and the pinned slab are reused by the next slab
-            // state for the next slab
-            if (cut < n) carry.assign(pin + cut, pin + n);
+            FHIP(hipStreamSynchronize(st)); // d_out is reused by the next slab
+            t_pack += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
             if (cut > 0) {
-                at_line_start = pin[cut - 1] == '\n';
+                at_line_start = raw[cut - 1] == '\n';
                 lead_open = at_line_start; // a cut inside a line is behind one of its non-blank bytes
             }
-            if (eof) break; // cut == n: everything has been consumed
+            if (last) break; // cut == n: everything has been consumed
+            reader.join();
+            if (s_next != IPCR_OK) return s_next;
+            n = n_next;
+            cur ^= 1;
         }
-        return finish_record();
+        const ipcr_status fs = finish_record();
+        if (getenv("IPCR_DEBUG_TIMES"))
+            fprintf(stderr, "fasta loader: read %.3f s (overlapped), cut + header search %.3f s, h2d + decode %.3f s, copy + pack %.3f s\n",
+                    t_read, t_host, t_decode, t_pack);
+        return fs;
     }
 };
 } // namespace

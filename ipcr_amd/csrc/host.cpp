@@ -1129,8 +1129,10 @@ ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     const double pack_ms_keep = s->stats.pack_ms;
     memset(&s->stats, 0, sizeof s->stats);
     s->stats.pack_ms = pack_ms_keep;
+    trace("enqueue>", s);
     ipcr_status st = genome_finalize(g);
     if (st != IPCR_OK) return st;
+    trace("finalized", s);
     s->last_rec_len = g->rec_len;
     s->last_rec_start = g->rec_start;
     pd.mode = (!p->modes_equal && genome_any_reset(g)) ? 1 : 0;
