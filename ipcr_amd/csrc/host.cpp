@@ -602,6 +602,8 @@ struct ipcr_genome {
     uint32_t *rst = nullptr;
     uint32_t *d_flags = nullptr; // per record, bit0 = holds a non-ACGTacgt byte
     uint64_t *d_rec_start = nullptr, *d_rec_len = nullptr;
+    uint32_t *d_block_rec = nullptr; // per block: last record that starts at or before the block (verify's first guess)
+    std::vector<uint32_t> block_rec;
     std::vector<uint64_t> rec_start, rec_len; // padded start, length
     std::vector<std::string> ids;             // record IDs (FASTA loader; empty for records added as bytes)
     mutable std::vector<uint8_t> flags;
@@ -632,6 +634,7 @@ ipcr_status genome_alloc(ipcr_genome *g, uint64_t cap_cols, uint32_t max_records
     HIPCHK(hipMalloc((void **)&g->rst, blocks * IPCR_BLOCK_RST_WORDS * 4ull));
     HIPCHK(hipMalloc((void **)&g->d_flags, (uint64_t)max_records * 4ull));
     HIPCHK(hipMalloc((void **)&g->d_rec_start, (uint64_t)max_records * 8ull));
+    HIPCHK(hipMalloc((void **)&g->d_block_rec, (blocks + 1) * 4ull));
     HIPCHK(hipMalloc((void **)&g->d_rec_len, (uint64_t)max_records * 8ull));
     HIPCHK(hipMemset(g->d_flags, 0, (uint64_t)max_records * 4ull));
     return IPCR_OK;
@@ -642,6 +645,8 @@ void genome_free_buffers(ipcr_genome *g) {
     if (g->rst) (void)hipFree(g->rst);
     if (g->d_flags) (void)hipFree(g->d_flags);
     if (g->d_rec_start) (void)hipFree(g->d_rec_start);
+    if (g->d_block_rec) (void)hipFree(g->d_block_rec);
+    g->d_block_rec = nullptr;
     if (g->d_rec_len) (void)hipFree(g->d_rec_len);
     g->planes = g->rst = g->d_flags = nullptr;
     g->d_rec_start = g->d_rec_len = nullptr;
@@ -697,6 +702,16 @@ ipcr_status genome_finalize(ipcr_genome *g) {
     }
     if (g->tables_dirty && !g->rec_start.empty()) {
         HIPCHK(hipMemcpyAsync(g->d_rec_start, g->rec_start.data(), g->rec_start.size() * 8ull, hipMemcpyHostToDevice, g->stream));
+        {
+            const uint64_t nb = (g->next_col + 63) / 64 + 1;
+            g->block_rec.resize(nb);
+            uint32_t r = 0;
+            for (uint64_t b = 0; b < nb; ++b) {
+                while (r + 1 < g->rec_start.size() && g->rec_start[r + 1] <= b * (uint64_t)IPCR_BLOCK_BASES) ++r;
+                g->block_rec[b] = r;
+            }
+            HIPCHK(hipMemcpyAsync(g->d_block_rec, g->block_rec.data(), nb * 4ull, hipMemcpyHostToDevice, g->stream));
+        }
         HIPCHK(hipMemcpyAsync(g->d_rec_len, g->rec_len.data(), g->rec_len.size() * 8ull, hipMemcpyHostToDevice, g->stream));
         g->tables_dirty = false;
     }
@@ -1050,6 +1065,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         v.rst = g->rst;
         v.pats = set.dev;
         v.rec_start = g->d_rec_start;
+        v.block_rec = g->d_block_rec;
         v.rec_len = g->d_rec_len;
         v.nrec = pd.nrec;
         v.max_mm = (uint32_t)p->cfg.max_mm;
@@ -1063,6 +1079,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             v.next_counts = gi == 0 ? cnt_next : nullptr;
             v.next_qcount = gi == 0 ? qc_next : nullptr;
             if (publish_enabled()) { // every kernel of the scan writes its first hits to the pinned buffer too
+                v.tickets = s->d_tickets;
                 v.pub_hits = reinterpret_cast<ipcr_hit_rec *>(static_cast<unsigned long long *>(s->pinned) + 8);
                 v.pre = (uint32_t)pd.pre;
             }

@@ -30,6 +30,8 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <sstream>
 #include <thread>
 
@@ -40,6 +42,8 @@ struct JitFilter {
     hipFunction_t fn = nullptr;
     unsigned waves_per_group = 4;
 };
+
+std::string count_code(int B, int k, int *cost = nullptr);
 
 namespace {
 
@@ -92,21 +96,42 @@ Plan make_plan(const ipcr_dev_pattern &p, int k, int B) {
     return pl;
 }
 
-Plan choose_plan(const ipcr_dev_pattern &p, int k) {
+// How many blocks?  Every row step pays the OR trees and the block counter; a window that passes
+// the block test pays the exact count in the rare branch -- and so do the other 63 lanes of its wave.
+// Estimated VALU instructions per row step and pattern:
+//   main(B)  = sum over blocks ceil((n-1)/2) [or3 chains] + counter(B, k)
+//   rare(B)  = 64 lanes * 32 strands * P(pass) * (exact counter over all unprotected positions + branch overhead)
+// B = k+1 (the classic pigeonhole split) unless the primer is so degenerate that its rare branch is not rare.
+// Kernels without the exact stage (many patterns: it would be emitted at W x patterns places, and hiprtc
+// time grows with it) and IPCR_JIT_TARGET_PPM use a fixed selectivity target instead.
+Plan choose_plan(const ipcr_dev_pattern &p, int k, bool exact_stage) {
     int U = 0;
     for (int j = 0; j < p.len; ++j)
         if (!(p.mask[j] & 16u)) ++U;
     if (U <= k) return make_plan(p, k, k + 1);
-    Plan best = make_plan(p, k, k + 1);
-    // false candidates per pattern-position the filter may let through (IPCR_JIT_TARGET_PPM overrides,
-    // in 1e-6 units).  Sweeps on MI355X: 2 ppm (~6000 per pattern per 3 Gb) is best while the kernel is
-    // HBM-bound (k <= 2); at k = 3 the block counter dominates the ALU work and 50 ppm is 8 % faster.
-    const double target = 1e-6 * (getenv("IPCR_JIT_TARGET_PPM") ? atof(getenv("IPCR_JIT_TARGET_PPM")) : (k >= 3 ? 50.0 : 2.0));
-    if (pass_prob(p, best, k) <= target) return best;
-    for (int B = k + 2; B <= U; ++B) {
+    if (getenv("IPCR_JIT_TARGET_PPM") || !exact_stage) {
+        // without the exact stage every window that passes costs the wave a memory round trip at its end:
+        // sweeps on MI355X put the best pass rate at ~2e-6 (k <= 2) and ~5e-6 (k = 3, where every extra
+        // block costs more counter levels)
+        const double target = 1e-6 * (getenv("IPCR_JIT_TARGET_PPM") ? atof(getenv("IPCR_JIT_TARGET_PPM")) : (k >= 3 ? 5.0 : 2.0));
+        Plan best = make_plan(p, k, k + 1);
+        for (int B = k + 2; B <= U && pass_prob(p, best, k) > target; ++B) best = make_plan(p, k, B);
+        return best;
+    }
+    int exact_ops = 0;
+    (void)count_code(U, k, &exact_ops);
+    Plan best;
+    double best_cost = 1e300;
+    for (int B = k + 1; B <= U; ++B) {
         Plan pl = make_plan(p, k, B);
-        best = pl;
-        if (pass_prob(p, pl, k) <= target) break;
+        int counter = 0;
+        (void)count_code((int)pl.blocks.size(), k, &counter);
+        double main_ops = counter;
+        for (const auto &blk : pl.blocks) main_ops += (double)((blk.size() - 1 + 1) / 2);
+        const bool exact = (int)pl.blocks.size() == U;
+        const double rare = exact ? 0.0 : 2048.0 * pass_prob(p, pl, k) * (exact_ops + 24.0);
+        const double cost = main_ops + rare;
+        if (cost < best_cost) { best_cost = cost; best = pl; }
     }
     return best;
 }
@@ -141,7 +166,7 @@ static int env_int(const char *name, int dflt, int lo, int hi) {
 //  * thermometer: u[t] = at least t bad blocks so far (one and-or per level per block);
 //  * carry-save adder tree: full adders (xor, xor, bitselect) compress the flags into binary
 //    weight planes; carries beyond the top bit of k only feed an overflow OR.
-std::string count_code(int B, int k) {
+std::string count_code(int B, int k, int *cost) {
     std::ostringstream th;
     int th_cost = 0;
     {
@@ -215,6 +240,7 @@ std::string count_code(int B, int k) {
     }
     const int force = env_int("IPCR_JIT_COUNTER", 0, 0, 2); // 1 = thermometer, 2 = adder tree
     const bool use_cs = force == 2 || (force == 0 && cs_cost < th_cost);
+    if (cost) *cost = use_cs ? cs_cost : th_cost;
     return use_cs ? cs.str() : th.str();
 }
 
@@ -237,11 +263,14 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
     const int QM = ((32 - D) / QPI) * QPI;   // quads done by the rolled main loop (its prefetch stays < 32)
     const int NFULL = QM / QPI;
     const int QW = (LM1 + 3) / 4;            // head quads stashed for the wrap phase
-    const int LIST_CAP = env_int("IPCR_JIT_LIST", 48, 1, 1024); // survivor words a wave keeps for its own verify pass
+    const int LIST_CAP = env_int("IPCR_JIT_LIST", 48, 1, 64);    // survivor words a wave keeps for its own verify pass
+    const int CAND_CAP = env_int("IPCR_JIT_CANDS", 128, 2, 1024); // candidate windows verified two per load round
 
+    // exact count in the rare branch (see row_code): emitted once per (row slot, pattern), so only for small kernels
+    const bool exact_stage = env_int("IPCR_JIT_EXACT", 1, 0, 1) != 0 && (int)pats.size() * W <= env_int("IPCR_JIT_EXACT_SITES", 160, 0, 100000);
     bool uses_n = false;
     std::vector<Plan> plans;
-    for (const auto &p : pats) plans.push_back(choose_plan(p, k));
+    for (const auto &p : pats) plans.push_back(choose_plan(p, k, exact_stage));
     // evaluation of every pattern for the window that starts at slot sr
     auto eval_code = [&](int sr) {
         std::ostringstream o;
@@ -289,10 +318,31 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
         b << "          u32 all = f0";
         for (size_t q = 1; q < pats.size(); ++q) b << " & f" << q;
         b << ";\n";
-        b << "          if (all != 0xFFFFFFFFu) { // rare: some window survived, hand the word to the verifier\n";
+        // rare: some window passed the block test.  Its rows are still in the register window, so the exact
+        // mismatch count of the 32 strands is taken right here (bit-sliced adder over the unprotected positions,
+        // ~2 ops per position); only windows with <= k mismatches go on to the list, and those are real hits
+        // unless they cross a record end.  The block test can therefore be coarse (few blocks, few ops per row).
+        b << "          if (__builtin_expect(all != 0xFFFFFFFFu, 0)) {\n";
         b << "            const u64 pos = posbase + (u64)(" << xexpr << " - " << LM1 << "u);\n";
-        for (size_t q = 0; q < pats.size(); ++q)
-            b << "            if (f" << q << " != 0xFFFFFFFFu) push(" << (qbase + q) << "ull, pos, ~f" << q << ", lcnt, lkey, lbits, queue, qcap, qcount, counts);\n";
+        const int sr0 = ((slot - LM1) % W + W) % W;
+        for (size_t q = 0; q < pats.size(); ++q) {
+            const Plan &pl = plans[q];
+            size_t U = 0;
+            for (const auto &blk : pl.blocks) U += blk.size();
+            const bool exact_already = !pl.counted || pl.blocks.size() == U;
+            b << "            if (f" << q << " != 0xFFFFFFFFu) {\n";
+            b << "              u32 f = f" << q << ";\n";
+            if (!exact_already && exact_stage) {
+                b << "              {\n";
+                int e = 0;
+                for (const auto &blk : pl.blocks)
+                    for (int j : blk) b << "            const u32 e" << e++ << " = " << plane_expr(pats[q].mask[j], (sr0 + j) % W, uses_n) << ";\n";
+                b << count_code((int)U, k);
+                b << "              }\n";
+            }
+            b << "              if (f != 0xFFFFFFFFu) push(" << (qbase + q) << "ull, pos, ~f, lcnt, lkey, lbits, queue, qcap, qcount, counts);\n";
+            b << "            }\n";
+        }
         b << "          }\n        }\n      }\n";
         return b.str();
     };
@@ -390,11 +440,23 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
          "  const u64 idx = atomicAdd(qcount, 1ull);\n"
          "  if (idx < qcap) { qent e; e.key = (q << 48) | pos; e.bits = bits; e.pad = 0u; queue[idx] = e; }\n"
          "}\n";
+    // the patterns of this kernel as constant tables (the verifier's per-position masks: low 4 bits =
+    // bases the primer position accepts, bit 4 = position inside the protected window)
+    s << "#define NPAT " << pats.size() << "u\n#define QBASE " << qbase << "u\n";
+    s << "__device__ const unsigned char __attribute__((aligned(16))) PMASK[NPAT * 32u] = {";
+    for (size_t q = 0; q < pats.size(); ++q)
+        for (int j = 0; j < 32; ++j) s << (q || j ? "," : "") << (j < pats[q].len ? (unsigned)pats[q].mask[j] : 0u);
+    s << "};\n__device__ const u32 PINFO[NPAT * 4u] = {"; // len, seed_off, seed_len, global_id
+    for (size_t q = 0; q < pats.size(); ++q)
+        s << (q ? "," : "") << pats[q].len << "u," << pats[q].seed_off << "u," << pats[q].seed_len << "u," << pats[q].global_id << "u";
+    s << "};\n";
+    s << "#define CAND_CAP " << CAND_CAP << "u\n";
     s << "// IPCR_WAVES_PER_GROUP " << WPG << "\n";
     s << "extern \"C\" __global__ void __launch_bounds__(" << WPG * 64 << ", " << WPS << ") ipcr_filter(const v4* __restrict__ planes, u64 nblocks,\n"
          "    qent* __restrict__ queue_all, u64 qcap, u64* __restrict__ qcount_all,\n"
          "    const u32* __restrict__ rst, const dpat* __restrict__ pats, const u64* __restrict__ rec_start,\n"
-         "    const u64* __restrict__ rec_len, u32 nrec, u32 max_mm, u32 check_rst, hitrec* __restrict__ hits, u64 hcap,\n"
+         "    const u64* __restrict__ rec_len, const u32* __restrict__ block_rec, u32 nrec, u32 max_mm, u32 check_rst,\n"
+         "    hitrec* __restrict__ hits, u64 hcap,\n"
          "    u64* __restrict__ counts, u64* __restrict__ next_counts, u64* __restrict__ next_qcount,\n"
          "    u32* __restrict__ tickets, u64* __restrict__ pub, hitrec* __restrict__ pub_hits, u32 pre, u32* __restrict__ pub_seq, u32 seq) {\n";
     s << "  const u32 lane = threadIdx.x & 63u;\n";
@@ -409,8 +471,14 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
     s << "  __shared__ u64 lkey_all[" << WPG << "][LIST_CAP];\n";
     s << "  __shared__ u32 lbits_all[" << WPG << "][LIST_CAP];\n";
     s << "  __shared__ u32 lcnt_all[" << WPG << "];\n";
+    s << "  __shared__ u64 candP_all[" << WPG << "][CAND_CAP];\n";
+    s << "  __shared__ unsigned char candq_all[" << WPG << "][CAND_CAP];\n";
     s << "  u64* lkey = lkey_all[wv]; u32* lbits = lbits_all[wv]; u32* lcnt = lcnt_all + wv;\n";
     s << "  if (lane == 0u) *lcnt = 0u;\n";
+    // this wave's copy of the pattern tables (tail verify: no global round trip in front of the tile loads)
+    s << "  __shared__ u32 ptab_all[" << WPG << "][NPAT * 12u];\n";
+    s << "  u32* ptab = ptab_all[wv];\n";
+    s << "  for (u32 t = lane; t < NPAT * 12u; t += 64u) ptab[t] = t < NPAT * 8u ? ((const u32*)PMASK)[t] : PINFO[t - NPAT * 8u];\n";
     s << "  const u32 shard = (u32)block & 255u; // candidate queue: 256 segments, one push counter each\n";
     s << "  qent* queue = queue_all + (u64)shard * qcap;\n";
     s << "  u64* qcount = qcount_all + shard * 16u;\n";
@@ -432,12 +500,66 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
     s << epi.str();
     // ---- exact verification of this wave's survivors (verifyAt, core/engine/ac.go:186-213 / the
     // inner loop of FindMatches, core/primer/match.go:67-84): lane j compares window position j
+    // Fast path (a few candidates per wave, the normal case): the surviving words are expanded into a
+    // list of candidate windows, and every load round checks TWO of them, one per half-wave (patterns
+    // are <= 32 nt); the record of the block is looked up once per wave.  Per candidate that is one
+    // L2 round trip instead of the chain list -> pattern -> record search -> tiles.
+    // Slow path (dense survivors: more than CAND_CAP windows): one window at a time, as before.
     s << "  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\");\n"
          "  u32 nl = (u32)__builtin_amdgcn_readfirstlane(*lcnt);\n"
-         "  if (nl > LIST_CAP) nl = LIST_CAP;\n"
+         "  if (nl > LIST_CAP) nl = LIST_CAP;\n" << (env_int("IPCR_JIT_NOTAIL", 0, 0, 1) ? "  nl = 0u; // TIMING EXPERIMENT ONLY\n" : "") <<
          "  const u32* planes32 = (const u32*)planes;\n"
          "  u32 ncand = 0u;\n"
          "  bool wrote = false;\n"
+         "  if (nl) {\n"
+         "    u64* candP = candP_all[wv]; unsigned char* candq = candq_all[wv];\n"
+         "    u64 ekey = 0ull; u32 ebits = 0u;\n"
+         "    if (lane < nl) { ekey = lkey[lane]; ebits = lbits[lane]; }\n"
+         "    const u32 mine = (u32)__builtin_popcount(ebits);\n"
+         "    u32 incl = mine;\n"
+         "    for (int d = 1; d < 64; d <<= 1) { const u32 up = __shfl_up(incl, d); if ((int)lane >= d) incl += up; }\n"
+         "    ncand = (u32)__builtin_amdgcn_readlane((int)incl, 63);\n"
+         "    if (ncand <= CAND_CAP) {\n"
+         "      u32 o = incl - mine;\n"
+         "      while (ebits) {\n"
+         "        const u32 bit = (u32)__builtin_ctz(ebits); ebits &= ebits - 1u;\n"
+         "        candP[o] = (ekey & 0xFFFFFFFFFFFFull) + ((u64)bit << 7); candq[o] = (unsigned char)((u32)(ekey >> 48) - QBASE); ++o;\n"
+         "      }\n"
+         "      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\");\n"
+         "      const u32 r0 = block_rec[block]; // record of the block's first base; candidates come in no particular order\n"
+         "      const u64 rs0 = rec_start[r0], rl0 = rec_len[r0], rn0 = (r0 + 1u < nrec) ? rec_start[r0 + 1u] : ~0ull;\n"
+         "      const u32 half = lane >> 5, j = lane & 31u;\n"
+         "      for (u32 i = 0u; i < ncand; i += 2u) {\n"
+         "        const u32 c = i + half;\n"
+         "        const bool live = c < ncand;\n"
+         "        const u64 P = live ? candP[c] : candP[i];\n"
+         "        const u32 q = live ? candq[c] : candq[i];\n"
+         "        const u32 g = base_bits(planes32, P + j); // always in bounds: >= 128 pad bases follow every record\n"
+         "        const u32* pi = ptab + NPAT * 8u + q * 4u;\n"
+         "        const u32 L = pi[0], soff = pi[1], slen = pi[2], gid = pi[3];\n"
+         "        const u32 m = (ptab[q * 8u + (j >> 2)] >> ((j & 3u) * 8u)) & 0xFFu;\n"
+         "        const u32 onehot = (g & 4u) ? 0u : (1u << (g & 3u));\n"
+         "        const bool mis = j < L && (m & onehot) == 0u;\n"
+         "        const bool prot = mis && (m & 16u);\n"
+         "        u32 r = r0; u64 rs = rs0, rl = rl0, rn = rn0;\n"
+         "        while (P >= rn) { ++r; rs = rn; rl = rec_len[r]; rn = (r + 1u < nrec) ? rec_start[r + 1u] : ~0ull; } // a block holds few records\n"
+         "        const u64 local = P - rs;\n"
+         "        const u32 mm = (u32)(__ballot(mis) >> (half * 32u));\n"
+         "        const u32 pv = (u32)(__ballot(prot) >> (half * 32u));\n"
+         "        const bool ok = live && pv == 0u && (u32)__builtin_popcount(mm) <= max_mm && local + L <= rl;\n"
+         "        u32 flag = 0u;\n"
+         "        if (check_rst) flag = ((u32)(__ballot(ok && j < slen && rst_bit(rst, P + soff + j)) >> (half * 32u))) != 0u ? 1u : 0u;\n"
+         "        if (__ballot(ok) != 0ull) wrote = true;\n"
+         "        if (ok && j == 0u) {\n"
+         "          const u64 slot = atomicAdd(counts + 1, 1ull);\n"
+         "          hitrec h; h.pos = local; h.record = r; h.pattern = gid | (flag << 31); h.m0 = (u64)mm; h.m1 = 0ull;\n"
+         "          if (slot < hcap) hits[slot] = h;\n"
+         "          if (pub_hits && slot < pre) pub_hits[slot] = h; // the first hits also go straight to the host's pinned buffer\n"
+         "        }\n"
+         "      }\n"
+         "      nl = 0u; // done\n"
+         "    } else ncand = 0u;\n"
+         "  }\n"
          "  for (u32 e = 0u; e < nl; ++e) {\n"
          "    const u64 key = lkey[e];\n"
          "    u32 bits = (u32)__builtin_amdgcn_readfirstlane(lbits[e]);\n"
@@ -471,11 +593,13 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
          "        const u64 slot = atomicAdd(counts + 1, 1ull);\n"
          "        hitrec h; h.pos = local; h.record = lo; h.pattern = gid | (flag << 31); h.m0 = mm; h.m1 = 0ull;\n"
          "        if (slot < hcap) hits[slot] = h;\n"
-         "        if (pub_hits && slot < pre) pub_hits[slot] = h; // the first hits also go straight to the host's pinned buffer\n"
+         "        if (pub_hits && slot < pre) pub_hits[slot] = h;\n"
          "      }\n"
          "    }\n"
          "  }\n"
-         "  if (lane == 0u && ncand) atomicAdd(counts + 2, (u64)ncand);\n";
+         "  // candidate statistics: one same-address atomic per wave (~12 ns each, serialised in L2) would cost more\n"
+         "  // than the verification itself once most waves have a candidate: 64 counters next to the tickets instead\n"
+         "  if (lane == 0u && ncand) { if (tickets) atomicAdd(tickets + ((u32)block & 63u) * 32u + 1u, ncand); else atomicAdd(counts + 2, (u64)ncand); }\n";
     // ---- the last wave of the scan hands the counters to the host (no copy operation behind the
     // kernel): two-level ticket, 64 first-level counters 128 B apart so that the ~12 ns same-address
     // atomics of thousands of finishing waves do not queue up behind one another
@@ -496,7 +620,15 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
          "      const u32 nsh = nblocks < 64ull ? (u32)nblocks : 64u;\n"
          "      if (t2 + 1u == nsh) { // every other wave of the scan has finished\n"
          "        __threadfence();\n"
-         "        if (lane < 4u) pub[lane] = __hip_atomic_load(counts + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+         "        u32 cs = __hip_atomic_load(tickets + lane * 32u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // candidate windows, 64 partial counts\n"
+         "        tickets[lane * 32u + 1u] = 0u;\n"
+         "        for (int off = 32; off > 0; off >>= 1) cs += __shfl_down(cs, off);\n"
+         "        const u32 cs_total = (u32)__builtin_amdgcn_readfirstlane((int)cs);\n"
+         "        if (lane < 4u) {\n"
+         "          u64 v = __hip_atomic_load(counts + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+         "          if (lane == 2u) { v += (u64)cs_total; counts[2] = v; }\n"
+         "          pub[lane] = v;\n"
+         "        }\n"
          "        if (lane == 0u) tickets[2048u] = 0u;\n"
          "        __threadfence_system();\n"
          "        if (lane == 0u) __hip_atomic_store(pub_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);\n"
@@ -510,16 +642,46 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
 
 namespace {
 
+// code objects of this process, keyed by (arch, source): scanning several genomes, or the same
+// primers under another HitCap / length window, does not pay hiprtc twice
+struct CodeCache {
+    std::mutex mu;
+    std::map<std::string, std::vector<char>> map;
+    size_t bytes = 0;
+};
+CodeCache &code_cache() {
+    static CodeCache c;
+    return c;
+}
+
+bool compile_group_uncached(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &err);
+
 // hiprtc -> code object for one group (no device needed except for the arch name)
 bool compile_group(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &err) {
+    const std::string key = arch + "\n" + src;
+    CodeCache &cc = code_cache();
+    {
+        std::lock_guard<std::mutex> lk(cc.mu);
+        const auto it = cc.map.find(key);
+        if (it != cc.map.end()) { code = it->second; return true; }
+    }
+    if (!compile_group_uncached(src, arch, code, err)) return false;
+    std::lock_guard<std::mutex> lk(cc.mu);
+    if (cc.bytes > ((size_t)256 << 20)) { cc.map.clear(); cc.bytes = 0; }
+    cc.bytes += key.size() + code.size();
+    cc.map.emplace(key, code);
+    return true;
+}
+
+bool compile_group_uncached(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &err) {
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "ipcr_filter.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         err = "hiprtcCreateProgram failed";
         return false;
     }
     const std::string archopt = "--offload-arch=" + arch;
-    const char *opts[] = {archopt.c_str(), "-O3"};
-    const hiprtcResult r = hiprtcCompileProgram(prog, 2, opts);
+    const char *opts[] = {archopt.c_str(), "-O3", "-fno-slp-vectorize", "-fno-vectorize"}; // nothing to vectorise: 15 % of the compile time
+    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
         hiprtcGetProgramLogSize(prog, &n);
@@ -771,7 +933,7 @@ hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint
     if (nblocks == 0) return hipSuccess;
     JitVerify a = v;
     void *args[] = {(void *)&planes, (void *)&nblocks, (void *)&queue, (void *)&qcap, (void *)&qcount,
-                    (void *)&a.rst, (void *)&a.pats, (void *)&a.rec_start, (void *)&a.rec_len, (void *)&a.nrec,
+                    (void *)&a.rst, (void *)&a.pats, (void *)&a.rec_start, (void *)&a.rec_len, (void *)&a.block_rec, (void *)&a.nrec,
                     (void *)&a.max_mm, (void *)&a.check_rst, (void *)&a.hits, (void *)&a.hcap, (void *)&a.counts,
                     (void *)&a.next_counts, (void *)&a.next_qcount, (void *)&a.tickets, (void *)&a.pub,
                     (void *)&a.pub_hits, (void *)&a.pre, (void *)&a.pub_seq, (void *)&a.seq};

@@ -30,6 +30,7 @@ struct JitVerify {
     const uint32_t *rst = nullptr;
     const ipcr_dev_pattern *pats = nullptr;
     const uint64_t *rec_start = nullptr, *rec_len = nullptr;
+    const uint32_t *block_rec = nullptr; // per block: last record starting at or before it
     uint32_t nrec = 0, max_mm = 0, check_rst = 0;
     ipcr_hit_rec *hits = nullptr;
     uint64_t hcap = 0;
