@@ -104,7 +104,7 @@ def main() -> None:
     dev = torch.device("cuda", local)
     cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective payloads live
     import torch.distributed as tdist
-    multi = world > 1
+    multi = world > 1 or bool(os.environ.get("IPCR_EXCHANGE_SELFTEST"))  # selftest: one rank runs the RCCL exchange too
 
     def revcomp(s: str) -> bytes:
         from ipcr_amd import primer
@@ -130,8 +130,9 @@ def main() -> None:
         _, _, offs = xchg.allgather(dist.hits_from_scratch(sc), nrec)
         rec_off = offs[rank]
 
-    sc2 = eng.NewSimulationScratch(cp)
-    scs = [sc, sc2]
+    # three scratches in rotation: one being swept, one being joined on the host, one whose hit buffer the
+    # all-gather of the pass before may still be reading (several GPUs); two would do on one GPU
+    scs = [sc, eng.NewSimulationScratch(cp), eng.NewSimulationScratch(cp)]
     for s_ in scs:  # untimed set-up: kernel specialisation (hiprtc) and buffer sizing happen here
         eng.ScanGenomeCount(genome, cp, s_)
 
@@ -141,25 +142,35 @@ def main() -> None:
         pass i+1 are already enqueued on the other scratch's stream; with several GPUs the all-gatherv
         of pass i's hit records (RCCL) runs under pass i+1 too.  Every pass is complete (filter ->
         verify -> hits -> match lists -> join -> products, hits exchanged) when run_steps returns."""
-        fms, n, work = [], 0, None
+        fms, n = [], 0
+        works = {}                        # pass -> exchange in flight (it reads that pass's scratch on the device)
         if k <= 0:
             return fms, n
-        eng.ScanGenomeBegin(genome, cp, scs[0])
+        ns = len(scs)
+
+        def begin(j):
+            # the all-gather of pass j-ns read the device hit buffer of the scratch pass j is about to reuse
+            for jj in [q for q in works if q <= j - ns]:
+                xchg.finish(works.pop(jj))
+            if j > 0 and not args.no_pipeline:
+                scs[j % ns].chain_after(scs[(j - 1) % ns])        # device: pass j's sweep behind pass j-1's
+            eng.ScanGenomeBegin(genome, cp, scs[j % ns])
+
+        begin(0)
         for i in range(k):
-            cur = scs[i & 1]
+            cur = scs[i % ns]
             if i + 1 < k and not args.no_pipeline:
-                scs[(i + 1) & 1].chain_after(cur)               # device: pass i+1's kernels after pass i's
-                eng.ScanGenomeBegin(genome, cp, scs[(i + 1) & 1])
+                begin(i + 1)
             n = eng.ScanGenomeEndCount(genome, cp, cur)          # this rank's partition of the join: its records
-            if i + 1 < k and args.no_pipeline:
-                eng.ScanGenomeBegin(genome, cp, scs[(i + 1) & 1])
             fms.append(cur.stats().filter_ms)
             if multi:
-                if work is not None:
-                    xchg.finish(work)
-                work = xchg.start(dist.hits_from_scratch(cur), nrec)   # all-gatherv of hit records, async
-        if multi and work is not None:
-            xchg.finish(work)
+                for jj in [q for q in works if q <= i - 2]:      # two receive slots
+                    xchg.finish(works.pop(jj))
+                works[i] = xchg.start_scratch(cur, nrec)         # all-gatherv of hit records, async, out of the device hit buffer
+            if i + 1 < k and args.no_pipeline:
+                begin(i + 1)
+        for jj in sorted(works):
+            xchg.finish(works.pop(jj))
         return fms, n
 
     run_steps(max(args.warmup, 0))
@@ -180,7 +191,7 @@ def main() -> None:
         ptot = torch.tensor([nprod], dtype=torch.int64, device=cdev)
         tdist.all_reduce(ptot, op=tdist.ReduceOp.SUM)
         nprod = int(ptot.item())
-    last = scs[(args.steps - 1) & 1]   # scratch holding the last pass
+    last = scs[(args.steps - 1) % len(scs)]   # scratch holding the last pass
 
     # ---- correctness outside the timed region: every planted amplicon must come back exactly ----
     if not multi:

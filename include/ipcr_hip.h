@@ -171,6 +171,14 @@ ipcr_status ipcr_scratch_stats(const ipcr_scratch *s, ipcr_scan_stats *out);
 /* results of the last scan on this scratch; pointers stay valid until the next scan/destroy */
 ipcr_status ipcr_scratch_products(const ipcr_scratch *s, const ipcr_product **out, int64_t *n);
 ipcr_status ipcr_scratch_hits(const ipcr_scratch *s, const ipcr_hit **out, int64_t *n);
+/* the same hit records where the kernels left them in device memory, for a device-to-device exchange
+ * (RCCL all-gather straight out of this buffer, no host staging): *dev_block points at a 64-byte
+ * header followed by `capacity` ipcr_hit slots, the first *n_hits of them valid, in device append
+ * order (unsorted, and a window found through several keys may appear twice: ipcr_join_hits sorts
+ * and removes duplicates).  Header = two sets of four uint64 {queue words, hits, candidate windows,
+ * fullest queue segment}; the set the last scan used is the non-zero one.  Valid until the next scan
+ * on this scratch; the address changes when the buffer regrows. */
+ipcr_status ipcr_scratch_device_hits(const ipcr_scratch *s, const void **dev_block, uint64_t *n_hits, uint64_t *capacity);
 
 /* ---- Engine.ForEachCompiledProduct / SimulateCompiledWithScratch -- compiled.go:141-267 ----
  * One record or chunk of upper-cased ASCII (host memory), chunk-local coordinates, products

@@ -86,6 +86,7 @@ SYMBOLS = {
     "ipcr_scratch_stats": (C.c_int, [C.c_void_p, C.POINTER(ScanStats)]),
     "ipcr_scratch_products": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(Product)), C.POINTER(C.c_int64)]),
     "ipcr_scratch_hits": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(Hit)), C.POINTER(C.c_int64)]),
+    "ipcr_scratch_device_hits": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ipcr_scan_chunk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "ipcr_genome_create": (C.c_int, [C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p)]),
     "ipcr_genome_destroy": (None, [C.c_void_p]),

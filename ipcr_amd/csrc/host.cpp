@@ -1577,6 +1577,15 @@ ipcr_status ipcr_scratch_hits(const ipcr_scratch *s, const ipcr_hit **out, int64
     return IPCR_OK;
 }
 
+ipcr_status ipcr_scratch_device_hits(const ipcr_scratch *s, const void **dev_block, uint64_t *n_hits, uint64_t *capacity) {
+    if (!s || !dev_block || !n_hits || !capacity) return fail(IPCR_ERR_INVALID, "null argument");
+    if (!s->d_hitbuf) return fail(IPCR_ERR_DEVICE, "host-only scratch has no device hit buffer");
+    *dev_block = s->d_hitbuf;
+    *n_hits = s->hits_raw.size();
+    *capacity = s->hcap;
+    return IPCR_OK;
+}
+
 ipcr_status ipcr_scan_genome_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g) {
     ipcr_status st = scratch_ready(p, s);
     if (st != IPCR_OK) return st;

@@ -34,10 +34,15 @@ def init_process_group(backend: Optional[str] = None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    # IPCR_EXCHANGE_SELFTEST=1: a one-rank job still joins a group and runs the exchange (RCCL on one GPU)
+    if (world > 1 or os.environ.get("IPCR_EXCHANGE_SELFTEST")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        except TypeError:  # older torch: no device_id
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local, backend
 
 
@@ -129,7 +134,8 @@ class HitExchanger:
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.active = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(group) > 1 or bool(os.environ.get("IPCR_EXCHANGE_SELFTEST")))
         self.world = dist.get_world_size(group) if self.active else 1
         self.rank = dist.get_rank(group) if self.active else 0
         self.device = device if device is not None else torch.device("cpu")
@@ -143,9 +149,13 @@ class HitExchanger:
         pin = self.device.type == "cuda"
         self.h_send = torch.zeros(n, dtype=torch.uint8, pin_memory=pin)
         self.h_recv = torch.zeros(self.world * n, dtype=torch.uint8, pin_memory=pin)
+        self._views, self._from_device, self._nrec_local, self._host_work = {}, False, 0, None
         if self.device.type == "cuda":
             self.d_send = torch.zeros(n, dtype=torch.uint8, device=self.device)
             self.d_recv = torch.zeros(self.world * n, dtype=torch.uint8, device=self.device)
+            self.d_recv_dev = [torch.zeros(self.world * (64 + cap * 32), dtype=torch.uint8, device=self.device) for _ in range(2)]
+            self._slot, self._done_slot = 0, 0
+            self.h_recv_dev = torch.zeros(self.world * (64 + cap * 32), dtype=torch.uint8, pin_memory=True)
         else:
             self.d_send, self.d_recv = self.h_send, self.h_recv
 
@@ -160,6 +170,9 @@ class HitExchanger:
         if len(local) > self.cap:
             raise RuntimeError(f"{len(local)} hit records exceed the exchange capacity {self.cap}; "
                                "call allgather() once first so every rank regrows it together")
+        self._from_device = False
+        if self._host_work is not None:               # one send buffer: the previous host-path exchange must be done
+            self._host_work.wait()
         n = len(local)
         hs = self.h_send.numpy()
         hs[:16].view(np.int64)[:] = (n, n_local_records)
@@ -167,12 +180,53 @@ class HitExchanger:
             hs[32:32 + n * 32] = local.view(np.uint8).reshape(-1)
         if self.d_send is not self.h_send:
             self.d_send.copy_(self.h_send, non_blocking=True)
-        return self.dist.all_gather_into_tensor(self.d_recv, self.d_send, group=self.group, async_op=True)
+        self._host_work = self.dist.all_gather_into_tensor(self.d_recv, self.d_send, group=self.group, async_op=True)
+        return self._host_work
+
+    # -- device form (RCCL): the hit records never visit the host on the sending side ---------------
+    class _DevView:
+        """zero-copy torch view of a raw device range (__cuda_array_interface__)"""
+        def __init__(self, ptr: int, nbytes: int):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    def start_scratch(self, scratch, n_local_records: int):
+        """All-gather straight out of the scratch's device hit buffer (64-byte counter header + the first
+        `cap` hit slots, ipcr_scratch_device_hits): no copy of the records to the host and back.  The
+        buffer must stay untouched until finish(): do not begin the scratch's next scan before."""
+        if not self.active:
+            return None
+        if self.device.type != "cuda":
+            return self.start(hits_from_scratch(scratch), n_local_records)
+        ptr, n, cap = scratch.device_hits()
+        if n > self.cap or cap < self.cap:
+            raise RuntimeError(f"{n} hit records / device capacity {cap} do not fit the exchange capacity {self.cap}; "
+                               "call allgather() once first so every rank regrows it together")
+        nbytes = 64 + self.cap * 32
+        key = (ptr, nbytes)
+        view = self._views.get(key)
+        if view is None:
+            view = self.torch.as_tensor(self._DevView(ptr, nbytes), device=self.device)
+            self._views = {k: v for k, v in self._views.items() if k[0] != ptr}
+            self._views[key] = view
+        self._nrec_local = n_local_records
+        self._from_device = True
+        # two receive slots: up to two exchanges may be in flight (three scratches in rotation), and the
+        # host later waits for ONE of them (its own event), not for the whole stream
+        slot = self._slot = (self._slot + 1) & 1
+        work = self.dist.all_gather_into_tensor(self.d_recv_dev[slot][: self.world * nbytes], view, group=self.group, async_op=True)
+        work.wait()                                   # current stream waits (no host block) ...
+        ev = self.torch.cuda.Event()
+        ev.record()                                   # ... so this event completes exactly when the all-gather has
+        return (work, ev, slot)
 
     def finish(self, work) -> None:
         """Wait until every rank's hit records of this step are resident in this rank's memory
         (`d_recv`: world x (header + cap records)); `gathered()` brings them to the host."""
         if work is None:
+            return
+        if isinstance(work, tuple):
+            work[1].synchronize()
+            self._done_slot = work[2]
             return
         work.wait()
         if self.device.type == "cuda":
@@ -182,9 +236,32 @@ class HitExchanger:
         """Host copy of the last gathered buffer -> same triple as allgather()."""
         if not self.active:
             raise RuntimeError("no exchange in a single-process job")
+        if self._from_device:
+            self.h_recv_dev.copy_(self.d_recv_dev[self._done_slot])
+            return self._unpack_device()
         if self.d_recv is not self.h_recv:
             self.h_recv.copy_(self.d_recv)
         return self._unpack()
+
+    def set_record_counts(self, counts) -> None:
+        """records per rank (static for a job; the device form does not resend them every step)"""
+        self._rec_counts = [int(c) for c in counts]
+
+    def _unpack_device(self):
+        nbytes = 64 + self.cap * 32
+        hr = self.h_recv_dev.numpy().reshape(self.world, nbytes)
+        hdr = hr[:, :64].copy().view(np.uint64).reshape(self.world, 8)
+        parts, ranges, offsets, off, pos = [], [], [], 0, 0
+        for r in range(self.world):
+            cnt = int(max(hdr[r, 1], hdr[r, 5]))     # the counter set of the last scan is the non-zero one
+            part = hr[r, 64:64 + cnt * 32].copy().view(HIT_DTYPE)
+            part["record"] += np.uint32(off)
+            parts.append(part)
+            ranges.append((pos, pos + cnt))
+            offsets.append(off)
+            pos += cnt
+            off += self._rec_counts[r]
+        return np.concatenate(parts), ranges, offsets
 
     def _unpack(self):
         hr = self.h_recv.numpy().reshape(self.world, (self.cap + 1) * 32)
@@ -222,6 +299,7 @@ class HitExchanger:
             hr = self.h_recv.numpy().reshape(self.world, (self.cap + 1) * 32)
             meta = hr[:, :16].copy().view(np.int64).reshape(self.world, 2)
             need = int(meta[:, 0].max())
+            self._rec_counts = [int(c) for c in meta[:, 1]]
             if need <= self.cap:
                 break
             cap = self.cap

@@ -195,6 +195,15 @@ class SimulationScratch:
         _lib.check(_lib.lib().ipcr_scratch_hits(self._h, C.byref(ptr), C.byref(n)))
         return ptr, n.value
 
+    def device_hits(self):
+        """(device address of the 64-byte header + hit slots, hits of the last scan, capacity in hits):
+        ipcr_scratch_device_hits, for a device-to-device exchange."""
+        ptr = C.c_void_p()
+        n = C.c_uint64()
+        cap = C.c_uint64()
+        _lib.check(_lib.lib().ipcr_scratch_device_hits(self._h, C.byref(ptr), C.byref(n), C.byref(cap)))
+        return ptr.value, n.value, cap.value
+
     def num_products(self) -> int:
         ptr = C.POINTER(_lib.Product)()
         n = C.c_int64()
