@@ -23,9 +23,15 @@ def short(name):
     return None
 
 
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: only the latest run of a directory counts"""
+    files = glob.glob(pattern, recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def pmc(dirname, counter):
     per = {}
-    for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(dirname, "**", "*counter_collection.csv")):
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
                 if row["Counter_Name"] != counter:
@@ -48,7 +54,7 @@ def main():
     if os.path.exists(serial):
         with open(os.path.join(dst, f"{tag}_bench_serial.json"), "w") as fh:
             fh.write(open(serial).read().strip().splitlines()[-1] + "\n")
-    stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    stats = newest(os.path.join(src, "stats", "**", "*kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
     fetch = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
