@@ -666,3 +666,55 @@ def test_pipelined_begin_end(hip):
     with pytest.raises(hip.lib.IpcrError):  # nothing in flight any more
         eng.ScanGenomeEndCount(g, cp, a)
     g.close()
+
+
+def test_device_hit_exchange_one_rank_rccl(hip, monkeypatch):
+    """ipcr_scratch_device_hits + HitExchanger.start_scratch: the all-gather reads the scratch's device hit
+    buffer through a zero-copy torch view (one-rank RCCL group: the collective, the header parsing and the
+    two-slot bookkeeping are the ones a multi-GPU job runs)"""
+    import numpy as np
+    import torch
+    import torch.distributed as tdist
+    from ipcr_amd import dist, workloads
+    monkeypatch.setenv("IPCR_EXCHANGE_SELFTEST", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29531")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    rng = random.Random(77)
+    pairs = workloads.c2_pairs()
+    g, _ = build_planted_genome(hip, rng, 3, 600_000, pairs[:1], 0x5eed4444, junk_every=2)
+    eng = hip.engine.New(hip.engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12))
+    cp = eng.CompilePanel(pairs)
+    scs = [eng.NewSimulationScratch(cp) for _ in range(3)]
+    started_here = not tdist.is_initialized()
+    dist.init_process_group("nccl")
+    try:
+        dev = torch.device("cuda", 0)
+        x = dist.HitExchanger(device=dev)
+        want_products = [p.sig() for p in eng.ScanGenome(g, cp, scs[0])]
+        _, _, offs = x.allgather(dist.hits_from_scratch(scs[0]), g.num_records)   # sizes the buffers, record counts
+        assert offs == [0]
+        works = []
+        for i in range(5):                                   # rotation as in bench.py: two exchanges in flight
+            sc = scs[i % 3]
+            eng.ScanGenomeHits(g, cp, sc)
+            while len(works) >= 2:
+                x.finish(works.pop(0))
+            works.append(x.start_scratch(sc, g.num_records))
+        for w in works:
+            x.finish(w)
+        hits, ranges, offs = x.gathered()
+        local = dist.hits_from_scratch(scs[4 % 3])
+        assert ranges == [(0, len(local))] and offs == [0] and len(local) > 0
+        key = lambda a: np.sort(a, order=["record", "pattern", "pos"])
+        assert np.array_equal(key(np.unique(hits)), key(local))       # device order, maybe duplicated -> same set
+        host = hip.engine.SimulationScratch(cp, host_only=True)
+        lens = [g.record_len(r) for r in range(g.num_records)]
+        flags = [g.record_flags(r) for r in range(g.num_records)]
+        prods = eng.JoinHits(cp, host, hits, lens, flags)
+        assert [p.sig() for p in prods] == want_products
+    finally:
+        if started_here and tdist.is_initialized():
+            tdist.destroy_process_group()
+    g.close()
