@@ -507,7 +507,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
     // Slow path (dense survivors: more than CAND_CAP windows): one window at a time, as before.
     s << "  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\");\n"
          "  u32 nl = (u32)__builtin_amdgcn_readfirstlane(*lcnt);\n"
-         "  if (nl > LIST_CAP) nl = LIST_CAP;\n" << (env_int("IPCR_JIT_NOTAIL", 0, 0, 1) ? "  nl = 0u; // TIMING EXPERIMENT ONLY\n" : "") <<
+         "  if (nl > LIST_CAP) nl = LIST_CAP;\n"
          "  const u32* planes32 = (const u32*)planes;\n"
          "  u32 ncand = 0u;\n"
          "  bool wrote = false;\n"
