@@ -133,8 +133,11 @@ def main() -> None:
     # three scratches in rotation: one being swept, one being joined on the host, one whose hit buffer the
     # all-gather of the pass before may still be reading (several GPUs); two would do on one GPU
     scs = [sc, eng.NewSimulationScratch(cp), eng.NewSimulationScratch(cp)]
+    expect_products = None
     for s_ in scs:  # untimed set-up: kernel specialisation (hiprtc) and buffer sizing happen here
-        eng.ScanGenomeCount(genome, cp, s_)
+        n_ = eng.ScanGenomeCount(genome, cp, s_)
+        assert expect_products in (None, n_)
+        expect_products = n_
 
     def run_steps(k):
         """k passes of the hot path, pipelined the way the reference's worker pool + collector are
@@ -162,6 +165,8 @@ def main() -> None:
             if i + 1 < k and not args.no_pipeline:
                 begin(i + 1)
             n = eng.ScanGenomeEndCount(genome, cp, cur)          # this rank's partition of the join: its records
+            if n != expect_products:                             # every pass is checked, not only the last one
+                raise SystemExit(f"pass {i}: {n} products, the set-up scan found {expect_products}")
             fms.append(cur.stats().filter_ms)
             if multi:
                 for jj in [q for q in works if q <= i - 2]:      # two receive slots

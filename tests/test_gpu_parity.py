@@ -665,6 +665,16 @@ def test_pipelined_begin_end(hip):
         assert n == len(want) and [p.sig() for p in scs[i & 1].products(g.ids)] == want
     with pytest.raises(hip.lib.IpcrError):  # nothing in flight any more
         eng.ScanGenomeEndCount(g, cp, a)
+    # many chained passes over three scratches: every pass must hand over complete results (counters, hit
+    # records and the sequence word reach pinned memory from different waves)
+    scs = [a, b, eng.NewSimulationScratch(cp)]
+    nhits = a.stats().hits
+    eng.ScanGenomeBegin(g, cp, scs[0])
+    for i in range(600):
+        if i + 1 < 600:
+            scs[(i + 1) % 3].chain_after(scs[i % 3])
+            eng.ScanGenomeBegin(g, cp, scs[(i + 1) % 3])
+        assert eng.ScanGenomeEndCount(g, cp, scs[i % 3]) == len(want) and scs[i % 3].stats().hits == nhits, i
     g.close()
 
 
