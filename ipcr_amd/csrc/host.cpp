@@ -615,6 +615,7 @@ struct ipcr_genome {
     uint8_t *staging = nullptr;
     uint64_t staging_cap = 0;
     hipStream_t stream = nullptr;
+    bool shared_stream = false; // stream belongs to a scratch (its private chunk genome): never destroyed here
     hipEvent_t e0 = nullptr, e1 = nullptr;
     double pack_ms = 0;
 };
@@ -665,7 +666,7 @@ void genome_clear(ipcr_genome *g) { // forget the records, keep the buffers
     g->total_bases = 0;
 }
 
-ipcr_status genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len) {
+ipcr_status genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len, bool wait = true) {
     const uint64_t cols = record_cols(len);
     if (g->rec_start.size() >= g->max_records) return fail(IPCR_ERR_CAPACITY, "genome holds its maximum of %u records", g->max_records);
     if (g->next_col + cols > g->cap_cols)
@@ -676,10 +677,12 @@ ipcr_status genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len)
     HIPCHK(hipEventRecord(g->e0, g->stream));
     HIPCHK(ipcr::launch_pack(g->stream, dseq, len, g->next_col, cols, g->planes, g->rst, g->d_flags + rec));
     HIPCHK(hipEventRecord(g->e1, g->stream));
-    HIPCHK(hipEventSynchronize(g->e1));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, g->e0, g->e1));
-    g->pack_ms += ms;
+    if (wait) {
+        HIPCHK(hipEventSynchronize(g->e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, g->e0, g->e1));
+        g->pack_ms += ms;
+    }
     g->rec_start.push_back(g->next_col * IPCR_COLUMN_BASES);
     g->rec_len.push_back(len);
     g->ids.emplace_back();
@@ -728,6 +731,26 @@ ipcr_status genome_finalize(ipcr_genome *g) {
     return IPCR_OK;
 }
 
+// chunk path (one record, the scratch's own stream): same preparation without waiting for anything; the
+// record's reset-byte flag arrives in *pinned_flag when the stream has passed this point
+ipcr_status genome_finalize_async(ipcr_genome *g, uint32_t *pinned_flag) {
+    const uint64_t need = (g->next_col + 63) / 64 * 64 + 64;
+    if (g->padded_until < need) {
+        const uint64_t from = std::max(g->next_col, g->padded_until);
+        HIPCHK(ipcr::launch_fill_pad(g->stream, g->planes, g->rst, from, need));
+        g->padded_until = need;
+    }
+    if (g->tables_dirty && !g->rec_start.empty()) {
+        HIPCHK(hipMemcpyAsync(g->d_rec_start, g->rec_start.data(), g->rec_start.size() * 8ull, hipMemcpyHostToDevice, g->stream));
+        HIPCHK(hipMemcpyAsync(g->d_rec_len, g->rec_len.data(), g->rec_len.size() * 8ull, hipMemcpyHostToDevice, g->stream));
+        const uint64_t nb = (g->next_col + 63) / 64 + 1;
+        HIPCHK(hipMemsetAsync(g->d_block_rec, 0, nb * 4ull, g->stream)); // one record: every block belongs to record 0
+        g->tables_dirty = false;
+    }
+    HIPCHK(hipMemcpyAsync(pinned_flag, g->d_flags, 4, hipMemcpyDeviceToHost, g->stream));
+    return IPCR_OK;
+}
+
 bool genome_any_reset(const ipcr_genome *g) {
     for (uint8_t f : g->flags)
         if (f & 1u) return true;
@@ -760,7 +783,7 @@ void ipcr_genome_destroy(ipcr_genome *g) {
     if (g->staging) (void)hipFree(g->staging);
     if (g->e0) (void)hipEventDestroy(g->e0);
     if (g->e1) (void)hipEventDestroy(g->e1);
-    if (g->stream) (void)hipStreamDestroy(g->stream);
+    if (g->stream && !g->shared_stream) (void)hipStreamDestroy(g->stream);
     delete g;
 }
 
@@ -1137,7 +1160,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
 }
 
 // first half of a scan: everything up to (and including) the enqueue; returns without waiting
-ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
+ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g, bool chunk = false) {
     ipcr_scratch::Pending &pd = s->pend;
     if (pd.active) return fail(IPCR_ERR_INVALID, "a scan is already in flight on this scratch (ipcr_scan_genome_end not called)");
     pd.t0 = std::chrono::steady_clock::now();
@@ -1147,18 +1170,21 @@ ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     memset(&s->stats, 0, sizeof s->stats);
     s->stats.pack_ms = pack_ms_keep;
     trace("enqueue>", s);
-    ipcr_status st = genome_finalize(g);
+    // chunk path: nothing is waited for before the sweep is enqueued.  Whether the record holds a reset byte is
+    // only known afterwards, so it is scanned the way a genome with such records is (rc patterns unprotected,
+    // the host applies the 5' window): right for both kinds of record, as in a resident genome that mixes them
+    ipcr_status st = chunk ? genome_finalize_async(g, pinned_seq(s) + 4) : genome_finalize(g);
     if (st != IPCR_OK) return st;
     trace("finalized", s);
     s->last_rec_len = g->rec_len;
     s->last_rec_start = g->rec_start;
-    pd.mode = (!p->modes_equal && genome_any_reset(g)) ? 1 : 0;
+    pd.mode = chunk ? (p->modes_equal ? 0 : 1) : ((!p->modes_equal && genome_any_reset(g)) ? 1 : 0);
     st = panel_upload(p, pd.mode);
     if (st != IPCR_OK) return st;
     const PatternSet &set = p->set[pd.mode];
     pd.nrec = (uint32_t)g->rec_start.size();
     pd.nblocks = (g->next_col + 63) / 64;
-    pd.check_rst = genome_any_reset(g) ? 1u : 0u;
+    pd.check_rst = (chunk || genome_any_reset(g)) ? 1u : 0u;
     s->stats.bases = g->total_bases;
     s->stats.tile_bytes = pd.nblocks * IPCR_BLOCK_PLANE_WORDS * 4ull;
     s->stats.n_patterns = (int32_t)set.ids.size();
@@ -1671,16 +1697,36 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         s->chunk = nullptr;
         st = ipcr_genome_create((need_cols + (need_cols >> 2)) * IPCR_COLUMN_BASES, 1, &s->chunk);
         if (st != IPCR_OK) return st;
+        // the private chunk genome lives on the scratch's stream: copy, pack, sweep and hand-over are one
+        // in-order sequence and the host waits once, at the end
+        (void)hipStreamDestroy(s->chunk->stream);
+        s->chunk->stream = s->stream;
+        s->chunk->shared_stream = true;
     }
-    genome_clear(s->chunk);
-    const double before = s->chunk->pack_ms;
-    st = ipcr_genome_add_record(s->chunk, seq, len);
+    ipcr_genome *g = s->chunk;
+    genome_clear(g);
+    if (len + 16 > g->staging_cap) {
+        if (g->staging) (void)hipFree(g->staging);
+        g->staging = nullptr;
+        g->staging_cap = len + 16 + (len >> 3);
+        HIPCHK(hipMalloc((void **)&g->staging, g->staging_cap));
+    }
+    if (len) HIPCHK(hipMemcpyAsync(g->staging, seq, len, hipMemcpyHostToDevice, g->stream));
+    st = genome_add_device(g, g->staging, len, false);
     if (st != IPCR_OK) return st;
-    s->stats.pack_ms = s->chunk->pack_ms - before;
-    st = scan_hits(p, s, s->chunk);
+    st = scan_enqueue(p, s, g, true);
+    if (st == IPCR_OK) st = scan_collect(p, s, g);
     if (st != IPCR_OK) return st;
-    uint8_t fl = (uint8_t)((s->chunk->flags[0] & 1u) ? 3u : 0u);
-    st = join_sorted_hits(p, s, s->chunk->rec_len.data(), &fl, 1, emit, user);
+    {
+        float ms = 0; // the pack kernel's events lie in front of the sweep on the same stream
+        HIPCHK(hipEventElapsedTime(&ms, g->e0, g->e1));
+        g->pack_ms += ms;
+        s->stats.pack_ms = ms;
+    }
+    g->flags.assign(1, (uint8_t)(pinned_seq(s)[4] & 1u));
+    g->flags_valid = true;
+    const uint8_t fl = (uint8_t)((g->flags[0] & 1u) | (p->modes_equal ? 0u : 2u));
+    st = join_sorted_hits(p, s, g->rec_len.data(), &fl, 1, emit, user);
     s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return st;
 }
