@@ -59,8 +59,8 @@ struct ipcr_index_shape {
     uint64_t valid_mask; // even bits of the k-mer positions the key reads (must all be valid bases)
 };
 
-struct ipcr_index_entry { // open-addressing hash table slot, 64 B
-    uint32_t tag;     // shape << 16 | key ; 0xFFFFFFFF = empty
+struct ipcr_index_entry { // 64 B; entry r belongs to the r-th distinct (shape, key) in sorted order
+    uint32_t next;    // further pattern with the same key (index into the same array), 0xFFFFFFFF = none
     uint32_t pattern; // set-local pattern index
     uint64_t ok[4];   // IUPAC masks as four position sets: even bit 2*(L-1-j) of ok[b] set when base b
                       // (A,C,G,T) is allowed at pattern position j -- pure ACGT primers are the one-hot case
@@ -71,15 +71,9 @@ struct ipcr_index_entry { // open-addressing hash table slot, 64 B
 };
 static_assert(sizeof(ipcr_index_entry) == 64, "index entries are read as four 16-byte loads");
 
-struct ipcr_index_meta { // per pattern
-    uint64_t prot2; // even bit 2*(L-1-j) set when position j is protected
-    uint8_t len;
-    uint8_t left;
-    uint8_t pad[6];
-};
-
 #define IPCR_INDEX_MAX_SHAPES 16
 #define IPCR_INDEX_BITMAP_WORDS 2048u // 65536 bits per shape
+#define IPCR_INDEX_GROUPS 256u        // rank prefix per 256 bitmap bits (8 words)
 
 // raw byte range [start, end) of one FASTA header line (its '\n' included) inside a slab
 struct ipcr_fasta_range {

@@ -173,17 +173,15 @@ struct PatternDef {
 struct IndexPlan {
     bool built = false, usable = false;
     std::vector<ipcr_index_shape> shapes;
-    std::vector<uint32_t> bitmaps;
-    std::vector<ipcr_index_entry> table;
-    uint32_t table_mask = 0;
-    std::vector<ipcr_index_meta> meta;
-    std::vector<uint32_t> leftover; // set-local patterns the index cannot serve (IUPAC, > 32 nt, ...)
-    ipcr_index_shape *d_shapes = nullptr;
-    uint32_t *d_bitmaps = nullptr;
+    // per shape: 2048 bitmap words (one bit per 16-bit key), then for all shapes the rank of the first key of
+    // every 256-bit group (uint16, relative to the shape's first entry), then the shapes' first entries
+    std::vector<uint32_t> lds_image;
+    std::vector<ipcr_index_entry> table; // entry r = first pattern of the r-th distinct (shape, key); more patterns of a key are chained
+    std::vector<uint32_t> leftover;      // set-local patterns the index cannot serve (> 32 nt, too degenerate, ...)
+    uint32_t *d_lds_image = nullptr;
     ipcr_index_entry *d_table = nullptr;
-    ipcr_index_meta *d_meta = nullptr;
     uint32_t *d_leftover = nullptr;
-    ipcr::JitFilter *jit = nullptr; // the same kernel with the key shapes baked in (hiprtc)
+    ipcr::JitFilter *jit = nullptr; // the kernel, with the key shapes baked in (hiprtc)
 };
 
 struct PatternSet {
@@ -226,7 +224,6 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     ix.built = true;
     const int k = p.cfg.max_mm;
     const size_t P = set.host.size();
-    ix.meta.assign(P, ipcr_index_meta{});
     struct Group { bool left; int t; int lmin; std::vector<uint32_t> members; };
     std::vector<Group> groups;
     struct Pat { uint64_t ok[4]; uint64_t prot2; int len; bool left; };
@@ -248,9 +245,6 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         if (!usable) { ix.leftover.push_back(q); continue; }
         pt.len = L;
         pt.left = d.left;
-        ix.meta[q].prot2 = pt.prot2;
-        ix.meta[q].len = (uint8_t)L;
-        ix.meta[q].left = d.left ? 1 : 0;
         int t = k == 0 ? L : std::min(d.tw_dev, L);
         if (t < 0) t = 0;
         bool found = false;
@@ -340,26 +334,53 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         if (dropped[q]) ix.leftover.push_back(q);
     std::sort(ents.begin(), ents.end());
     ents.erase(std::unique(ents.begin(), ents.end()), ents.end());
-    ix.bitmaps.assign(std::max<size_t>(1, ix.shapes.size()) * IPCR_INDEX_BITMAP_WORDS, 0u);
-    uint32_t slots = 1024;
-    while (slots < ents.size() * 4) slots *= 2;
-    ipcr_index_entry empty{};
-    empty.tag = 0xFFFFFFFFu;
-    ix.table.assign(slots, empty);
-    ix.table_mask = slots - 1;
-    for (auto &e : ents) {
-        const uint32_t s = e.first >> 16, key = e.first & 0xFFFFu;
-        ix.bitmaps[s * IPCR_INDEX_BITMAP_WORDS + (key >> 5)] |= 1u << (key & 31u);
-        uint32_t h = (e.first * 2654435761u) & ix.table_mask;
-        while (ix.table[h].tag != 0xFFFFFFFFu) h = (h + 1) & ix.table_mask;
-        ipcr_index_entry en{};
-        en.tag = e.first;
-        en.pattern = e.second;
-        for (int bb = 0; bb < 4; ++bb) en.ok[bb] = pats[e.second].ok[bb];
-        en.prot2 = pats[e.second].prot2;
-        en.len = (uint32_t)pats[e.second].len;
-        en.left = pats[e.second].left ? 1u : 0u;
-        ix.table[h] = en;
+    // Direct index instead of a hash table: a set bitmap bit means the key is in the panel, and its rank among
+    // the set bits IS the index of its entry -- one entry load per hit, no tag compare, no probing.  The rank
+    // comes from a per-256-bit-group prefix (uint16, LDS) plus popcounts inside the group.
+    const size_t NS = ix.shapes.size();
+    const size_t img_words = NS * IPCR_INDEX_BITMAP_WORDS + NS * (IPCR_INDEX_GROUPS / 2) + NS;
+    ix.lds_image.assign(std::max<size_t>(1, img_words), 0u);
+    uint16_t *prefix = reinterpret_cast<uint16_t *>(ix.lds_image.data() + NS * IPCR_INDEX_BITMAP_WORDS);
+    uint32_t *base = ix.lds_image.data() + NS * IPCR_INDEX_BITMAP_WORDS + NS * (IPCR_INDEX_GROUPS / 2);
+    size_t ndistinct = 0;
+    for (size_t i = 0; i < ents.size(); ++i)
+        if (i == 0 || ents[i].first != ents[i - 1].first) ++ndistinct;
+    ipcr_index_entry blank{};
+    blank.next = 0xFFFFFFFFu;
+    ix.table.assign(ndistinct, blank);
+    auto fill = [&](ipcr_index_entry &en, uint32_t q) {
+        en.pattern = q;
+        for (int bb = 0; bb < 4; ++bb) en.ok[bb] = pats[q].ok[bb];
+        en.prot2 = pats[q].prot2;
+        en.len = (uint32_t)pats[q].len;
+        en.left = pats[q].left ? 1u : 0u;
+    };
+    std::vector<uint32_t> shape_count(NS + 1, 0);
+    size_t r = 0;
+    for (size_t i = 0; i < ents.size();) {
+        const uint32_t tag = ents[i].first, sidx = tag >> 16, key = tag & 0xFFFFu;
+        ix.lds_image[sidx * IPCR_INDEX_BITMAP_WORDS + (key >> 5)] |= 1u << (key & 31u);
+        ++shape_count[sidx];
+        fill(ix.table[r], ents[i].second);
+        uint32_t tail = (uint32_t)r;
+        for (++i; i < ents.size() && ents[i].first == tag; ++i) { // further patterns with the same key
+            ipcr_index_entry more = blank;
+            fill(more, ents[i].second);
+            ix.table[tail].next = (uint32_t)ix.table.size();
+            tail = (uint32_t)ix.table.size();
+            ix.table.push_back(more);
+        }
+        ++r;
+    }
+    uint32_t run = 0;
+    for (size_t sidx = 0; sidx < NS; ++sidx) {
+        base[sidx] = run;
+        uint32_t within = 0;
+        for (uint32_t g = 0; g < IPCR_INDEX_GROUPS; ++g) {
+            prefix[sidx * IPCR_INDEX_GROUPS + g] = (uint16_t)within; // < 65536: a shape has at most 65536 keys, the last group starts below that
+            for (uint32_t w = 0; w < 8; ++w) within += (uint32_t)__builtin_popcount(ix.lds_image[sidx * IPCR_INDEX_BITMAP_WORDS + g * 8 + w]);
+        }
+        run += shape_count[sidx];
     }
     std::sort(ix.leftover.begin(), ix.leftover.end());
     ix.usable = !ix.shapes.empty() && !ents.empty();
@@ -508,10 +529,8 @@ void ipcr_panel_destroy(ipcr_panel *p) {
     if (!p) return;
     for (auto &s : p->set) {
         if (s.index.jit) ipcr::jit_destroy(s.index.jit);
-        if (s.index.d_shapes) (void)hipFree(s.index.d_shapes);
-        if (s.index.d_bitmaps) (void)hipFree(s.index.d_bitmaps);
+        if (s.index.d_lds_image) (void)hipFree(s.index.d_lds_image);
         if (s.index.d_table) (void)hipFree(s.index.d_table);
-        if (s.index.d_meta) (void)hipFree(s.index.d_meta);
         if (s.index.d_leftover) (void)hipFree(s.index.d_leftover);
         if (s.dev) (void)hipFree(s.dev);
         for (ipcr::JitFilter *f : s.jit) ipcr::jit_destroy(f);
@@ -942,18 +961,16 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode) {
         if (!s.index.built) build_index(*p, s);
         IndexPlan &ix = s.index;
         if (ix.usable) {
-            HIPCHK(hipMalloc((void **)&ix.d_shapes, ix.shapes.size() * sizeof(ipcr_index_shape)));
-            HIPCHK(hipMemcpy(ix.d_shapes, ix.shapes.data(), ix.shapes.size() * sizeof(ipcr_index_shape), hipMemcpyHostToDevice));
-            HIPCHK(hipMalloc((void **)&ix.d_bitmaps, ix.bitmaps.size() * 4));
-            HIPCHK(hipMemcpy(ix.d_bitmaps, ix.bitmaps.data(), ix.bitmaps.size() * 4, hipMemcpyHostToDevice));
+            std::string jerr;
+            ix.jit = ipcr::jit_build_index(ix.shapes, jerr);
+            if (!ix.jit) {
+                ix.usable = false; // no hiprtc: the table-driven kernel serves
+                return IPCR_OK;
+            }
+            HIPCHK(hipMalloc((void **)&ix.d_lds_image, ix.lds_image.size() * 4));
+            HIPCHK(hipMemcpy(ix.d_lds_image, ix.lds_image.data(), ix.lds_image.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMalloc((void **)&ix.d_table, ix.table.size() * sizeof(ipcr_index_entry)));
             HIPCHK(hipMemcpy(ix.d_table, ix.table.data(), ix.table.size() * sizeof(ipcr_index_entry), hipMemcpyHostToDevice));
-            HIPCHK(hipMalloc((void **)&ix.d_meta, ix.meta.size() * sizeof(ipcr_index_meta)));
-            HIPCHK(hipMemcpy(ix.d_meta, ix.meta.data(), ix.meta.size() * sizeof(ipcr_index_meta), hipMemcpyHostToDevice));
-            if (!(getenv("IPCR_INDEX_NOJIT") && atoi(getenv("IPCR_INDEX_NOJIT")))) {
-                std::string jerr;
-                ix.jit = ipcr::jit_build_index(ix.shapes, jerr); // nullptr: the precompiled kernel serves
-            }
             if (!ix.leftover.empty()) {
                 HIPCHK(hipMalloc((void **)&ix.d_leftover, ix.leftover.size() * 4));
                 HIPCHK(hipMemcpy(ix.d_leftover, ix.leftover.data(), ix.leftover.size() * 4, hipMemcpyHostToDevice));
@@ -1121,14 +1138,8 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     } else if (set.index.usable) {
         const IndexPlan &ix = set.index;
         const bool more = !ix.leftover.empty();
-        if (ix.jit)
-            HIPCHK(ipcr::jit_launch_index(ix.jit, lane, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
-                                          ix.d_table, ix.table_mask, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
-                                          qc, s->ev[0], more ? nullptr : s->ev[1]));
-        else
-            HIPCHK(ipcr::launch_filter_index(lane, g->planes, nblocks, ix.d_shapes, (uint32_t)ix.shapes.size(), ix.d_bitmaps,
-                                             ix.d_table, ix.table_mask, ix.d_meta, (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap,
-                                             qc, s->ev[0], more ? nullptr : s->ev[1]));
+        HIPCHK(ipcr::jit_launch_index(ix.jit, lane, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_lds_image, ix.d_table,
+                                      (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, qc, s->ev[0], more ? nullptr : s->ev[1]));
         if (more) // patterns the index cannot key
             HIPCHK(ipcr::launch_filter_generic(lane, g->planes, nblocks, set.dev, (uint32_t)ix.leftover.size(),
                                                (uint32_t)p->cfg.max_mm, ix.d_leftover, s->d_queue, s->qcap, qc,

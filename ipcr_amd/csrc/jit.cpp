@@ -813,20 +813,80 @@ template <int S> __device__ __forceinline__ void probe_all(u64 km, u64 im, const
     probe_all<S + 1>(km, im, lds, keys, hitmask);
   }
 }
+// LDS image (host.cpp: build_index): NS bitmaps of 2048 words | NS x 256 uint16 group prefixes | NS first-entry indices
+#define PREFIX_WORD0 (NS * 2048u)
+#define BASE_WORD0 (NS * 2048u + NS * 128u)
+#define LDS_WORDS (NS * 2048u + NS * 128u + NS)
+#define QCAP 128u   // per-wave queue of key hits (24-byte entries), flushed at full lane occupancy
+#define QWORDS 6u
 extern "C" __global__ void __launch_bounds__(512) ipcr_index_filter(const u32* __restrict__ planes, u64 ncolpairs,
-    const u32* __restrict__ bitmaps, const v4* __restrict__ table, u32 table_mask, u32 max_mm,
+    const u32* __restrict__ lds_image, const v4* __restrict__ table, u32 max_mm,
     qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {
   extern __shared__ u32 lds[];
-  for (u32 i = threadIdx.x; i < NS * 2048u; i += blockDim.x) lds[i] = bitmaps[i];
+  for (u32 i = threadIdx.x; i < LDS_WORDS; i += blockDim.x) lds[i] = lds_image[i];
   __syncthreads();
+  const unsigned short* prefix = reinterpret_cast<const unsigned short*>(lds + PREFIX_WORD0);
   const u32 lane = threadIdx.x & 63u, half = lane >> 5, bit = lane & 31u;
+  u32* wq = lds + ((LDS_WORDS + 3u) & ~3u) + (threadIdx.x >> 6) * (QCAP * QWORDS); // this wave's hit queue
+  u32 qn = 0; // entries queued (wave-uniform)
   const u64 wave0 = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);
   for (u64 cp = wave0; cp < ncolpairs; cp += nwaves) {
+    // A key hit means: look the patterns of that key up and compare them with the k-mer.  Doing that where the
+    // hit occurs keeps ~10 of 64 lanes busy at EVERY base step (some lane always hits with thousands of keys), and
+    // the step then costs twice the instructions plus an L2 round trip.  So hits are queued (k-mer, key, where) and
+    // the queue is drained 64 at a time: every lane one hit, 64 independent entry loads in flight.
+    auto flush = [&]() __attribute__((always_inline)) {
+      for (u32 base = 0; base < qn; base += 64u) {
+        const u32 i = base + lane;
+        if (i < qn) {
+          const u32* e = wq + i * QWORDS;
+          const u64 km = ((u64)e[1] << 32) | e[0], im = ((u64)e[3] << 32) | e[2];
+          const u32 meta = e[4], where = e[5];
+          const u32 s = meta >> 16, key = meta & 0xFFFFu;
+          const u32 ol = where & 63u;
+          const int erow = (int)(where >> 6);
+          const u64 strand_base = ((((cp * 2u + (ol >> 5)) << 5) + (ol & 31u)) << 7);
+          // the key is in the panel; its rank among the shape's keys is the index of its entry
+          const u32 grp = key >> 8, wi = (key >> 5) & 7u, bi = key & 31u;
+          const v4* gw = reinterpret_cast<const v4*>(lds + s * 2048u + grp * 8u);
+          const v4 g0 = gw[0], g1 = gw[1];
+          const u32 gword[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+          u32 rank = lds[BASE_WORD0 + s] + (u32)prefix[s * 256u + grp];
+#pragma unroll
+          for (u32 j = 0; j < 8u; ++j) {
+            const u32 m = j < wi ? 0xFFFFFFFFu : (j == wi ? ((1u << bi) - 1u) : 0u);
+            rank += (u32)__builtin_popcount(gword[j] & m);
+          }
+          for (u32 idx = rank; idx != 0xFFFFFFFFu;) {
+            const v4 e0 = table[idx * 4u], e1 = table[idx * 4u + 1u], e2 = table[idx * 4u + 2u], e3 = table[idx * 4u + 3u];
+            const u64 okA = ((u64)e0.w << 32) | e0.z, okC = ((u64)e1.y << 32) | e1.x;
+            const u64 okG = ((u64)e1.w << 32) | e1.z, okT = ((u64)e2.y << 32) | e2.x;
+            const u64 prot2 = ((u64)e2.w << 32) | e2.z;
+            const u32 L = e3.x, left = e3.y;
+            const u32 sft = left ? 64u - 2u * L : 0u;
+            const u64 x = km >> sft, iv = im >> sft;
+            const u64 wm = (L >= 32u) ? ~0ull : ((1ull << (2u * L)) - 1ull);
+            const u64 E = 0x5555555555555555ull;
+            const u64 lo = x & E, hi = (x >> 1) & E;
+            const u64 match = (~lo & ~hi & okA) | (lo & ~hi & okC) | (~lo & hi & okG) | (lo & hi & okT);
+            const u64 mm2 = ((~match & E) | iv) & wm;
+            const int srow = left ? erow - 31 : erow - (int)L + 1;
+            if ((mm2 & prot2) == 0ull && (u32)__popcll(mm2) <= max_mm && srow >= 0 && srow < 128) {
+              const u32 shard = (u32)cp & 255u;
+              const u64 qi = atomicAdd(qcount + shard * 16u, 1ull);
+              if (qi < qcap) { qent qe; qe.key = ((u64)e0.y << 48) | (strand_base + (u64)srow); qe.bits = 1u; qe.pad = 0u; queue[(u64)shard * qcap + qi] = qe; }
+            }
+            idx = e0.x; // further pattern with the same key (rare)
+          }
+        }
+      }
+      qn = 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // queue slots are rewritten by other lanes next
+    };
     const u64 col = cp * 2u + half;
     const u64 ncol = (bit == 31u) ? col + 1u : col;
     const u32 nbit = (bit + 1u) & 31u;
-    const u64 strand_base = ((col << 5) + bit) << 7;
     u64 km = 0, im = 0x5555555555555555ull;
     for (u32 rq = 0; rq < 40u; ++rq) {
       const bool wrap = rq >= 32u;
@@ -841,50 +901,42 @@ extern "C" __global__ void __launch_bounds__(512) ipcr_index_filter(const u32* _
         const u32 code = ((qlo[t] >> b) & 1u) | (((qhi[t] >> b) & 1u) << 1);
         km = (km << 2) | code;
         im = (im << 2) | ((qiv[t] >> b) & 1u);
-        const int erow = (int)(rq * 4u + t);
+        const u32 erow = rq * 4u + t;
         u32 keys[NS];
         u32 hitmask = 0;
         probe_all<0>(km, im, lds, keys, hitmask);
-        while (hitmask) {
-          const u32 s = (u32)__builtin_ctz(hitmask);
-          hitmask &= hitmask - 1u;
-          u32 key = 0;
+        if (__ballot(hitmask != 0u) != 0ull) {
 #pragma unroll
-          for (int u = 0; u < NS; ++u) key = ((u32)u == s) ? keys[u] : key;
-          const u32 tag = (s << 16) | key;
-          u32 h = (tag * 2654435761u) & table_mask;
-          for (;;) {
-            const v4 e0 = table[h * 4u];
-            if (e0.x == 0xFFFFFFFFu) break;
-            if (e0.x == tag) {
-              const v4 e1 = table[h * 4u + 1u], e2 = table[h * 4u + 2u], e3 = table[h * 4u + 3u];
-              const u64 okA = ((u64)e0.w << 32) | e0.z, okC = ((u64)e1.y << 32) | e1.x;
-              const u64 okG = ((u64)e1.w << 32) | e1.z, okT = ((u64)e2.y << 32) | e2.x;
-              const u64 prot2 = ((u64)e2.w << 32) | e2.z;
-              const u32 L = e3.x, left = e3.y;
-              const u32 sft = left ? 64u - 2u * L : 0u;
-              const u64 x = km >> sft, iv = im >> sft;
-              const u64 wm = (L >= 32u) ? ~0ull : ((1ull << (2u * L)) - 1ull);
-              const u64 E = 0x5555555555555555ull;
-              const u64 lo = x & E, hi = (x >> 1) & E;
-              const u64 match = (~lo & ~hi & okA) | (lo & ~hi & okC) | (~lo & hi & okG) | (lo & hi & okT);
-              const u64 mm2 = ((~match & E) | iv) & wm;
-              const int srow = left ? erow - 31 : erow - (int)L + 1;
-              if ((mm2 & prot2) == 0ull && (u32)__popcll(mm2) <= max_mm && srow >= 0 && srow < 128) {
-                const u32 shard = (u32)cp & 255u;
-                const u64 idx = atomicAdd(qcount + shard * 16u, 1ull);
-                if (idx < qcap) { qent qe; qe.key = ((u64)e0.y << 48) | (strand_base + (u64)srow); qe.bits = 1u; qe.pad = 0u; queue[(u64)shard * qcap + idx] = qe; }
+          for (int s = 0; s < NS; ++s) {
+            const bool mine = (hitmask >> s) & 1u;
+            const u64 bal = __ballot(mine);
+            if (bal != 0ull) {
+              const u32 n = (u32)__popcll(bal);
+              if (qn + n > QCAP) flush();
+              if (mine) {
+                const u32 slot = qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                u32* e = wq + slot * QWORDS;
+                e[0] = (u32)km; e[1] = (u32)(km >> 32); e[2] = (u32)im; e[3] = (u32)(im >> 32);
+                e[4] = ((u32)s << 16) | keys[s]; e[5] = lane | (erow << 6);
               }
+              qn += n;
             }
-            h = (h + 1u) & table_mask;
           }
+          if (qn >= 64u) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); flush(); }
         }
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    flush(); // `where` is relative to this column pair
   }
 }
 )SRC";
     return s.str();
+}
+
+static unsigned index_lds_bytes(unsigned nshapes) { // bitmaps + group prefixes + first-entry indices (build_index) + 8 hit queues
+    const unsigned image = nshapes * (IPCR_INDEX_BITMAP_WORDS * 4u + IPCR_INDEX_GROUPS * 2u + 4u);
+    return ((image + 15u) & ~15u) + 8u * 128u * 24u;
 }
 
 JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, std::string &err) {
@@ -908,22 +960,24 @@ JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, std::str
         jit_destroy(f);
         return nullptr;
     }
-    const unsigned lds = (unsigned)shapes.size() * 8192u;
+    const unsigned lds = index_lds_bytes((unsigned)shapes.size());
     if (lds > 48u * 1024u) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(f->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     return f;
 }
 
 hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint32_t nshapes,
-                            const uint32_t *bitmaps, const void *table, uint32_t table_mask, uint32_t max_mm, void *queue,
+                            const uint32_t *lds_image, const void *table, uint32_t max_mm, void *queue,
                             uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0) return hipSuccess;
     uint64_t ncolpairs = nblocks * 32u;
-    const unsigned lds = nshapes * 8192u;
+    const unsigned lds = index_lds_bytes(nshapes);
+    // persistent 8-wave workgroups: the bitmaps are staged into LDS once per workgroup; as many
+    // workgroups per CU as the 160 KiB of LDS admit (at most 4 = all 32 wave slots)
     unsigned per_cu = (160u * 1024u) / (lds ? lds : 1u);
     per_cu = per_cu < 1u ? 1u : (per_cu > 4u ? 4u : per_cu);
     uint64_t grid = 256ull * per_cu;
     if (grid * 8u > ncolpairs) grid = (ncolpairs + 7u) / 8u;
-    void *args[] = {(void *)&planes, (void *)&ncolpairs, (void *)&bitmaps, (void *)&table, (void *)&table_mask,
+    void *args[] = {(void *)&planes, (void *)&ncolpairs, (void *)&lds_image, (void *)&table,
                     (void *)&max_mm, (void *)&queue, (void *)&qcap, (void *)&qcount};
     return hipExtModuleLaunchKernel(f->fn, (unsigned)grid * 512u, 1, 1, 512, 1, 1, lds, st, args, nullptr, start, stop, 0);
 }

@@ -48,11 +48,11 @@ struct JitVerify {
 };
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,
                       uint64_t qcap, unsigned long long *qcount, const JitVerify &v, hipEvent_t start, hipEvent_t stop);
-// seed-index filter specialised on the panel's key shapes (same results as kernels.hip's)
+// seed-index filter for large panels, with the panel's key shapes baked in (host.cpp: build_index)
 std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes);
 JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, std::string &err);
 hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint32_t nshapes,
-                            const uint32_t *bitmaps, const void *table, uint32_t table_mask, uint32_t max_mm, void *queue,
+                            const uint32_t *lds_image, const void *table, uint32_t max_mm, void *queue,
                             uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop);
 void jit_destroy(JitFilter *f);
 

@@ -220,134 +220,6 @@ template __global__ void filter_generic_kernel<17>(const uint32_t *, uint64_t, c
                                                    uint32_t, const uint32_t *, ipcr_queue_entry *, uint64_t,
                                                    unsigned long long *);
 
-// ------------------------------------------------------------------ seed-index filter
-// For panels too large to unroll into code (thousands of patterns): cost per genome base is
-// independent of the panel size.  One THREAD walks one strand (bit `bit` of column `col`) down
-// its 128 rows plus 32 rows of the next strand, keeping the last 32 bases as a rolling 2-bit
-// k-mer (and an invalid-base mask).  At every base, each shape's key is cut out of the k-mer and
-// looked up in a 64-Kbit bitmap in LDS; on a hit the (shape,key) -> patterns hash table in
-// global memory (L2-resident) is probed and each listed pattern is checked exactly with a 2-bit
-// XOR/popcount against the k-mer (pure-ACGT patterns only; others go to the table-driven
-// kernel).  Survivors are queued for the verifier like every other filter's.
-template <int NS>
-__global__ __launch_bounds__(512) void filter_index_kernel(const uint32_t *__restrict__ planes, uint64_t ncolpairs,
-                                                            const ipcr_index_shape *__restrict__ shapes, uint32_t nshapes,
-                                                            const uint32_t *__restrict__ bitmaps,
-                                                            const ipcr_index_entry *__restrict__ table, uint32_t table_mask,
-                                                            const ipcr_index_meta *__restrict__ /*meta: folded into the table entries*/, uint32_t max_mm,
-                                                            ipcr_queue_entry *__restrict__ queue, uint64_t qcap,
-                                                            unsigned long long *__restrict__ qcount) {
-    extern __shared__ uint32_t lds_bitmaps[]; // nshapes * 2048 words, staged once per (persistent) workgroup
-    for (uint32_t i = threadIdx.x; i < nshapes * IPCR_INDEX_BITMAP_WORDS; i += blockDim.x) lds_bitmaps[i] = bitmaps[i];
-    __syncthreads();
-    // shape parameters are wave-uniform: keep them in (scalar) registers for the whole kernel
-    uint32_t s_tw_shift[NS], s_blk_shift[NS], s_tw_bits[NS], s_tw_mask[NS], s_blk_mask[NS];
-    uint64_t s_valid[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const bool on = (uint32_t)s < nshapes;
-        const ipcr_index_shape sh = shapes[on ? s : 0];
-        s_tw_shift[s] = sh.tw_shift; s_blk_shift[s] = sh.blk_shift; s_tw_bits[s] = sh.tw_bits;
-        s_tw_mask[s] = sh.tw_mask; s_blk_mask[s] = sh.blk_mask;
-        s_valid[s] = on ? sh.valid_mask : ~0ull; // all-ones never passes once a k-mer is being tracked (odd bits are 0 in im, but
-                                                 // the guard below also tests `on`)
-    }
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t half = lane >> 5, bit = lane & 31u;
-    const uint64_t wave0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    for (uint64_t cp = wave0; cp < ncolpairs; cp += nwaves) {
-        const uint64_t col = cp * 2u + half;
-        // successor strand for the wrap rows: next bit of the same column, or bit 0 of the next column
-        const uint64_t ncol = (bit == 31u) ? col + 1u : col;
-        const uint32_t nbit = (bit + 1u) & 31u;
-        const uint64_t strand_base = ((col << 5) + bit) << IPCR_TILE_LOG_N;
-        uint64_t km = 0, im = 0x5555555555555555ull; // nothing seen yet = all invalid
-        for (uint32_t rq = 0; rq < 40u; ++rq) { // 32 row quads of the strand + 8 of the next
-            const bool wrap = rq >= 32u;
-            const uint64_t c = wrap ? ncol : col;
-            const uint32_t b = wrap ? nbit : bit;
-            const uint32_t r0 = (rq & 31u) * 4u;
-            const uint64_t w = ipcr_plane_word(c >> 6, r0, 0, (uint32_t)(c & 63u));
-            const uint4 qlo = *reinterpret_cast<const uint4 *>(planes + w);
-            const uint4 qhi = *reinterpret_cast<const uint4 *>(planes + w + 256u);
-            const uint4 qiv = *reinterpret_cast<const uint4 *>(planes + w + 512u);
-            const uint32_t alo[4] = {qlo.x, qlo.y, qlo.z, qlo.w};
-            const uint32_t ahi[4] = {qhi.x, qhi.y, qhi.z, qhi.w};
-            const uint32_t aiv[4] = {qiv.x, qiv.y, qiv.z, qiv.w};
-#pragma unroll
-            for (uint32_t t = 0; t < 4u; ++t) {
-                const uint32_t code = ((alo[t] >> b) & 1u) | (((ahi[t] >> b) & 1u) << 1);
-                km = (km << 2) | code;
-                im = (im << 2) | ((aiv[t] >> b) & 1u);
-                const int32_t erow = (int32_t)(rq * 4u + t); // row of the newest base, own-strand coordinates
-                // all shapes' bitmap probes are issued together (independent LDS reads)
-                uint32_t keys[NS], words[NS];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    keys[s] = ((uint32_t)(km >> s_tw_shift[s]) & s_tw_mask[s]) |
-                              (((uint32_t)(km >> s_blk_shift[s]) & s_blk_mask[s]) << s_tw_bits[s]);
-                    words[s] = lds_bitmaps[((uint32_t)s < nshapes ? s : 0) * IPCR_INDEX_BITMAP_WORDS + (keys[s] >> 5)];
-                }
-                uint32_t hitmask = 0;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const bool ok = (uint32_t)s < nshapes && (im & s_valid[s]) == 0ull && ((words[s] >> (keys[s] & 31u)) & 1u);
-                    hitmask |= ok ? (1u << s) : 0u;
-                }
-                while (hitmask) { // some key is in the panel: look the patterns up and check them exactly
-                    const uint32_t s = (uint32_t)__builtin_ctz(hitmask);
-                    hitmask &= hitmask - 1u;
-                    uint32_t key = 0;
-#pragma unroll
-                    for (int u = 0; u < NS; ++u) key = ((uint32_t)u == s) ? keys[u] : key;
-                    const uint32_t tag = (s << 16) | key;
-                    uint32_t h = (tag * 2654435761u) & table_mask;
-                    for (;;) {
-                        const uint4 e0 = reinterpret_cast<const uint4 *>(table)[h * 4u];
-                        if (e0.x == 0xFFFFFFFFu) break;
-                        ipcr_index_entry e;
-                        e.tag = e0.x; e.pattern = e0.y;
-                        if (e.tag == tag) {
-                            const uint4 e1 = reinterpret_cast<const uint4 *>(table)[h * 4u + 1u];
-                            const uint4 e2 = reinterpret_cast<const uint4 *>(table)[h * 4u + 2u];
-                            const uint4 e3 = reinterpret_cast<const uint4 *>(table)[h * 4u + 3u];
-                            e.ok[0] = ((uint64_t)e0.w << 32) | e0.z;
-                            e.ok[1] = ((uint64_t)e1.y << 32) | e1.x;
-                            e.ok[2] = ((uint64_t)e1.w << 32) | e1.z;
-                            e.ok[3] = ((uint64_t)e2.y << 32) | e2.x;
-                            e.prot2 = ((uint64_t)e2.w << 32) | e2.z;
-                            e.len = e3.x; e.left = e3.y;
-                            const uint32_t L = e.len;
-                            const uint32_t sft = e.left ? 64u - 2u * L : 0u;
-                            const uint64_t x = km >> sft, iv = im >> sft;
-                            const uint64_t wm = (L >= 32u) ? ~0ull : ((1ull << (2u * L)) - 1ull);
-                            const uint64_t E = 0x5555555555555555ull;
-                            const uint64_t lo = x & E, hi = (x >> 1) & E;
-                            const uint64_t match = (~lo & ~hi & e.ok[0]) | (lo & ~hi & e.ok[1]) | (~lo & hi & e.ok[2]) | (lo & hi & e.ok[3]);
-                            const uint64_t mm2 = ((~match & E) | iv) & wm;
-                            const int32_t srow = e.left ? erow - 31 : erow - (int32_t)L + 1;
-                            if ((mm2 & e.prot2) == 0ull && (uint32_t)__popcll(mm2) <= max_mm && srow >= 0 &&
-                                srow < (int32_t)IPCR_TILE_N) {
-                                const uint32_t shard = (uint32_t)cp & (IPCR_QUEUE_SHARDS - 1u);
-                                const unsigned long long idx = atomicAdd(qcount + shard * IPCR_QUEUE_COUNTER_STRIDE, 1ull);
-                                if (idx < qcap) {
-                                    ipcr_queue_entry qe;
-                                    qe.key = ((uint64_t)e.pattern << 48) | (strand_base + (uint64_t)srow);
-                                    qe.bits = 1u;
-                                    qe.pad = 0;
-                                    queue[(uint64_t)shard * qcap + idx] = qe;
-                                }
-                            }
-                        }
-                        h = (h + 1u) & table_mask;
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------ verify
 // verifyAt (core/engine/ac.go:186-213) / the inner loop of FindMatches
 // (core/primer/match.go:67-84) for one candidate per thread, straight from the tiles.
@@ -614,42 +486,6 @@ hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_
         hipExtLaunchKernelGGL(filter_generic_kernel<17>, grid, dim3(256), 0, st, start, stop, 0, planes, nblocks, pats,
                               npat, max_mm, sel, queue, qcap, qcount);
     return hipGetLastError();
-}
-
-template <int NS>
-static hipError_t launch_index_ns(hipStream_t st, const uint32_t *planes, uint64_t ncolpairs, const ipcr_index_shape *shapes,
-                                  uint32_t nshapes, const uint32_t *bitmaps, const ipcr_index_entry *table,
-                                  uint32_t table_mask, const ipcr_index_meta *meta, uint32_t max_mm, ipcr_queue_entry *queue,
-                                  uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop) {
-    const uint32_t lds = nshapes * IPCR_INDEX_BITMAP_WORDS * 4u;
-    if (lds > 48u * 1024u) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(filter_index_kernel<NS>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    // persistent 8-wave workgroups: the bitmaps are staged into LDS once per workgroup; as many
-    // workgroups per CU as the 160 KiB of LDS admit (at most 4 = all 32 wave slots)
-    uint32_t per_cu = (160u * 1024u) / (lds ? lds : 1u);
-    per_cu = per_cu < 1u ? 1u : (per_cu > 4u ? 4u : per_cu);
-    uint64_t grid = 256ull * per_cu;
-    if (grid * 8u > ncolpairs) grid = (ncolpairs + 7u) / 8u;
-    hipExtLaunchKernelGGL(filter_index_kernel<NS>, dim3((uint32_t)grid), dim3(512), lds, st, start, stop, 0, planes,
-                          ncolpairs, shapes, nshapes, bitmaps, table, table_mask, meta, max_mm, queue, qcap, qcount);
-    return hipGetLastError();
-}
-
-hipError_t launch_filter_index(hipStream_t st, const uint32_t *planes, uint64_t nblocks,
-                               const ipcr_index_shape *shapes, uint32_t nshapes, const uint32_t *bitmaps,
-                               const ipcr_index_entry *table, uint32_t table_mask, const ipcr_index_meta *meta,
-                               uint32_t max_mm, ipcr_queue_entry *queue, uint64_t qcap, unsigned long long *qcount,
-                               hipEvent_t start, hipEvent_t stop) {
-    if (nblocks == 0 || nshapes == 0) return hipSuccess;
-    const uint64_t ncolpairs = nblocks * 32u;
-    if (nshapes <= 4u)
-        return launch_index_ns<4>(st, planes, ncolpairs, shapes, nshapes, bitmaps, table, table_mask, meta, max_mm, queue, qcap, qcount, start, stop);
-    if (nshapes <= 8u)
-        return launch_index_ns<8>(st, planes, ncolpairs, shapes, nshapes, bitmaps, table, table_mask, meta, max_mm, queue, qcap, qcount, start, stop);
-    return launch_index_ns<IPCR_INDEX_MAX_SHAPES>(st, planes, ncolpairs, shapes, nshapes, bitmaps, table, table_mask, meta, max_mm, queue, qcap, qcount, start, stop);
 }
 
 hipError_t launch_verify(hipStream_t st, const uint32_t *planes, const uint32_t *rst,

@@ -14,11 +14,6 @@ hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_
                                  const ipcr_dev_pattern *pats, uint32_t npat, uint32_t max_mm, const uint32_t *sel,
                                  ipcr_queue_entry *queue, uint64_t qcap, unsigned long long *qcount,
                                  hipEvent_t start, hipEvent_t stop);
-hipError_t launch_filter_index(hipStream_t st, const uint32_t *planes, uint64_t nblocks,
-                               const ipcr_index_shape *shapes, uint32_t nshapes, const uint32_t *bitmaps,
-                               const ipcr_index_entry *table, uint32_t table_mask, const ipcr_index_meta *meta,
-                               uint32_t max_mm, ipcr_queue_entry *queue, uint64_t qcap, unsigned long long *qcount,
-                               hipEvent_t start, hipEvent_t stop);
 hipError_t launch_verify(hipStream_t st, const uint32_t *planes, const uint32_t *rst,
                          const ipcr_dev_pattern *pats, uint32_t max_mm, const uint64_t *rec_start,
                          const uint64_t *rec_len, uint32_t nrec, uint32_t check_rst, const ipcr_queue_entry *queue,
