@@ -55,3 +55,75 @@ def test_config_c2_full_size_properties():
     r, start, _ = plants[0]
     assert genome.read(r, start, 180) == bytes(host0[start:start + 180]) if r == 0 else True
     genome.close()
+
+
+def test_config_c3_full_size_properties():
+    """BASELINE.json configs[2]: 27F/1492R with IUPAC codes, k=3, --circular, 3.0 Gb.  Planted sites use
+    concrete bases for the ambiguity codes (M -> A/C, Y -> C/T) and up to three substitutions outside the 3'
+    window; one amplicon per record spans the origin.  Checked: every plant comes back with its mismatch
+    positions, hit lists are sorted and unique, scans are idempotent, and a 20 Mb window of record 0 around two
+    plants agrees with the CPU oracle (linear scan of the same bytes)."""
+    torch = pytest.importorskip("torch")
+    import random
+    from ipcr_amd import engine, primer, workloads
+
+    rng = random.Random(303)
+    pairs = workloads.c3_pairs()
+    fwd, rev = pairs[0].Forward, pairs[0].Reverse
+    rc_rev = primer.RevComp(rev).decode()
+    nrec, reclen = 24, 125_000_000
+    cfg = engine.Config(MaxMM=3, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12, Circular=True)
+    eng = engine.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    sc = eng.NewSimulationScratch(cp)
+
+    def concrete(s):
+        return "".join(rng.choice([b for b in "ACGT" if O.base_match(b, ch)]) for ch in s)
+
+    genome = engine.Genome(nrec * reclen, nrec)
+    buf = torch.empty(reclen, dtype=torch.uint8, device="cuda:0")
+    plants, host0 = [], None
+    for r in range(nrec):
+        engine.lcg_fill_device(buf.data_ptr(), reclen, 0x5eed3333 + r)
+        for t in range(20):
+            start = 1_000_000 + t * 6_000_000 + rng.randrange(1000)
+            site = list(concrete(fwd))
+            idx = sorted(rng.sample(range(0, len(fwd) - 3), rng.choice([0, 1, 2, 3])))   # 3' window stays clean
+            for j in idx:
+                site[j] = O.different_base(site[j]) if fwd[j] in "ACGT" else site[j]
+            idx = tuple(j for j in idx if fwd[j] in "ACGT")
+            buf[start:start + len(fwd)] = torch.tensor(list("".join(site).encode()), dtype=torch.uint8)
+            buf[start + 400 - len(rc_rev):start + 400] = torch.tensor(list(concrete(rc_rev).encode()), dtype=torch.uint8)
+            plants.append((r, start, idx))
+        # origin-spanning amplicon: forward site near the end, reverse site near the start of the record
+        buf[reclen - 150:reclen - 150 + len(fwd)] = torch.tensor(list(concrete(fwd).encode()), dtype=torch.uint8)
+        buf[100:100 + len(rc_rev)] = torch.tensor(list(concrete(rc_rev).encode()), dtype=torch.uint8)
+        torch.cuda.synchronize()
+        if r == 0:
+            host0 = buf[:20_000_000].cpu().numpy().copy()
+        genome.add_record_device("chr%d" % (r + 1), buf.data_ptr(), reclen)
+    del buf
+
+    prods = eng.ScanGenome(genome, cp, sc)
+    assert sc.stats().kernel_kind == 1
+    found = {(p.Record, p.Start): p for p in prods if p.ExperimentID == "16S" and p.Type == "forward" and p.Length == 400}
+    for (r, start, idx) in plants:
+        p = found[(r, start)]
+        assert (p.FwdMM, p.FwdMismatchIdx, p.RevMM) == (len(idx), idx, 0), (r, start, idx, p)
+    wraps = [p for p in prods if p.ExperimentID == "16S" and p.Type == "forward" and p.Start > p.End]
+    assert {p.Record for p in wraps} == set(range(nrec))
+    assert all(p.Start == reclen - 150 and p.End == 100 + len(rc_rev) and p.Length == 150 + 100 + len(rc_rev) for p in wraps)
+    hits = sc.hits()
+    keys = [(h.Record, h.Pattern, h.Pos) for h in hits]
+    assert keys == sorted(keys) and len(set(keys)) == len(keys) and all(h.Mismatches <= 3 for h in hits)
+    again = eng.ScanGenome(genome, cp, sc)
+    assert [p.sig() for p in again] == [p.sig() for p in prods]
+    # a 20 Mb prefix of record 0 against the CPU oracle (linear: the prefix is not a circular record)
+    lin = engine.Config(MaxMM=3, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12, Circular=False)
+    want = O.simulate_batch(O.Config(max_mm=3, terminal_window=3, max_len=2000, hit_cap=10000, seed_len=12),
+                            bytes(host0), [O.Pair(p.ID, p.Forward, p.Reverse, p.MinProduct, p.MaxProduct) for p in pairs])
+    got = engine.New(lin).SimulateBatch("chr1", bytes(host0), pairs)
+    assert [g.sig() for g in got] == [w.sig() for w in want] and len(want) >= 4
+    inside = [p.sig() for p in prods if p.Record == 0 and p.Start <= p.End and p.End <= 20_000_000 - 2000]
+    assert inside == [w.sig() for w in want if w.end <= 20_000_000 - 2000]
+    genome.close()
