@@ -64,6 +64,54 @@ def split_chunk_suffix(seq_id: str):
     return seq_id[:colon], start, True
 
 
+def compute_overlap(max_len: int, max_primer_len: int) -> int:
+    """runutil.ComputeOverlap -- internal/runutil/runutil.go:20-31"""
+    if max_len > 0:
+        return max_len
+    return max(max_primer_len - 1, 0)
+
+
+def validate_chunking(circular: bool, chunk_size: int, max_len: int, max_primer_len: int):
+    """runutil.ValidateChunking -- internal/runutil/runutil.go:33-62: (chunk, overlap, warnings)"""
+    if chunk_size <= 0:
+        return 0, 0, []
+    if circular:
+        return 0, 0, ["chunking disabled for circular templates"]
+    if max_len <= 0:
+        return 0, 0, ["chunking disabled: a finite effective max product length is required to compute safe overlap"]
+    if chunk_size <= max_len:
+        return 0, 0, [f"chunk-size ({chunk_size}) <= effective max product length ({max_len}): disabling chunking"]
+    return chunk_size, compute_overlap(max_len, max_primer_len), []
+
+
+class Collector:
+    """The pipeline's collector goroutine -- internal/pipeline/pipeline.go:127-161: chunk-local coordinates become
+    record-global ones (any ID ending ':<int>-...' counts as a chunk, ids.go:11-27), products seen in the overlap
+    of two chunks are dropped by a bounded FIFO/LRU set (runutil/lru_set.go, default 200 000 keys)."""
+
+    def __init__(self, cap: int = 0):
+        from collections import OrderedDict
+        self.cap = cap if cap > 0 else 200_000
+        self.seen = OrderedDict()
+
+    def add(self, source_file: str, p: engine.Product):
+        base, off, ok = split_chunk_suffix(p.SequenceID)
+        if not ok:
+            base, off = p.SequenceID, 0
+        gs, ge = p.Start + off, p.End + off
+        k = (base, source_file, gs, ge, p.Type, p.ExperimentID)
+        if k in self.seen:
+            self.seen.move_to_end(k, last=False)
+            return None
+        self.seen[k] = True
+        self.seen.move_to_end(k, last=False)
+        if len(self.seen) > self.cap:
+            self.seen.popitem(last=True)
+        if ok:
+            p.SequenceID, p.Start, p.End = base, gs, ge
+        return p
+
+
 def product_sort_key(source_file: str, p: engine.Product):
     """common.LessProduct -- internal/common/sort.go:34-78 as a sort key."""
     base, off, ok = split_chunk_suffix(p.SequenceID)
@@ -101,6 +149,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--probe-max-mm", "-M", type=int, default=0)
     ap.add_argument("--require-probe", action=argparse.BooleanOptionalAction, default=True)
     ap.add_argument("--no-match-exit-code", type=int, default=0)
+    ap.add_argument("--chunk-size", type=int, default=0, help="scan rolling chunks through ipcr_scan_chunk (0 = whole records resident)")
+    ap.add_argument("--dedup-cap", type=int, default=0)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("fasta", nargs="*")
     return ap
@@ -137,7 +187,27 @@ def run(argv: Optional[Sequence[str]] = None, stdout=None, stderr=None) -> int:
     cp = eng.CompilePanel(pairs)
     sc = eng.NewSimulationScratch(cp)
     rows = []
+    max_primer_len = max((max(len(p.Forward), len(p.Reverse)) for p in pairs), default=0)
+    chunk, overlap, warns = validate_chunking(o.circular, o.chunk_size, cfg.MaxLen, max_primer_len)
+    if chunk and o.probe:
+        chunk, warns = 0, warns + ["chunking disabled: the probe rescan reads amplicons from the resident genome"]
+    for w in warns:
+        print(f"warning: {w}", file=stderr)
+    collector = Collector(o.dedup_cap)
     for path in seq_files:
+        if chunk:
+            # the reference's data path: every rolling chunk goes through the engine on its own
+            # (ForEachCompiledProduct = ipcr_scan_chunk), the collector restores record coordinates
+            from . import fasta
+            try:
+                for rec in fasta.StreamChunks(path, chunk, overlap):
+                    for p in eng.SimulateCompiledWithScratch(rec.ID, rec.Seq, cp, sc):
+                        p = collector.add(path, p)
+                        if p is not None:
+                            rows.append((path, p, None))
+            except _lib.IpcrError as e:
+                print(f"error: {e}", file=stderr)
+            continue
         size = os.path.getsize(path) if path != "-" and os.path.exists(path) else (1 << 28)
         factor = 8 if path.endswith(".gz") else 1
         g = engine.Genome(max(size * factor, 1 << 20), max_records=1 << 16)
@@ -166,6 +236,13 @@ def run(argv: Optional[Sequence[str]] = None, stdout=None, stderr=None) -> int:
                 site = amp.upper()[h.pos:h.pos + len(primer.Normalize(o.probe))].decode()
             rows.append((path, p, (h, site)))
         g.close()
+    if not chunk:  # the collector sees every product in the reference, chunked or not (ids.go quirk included)
+        kept = []
+        for path, p, ph in rows:
+            p = collector.add(path, p)
+            if p is not None:
+                kept.append((path, p, ph))
+        rows = kept
     if o.sort:
         rows.sort(key=lambda t: product_sort_key(t[0], t[1]))
     if not o.no_header:

@@ -141,3 +141,34 @@ def test_cli_end_to_end_matches_oracle(tmp_path):
     lines = out.getvalue().splitlines()
     assert rc == 0 and lines[0] == cli.TSV_HEADER_PROBE and len(lines) >= 2
     assert all(l.split("\t")[13] == "true" for l in lines[1:])
+
+
+def test_chunking_rules():  # internal/runutil/runutil_test.go:20-59
+    assert cli.compute_overlap(100, 21) == 100 and cli.compute_overlap(0, 21) == 20
+    assert cli.validate_chunking(False, 0, 500, 25) == (0, 0, [])
+    for args in ((True, 1000, 500, 25), (False, 1000, 0, 25), (False, 500, 500, 25)):
+        cs, ov, warns = cli.validate_chunking(*args)
+        assert (cs, ov) == (0, 0) and len(warns) == 1
+    assert cli.validate_chunking(False, 2000, 500, 25) == (2000, 500, [])
+
+
+def test_sort_uses_source_and_global_chunk_coords():  # internal/common/sort_score_test.go:24-42
+    P = engine.Product
+    ps = [("b.fa", P("x", "s", 0, 8, 8, "forward", 0, 0, (), ())),
+          ("a.fa", P("x", "s:10-20", 2, 8, 6, "forward", 0, 0, (), ())),
+          ("a.fa", P("x", "s", 4, 10, 6, "forward", 0, 0, (), ()))]
+    ps.sort(key=lambda t: cli.product_sort_key(t[0], t[1]))
+    assert [(f, p.SequenceID, p.Start) for f, p in ps] == [("a.fa", "s", 4), ("a.fa", "s:10-20", 2), ("b.fa", "s", 0)]
+
+
+def test_collector_rebases_and_dedups():  # internal/pipeline/pipeline.go:127-161, runutil/lru_set.go
+    P = engine.Product
+    c = cli.Collector(cap=2)
+    a = c.add("f.fa", P("x", "s:100-200", 5, 25, 20, "forward", 0, 0, (), ()))
+    assert (a.SequenceID, a.Start, a.End) == ("s", 105, 125)
+    assert c.add("f.fa", P("x", "s:90-190", 15, 35, 20, "forward", 0, 0, (), ())) is None      # same global product
+    assert c.add("g.fa", P("x", "s:90-190", 15, 35, 20, "forward", 0, 0, (), ())) is not None  # other file
+    b = c.add("f.fa", P("x", "plain", 1, 9, 8, "revcomp", 0, 0, (), ()))
+    assert (b.SequenceID, b.Start) == ("plain", 1)
+    # capacity 2: the first key has been evicted by now and is accepted again (bounded de-dup, as in the reference)
+    assert c.add("f.fa", P("x", "s:100-200", 5, 25, 20, "forward", 0, 0, (), ())) is not None

@@ -116,3 +116,52 @@ def test_cli_uses_record_ids_from_loader(tmp_path):
     rows = out.getvalue().splitlines()
     assert rc == 0 and rows[0] == cli.TSV_HEADER
     assert any(row.split("\t")[1] == "chrA" for row in rows[1:])
+
+
+def _cli(args):
+    import io
+    from ipcr_amd import cli
+    out, err = io.StringIO(), io.StringIO()
+    rc = cli.run(args, stdout=out, stderr=err)
+    assert rc == 0, err.getvalue()
+    return out.getvalue(), err.getvalue()
+
+
+def test_chunking_keeps_boundary_hits(tmp_path):  # internal/integration/integration_test.go:125-225
+    """--chunk-size output == unchunked output: rolling chunks through ipcr_scan_chunk, collector rebasing and
+    de-duplication (internal/pipeline/pipeline.go:127-161) against the resident whole-record scan"""
+    fa = tmp_path / "chunk.fa"
+    fa.write_text(">s\nACGTACGTACGTACGTACGTACGTACGT\n")
+    base = ["--forward", "ACGTAC", "--reverse", "ACGTAC", "--sort", "--max-length", "8"]
+    whole, _ = _cli(base + [str(fa)])
+    chunked, _ = _cli(base + ["--chunk-size", "16", str(fa)])
+    assert whole == chunked and len(whole.splitlines()) > 3
+    # chunk-size <= max product length disables chunking with the reference's warning (runutil.go:54-57)
+    same, warn = _cli(base + ["--chunk-size", "8", str(fa)])
+    assert same == whole and "disabling chunking" in warn
+
+
+def test_chunked_equals_unchunked_on_planted_records(tmp_path):
+    import ipcr_oracle as O
+    rng = random.Random(91)
+    fwd, rev = "ACGTTGCATGCAAGCTTA", "GGCCTTAAGGCCATATCG"
+    rc = O.revcomp(rev).decode()
+    recs = []
+    for r in range(3):
+        s = list(O.bench_dna(60000 + 777 * r, 500 + r).decode())
+        for t in range(12):                     # amplicons everywhere, many across chunk boundaries
+            a = 300 + t * 4900 + rng.randrange(50)
+            ln = rng.choice([150, 400, 900])
+            s[a:a + len(fwd)] = fwd
+            s[a + ln - len(rc):a + ln] = rc
+        if r == 1:
+            s[20000:20040] = "N" * 40
+        recs.append(("ctg%d" % r, "".join(s)))
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(">%s desc\n%s\n" % (i, "\n".join(s[j:j + 60] for j in range(0, len(s), 60))) for i, s in recs))
+    base = ["-f", fwd, "-r", rev, "-m", "1", "--sort", "--max-length", "1000"]
+    whole, _ = _cli(base + [str(fa)])
+    assert len(whole.splitlines()) >= 30
+    for cs in (5000, 7777, 20000):
+        chunked, _ = _cli(base + ["--chunk-size", str(cs), str(fa)])
+        assert chunked == whole, cs
