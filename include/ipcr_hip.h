@@ -259,6 +259,32 @@ ipcr_status ipcr_probe_best_hit(const uint8_t *amplicon, uint64_t len, const cha
 ipcr_status ipcr_probe_products(ipcr_scratch *s, const ipcr_genome *g, const char *probe, int32_t max_mm,
                                 ipcr_probe_hit *out, int64_t n_out);
 
+/* ---- nested PCR: visitors.Nested.Visit -- internal/visitors/nested.go:17-66 ----
+ * The reference builds a new engine and scans the amplicon of every outer product on the collector
+ * goroutine.  Batched form: the amplicons of all windows are gathered on the device, packed as the
+ * records of a scratch-private genome and scanned with the compiled inner panel in one launch; per
+ * window the best inner product is chosen by the reference's rule (fewest total mismatches, longest,
+ * leftmost start, end, pair ID).  Coordinates of the inner product are relative to the amplicon.
+ * A window with start > end is an origin-spanning amplicon (record[start:] ++ record[:end]). */
+typedef struct ipcr_window {
+    int64_t start, end;
+    int32_t record;
+    int32_t reserved;
+} ipcr_window;
+typedef struct ipcr_nested_hit {
+    int32_t found;          /* 0: no inner product in this amplicon */
+    int32_t pair;           /* index into the inner panel's pairs */
+    int32_t type;           /* 0 forward, 1 revcomp */
+    int32_t fwd_mm, rev_mm;
+    int32_t reserved;
+    int64_t start, end, length;
+} ipcr_nested_hit;
+ipcr_status ipcr_nested_windows(const ipcr_genome *g, const ipcr_window *windows, int64_t n, const ipcr_panel *inner,
+                                ipcr_scratch *inner_scratch, ipcr_nested_hit *out);
+/* every product of the last scan on `outer` (out[i] <-> product i) */
+ipcr_status ipcr_nested_products(const ipcr_scratch *outer, const ipcr_genome *g, const ipcr_panel *inner,
+                                 ipcr_scratch *inner_scratch, ipcr_nested_hit *out, int64_t n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,16 @@ class ProbeHit(C.Structure):
     _fields_ = [("found", C.c_int32), ("strand", C.c_int32), ("pos", C.c_int32), ("mm", C.c_int32)]
 
 
+class Window(C.Structure):
+    _fields_ = [("start", C.c_int64), ("end", C.c_int64), ("record", C.c_int32), ("reserved", C.c_int32)]
+
+
+class NestedHit(C.Structure):
+    _fields_ = [("found", C.c_int32), ("pair", C.c_int32), ("type", C.c_int32), ("fwd_mm", C.c_int32),
+                ("rev_mm", C.c_int32), ("reserved", C.c_int32), ("start", C.c_int64), ("end", C.c_int64),
+                ("length", C.c_int64)]
+
+
 class ScanStats(C.Structure):
     _fields_ = [("pack_ms", C.c_double), ("filter_ms", C.c_double), ("verify_ms", C.c_double),
                 ("total_ms", C.c_double), ("bases", C.c_uint64), ("tile_bytes", C.c_uint64),
@@ -114,6 +124,8 @@ SYMBOLS = {
                                  C.POINTER(C.c_uint8), C.c_uint32, C.c_void_p, C.c_void_p]),
     "ipcr_probe_best_hit": (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_int32, C.POINTER(ProbeHit)]),
     "ipcr_probe_products": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(ProbeHit), C.c_int64]),
+    "ipcr_nested_windows": (C.c_int, [C.c_void_p, C.POINTER(Window), C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(NestedHit)]),
+    "ipcr_nested_products": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NestedHit), C.c_int64]),
 }
 
 _lib = None

@@ -932,6 +932,7 @@ struct ipcr_scratch {
     ipcr_genome *chunk = nullptr; // private genome of ipcr_scan_chunk
     // probe buffers
     uint8_t *d_amps = nullptr; uint64_t amps_cap = 0;
+    ipcr_genome *nest = nullptr; // amplicons of a nested-PCR batch, one record each (ipcr_nested_windows)
     void *d_probe_misc = nullptr; uint64_t probe_misc_cap = 0;
 };
 
@@ -1580,6 +1581,7 @@ void ipcr_scratch_destroy(ipcr_scratch *s) {
         (void)hipStreamSynchronize(s->stream);
     }
     if (s->chunk) ipcr_genome_destroy(s->chunk);
+    if (s->nest) ipcr_genome_destroy(s->nest);
     if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->d_qcounts) (void)hipFree(s->d_qcounts);
     if (s->d_hitbuf) (void)hipFree(s->d_hitbuf);
@@ -1860,6 +1862,113 @@ ipcr_status ipcr_probe_products(ipcr_scratch *s, const ipcr_genome *g, const cha
     HIPCHK(hipMemcpyAsync(doffs, offs.data(), (n + 1) * 8, hipMemcpyHostToDevice, s->stream));
     HIPCHK(ipcr::launch_gather(s->stream, g->planes, g->rst, dsegs, (uint32_t)n, s->d_amps));
     return run_probe(s->stream, s->d_amps, doffs, (uint32_t)n, prb, max_mm, misc, out);
+}
+
+// ------------------------------------------------------------------------------ nested PCR
+
+ipcr_status ipcr_nested_windows(const ipcr_genome *g, const ipcr_window *windows, int64_t n64, const ipcr_panel *inner,
+                                ipcr_scratch *s, ipcr_nested_hit *out) {
+    ipcr_status st = scratch_ready(inner, s);
+    if (st != IPCR_OK) return st;
+    if (!g || n64 < 0 || (n64 && (!windows || !out))) return fail(IPCR_ERR_INVALID, "ipcr_nested_windows: null argument");
+    const size_t n = (size_t)n64;
+    if (n == 0) return IPCR_OK;
+    memset(out, 0, n * sizeof *out);
+    st = genome_finalize(const_cast<ipcr_genome *>(g)); // the gather below reads the tiles: padding and packing must be complete
+    if (st != IPCR_OK) return st;
+    // amplicon = record[start:end], or record[start:] ++ record[:end] for wrap-around products
+    // (internal/pipeline/pipeline.go:80-89); every amplicon starts 16-byte aligned (pack kernel input)
+    std::vector<ipcr_amp_seg> segs(n);
+    std::vector<uint64_t> offs(n), lens(n);
+    uint64_t off = 0, cols = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const ipcr_window &w = windows[i];
+        if (w.record < 0 || (size_t)w.record >= g->rec_start.size()) return fail(IPCR_ERR_INVALID, "window %zu: record outside the genome", i);
+        const uint64_t rs = g->rec_start[(size_t)w.record], rl = g->rec_len[(size_t)w.record];
+        if (w.start < 0 || w.end < 0 || (uint64_t)w.start > rl || (uint64_t)w.end > rl) return fail(IPCR_ERR_INVALID, "window %zu outside its record", i);
+        ipcr_amp_seg sg{};
+        if (w.start <= w.end) { sg.pa = rs + (uint64_t)w.start; sg.len_a = (uint64_t)(w.end - w.start); sg.pb = rs; sg.len_b = 0; }
+        else { sg.pa = rs + (uint64_t)w.start; sg.len_a = rl - (uint64_t)w.start; sg.pb = rs; sg.len_b = (uint64_t)w.end; }
+        sg.out_off = off;
+        offs[i] = off;
+        lens[i] = sg.len_a + sg.len_b;
+        off = (off + lens[i] + 15) & ~15ull;
+        cols += record_cols(lens[i]);
+        segs[i] = sg;
+    }
+    if (off + 16 > s->amps_cap) {
+        if (s->d_amps) (void)hipFree(s->d_amps);
+        s->d_amps = nullptr;
+        s->amps_cap = off + 16 + (off >> 2);
+        HIPCHK(hipMalloc((void **)&s->d_amps, s->amps_cap));
+    }
+    const uint64_t misc_bytes = n * sizeof(ipcr_amp_seg) + 64;
+    if (misc_bytes > s->probe_misc_cap) {
+        if (s->d_probe_misc) (void)hipFree(s->d_probe_misc);
+        s->d_probe_misc = nullptr;
+        s->probe_misc_cap = misc_bytes * 2;
+        HIPCHK(hipMalloc(&s->d_probe_misc, s->probe_misc_cap));
+    }
+    ipcr_amp_seg *dsegs = static_cast<ipcr_amp_seg *>(s->d_probe_misc);
+    HIPCHK(hipMemcpyAsync(dsegs, segs.data(), n * sizeof(ipcr_amp_seg), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(ipcr::launch_gather(s->stream, g->planes, g->rst, dsegs, (uint32_t)n, s->d_amps));
+    // the amplicons become the records of a private genome on this scratch's stream: no waits between the packs
+    if (!s->nest || s->nest->cap_cols < cols + 64 || s->nest->max_records < n) {
+        if (s->nest) ipcr_genome_destroy(s->nest);
+        s->nest = nullptr;
+        st = ipcr_genome_create((cols + (cols >> 2) + 64) * IPCR_COLUMN_BASES, (uint32_t)std::max<size_t>(n + (n >> 2), 16), &s->nest);
+        if (st != IPCR_OK) return st;
+        (void)hipStreamDestroy(s->nest->stream);
+        s->nest->stream = s->stream;
+        s->nest->shared_stream = true;
+    }
+    genome_clear(s->nest);
+    for (size_t i = 0; i < n; ++i) {
+        st = genome_add_device(s->nest, s->d_amps + offs[i], lens[i], false);
+        if (st != IPCR_OK) return st;
+    }
+    st = scan_hits(inner, s, s->nest);
+    if (st != IPCR_OK) return st;
+    std::vector<uint8_t> fl(n);
+    const bool any = genome_any_reset(s->nest);
+    for (size_t r = 0; r < n; ++r) fl[r] = (uint8_t)((s->nest->flags[r] & 1u) | (any ? 2u : 0u));
+    st = join_sorted_hits(inner, s, s->nest->rec_len.data(), fl.data(), (uint32_t)n, nullptr, nullptr);
+    if (st != IPCR_OK) return st;
+    // best inner product per amplicon: fewest total mismatches, longest, leftmost, end, pair ID (nested.go:35-51);
+    // ties keep the engine's emission order (sort.SliceStable)
+    for (const ipcr_product &pr : s->products) {
+        ipcr_nested_hit &b = out[(size_t)pr.record];
+        bool better = !b.found;
+        if (!better) {
+            const int mi = pr.fwd_mm + pr.rev_mm, mj = b.fwd_mm + b.rev_mm;
+            if (mi != mj) better = mi < mj;
+            else if (pr.length != b.length) better = pr.length > b.length;
+            else if (pr.start != b.start) better = pr.start < b.start;
+            else if (pr.end != b.end) better = pr.end < b.end;
+            else better = inner->id[(size_t)pr.pair] < inner->id[(size_t)b.pair];
+        }
+        if (better) {
+            b.found = 1; b.pair = pr.pair; b.type = pr.type; b.fwd_mm = pr.fwd_mm; b.rev_mm = pr.rev_mm;
+            b.start = pr.start; b.end = pr.end; b.length = pr.length;
+        }
+    }
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_nested_products(const ipcr_scratch *outer, const ipcr_genome *g, const ipcr_panel *inner,
+                                 ipcr_scratch *s, ipcr_nested_hit *out, int64_t n_out) {
+    if (!outer) return fail(IPCR_ERR_INVALID, "ipcr_nested_products: null argument");
+    if (outer == s) return fail(IPCR_ERR_INVALID, "ipcr_nested_products: the inner scan needs a scratch of its own");
+    const size_t n = outer->products.size();
+    if ((int64_t)n != n_out) return fail(IPCR_ERR_INVALID, "n_out (%lld) != products of the last scan (%zu)", (long long)n_out, n);
+    std::vector<ipcr_window> w(n);
+    for (size_t i = 0; i < n; ++i) {
+        w[i].start = outer->products[i].start;
+        w[i].end = outer->products[i].end;
+        w[i].record = outer->products[i].record;
+        w[i].reserved = 0;
+    }
+    return ipcr_nested_windows(g, w.data(), (int64_t)n, inner, s, out);
 }
 
 } // extern "C"
