@@ -18,78 +18,88 @@
 #define IPCR_VERIFY_BLOCKS 1024 // more blocks do not help (latency floor ~30 us), fewer are slower
 
 // ------------------------------------------------------------------------------- pack
-// One wavefront packs 64 consecutive strands (two columns).  Lane = strand: it walks its
-// own 128 contiguous bytes (16 B per load, all 8 loads of a strand hit one 128-B line),
-// and every row is transposed into words with four wave ballots -- no LDS, no atomics.
-// Semantics: inv = byte is not an upper-case A/C/G/T (core/primer/iupac.go:62-67);
-// rst = byte is outside ACGTacgt (core/engine/ac.go:16-30); bases past the record end are
-// inv=1,rst=0 padding.
+// ASCII -> strand-major bit planes.  Bit b of the output word (column, row r) is base r of the column's
+// strand b, i.e. a 32 x 128 byte -> bit transpose per column.  One wavefront packs two columns (8 KB of
+// sequence): it stages them in its own slice of LDS with coalesced 16-byte loads; then lane (h, q) owns
+// row-quad q of column h and walks the 32 strands, four bases (one dword) at a time:
+//  * the four bytes are classified together (SWAR): upper-case fold, a 4-entry byte LUT through
+//    v_perm_b32 (index = bits 1..3 of the letter) gives the letter the byte would have to be, an exact
+//    zero-byte test of the XOR says whether it is one of ACGT -- ~23 ops per dword instead of ~12 per byte;
+//  * the per-byte flags are shifted into SWAR accumulators (one bit per strand and row) and moved to the
+//    four output words every 8 strands.
+// The first version (lane = strand, four wave ballots per row) needed ~30 VALU ops per base and ran at
+// 0.9 Tbases/s; no ballots, no atomics here either.
+// Semantics: inv = byte is not an upper-case A/C/G/T (core/primer/iupac.go:62-67); rst = byte is outside
+// ACGTacgt (core/engine/ac.go:16-30); bases past the record end are inv=1,rst=0 padding (staged as 'a').
+__device__ __forceinline__ uint32_t swar_zero_bytes(uint32_t x) { // 0x80 in every byte of x that is zero, exactly
+    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | x) & 0x80808080u;
+}
+
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ seq, uint64_t len,
                                                    uint64_t col0, uint64_t ncol,
                                                    uint32_t *__restrict__ planes,
                                                    uint32_t *__restrict__ rst,
                                                    uint32_t *__restrict__ rec_flags) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t pairidx = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (pairidx * 2u >= ncol) return;
-    const uint64_t gcol = col0 + pairidx * 2u;
-    const uint64_t base = (pairidx * 64u + lane) * IPCR_TILE_N; // record-local first base of my strand
-    uint32_t saw_rst = 0;
-
-    for (uint32_t rg = 0; rg < 8; ++rg) {
-        const uint64_t p0 = base + rg * 16u;
-        uint32_t w[4] = {0, 0, 0, 0};
-        uint32_t realmask; // bit t: byte t is inside the record
+    __shared__ uint32_t s_in[4][2048]; // per wave: 2 columns x 32 strands x 32 dwords
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t pairidx = (uint64_t)blockIdx.x * 4u + wv;
+    if (pairidx * 2u >= ncol) return; // waves are independent (no workgroup barrier below)
+    uint32_t *mine = s_in[wv];
+    const uint64_t base = pairidx * 2u * IPCR_COLUMN_BASES; // record-local first base of my column pair
+#pragma unroll
+    for (uint32_t it = 0; it < 8u; ++it) {
+        const uint32_t idx = it * 64u + lane; // 16-byte piece of the 8 KB
+        const uint64_t p0 = base + (uint64_t)idx * 16u;
+        uint4 v;
         if (p0 + 16u <= len) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(seq + p0);
-            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            realmask = 0xFFFFu;
+            v = *reinterpret_cast<const uint4 *>(seq + p0);
         } else {
-            realmask = 0;
-            for (uint32_t t = 0; t < 16; ++t) {
-                if (p0 + t < len) {
-                    w[t >> 2] |= (uint32_t)seq[p0 + t] << ((t & 3u) * 8u);
-                    realmask |= 1u << t;
-                }
-            }
+            uint32_t w[4] = {0x61616161u, 0x61616161u, 0x61616161u, 0x61616161u}; // 'a': inv = 1, rst = 0, code 0
+            for (uint32_t t = 0; t < 16u; ++t)
+                if (p0 + t < len) w[t >> 2] = (w[t >> 2] & ~(0xFFu << ((t & 3u) * 8u))) | ((uint32_t)seq[p0 + t] << ((t & 3u) * 8u));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        *reinterpret_cast<uint4 *>(mine + idx * 4u) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // my LDS slice: written and read by this wave only
+    const uint32_t h = lane >> 5, q = lane & 31u;
+    uint32_t olo[4] = {0, 0, 0, 0}, ohi[4] = {0, 0, 0, 0}, oiv[4] = {0, 0, 0, 0}, ors[4] = {0, 0, 0, 0};
+    for (uint32_t g = 0; g < 4u; ++g) {
+        uint32_t alo = 0, ahi = 0, aiv = 0, ars = 0;
+#pragma unroll
+        for (int t = 7; t >= 0; --t) { // strand g*8+7 first: it ends up in bit 7 of its byte lane
+            const uint32_t w = mine[(h * 32u + g * 8u + (uint32_t)t) * 32u + q];
+            const uint32_t u = w & 0xDFDFDFDFu;
+            const uint32_t idx = (u >> 1) & 0x07070707u;                  // A 0, C 1, T 2, G 3 (4..7: no letter of ours)
+            const uint32_t e = __builtin_amdgcn_perm(0u, 0x47544341u, idx); // the letter that index stands for
+            const uint32_t acgt = swar_zero_bytes(e ^ u) >> 7;            // 1 per byte that is one of ACGTacgt
+            const uint32_t lower = (w >> 5) & 0x01010101u;
+            const uint32_t c = (idx ^ (idx >> 1)) & 0x03030303u;           // A 0, C 1, G 2, T 3
+            alo = (alo << 1) | (c & acgt);
+            ahi = (ahi << 1) | ((c >> 1) & acgt);
+            aiv = (aiv << 1) | ((acgt & ~lower) ^ 0x01010101u);
+            ars = (ars << 1) | (acgt ^ 0x01010101u);
         }
 #pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
-            uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0; // lanes 0..7 collect rows 4q..4q+3
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                const uint32_t b = (w[q] >> (k * 8u)) & 0xFFu;
-                const bool real = (realmask >> (q * 4u + k)) & 1u;
-                const uint32_t u = b & 0xDFu;
-                const bool isacgt = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
-                const bool valid = isacgt & (b == u) & real;
-                uint32_t c = (b >> 1) & 3u; // A0 C1 G3 T2
-                c ^= c >> 1;                // A0 C1 G2 T3
-                const bool reset = real & !isacgt;
-                saw_rst |= reset ? 1u : 0u;
-                const uint64_t blo = __ballot(isacgt && (c & 1u));
-                const uint64_t bhi = __ballot(isacgt && (c & 2u));
-                const uint64_t binv = __ballot(!valid);
-                const uint64_t brs = __ballot(reset);
-                // lane 2*plane + half keeps the word of (plane, column half) for this row
-                const uint64_t bsel = (lane < 2u) ? blo : (lane < 4u) ? bhi : (lane < 6u) ? binv : brs;
-                const uint32_t o = (lane & 1u) ? (uint32_t)(bsel >> 32) : (uint32_t)bsel;
-                if (k == 0) o0 = o; else if (k == 1) o1 = o; else if (k == 2) o2 = o; else o3 = o;
-            }
-            const uint32_t row = rg * 16u + q * 4u;
-            if (lane < 8u) {
-                const uint64_t col = gcol + (lane & 1u);
-                const uint64_t block = col >> 6;
-                const uint32_t ln = (uint32_t)(col & 63u);
-                const uint4 out = make_uint4(o0, o1, o2, o3);
-                if (lane < 6u)
-                    *reinterpret_cast<uint4 *>(planes + ipcr_plane_word(block, row, lane >> 1, ln)) = out;
-                else
-                    *reinterpret_cast<uint4 *>(rst + ipcr_rst_word(block, row, ln)) = out;
-            }
+        for (uint32_t k = 0; k < 4u; ++k) {
+            olo[k] |= ((alo >> (8u * k)) & 0xFFu) << (8u * g);
+            ohi[k] |= ((ahi >> (8u * k)) & 0xFFu) << (8u * g);
+            oiv[k] |= ((aiv >> (8u * k)) & 0xFFu) << (8u * g);
+            ors[k] |= ((ars >> (8u * k)) & 0xFFu) << (8u * g);
         }
     }
-    if (__ballot(saw_rst) != 0 && lane == 0) atomicOr(rec_flags, 1u);
+    const uint64_t col = col0 + pairidx * 2u + h;
+    if (pairidx * 2u + h < ncol) {
+        const uint64_t block = col >> 6;
+        const uint32_t ln = (uint32_t)(col & 63u);
+        *reinterpret_cast<uint4 *>(planes + ipcr_plane_word(block, q * 4u, 0, ln)) = make_uint4(olo[0], olo[1], olo[2], olo[3]);
+        *reinterpret_cast<uint4 *>(planes + ipcr_plane_word(block, q * 4u, 1, ln)) = make_uint4(ohi[0], ohi[1], ohi[2], ohi[3]);
+        *reinterpret_cast<uint4 *>(planes + ipcr_plane_word(block, q * 4u, 2, ln)) = make_uint4(oiv[0], oiv[1], oiv[2], oiv[3]);
+        *reinterpret_cast<uint4 *>(rst + ipcr_rst_word(block, q * 4u, ln)) = make_uint4(ors[0], ors[1], ors[2], ors[3]);
+    }
+    const bool saw_rst = (ors[0] | ors[1] | ors[2] | ors[3]) != 0u;
+    if (__ballot(saw_rst) != 0ull && lane == 0u) atomicOr(rec_flags, 1u);
 }
 
 // fill columns [col_begin, col_end) with padding (inv=1, everything else 0)
