@@ -828,7 +828,9 @@ ipcr_status ipcr_genome_add_record_device(ipcr_genome *g, const void *dev_seq, u
 
 // hooks for fasta.cpp (the FASTA loader packs records it has normalised on the device)
 ipcr_status ipcr_internal_genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len, const char *id) {
-    const ipcr_status st = genome_add_device(g, dseq, len);
+    // no wait per record (a fragmented assembly has tens of thousands): the loader's copies and packs are
+    // in order on the genome's stream, and every scan starts with genome_finalize, which waits for it
+    const ipcr_status st = genome_add_device(g, dseq, len, false);
     if (st == IPCR_OK && id) g->ids.back() = id;
     return st;
 }
