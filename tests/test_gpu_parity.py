@@ -728,3 +728,36 @@ def test_device_hit_exchange_one_rank_rccl(hip, monkeypatch):
         if started_here and tdist.is_initialized():
             tdist.destroy_process_group()
     g.close()
+
+
+def test_many_tiny_records_in_one_block(hip):
+    """hundreds of short records (empty, shorter than a primer, a few kb) share tile blocks: the in-kernel
+    verifier starts from the block's first record and walks to the candidate's; every record vs the oracle"""
+    rng = random.Random(515)
+    E, P = hip.engine, hip.primer.Pair
+    pairs = hip.primer.AddSelfPairs([P("p", "ACGTTGCATGCAAGCT", "GGCCTTAAGGCCATAT", 0, 0)])
+    fwd, rc = pairs[0].Forward, O.revcomp(pairs[0].Reverse).decode()
+    seqs = []
+    for r in range(400):
+        n = rng.choice([0, 5, 15, 16, 40, 300, 1500, 3000, 9000])
+        s = [rng.choice("ACGT") for _ in range(n)]
+        if n >= 300 and rng.random() < 0.7:
+            a = rng.randrange(0, n - 200)
+            s[a:a + 16] = fwd
+            s[a + 150:a + 166] = rc
+            if rng.random() < 0.3:
+                s[a + 3] = O.different_base(s[a + 3])
+        if n >= 40 and rng.random() < 0.2:
+            q = rng.randrange(n)
+            s[q] = "N"
+        if n >= 16 and rng.random() < 0.2:       # a site flush with the record end
+            s[n - 16:n] = rc
+        seqs.append("".join(s).encode())
+    g = E.Genome(sum(len(s) for s in seqs) + 8192 * (len(seqs) + 2), max_records=len(seqs) + 1)
+    for r, s in enumerate(seqs):
+        g.add_record("chr%d" % (r + 1), s)
+    for cfg in (E.Config(MaxMM=1, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12),
+                E.Config(MaxMM=2, TerminalWindow=0, MaxLen=0, HitCap=0, SeedLen=12, Circular=True)):
+        _, _, sc, got = scan_and_compare(hip, cfg, pairs, g, seqs)
+        assert sc.stats().kernel_kind == 1 and len(got) > 100
+    g.close()
