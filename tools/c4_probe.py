@@ -29,4 +29,4 @@ t0 = time.time(); n = eng.ScanGenomeCount(g, cp, sc); print(f"first scan (incl. 
 for i in range(3):
     t0 = time.time(); n = eng.ScanGenomeCount(g, cp, sc); dt = time.time() - t0
     st = sc.stats()
-    print(f"scan: {dt*1e3:.1f} ms  filter {st.filter_ms:.1f} ms verify {st.verify_ms:.2f} ms  products {n} hits {st.hits} cand {st.candidates} kind {st.kernel_kind} -> {g.total_bases/dt/1e9:.1f} Gbases/s", flush=True)
+    print(f"scan: {dt*1e3:.1f} ms  filter {st.filter_ms:.1f} ms verify {st.verify_ms:.2f} ms sort {st.sort_ms:.2f} join {st.join_ms:.2f} wait {st.wait_ms:.2f}  products {n} hits {st.hits} cand {st.candidates} kind {st.kernel_kind} -> {g.total_bases/dt/1e9:.1f} Gbases/s", flush=True)
