@@ -1084,7 +1084,8 @@ ipcr_status wait_published(ipcr_scratch *s) {
     }
 }
 
-// enqueue one attempt: filter kernel(s), verify kernel, read-back of counters + first hits
+// enqueue one attempt: the specialised filter alone (it verifies and publishes itself), or the seed-index /
+// table-driven filter + verify kernel + read-back of counters and first hits behind a marker event
 ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     ipcr_scratch::Pending &pd = s->pend;
     const PatternSet &set = p->set[pd.mode];

@@ -295,7 +295,6 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
                 o << count_code(B, k);
             }
             o << "            f" << q << " = f;\n          }\n";
-            if (env_int("IPCR_JIT_SCHEDBAR", 0, 0, 1)) o << "          __builtin_amdgcn_sched_barrier(0);\n";
         }
         return o.str();
     };
