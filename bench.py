@@ -35,7 +35,7 @@ N_PLANTS = 1000
 PRODUCT_LEN = 180
 
 
-def build_genome(torch, engine, workloads, oracle_revcomp, genome_idx: int, records: int, record_len: int,
+def build_genome(torch, engine, workloads, revcomp_fn, genome_idx: int, records: int, record_len: int,
                  keep_host_record0: bool):
     """Synthetic genome of SURVEY.md 8(d): LCG stream seed 0x5eed1234+g cut into records, amplicons
     planted as makeEngineBenchFixture does (performance_benchmark_test.go:47-62)."""
@@ -43,7 +43,7 @@ def build_genome(torch, engine, workloads, oracle_revcomp, genome_idx: int, reco
     g = engine.Genome(records * record_len, records)
     pair = W.bench_pair(0)
     fwd = pair.Forward
-    rc_rev = oracle_revcomp(pair.Reverse)
+    rc_rev = revcomp_fn(pair.Reverse)
     buf = torch.empty(record_len, dtype=torch.uint8, device="cuda")
     plants = []  # (record, start, n_mismatches)
     per_rec = (N_PLANTS + records - 1) // records

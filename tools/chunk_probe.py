@@ -1,11 +1,13 @@
 """PCIe-inclusive rate of the drop-in entry point: ipcr_scan_chunk on host ASCII (dev tool)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-import ipcr_oracle as O
+import torch
 from ipcr_amd import engine, workloads
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 125_000_000
-seq = O.bench_dna(n, 0x5eed1234)
+buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+engine.lcg_fill_device(buf.data_ptr(), n, 0x5eed1234)   # the benchmark genome, generated on the device
+seq = buf.cpu().numpy().tobytes()
+del buf
 eng = engine.New(engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12))
 cp = eng.CompilePanel(workloads.c2_pairs())
 sc = eng.NewSimulationScratch(cp)

@@ -2,14 +2,16 @@
 """Load + scan time of a fragmented assembly (many short records): tools/many_records_probe.py [records] [len]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import numpy as np
-import ipcr_oracle as O
+import torch
 from ipcr_amd import engine, workloads
 
 nrec = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 reclen = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
-seq = np.frombuffer(O.bench_dna(nrec * reclen, 0x5eed9999), dtype=np.uint8)
+buf = torch.empty(nrec * reclen, dtype=torch.uint8, device="cuda:0")
+engine.lcg_fill_device(buf.data_ptr(), nrec * reclen, 0x5eed9999)
+seq = buf.cpu().numpy()
+del buf
 path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "many_%d.fa" % os.getpid())
 with open(path, "wb") as fh:
     for r in range(nrec):
