@@ -34,6 +34,7 @@
 #include <mutex>
 #include <sstream>
 #include <thread>
+#include <unistd.h>
 
 namespace ipcr {
 
@@ -664,7 +665,37 @@ bool compile_group(const std::string &src, const std::string &arch, std::vector<
         const auto it = cc.map.find(key);
         if (it != cc.map.end()) { code = it->second; return true; }
     }
-    if (!compile_group_uncached(src, arch, code, err)) return false;
+    // IPCR_JIT_CACHE_DIR: code objects also persist on disk (a CLI that is run again with the same primers
+    // skips hiprtc); file name = 64-bit FNV-1a of (arch, source) + source length
+    std::string disk;
+    if (const char *dir = getenv("IPCR_JIT_CACHE_DIR")) {
+        if (*dir) {
+            unsigned long long h = 1469598103934665603ull;
+            for (const unsigned char ch : key) { h ^= ch; h *= 1099511628211ull; }
+            char name[64];
+            snprintf(name, sizeof name, "/ipcr_%016llx_%zu.hsaco", h, key.size());
+            disk = std::string(dir) + name;
+            if (FILE *fh = fopen(disk.c_str(), "rb")) {
+                std::vector<char> buf;
+                char tmp[1 << 16];
+                size_t n;
+                while ((n = fread(tmp, 1, sizeof tmp, fh)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+                fclose(fh);
+                if (buf.size() > 64 && memcmp(buf.data(), "\177ELF", 4) == 0) code.swap(buf);
+            }
+        }
+    }
+    if (code.empty()) {
+        if (!compile_group_uncached(src, arch, code, err)) return false;
+        if (!disk.empty()) { // write next to the target, then rename: readers never see a partial file
+            const std::string tmpname = disk + ".tmp" + std::to_string((unsigned long long)getpid());
+            if (FILE *fh = fopen(tmpname.c_str(), "wb")) {
+                const bool ok = fwrite(code.data(), 1, code.size(), fh) == code.size();
+                fclose(fh);
+                if (!ok || rename(tmpname.c_str(), disk.c_str()) != 0) (void)remove(tmpname.c_str());
+            }
+        }
+    }
     std::lock_guard<std::mutex> lk(cc.mu);
     if (cc.bytes > ((size_t)256 << 20)) { cc.map.clear(); cc.bytes = 0; }
     cc.bytes += key.size() + code.size();

@@ -761,3 +761,18 @@ def test_many_tiny_records_in_one_block(hip):
         _, _, sc, got = scan_and_compare(hip, cfg, pairs, g, seqs)
         assert sc.stats().kernel_kind == 1 and len(got) > 100
     g.close()
+
+
+def test_jit_disk_cache(hip, tmp_path, monkeypatch):
+    """IPCR_JIT_CACHE_DIR: the code object of a panel is written once and loaded by the next panel with the
+    same source (another engine object, same primers and k)"""
+    monkeypatch.setenv("IPCR_JIT_CACHE_DIR", str(tmp_path))
+    E, P = hip.engine, hip.primer.Pair
+    pairs = [P("disk", "ACGTTGCAAGGCTTAA", "TTGGCCAATTGGAACC", 0, 0)]
+    seq = (b"TTTT" + b"ACGTTGCAAGGCTTAA" + b"ACGT" * 20 + O.revcomp(b"TTGGCCAATTGGAACC") + b"GGGG") * 3
+    cfg = E.Config(MaxMM=1, TerminalWindow=2, MaxLen=500, HitCap=100, SeedLen=12)
+    first = check(hip, cfg, seq, pairs)
+    files = sorted(f.name for f in tmp_path.iterdir())
+    assert len(files) >= 1 and all(f.endswith(".hsaco") for f in files)
+    again = check(hip, cfg, seq, pairs)          # served from memory or disk, same answer
+    assert [p.sig() for p in again] == [p.sig() for p in first] and sorted(f.name for f in tmp_path.iterdir()) == files
