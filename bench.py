@@ -155,7 +155,7 @@ def main() -> None:
             # the all-gather of pass j-ns read the device hit buffer of the scratch pass j is about to reuse
             for jj in [q for q in works if q <= j - ns]:
                 xchg.finish(works.pop(jj))
-            if j > 0 and not args.no_pipeline:
+            if j > 0 and not args.no_pipeline and not os.environ.get("IPCR_BENCH_NO_CHAIN"):
                 scs[j % ns].chain_after(scs[(j - 1) % ns])        # device: pass j's sweep behind pass j-1's
             eng.ScanGenomeBegin(genome, cp, scs[j % ns])
 
