@@ -129,6 +129,7 @@ def main() -> None:
         eng.ScanGenomeHits(genome, cp, sc)
         _, _, offs = xchg.allgather(dist.hits_from_scratch(sc), nrec)
         rec_off = offs[rank]
+        xchg.agree_on_device_path(sc)   # zero-copy view of the device hit buffer on every rank, or the host copy on all
 
     # three scratches in rotation: one being swept, one being joined on the host, one whose hit buffer the
     # all-gather of the pass before may still be reading (several GPUs); two would do on one GPU
@@ -261,7 +262,8 @@ def main() -> None:
             "gbases_per_s_incl_pack": round(genome.total_bases * world / ((genome.pack_ms + ms_per_step) * 1e-3) / 1e9, 1),
             "step_breakdown_ms_rank0": {k: round(getattr(last.stats(), k), 4) for k in
                                         ("filter_ms", "verify_ms", "enqueue_ms", "wait_ms", "sort_ms", "join_ms", "total_ms")},
-            "parallelism": ("1 genome per GPU, one all-gatherv of hit records per step (%s), join partitioned by record" % backend)
+            "parallelism": ("1 genome per GPU, one all-gatherv of hit records per step (%s, %s), join partitioned by record"
+                            % (backend, "out of the device hit buffer" if xchg.device_path else "host copy of the hits"))
                            if multi else "single GPU",
         },
         "roofline": {
