@@ -47,6 +47,7 @@ a, b = x_ranges[rank]
 assert np.array_equal(x_hits[a:b]["pos"], local_hits["pos"])
 x2, _, _ = xchg.allgather(local_hits, len(lens))          # steady state: one collective
 assert np.array_equal(x2, all_hits)
+assert xchg.agree_on_device_path(None) is False             # CPU job: every rank settles on the host copy (one all-reduce)
 work = xchg.start(local_hits, len(lens))                   # overlapped form: enqueue, join own records, wait
 xchg.finish(work)
 x3, r3, o3 = xchg.gathered()
