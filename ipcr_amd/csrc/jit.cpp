@@ -827,28 +827,45 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes) {
     arr("u32", "TW_BITS", [](const ipcr_index_shape &x) { return std::to_string(x.tw_bits) + "u"; });
     arr("u32", "TW_MASK", [](const ipcr_index_shape &x) { return std::to_string(x.tw_mask) + "u"; });
     arr("u32", "BLK_MASK", [](const ipcr_index_shape &x) { return std::to_string(x.blk_mask) + "u"; });
-    arr("u64", "VALID", [](const ipcr_index_shape &x) { return std::to_string(x.valid_mask) + "ull"; });
+    arr("u32", "VALID32", [](const ipcr_index_shape &x) { // one bit per base (bit u = u bases before the newest) instead of two
+        uint32_t m = 0;
+        for (int u = 0; u < 32; ++u)
+            if (x.valid_mask & (1ull << (2 * u))) m |= 1u << u;
+        return std::to_string(m) + "u";
+    });
     s << R"SRC(
 template <int S> struct key_of {
   static __device__ __forceinline__ u32 get(u64 km) {
     return ((u32)(km >> TW_SHIFT[S]) & TW_MASK[S]) | (((u32)(km >> BLK_SHIFT[S]) & BLK_MASK[S]) << TW_BITS[S]);
   }
 };
-template <int S> __device__ __forceinline__ void probe_all(u64 km, u64 im, const u32* lds, u32* keys, u32& hitmask) {
+// all shapes' bitmap words are read unconditionally and together (independent LDS reads, one wait); a read placed
+// behind the validity test costs a divergent branch and an exposed LDS round trip per shape and base
+template <int S> __device__ __forceinline__ void read_all(u64 km, const u32* lds, u32* keys, u32* words) {
   if constexpr (S < NS) {
     const u32 k = key_of<S>::get(km);
     keys[S] = k;
-    const u32 w = lds[S * 2048 + (k >> 5)];
-    if ((im & VALID[S]) == 0ull && ((w >> (k & 31u)) & 1u)) hitmask |= 1u << S;
-    probe_all<S + 1>(km, im, lds, keys, hitmask);
+    words[S] = lds[S * 2048 + (k >> 5)];
+    read_all<S + 1>(km, lds, keys, words);
   }
+}
+template <int S> __device__ __forceinline__ void test_all(u32 bad, const u32* keys, const u32* words, u32& hitmask) {
+  if constexpr (S < NS) {
+    const u32 bit = __builtin_amdgcn_ubfe(words[S], keys[S] & 31u, 1u);
+    hitmask |= ((bad & VALID32[S]) == 0u ? bit : 0u) << S;
+    test_all<S + 1>(bad, keys, words, hitmask);
+  }
+}
+template <int S> __device__ __forceinline__ u32 key_at(u32 s, u64 km) { // key of shape s (run-time index) from a stored k-mer
+  if constexpr (S + 1 < NS) return s == (u32)S ? key_of<S>::get(km) : key_at<S + 1>(s, km);
+  else return key_of<S>::get(km);
 }
 // LDS image (host.cpp: build_index): NS bitmaps of 2048 words | NS x 256 uint16 group prefixes | NS first-entry indices
 #define PREFIX_WORD0 (NS * 2048u)
 #define BASE_WORD0 (NS * 2048u + NS * 128u)
 #define LDS_WORDS (NS * 2048u + NS * 128u + NS)
-#define QCAP 128u   // per-wave queue of key hits (24-byte entries), flushed at full lane occupancy
-#define QWORDS 6u
+#define QCAP 128u   // per-wave queue of key hits (20-byte entries), flushed at full lane occupancy
+#define QWORDS 5u
 extern "C" __global__ void __launch_bounds__(512) ipcr_index_filter(const u32* __restrict__ planes, u64 ncolpairs,
     const u32* __restrict__ lds_image, const v4* __restrict__ table, u32 max_mm,
     qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {
@@ -872,11 +889,13 @@ extern "C" __global__ void __launch_bounds__(512) ipcr_index_filter(const u32* _
         if (i < qn) {
           const u32* e = wq + i * QWORDS;
           const u64 km = ((u64)e[1] << 32) | e[0], im = ((u64)e[3] << 32) | e[2];
-          const u32 meta = e[4], where = e[5];
-          const u32 s = meta >> 16, key = meta & 0xFFFFu;
+          const u32 where = e[4];
           const u32 ol = where & 63u;
-          const int erow = (int)(where >> 6);
+          const int erow = (int)((where >> 6) & 0xFFu);
           const u64 strand_base = ((((cp * 2u + (ol >> 5)) << 5) + (ol & 31u)) << 7);
+          for (u32 smask = where >> 14; smask; smask &= smask - 1u) { // the shapes whose key hit at this base (usually one)
+          const u32 s = (u32)__builtin_ctz(smask);
+          const u32 key = key_at<0>(s, km);
           // the key is in the panel; its rank among the shape's keys is the index of its entry
           const u32 grp = key >> 8, wi = (key >> 5) & 7u, bi = key & 31u;
           const v4* gw = reinterpret_cast<const v4*>(lds + s * 2048u + grp * 8u);
@@ -909,6 +928,7 @@ extern "C" __global__ void __launch_bounds__(512) ipcr_index_filter(const u32* _
             }
             idx = e0.x; // further pattern with the same key (rare)
           }
+          }
         }
       }
       qn = 0;
@@ -918,40 +938,44 @@ extern "C" __global__ void __launch_bounds__(512) ipcr_index_filter(const u32* _
     const u64 ncol = (bit == 31u) ? col + 1u : col;
     const u32 nbit = (bit + 1u) & 31u;
     u64 km = 0, im = 0x5555555555555555ull;
+    u32 bad = 0xFFFFFFFFu; // the same invalid-base flags, one bit per base: the per-shape key tests are 32-bit
+    // row quads: 32 of my strand, then 8 of the next one; quad rq+1 is loaded while quad rq is processed
+    auto quad_addr = [&](u32 rq) {
+      const u64 c = rq >= 32u ? ncol : col;
+      return planes + ((((c >> 6) * 32u + (rq & 31u)) * 3u * 64u + (u32)(c & 63u)) << 2); // tile_layout.h: ipcr_plane_word
+    };
+    const u32* pa = quad_addr(0u);
+    v4 nlo = *reinterpret_cast<const v4*>(pa), nhi = *reinterpret_cast<const v4*>(pa + 256u), niv = *reinterpret_cast<const v4*>(pa + 512u);
     for (u32 rq = 0; rq < 40u; ++rq) {
-      const bool wrap = rq >= 32u;
-      const u64 c = wrap ? ncol : col;
-      const u32 b = wrap ? nbit : bit;
-      const u64 w = (((c >> 6) * 32u + (rq & 31u)) * 3u * 64u + (u32)(c & 63u)) << 2; // tile_layout.h: ipcr_plane_word
-      const v4 qlo = *reinterpret_cast<const v4*>(planes + w);
-      const v4 qhi = *reinterpret_cast<const v4*>(planes + w + 256u);
-      const v4 qiv = *reinterpret_cast<const v4*>(planes + w + 512u);
+      const u32 b = rq >= 32u ? nbit : bit;
+      const v4 qlo = nlo, qhi = nhi, qiv = niv;
+      if (rq + 1u < 40u) {
+        pa = quad_addr(rq + 1u);
+        nlo = *reinterpret_cast<const v4*>(pa); nhi = *reinterpret_cast<const v4*>(pa + 256u); niv = *reinterpret_cast<const v4*>(pa + 512u);
+      }
 #pragma unroll
       for (u32 t = 0; t < 4u; ++t) {
         const u32 code = ((qlo[t] >> b) & 1u) | (((qhi[t] >> b) & 1u) << 1);
         km = (km << 2) | code;
-        im = (im << 2) | ((qiv[t] >> b) & 1u);
+        const u32 inv = (qiv[t] >> b) & 1u;
+        im = (im << 2) | inv;
+        bad = (bad << 1) | inv;
         const u32 erow = rq * 4u + t;
-        u32 keys[NS];
+        u32 keys[NS], words[NS];
         u32 hitmask = 0;
-        probe_all<0>(km, im, lds, keys, hitmask);
-        if (__ballot(hitmask != 0u) != 0ull) {
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            const bool mine = (hitmask >> s) & 1u;
-            const u64 bal = __ballot(mine);
-            if (bal != 0ull) {
-              const u32 n = (u32)__popcll(bal);
-              if (qn + n > QCAP) flush();
-              if (mine) {
-                const u32 slot = qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                u32* e = wq + slot * QWORDS;
-                e[0] = (u32)km; e[1] = (u32)(km >> 32); e[2] = (u32)im; e[3] = (u32)(im >> 32);
-                e[4] = ((u32)s << 16) | keys[s]; e[5] = lane | (erow << 6);
-              }
-              qn += n;
-            }
+        read_all<0>(km, lds, keys, words);
+        test_all<0>(bad, keys, words, hitmask);
+        const u64 bal = __ballot(hitmask != 0u);
+        if (bal != 0ull) { // one queue entry per lane whatever the number of shapes that hit: (k-mer, shapes, where)
+          const u32 n = (u32)__popcll(bal);
+          if (qn + n > QCAP) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); flush(); }
+          if (hitmask != 0u) {
+            const u32 slot = qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+            u32* e = wq + slot * QWORDS;
+            e[0] = (u32)km; e[1] = (u32)(km >> 32); e[2] = (u32)im; e[3] = (u32)(im >> 32);
+            e[4] = lane | (erow << 6) | (hitmask << 14);
           }
+          qn += n;
           if (qn >= 64u) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); flush(); }
         }
       }
@@ -966,7 +990,7 @@ extern "C" __global__ void __launch_bounds__(512) ipcr_index_filter(const u32* _
 
 static unsigned index_lds_bytes(unsigned nshapes) { // bitmaps + group prefixes + first-entry indices (build_index) + 8 hit queues
     const unsigned image = nshapes * (IPCR_INDEX_BITMAP_WORDS * 4u + IPCR_INDEX_GROUPS * 2u + 4u);
-    return ((image + 15u) & ~15u) + 8u * 128u * 24u;
+    return ((image + 15u) & ~15u) + 8u * 128u * 20u;
 }
 
 JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, std::string &err) {
