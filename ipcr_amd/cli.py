@@ -127,6 +127,26 @@ def format_row(source_file: str, p: engine.Product) -> str:
                       str(p.FwdMM), str(p.RevMM), ints_csv(p.FwdMismatchIdx), ints_csv(p.RevMismatchIdx)])
 
 
+def format_jsonl(source_file: str, p: engine.Product) -> str:
+    """One line of --output jsonl: api.ProductV1 (pkg/api/products_v1.go:6-25) as encoding/json writes it -- field
+    order of the struct, zero / empty `omitempty` fields left out, compact separators, <, > and & escaped."""
+    import json
+    d = {"experiment_id": p.ExperimentID, "sequence_id": p.SequenceID, "start": p.Start, "end": p.End,
+         "length": p.Length, "type": p.Type}
+    if p.FwdMM:
+        d["fwd_mm"] = p.FwdMM
+    if p.RevMM:
+        d["rev_mm"] = p.RevMM
+    if p.FwdMismatchIdx:
+        d["fwd_mm_i"] = list(p.FwdMismatchIdx)
+    if p.RevMismatchIdx:
+        d["rev_mm_i"] = list(p.RevMismatchIdx)
+    if source_file:
+        d["source_file"] = source_file
+    text = json.dumps(d, separators=(",", ":"), ensure_ascii=False)
+    return text.replace("<", "\\u003c").replace(">", "\\u003e").replace("&", "\\u0026")
+
+
 def build_parser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser(prog="ipcr-hip", add_help=True)
     ap.add_argument("--primers", "-p", default="")
@@ -142,6 +162,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--seed-length", type=int, default=12)
     ap.add_argument("--circular", "-c", action="store_true")
     ap.add_argument("--sort", action="store_true")
+    ap.add_argument("--output", "-o", default="text", choices=["text", "jsonl"])
     ap.add_argument("--no-header", action="store_true")
     ap.add_argument("--multiplex", action="store_true", help="ipcr-multiplex self-pair rule (unique oligos)")
     ap.add_argument("--probe", "-P", default="")
@@ -245,6 +266,10 @@ def run(argv: Optional[Sequence[str]] = None, stdout=None, stderr=None) -> int:
         rows = kept
     if o.sort:
         rows.sort(key=lambda t: product_sort_key(t[0], t[1]))
+    if o.output == "jsonl" and not o.probe:
+        for path, p, _ in rows:
+            print(format_jsonl(path, p), file=stdout)
+        return o.no_match_exit_code if (not rows and o.no_match_exit_code) else 0
     if not o.no_header:
         print(TSV_HEADER_PROBE if o.probe else TSV_HEADER, file=stdout)
     for path, p, ph in rows:

@@ -172,3 +172,15 @@ def test_collector_rebases_and_dedups():  # internal/pipeline/pipeline.go:127-16
     assert (b.SequenceID, b.Start) == ("plain", 1)
     # capacity 2: the first key has been evicted by now and is accepted again (bounded de-dup, as in the reference)
     assert c.add("f.fa", P("x", "s:100-200", 5, 25, 20, "forward", 0, 0, (), ())) is not None
+
+
+def test_jsonl_rows():  # pkg/api/products_v1.go:6-25 through encoding/json (internal/jsonlutil/jsonlutil.go)
+    import json
+    P = engine.Product
+    a = P("x", "s:0-4", 0, 4, 4, "forward", 0, 0, (), ())
+    assert cli.format_jsonl("", a) == '{"experiment_id":"x","sequence_id":"s:0-4","start":0,"end":4,"length":4,"type":"forward"}'
+    b = P("a<b", "chr1", 10, 30, 20, "revcomp", 1, 2, (3,), (9, 4))
+    line = cli.format_jsonl("g&h.fa", b)
+    assert line == ('{"experiment_id":"a\\u003cb","sequence_id":"chr1","start":10,"end":30,"length":20,"type":"revcomp",'
+                    '"fwd_mm":1,"rev_mm":2,"fwd_mm_i":[3],"rev_mm_i":[9,4],"source_file":"g\\u0026h.fa"}')
+    assert json.loads(line)["experiment_id"] == "a<b" and json.loads(line)["source_file"] == "g&h.fa"
