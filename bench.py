@@ -225,8 +225,10 @@ def main() -> None:
     alg_bytes = genome.total_bases * BYTES_PER_BASE
     achieved = alg_bytes / (fms_avg * 1e-3) / 1e9
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_filter_pmc.json")
-    if os.path.exists(tfile):
+    import glob
+    pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_filter_pmc.json")))   # latest round's PMC passes
+    tfile = pmc_files[-1] if pmc_files else ""
+    if tfile and os.path.exists(tfile):
         try:
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         except Exception:
