@@ -277,6 +277,7 @@ def main() -> None:
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
             "algorithmic_bytes_per_launch": int(alg_bytes),
+            "frac_of_copy_peak": round(achieved / 6290.0, 4),  # 6.29 TB/s: what a float4 copy reaches (MI355X_MICROARCH.md)
             "avg_launch_ms": round(fms_avg, 4),
             "gbases_per_s_kernel": round(genome.total_bases / (fms_avg * 1e-3) / 1e9, 1),
         },
