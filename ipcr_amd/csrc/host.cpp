@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -1056,9 +1057,11 @@ uint32_t *pinned_seq(const ipcr_scratch *s) {
     return reinterpret_cast<uint32_t *>(static_cast<char *>(s->pinned) + 64 + PREFIX_HITS * sizeof(ipcr_hit));
 }
 
+std::atomic<bool> g_publish_broken{false}; // a sweep ended without its results reaching pinned memory: copy path from then on
+
 bool publish_enabled() { // IPCR_PUBLISH=0: read-back by a copy operation behind the kernel instead
     static const bool on = env_flag("IPCR_PUBLISH", true);
-    return on;
+    return on && !g_publish_broken.load(std::memory_order_relaxed);
 }
 
 // the specialised filter's last wave has written counters, first hits and finally the scan's
@@ -1074,9 +1077,9 @@ ipcr_status wait_published(ipcr_scratch *s) {
         __builtin_ia32_pause();
         if ((spin & 0xFFFFu) == 0) { // a fault on the stream would otherwise spin for ever
             const hipError_t q = hipStreamQuery(lane);
-            if (q == hipSuccess) { // stream drained: the word is there, or the kernel died
+            if (q == hipSuccess) { // stream drained: the word is there, or device stores do not reach this host's pinned memory
                 if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == want) return IPCR_OK;
-                return fail(IPCR_ERR_DEVICE, "specialised filter finished without publishing its results");
+                return IPCR_ERR_UNSUPPORTED; // caller: switch to the copy path and rescan
             }
             if (q != hipErrorNotReady) return fail(IPCR_ERR_DEVICE, "HIP: %s", hipGetErrorString(q));
             if (ms_since(t0) > 120000.0) return fail(IPCR_ERR_DEVICE, "scan did not finish within 120 s");
@@ -1131,6 +1134,8 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
                 v.tickets = s->d_tickets;
                 v.pub = static_cast<unsigned long long *>(s->pinned) + 4u * pd.cset_used;
                 v.pub_seq = pinned_seq(s);
+                static const bool break_it = env_flag("IPCR_TEST_BREAK_PUBLISH", false); // tests: the word never reaches the host
+                if (break_it) v.pub_seq = s->d_tickets + 2064;
                 v.seq = s->seq;
                 pd.published = true;
             }
@@ -1222,6 +1227,16 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         trace("wait>", s);
         if (pd.published) {
             const ipcr_status ws = wait_published(s);
+            if (ws == IPCR_ERR_UNSUPPORTED) {
+                // never seen on the boxes this was developed on; a platform where the kernel's stores to pinned host
+                // memory are not visible would otherwise fail every scan.  Results are still complete in device memory.
+                g_publish_broken.store(true);
+                static std::atomic<bool> told{false};
+                if (!told.exchange(true)) fprintf(stderr, "ipcr_hip: in-kernel hand-over did not reach pinned memory; using the copy path\n");
+                const ipcr_status rs = scan_launch(p, s, g);
+                if (rs != IPCR_OK) return rs;
+                continue;
+            }
             if (ws != IPCR_OK) return ws;
         } else if (pd.on_lane) HIPCHK(hipEventSynchronize(s->ev_done)); // the lane already carries the next scan
         else HIPCHK(hipStreamSynchronize(s->stream));

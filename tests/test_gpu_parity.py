@@ -776,3 +776,31 @@ def test_jit_disk_cache(hip, tmp_path, monkeypatch):
     assert len(files) >= 1 and all(f.endswith(".hsaco") for f in files)
     again = check(hip, cfg, seq, pairs)          # served from memory or disk, same answer
     assert [p.sig() for p in again] == [p.sig() for p in first] and sorted(f.name for f in tmp_path.iterdir()) == files
+
+
+def test_fallback_when_hand_over_does_not_arrive(tmp_path):
+    """If the sweep's sequence word never shows up in pinned memory (simulated: it is written to device memory
+    instead), the scan notices once the stream has drained, switches the process to the copy path and rescans;
+    results are the same.  Runs in a child process: the switch is process-wide."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import ipcr_oracle as O
+        from ipcr_amd import engine, primer
+        seq = (b"TTTT" + b"ACGTTGCAAGGCTTAA" + b"ACGT" * 30 + O.revcomp(b"TTGGCCAATTGGAACC") + b"GGGG") * 5
+        pairs = [primer.Pair("p", "ACGTTGCAAGGCTTAA", "TTGGCCAATTGGAACC", 0, 0)]
+        cfg = engine.Config(MaxMM=1, TerminalWindow=2, MaxLen=500, HitCap=100, SeedLen=12)
+        eng = engine.New(cfg); cp = eng.CompilePanel(pairs); sc = eng.NewSimulationScratch(cp)
+        want = [w.sig() for w in O.simulate_batch(O.Config(max_mm=1, terminal_window=2, max_len=500, hit_cap=100, seed_len=12), seq,
+                                                  [O.Pair("p", pairs[0].Forward, pairs[0].Reverse, 0, 0)])]
+        for i in range(3):
+            got = [p.sig() for p in eng.SimulateCompiledWithScratch("s", seq, cp, sc)]
+            assert got == want and len(got) >= 5, (i, got, want)
+        print("OK", sc.stats().kernel_kind)
+    """ % (root, os.path.join(root, "oracle")))
+    env = dict(os.environ, IPCR_TEST_BREAK_PUBLISH="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK 1" in r.stdout, (r.stdout, r.stderr)
+    assert "using the copy path" in r.stderr
