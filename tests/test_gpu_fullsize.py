@@ -127,3 +127,62 @@ def test_config_c3_full_size_properties():
     inside = [p.sig() for p in prods if p.Record == 0 and p.Start <= p.End and p.End <= 20_000_000 - 2000]
     assert inside == [w.sig() for w in want if w.end <= 20_000_000 - 2000]
     genome.close()
+
+
+def test_config_c4_full_size_properties():
+    """BASELINE.json configs[3] on one GPU's share: the 1024-row panel (3072 pairs / 4096 distinct patterns through
+    ipcr-multiplex's self-pair rule) over a 3.0 Gb genome with 960 planted amplicons of 960 different pairs.
+    Checked: seed-index filter in use, every plant found exactly (k=2 sites included), hits sorted and unique,
+    idempotence, and the pattern-sharded run (pairs split in two halves, as a primer x genome tiling would) gives the
+    same products."""
+    torch = pytest.importorskip("torch")
+    from ipcr_amd import engine, primer, workloads
+
+    npairs, nrec, reclen = 1024, 24, 125_000_000
+    pairs = workloads.c4_pairs(npairs)
+    base = {p.ID: p for p in pairs[:npairs]}
+    genome = engine.Genome(nrec * reclen, nrec)
+    buf = torch.empty(reclen, dtype=torch.uint8, device="cuda:0")
+    plants = {}
+    for r in range(nrec):
+        engine.lcg_fill_device(buf.data_ptr(), reclen, 0x5eed1234, r * reclen)
+        for t in range(40):
+            p = pairs[(r * 40 + t) % npairs]
+            start = 5000 + t * 100000
+            site = list(p.Forward)
+            nm = (r + t) % 3
+            if nm >= 1:
+                site[4] = workloads.different_base(site[4])
+            if nm >= 2:
+                site[11] = workloads.different_base(site[11])
+            buf[start:start + 20] = torch.tensor(list("".join(site).encode()), dtype=torch.uint8)
+            buf[start + 160:start + 180] = torch.tensor(list(primer.RevComp(p.Reverse)), dtype=torch.uint8)
+            plants[(r, start, p.ID)] = nm
+        torch.cuda.synchronize()
+        genome.add_record_device("chr%d" % (r + 1), buf.data_ptr(), reclen)
+    del buf
+    cfg = engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)
+    eng = engine.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    assert cp.num_patterns == 4096
+    sc = eng.NewSimulationScratch(cp)
+    prods = eng.ScanGenome(genome, cp, sc)
+    assert sc.stats().kernel_kind == 3
+    found = {(p.Record, p.Start, p.ExperimentID): p for p in prods if p.Type == "forward" and p.Length == 180 and p.ExperimentID in base}
+    for key, nm in plants.items():
+        p = found[key]
+        assert (p.FwdMM, p.FwdMismatchIdx, p.RevMM) == (nm, () if nm == 0 else ((4,) if nm == 1 else (4, 11)), 0)
+    hits = sc.hits()
+    keys = [(h.Record, h.Pattern, h.Pos) for h in hits]
+    assert keys == sorted(keys) and len(set(keys)) == len(keys) and all(h.Mismatches <= 2 for h in hits)
+    want = [p.sig() for p in prods]
+    assert [p.sig() for p in eng.ScanGenome(genome, cp, sc)] == want
+    # primer x genome tiling: two sub-panels over the same genome, products merged per pair
+    half = []
+    for sub in (pairs[0::2], pairs[1::2]):
+        cps = eng.CompilePanel(sub)
+        scs = eng.NewSimulationScratch(cps)
+        half += [(p.Record, p.ExperimentID) + p.sig()[1:] for p in eng.ScanGenome(genome, cps, scs)]
+        scs.close(); cps.close()
+    assert sorted(half) == sorted((p.Record, p.ExperimentID) + p.sig()[1:] for p in prods)
+    genome.close()
