@@ -186,3 +186,69 @@ def test_config_c4_full_size_properties():
         scs.close(); cps.close()
     assert sorted(half) == sorted((p.Record, p.ExperimentID) + p.sig()[1:] for p in prods)
     genome.close()
+
+
+def test_config_c5_full_size_probe_rescan():
+    """BASELINE.json configs[4]: pair + internal probe, k=2, 3.0 Gb.  1000 planted amplicons carry the probe at a
+    known offset: on the + strand, as its reverse complement, with one or two substitutions, or not at all; the
+    batched rescan (amplicon gather + probe kernel over all products of the scan) must report exactly that for
+    every product, and agree with oligo.BestHit restated in the oracle on the amplicons of record 0."""
+    torch = pytest.importorskip("torch")
+    import random
+    from ipcr_amd import _lib, engine, primer, workloads
+
+    rng = random.Random(55)
+    pairs = workloads.c2_pairs()
+    fwd, rc_rev = pairs[0].Forward, primer.RevComp(pairs[0].Reverse).decode()
+    probe = "TGGACCTTAGCAGGTCATTCAG"
+    rc_probe = primer.RevComp(probe).decode()
+    nrec, reclen = 24, 125_000_000
+    genome = engine.Genome(nrec * reclen, nrec)
+    buf = torch.empty(reclen, dtype=torch.uint8, device="cuda:0")
+    plants, host0 = {}, None
+    for r in range(nrec):
+        engine.lcg_fill_device(buf.data_ptr(), reclen, 0x5eed5555 + r)
+        for t in range(42):
+            if len(plants) >= 1000:
+                break
+            start = 2_000_000 + t * 2_900_000 + rng.randrange(500)
+            kind = rng.choice(["plus", "minus", "mm1", "mm2", "none"])
+            off = 30 + rng.randrange(90)
+            buf[start:start + 20] = torch.tensor(list(fwd.encode()), dtype=torch.uint8)
+            buf[start + 180 - 20:start + 180] = torch.tensor(list(rc_rev.encode()), dtype=torch.uint8)   # the pair allows 128..212
+            site = list(probe if kind != "minus" else rc_probe)
+            if kind in ("mm1", "mm2"):
+                site[5] = workloads.different_base(site[5])
+            if kind == "mm2":
+                site[15] = workloads.different_base(site[15])
+            if kind != "none":
+                buf[start + off:start + off + len(probe)] = torch.tensor(list("".join(site).encode()), dtype=torch.uint8)
+            plants[(r, start)] = (kind, off)
+        torch.cuda.synchronize()
+        if r == 0:
+            host0 = buf.cpu().numpy().tobytes()
+        genome.add_record_device("chr%d" % (r + 1), buf.data_ptr(), reclen)
+    del buf
+    eng = engine.New(engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12))
+    cp = eng.CompilePanel(pairs)
+    sc = eng.NewSimulationScratch(cp)
+    prods = eng.ScanGenome(genome, cp, sc)
+    mine = [i for i, p in enumerate(prods) if (p.Record, p.Start) in plants and p.Length == 180 and p.ExperimentID == "bench_000" and p.Type == "forward"]
+    assert len(mine) == len(plants) == 1000
+    for k in (0, 2):
+        out = (_lib.ProbeHit * len(prods))()
+        _lib.check(_lib.lib().ipcr_probe_products(sc._h, genome._h, probe.encode(), k, out, len(prods)))
+        for i in mine:
+            kind, off = plants[(prods[i].Record, prods[i].Start)]
+            h = out[i]
+            expect_found = kind in ("plus", "minus") or (k == 2 and kind in ("mm1", "mm2"))
+            assert bool(h.found) == expect_found, (kind, k, h.found)
+            if expect_found:
+                assert (chr(h.strand), h.pos, h.mm) == ("-" if kind == "minus" else "+", off, {"plus": 0, "minus": 0, "mm1": 1, "mm2": 2}[kind])
+        for i, p in enumerate(prods):                 # every product of record 0 (plants and background) vs the oracle
+            if p.Record != 0 or p.Start > p.End:
+                continue
+            w = O.best_hit(host0[p.Start:p.End], probe, k)
+            assert (bool(out[i].found), chr(out[i].strand) if out[i].found else "", out[i].pos, out[i].mm) == \
+                (w.found, w.strand, w.pos if w.found else 0, w.mm if w.found else 0)
+    genome.close()
