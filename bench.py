@@ -76,6 +76,10 @@ def build_genome(torch, engine, workloads, revcomp_fn, genome_idx: int, records:
 
 
 def main() -> None:
+    # HIP maps streams onto a few hardware queues (4 by default), in creation order.  This job has a dozen (three
+    # scratches, the genome, torch, RCCL): when the sweep lane shares a queue with the collective's stream, every
+    # all-gather is serialised between two sweeps (+25 us per step measured).  One queue per stream instead.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # one step is ~0.2 ms: the default region (about half a second) is long enough for the clocks to settle; the
@@ -147,6 +151,7 @@ def main() -> None:
         of pass i's hit records (RCCL) runs under pass i+1 too.  Every pass is complete (filter ->
         verify -> hits -> match lists -> join -> products, hits exchanged) when run_steps returns."""
         fms, n = [], 0
+        xt = [0.0, 0.0, 0]
         works = {}                        # pass -> exchange in flight (it reads that pass's scratch on the device)
         if k <= 0:
             return fms, n
@@ -170,13 +175,20 @@ def main() -> None:
                 raise SystemExit(f"pass {i}: {n} products, the set-up scan found {expect_products}")
             fms.append(cur.stats().filter_ms)
             if multi:
+                tq = time.perf_counter()
                 for jj in [q for q in works if q <= i - 2]:      # two receive slots
                     xchg.finish(works.pop(jj))
+                tr = time.perf_counter()
                 works[i] = xchg.start_scratch(cur, nrec)         # all-gatherv of hit records, async, out of the device hit buffer
+                xt[0] += tr - tq
+                xt[1] += time.perf_counter() - tr
+                xt[2] += 1
             if i + 1 < k and args.no_pipeline:
                 begin(i + 1)
         for jj in sorted(works):
             xchg.finish(works.pop(jj))
+        if multi and xt[2] and os.environ.get("IPCR_DEBUG_TIMES"):
+            print("exchange host time per pass: finish %.1f us, start %.1f us" % (1e6 * xt[0] / xt[2], 1e6 * xt[1] / xt[2]), file=sys.stderr)
         return fms, n
 
     # part of the untimed set-up: the first ~50 sweeps after idle run 15-25 % slower (clock ramp);

@@ -910,6 +910,7 @@ struct ipcr_scratch {
     std::shared_ptr<Lane> lane_next;  // lane of the next scan (null: own)
     std::shared_ptr<Lane> lane_used;  // lane the last scan ran on
     hipEvent_t ev_done = nullptr;     // recorded behind a scan's read-back when it runs on a shared lane
+    hipStream_t cstream = nullptr;    // fetches the hit records of a published scan (never waits behind a sweep)
     struct Pending { // a scan enqueued by scan_enqueue and not yet collected
         bool active = false, empty = false;
         int mode = 0;
@@ -1126,6 +1127,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             v.next_counts = gi == 0 ? cnt_next : nullptr;
             v.next_qcount = gi == 0 ? qc_next : nullptr;
             if (publish_enabled()) { // every kernel of the scan writes its first hits to the pinned buffer too
+                v.seq = s->seq;
                 v.tickets = s->d_tickets;
                 v.pub_hits = reinterpret_cast<ipcr_hit_rec *>(static_cast<unsigned long long *>(s->pinned) + 8);
                 v.pre = (uint32_t)pd.pre;
@@ -1292,12 +1294,46 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         }
         std::vector<ipcr_hit> &raw = s->hits_raw;
         raw.resize(nhit);
-        const uint64_t got = std::min<uint64_t>(nhit, pd.pre);
-        if (got) memcpy(raw.data(), ph, got * sizeof(ipcr_hit));
+        uint64_t got = std::min<uint64_t>(nhit, pd.pre);
+        if (pd.published && got) {
+            // the records were written to pinned memory by whichever wave found them; each carries this scan's tag in
+            // its last word, written last: wait for the ones still on their way (normally none), fetch them from device
+            // memory if that takes long
+            const volatile ipcr_hit *vh = ph;
+            bool complete = true;
+            const auto tw0 = std::chrono::steady_clock::now();
+            for (uint64_t i = 0; i < got && complete; ++i) {
+                const uint64_t tag = ((uint64_t)s->seq << 32) | (uint32_t)i;
+                for (uint64_t spin = 1; vh[i].mm_mask[1] != tag; ++spin) {
+                    __builtin_ia32_pause();
+                    if ((spin & 0xFFFu) == 0 && ms_since(tw0) > 2.0) { complete = false; break; }
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (!complete) {
+                HIPCHK(hipEventSynchronize(s->ev[1]));
+                HIPCHK(hipMemcpyAsync(const_cast<ipcr_hit *>(ph), s->d_hits, got * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->cstream));
+                HIPCHK(hipStreamSynchronize(s->cstream));
+            }
+            memcpy(raw.data(), ph, got * sizeof(ipcr_hit));
+            for (uint64_t i = 0; i < got; ++i) raw[i].mm_mask[1] = 0; // patterns of the specialised filter are <= 32 nt
+        } else if (got) {
+            memcpy(raw.data(), ph, got * sizeof(ipcr_hit));
+        }
         if (nhit > got) HIPCHK(hipMemcpy(raw.data() + got, s->d_hits + got, (nhit - got) * sizeof(ipcr_hit), hipMemcpyDeviceToHost));
         s->prefix_hint = std::max<uint64_t>(256, nhit + nhit / 4 + 16);
         float fms = 0, vms = 0;
         if (pd.published) HIPCHK(hipEventSynchronize(s->ev[1])); // the kernel retires a moment after its last wave
+        static const bool check_pub = env_flag("IPCR_DEBUG_PUBLISH_CHECK", false);
+        if (check_pub && pd.published && got) { // what the host took from pinned memory vs what the kernel left in device memory
+            std::vector<ipcr_hit> dev(got);
+            HIPCHK(hipMemcpy(dev.data(), s->d_hits, got * sizeof(ipcr_hit), hipMemcpyDeviceToHost));
+            uint64_t diff = 0;
+            for (uint64_t i = 0; i < got; ++i)
+                if (memcmp(&dev[i], &raw[i], sizeof(ipcr_hit)) != 0) ++diff;
+            if (diff) fprintf(stderr, "publish check: %llu of %llu hit records had not reached pinned memory when they were read\n",
+                              (unsigned long long)diff, (unsigned long long)got);
+        }
         trace("retired", s);
         HIPCHK(hipEventElapsedTime(&fms, s->ev[0], s->ev[1]));
         if (pd.verified) HIPCHK(hipEventElapsedTime(&vms, s->ev[2], s->ev[3]));
@@ -1564,8 +1600,21 @@ ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out) {
     auto build = [&]() -> ipcr_status {
         HIPCHK(hipGetDevice(&raw->device));
         raw->own_lane = std::make_shared<ipcr_scratch::Lane>();
-        HIPCHK(hipStreamCreateWithFlags(&raw->own_lane->s, hipStreamNonBlocking));
+        {
+            // Streams share a few hardware queues (creation order decides which); a sweep lane that lands on the queue
+            // of, say, the RCCL stream has every collective queued between two sweeps (+25 us per step measured).
+            // IPCR_LANE_PRIORITY=1 asks for a queue of the high-priority class instead.
+            static const int lane_prio = env_flag("IPCR_LANE_PRIORITY", false) ? 1 : 0;
+            if (lane_prio) {
+                int lo = 0, hi = 0; // numerically lower = higher priority
+                HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                HIPCHK(hipStreamCreateWithPriority(&raw->own_lane->s, hipStreamNonBlocking, hi));
+            } else {
+                HIPCHK(hipStreamCreateWithFlags(&raw->own_lane->s, hipStreamNonBlocking));
+            }
+        }
         raw->stream = raw->own_lane->s;
+        HIPCHK(hipStreamCreateWithFlags(&raw->cstream, hipStreamNonBlocking));
         for (auto &e : raw->ev) HIPCHK(hipEventCreate(&e));
         raw->qcap = QCAP_INIT;
         raw->hcap = HCAP_INIT;
@@ -1614,6 +1663,7 @@ void ipcr_scratch_destroy(ipcr_scratch *s) {
     for (auto &e : s->ev)
         if (e) (void)hipEventDestroy(e);
     if (s->ev_done) (void)hipEventDestroy(s->ev_done);
+    if (s->cstream) (void)hipStreamDestroy(s->cstream);
     // the stream goes with the last scratch that shares it (own_lane / lane_used references)
     delete s;
 }

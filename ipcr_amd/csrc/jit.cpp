@@ -554,7 +554,10 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
          "          const u64 slot = atomicAdd(counts + 1, 1ull);\n"
          "          hitrec h; h.pos = local; h.record = r; h.pattern = gid | (flag << 31); h.m0 = (u64)mm; h.m1 = 0ull;\n"
          "          if (slot < hcap) hits[slot] = h;\n"
-         "          if (pub_hits && slot < pre) pub_hits[slot] = h; // the first hits also go straight to the host's pinned buffer\n"
+         "          if (pub_hits && slot < pre) { // the first hits also go straight to the host's pinned buffer, tagged with the\n"
+         "            h.m1 = ((u64)seq << 32) | (u32)slot; // scan: stores of different XCDs are not ordered with the last wave's\n"
+         "            pub_hits[slot] = h;                  // sequence word, so the host checks that every record has arrived\n"
+         "          }\n"
          "        }\n"
          "      }\n"
          "      nl = 0u; // done\n"
@@ -593,7 +596,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
          "        const u64 slot = atomicAdd(counts + 1, 1ull);\n"
          "        hitrec h; h.pos = local; h.record = lo; h.pattern = gid | (flag << 31); h.m0 = mm; h.m1 = 0ull;\n"
          "        if (slot < hcap) hits[slot] = h;\n"
-         "        if (pub_hits && slot < pre) pub_hits[slot] = h;\n"
+         "        if (pub_hits && slot < pre) { h.m1 = ((u64)seq << 32) | (u32)slot; pub_hits[slot] = h; }\n"
          "      }\n"
          "    }\n"
          "  }\n"

@@ -35,10 +35,13 @@ struct JitVerify {
     ipcr_hit_rec *hits = nullptr;
     uint64_t hcap = 0;
     unsigned long long *counts = nullptr, *next_counts = nullptr, *next_qcount = nullptr;
-    // publishing: every kernel writes the first `pre` hit records to pub_hits (pinned host memory) as
-    // they are found; in the last kernel of a scan (pub != null) the last wave to finish writes the
-    // counter set to pub[0..3] and then `seq` to *pub_seq, both in pinned host memory.
-    // tickets: 65 zeroed counters, 32 words apart, left zeroed again.
+    // hand-over: every kernel also writes the first `pre` hit records to pub_hits (pinned host memory) as they are
+    // found, with (seq << 32 | slot) in the upper mask word (always zero for patterns <= 64 nt): stores of waves on
+    // different XCDs are not ordered with the last wave's sequence word -- with several processes on the GPU the host
+    // saw it before 40 % of the records -- so the host checks the tag of every record it takes and waits for
+    // stragglers.  In the last kernel of a scan (pub != null) the last wave to finish writes the counter set to
+    // pub[0..3] and then `seq` to *pub_seq (one wave, system fence in between).
+    // tickets: 65 zeroed counters, 32 words apart, left zeroed again (+ one statistics counter next to each).
     uint32_t *tickets = nullptr;
     unsigned long long *pub = nullptr;
     ipcr_hit_rec *pub_hits = nullptr;
