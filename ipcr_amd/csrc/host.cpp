@@ -1320,10 +1320,12 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         } else if (got) {
             memcpy(raw.data(), ph, got * sizeof(ipcr_hit));
         }
+        // the kernel retires a moment after its last wave; only then is device memory (records beyond the pinned
+        // prefix, the buffer an all-gather may read next) guaranteed to hold what its waves wrote
+        if (pd.published) HIPCHK(hipEventSynchronize(s->ev[1]));
         if (nhit > got) HIPCHK(hipMemcpy(raw.data() + got, s->d_hits + got, (nhit - got) * sizeof(ipcr_hit), hipMemcpyDeviceToHost));
         s->prefix_hint = std::max<uint64_t>(256, nhit + nhit / 4 + 16);
         float fms = 0, vms = 0;
-        if (pd.published) HIPCHK(hipEventSynchronize(s->ev[1])); // the kernel retires a moment after its last wave
         static const bool check_pub = env_flag("IPCR_DEBUG_PUBLISH_CHECK", false);
         if (check_pub && pd.published && got) { // what the host took from pinned memory vs what the kernel left in device memory
             std::vector<ipcr_hit> dev(got);
