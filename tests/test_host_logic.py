@@ -218,6 +218,27 @@ def test_filter_source_is_generated_for_the_headline_panels():
     assert engine.New(engine.Config(MaxMM=1)).CompilePanel([primer.Pair("l", long_p, long_p)]).filter_source(0) == ""
 
 
+def test_generated_filter_structure():
+    """what the generator decides for the headline panel: the coarse k+1 block split with the exact count in the rare
+    branch, pattern tables that match the panel, and no exact stage once a kernel holds many patterns"""
+    import re
+    from ipcr_amd import workloads
+    cp = engine.New(engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12)).CompilePanel(workloads.c2_pairs())
+    src = cp.filter_source(0)
+    assert len(re.findall(r"// pattern \d+: len 20, 5 protected, 3 blocks", src)) >= 4   # B = k + 1
+    assert "__builtin_expect(all != 0xFFFFFFFFu, 0)" in src and "const u32 e14 =" in src   # exact count over 15 positions
+    m = re.search(r"PMASK\[NPAT \* 32u\] = \{([0-9,]+)\}", src)
+    table = [int(v) for v in m.group(1).split(",")]
+    assert len(table) == 4 * 32
+    fwd = workloads.c2_pairs()[0].Forward
+    code = {"A": 1, "C": 2, "G": 4, "T": 8}
+    want = [code[b] | (16 if j >= 15 else 0) for j, b in enumerate(fwd)] + [0] * 12    # 3' window = last five positions
+    assert any(table[q * 32:(q + 1) * 32] == want for q in range(4))
+    many = engine.New(engine.Config(MaxMM=2, TerminalWindow=3)).CompilePanel(workloads.c4_pairs(8))
+    big_src = many.filter_source(0)                                                       # 12 patterns per kernel: > 160 sites
+    assert "ipcr_filter" in big_src and "const u32 e14 =" not in big_src
+
+
 def test_workload_primers_match_reference_generator():  # performance_benchmark_test.go:78-93
     from ipcr_amd import workloads
     for idx in (0, 1, 2, 3, 77, 2047):
