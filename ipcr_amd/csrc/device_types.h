@@ -79,3 +79,9 @@ static_assert(sizeof(ipcr_index_entry) == 64, "index entries are read as four 16
 struct ipcr_fasta_range {
     uint64_t start, end;
 };
+
+// one record of a batched pack launch: 16-byte aligned source bytes, destination columns, index of its flag word
+struct ipcr_pack_rec {
+    uint64_t src_off, len, col0;
+    uint32_t ncol, flag_idx;
+};

@@ -714,6 +714,46 @@ ipcr_status genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len,
     return IPCR_OK;
 }
 
+// many records whose bytes lie in one device buffer (every one 16-byte aligned): one pack launch for all of them
+ipcr_status genome_add_device_batch(ipcr_genome *g, const uint8_t *dbase, const uint64_t *offs, const uint64_t *lens, size_t n,
+                                    void *d_tmp, size_t tmp_bytes) {
+    if (n == 0) return IPCR_OK;
+    if (g->rec_start.size() + n > g->max_records) return fail(IPCR_ERR_CAPACITY, "genome holds its maximum of %u records", g->max_records);
+    if ((reinterpret_cast<uintptr_t>(dbase) & 15u) != 0) return fail(IPCR_ERR_INVALID, "device sequence pointer must be 16-byte aligned");
+    std::vector<ipcr_pack_rec> recs(n);
+    std::vector<uint32_t> prefix(n + 1, 0);
+    uint64_t col = g->next_col;
+    const uint32_t first = (uint32_t)g->rec_start.size();
+    for (size_t i = 0; i < n; ++i) {
+        if (offs[i] & 15u) return fail(IPCR_ERR_INVALID, "record %zu of the batch is not 16-byte aligned", i);
+        const uint64_t cols = record_cols(lens[i]);
+        recs[i] = ipcr_pack_rec{offs[i], lens[i], col, (uint32_t)cols, first + (uint32_t)i};
+        prefix[i + 1] = prefix[i] + (uint32_t)(cols / 2u);
+        col += cols;
+    }
+    if (col > g->cap_cols)
+        return fail(IPCR_ERR_CAPACITY, "genome capacity exceeded (%llu columns > %llu)", (unsigned long long)col, (unsigned long long)g->cap_cols);
+    const size_t need = n * sizeof(ipcr_pack_rec) + (n + 1) * 4 + 16;
+    if (need > tmp_bytes) return fail(IPCR_ERR_CAPACITY, "batch table does not fit its device buffer");
+    ipcr_pack_rec *d_recs = static_cast<ipcr_pack_rec *>(d_tmp);
+    uint32_t *d_prefix = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_tmp) + ((n * sizeof(ipcr_pack_rec) + 15) & ~(size_t)15));
+    HIPCHK(hipMemcpyAsync(d_recs, recs.data(), n * sizeof(ipcr_pack_rec), hipMemcpyHostToDevice, g->stream));
+    HIPCHK(hipMemcpyAsync(d_prefix, prefix.data(), (n + 1) * 4, hipMemcpyHostToDevice, g->stream));
+    HIPCHK(ipcr::launch_pack_batch(g->stream, dbase, d_recs, d_prefix, (uint32_t)n, prefix[n], g->planes, g->rst, g->d_flags));
+    HIPCHK(hipStreamSynchronize(g->stream)); // recs / prefix are host vectors of this call
+    for (size_t i = 0; i < n; ++i) {
+        g->rec_start.push_back(recs[i].col0 * IPCR_COLUMN_BASES);
+        g->rec_len.push_back(lens[i]);
+        g->ids.emplace_back();
+        g->total_bases += lens[i];
+    }
+    g->next_col = col;
+    if (g->padded_until < g->next_col) g->padded_until = g->next_col;
+    g->tables_dirty = true;
+    g->flags_valid = false;
+    return IPCR_OK;
+}
+
 // before a scan: the rest of the last block and one block beyond must be padding, and the
 // record tables must be on the device
 ipcr_status genome_finalize(ipcr_genome *g) {
@@ -1976,7 +2016,7 @@ ipcr_status ipcr_nested_windows(const ipcr_genome *g, const ipcr_window *windows
         s->amps_cap = off + 16 + (off >> 2);
         HIPCHK(hipMalloc((void **)&s->d_amps, s->amps_cap));
     }
-    const uint64_t misc_bytes = n * sizeof(ipcr_amp_seg) + 64;
+    const uint64_t misc_bytes = n * (sizeof(ipcr_amp_seg) + sizeof(ipcr_pack_rec) + 4) + 256;
     if (misc_bytes > s->probe_misc_cap) {
         if (s->d_probe_misc) (void)hipFree(s->d_probe_misc);
         s->d_probe_misc = nullptr;
@@ -1997,8 +2037,10 @@ ipcr_status ipcr_nested_windows(const ipcr_genome *g, const ipcr_window *windows
         s->nest->shared_stream = true;
     }
     genome_clear(s->nest);
-    for (size_t i = 0; i < n; ++i) {
-        st = genome_add_device(s->nest, s->d_amps + offs[i], lens[i], false);
+    {   // one pack launch for all amplicons; its record table goes behind the segment table in the same device buffer
+        const uint64_t seg_bytes = (n * sizeof(ipcr_amp_seg) + 63) & ~63ull;
+        st = genome_add_device_batch(s->nest, s->d_amps, offs.data(), lens.data(), n, static_cast<uint8_t *>(s->d_probe_misc) + seg_bytes,
+                                     (size_t)(s->probe_misc_cap - seg_bytes));
         if (st != IPCR_OK) return st;
     }
     st = scan_hits(inner, s, s->nest);

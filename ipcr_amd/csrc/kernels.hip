@@ -36,16 +36,10 @@ __device__ __forceinline__ uint32_t swar_zero_bytes(uint32_t x) { // 0x80 in eve
     return ~(t | x) & 0x80808080u;
 }
 
-__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ seq, uint64_t len,
-                                                   uint64_t col0, uint64_t ncol,
-                                                   uint32_t *__restrict__ planes,
-                                                   uint32_t *__restrict__ rst,
-                                                   uint32_t *__restrict__ rec_flags) {
-    __shared__ uint32_t s_in[4][2048]; // per wave: 2 columns x 32 strands x 32 dwords
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint64_t pairidx = (uint64_t)blockIdx.x * 4u + wv;
-    if (pairidx * 2u >= ncol) return; // waves are independent (no workgroup barrier below)
-    uint32_t *mine = s_in[wv];
+__device__ __forceinline__ void pack_pair(const uint8_t *__restrict__ seq, uint64_t len, uint64_t col0, uint64_t ncol,
+                                          uint64_t pairidx, uint32_t lane, uint32_t *mine,
+                                          uint32_t *__restrict__ planes, uint32_t *__restrict__ rst,
+                                          uint32_t *__restrict__ rec_flags) {
     const uint64_t base = pairidx * 2u * IPCR_COLUMN_BASES; // record-local first base of my column pair
 #pragma unroll
     for (uint32_t it = 0; it < 8u; ++it) {
@@ -100,6 +94,37 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
     }
     const bool saw_rst = (ors[0] | ors[1] | ors[2] | ors[3]) != 0u;
     if (__ballot(saw_rst) != 0ull && lane == 0u) atomicOr(rec_flags, 1u);
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ seq, uint64_t len,
+                                                   uint64_t col0, uint64_t ncol,
+                                                   uint32_t *__restrict__ planes,
+                                                   uint32_t *__restrict__ rst,
+                                                   uint32_t *__restrict__ rec_flags) {
+    __shared__ uint32_t s_in[4][2048]; // per wave: 2 columns x 32 strands x 32 dwords
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t pairidx = (uint64_t)blockIdx.x * 4u + wv;
+    if (pairidx * 2u >= ncol) return; // waves are independent (no workgroup barrier)
+    pack_pair(seq, len, col0, ncol, pairidx, lane, s_in[wv], planes, rst, rec_flags);
+}
+
+// many records in one launch (a nested-PCR batch has thousands of short amplicons, one launch each costs ~17 us):
+// wave = one column pair of one record, found by binary search in the prefix of the records' pair counts
+__global__ __launch_bounds__(256) void pack_batch_kernel(const uint8_t *__restrict__ base, const ipcr_pack_rec *__restrict__ recs,
+                                                         const uint32_t *__restrict__ pair_prefix, uint32_t nrec,
+                                                         uint32_t *__restrict__ planes, uint32_t *__restrict__ rst,
+                                                         uint32_t *__restrict__ rec_flags) {
+    __shared__ uint32_t s_in[4][2048];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t gp = (uint64_t)blockIdx.x * 4u + wv;
+    if (gp >= pair_prefix[nrec]) return;
+    uint32_t lo = 0, hi = nrec; // record whose pair range holds gp
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pair_prefix[mid] <= gp) lo = mid; else hi = mid;
+    }
+    const ipcr_pack_rec r = recs[lo];
+    pack_pair(base + r.src_off, r.len, r.col0, r.ncol, gp - pair_prefix[lo], lane, s_in[wv], planes, rst, rec_flags + r.flag_idx);
 }
 
 // fill columns [col_begin, col_end) with padding (inv=1, everything else 0)
@@ -465,6 +490,14 @@ hipError_t launch_pack(hipStream_t st, const uint8_t *seq, uint64_t len, uint64_
     const uint64_t grid = (pairs + 3u) / 4u;
     if (grid == 0) return hipSuccess;
     pack_kernel<<<dim3((uint32_t)grid), dim3(256), 0, st>>>(seq, len, col0, ncol, planes, rst, rec_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_batch(hipStream_t st, const uint8_t *base, const ipcr_pack_rec *recs, const uint32_t *pair_prefix,
+                             uint32_t nrec, uint64_t total_pairs, uint32_t *planes, uint32_t *rst, uint32_t *rec_flags) {
+    const uint64_t grid = (total_pairs + 3u) / 4u;
+    if (grid == 0 || nrec == 0) return hipSuccess;
+    pack_batch_kernel<<<dim3((uint32_t)grid), dim3(256), 0, st>>>(base, recs, pair_prefix, nrec, planes, rst, rec_flags);
     return hipGetLastError();
 }
 

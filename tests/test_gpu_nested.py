@@ -86,3 +86,33 @@ def test_nested_products_vs_oracle():
         assert found >= 10
         assert len(nested.NestedProducts(sco, prods, g, cpi, sci, require_inner=True)) == found
     g.close()
+
+
+def test_nested_large_batch_matches_per_window_calls():
+    """4000 windows (overlapping, of many lengths, some empty) in one batch == the same windows one call each for a
+    sample: the batched pack places every amplicon where its record table says"""
+    from ipcr_amd import engine, nested, primer
+    rng = random.Random(808)
+    seq = list(O.bench_dna(400_000, 4242).decode())
+    inner = [primer.Pair("i1", "TTGACCGATTAC", "CCGGTTAACGGA"), primer.Pair("i2", "GATTACAGGTCA", "ACGGATTCAGGC")]
+    for t in range(300):
+        ip = inner[t % 2]
+        b = 500 + t * 1300
+        seq[b:b + 12] = ip.Forward
+        seq[b + 90:b + 102] = O.revcomp(ip.Reverse).decode()
+    g = engine.Genome(500_000, 2)
+    g.add_record("r", "".join(seq).encode())
+    eng = engine.New(engine.Config(MaxMM=1, TerminalWindow=2, MaxLen=1000, HitCap=100, SeedLen=12))
+    cp = eng.CompilePanel(inner)
+    sc = eng.NewSimulationScratch(cp)
+    windows = []
+    for _ in range(4000):
+        a = rng.randrange(0, 399_000)
+        windows.append((0, a, a + rng.choice([0, 7, 60, 130, 400, 900])))
+    got = nested.NestedWindows(g, windows, cp, sc)
+    assert sum(n.InnerFound for n in got) >= 300
+    for i in rng.sample(range(4000), 60):
+        one = nested.NestedWindows(g, [windows[i]], cp, sc)[0]
+        assert (one.InnerFound, one.InnerPairID, one.InnerStart, one.InnerEnd, one.InnerFwdMM, one.InnerRevMM) == \
+            (got[i].InnerFound, got[i].InnerPairID, got[i].InnerStart, got[i].InnerEnd, got[i].InnerFwdMM, got[i].InnerRevMM)
+    g.close()
