@@ -100,17 +100,17 @@ typedef struct {
 typedef struct {
     double pack_ms;       /* ASCII -> tile pack kernel (0 when the genome was already resident) */
     double filter_ms;     /* dominant kernel: bit-sliced k-mismatch filter over the tiles (HIP events) */
-    double verify_ms;     /* per-candidate verify kernel */
+    double verify_ms;     /* stand-alone verify kernel (0 when the specialised filter verified its survivors itself) */
     double total_ms;      /* host wall time of the call */
     uint64_t bases;       /* genome bases scanned */
     uint64_t tile_bytes;  /* bytes of encoded tiles the filter kernel reads once */
-    uint64_t candidates;  /* filter survivors handed to the verifier */
+    uint64_t candidates;  /* windows that reached the exact verifier (in-kernel or stand-alone) */
     uint64_t hits;        /* verified primer.Match records */
     uint64_t products;
     int32_t kernel_kind;  /* 1 = panel-specialised (runtime-compiled) filter, 2 = table-driven filter, 3 = seed-index filter */
     int32_t n_patterns;
-    double enqueue_ms;    /* host time to enqueue memset + kernels + copies */
-    double wait_ms;       /* host time blocked in the stream synchronise */
+    double enqueue_ms;    /* host time to enqueue the kernels (+ copy and marker where the kernel does not publish itself) */
+    double wait_ms;       /* host time waiting for the results (sequence word in pinned memory, or event / stream) */
     double sort_ms;       /* host: hit records -> (record, pattern, pos) order */
     double join_ms;       /* host: match lists + amplicon join */
 } ipcr_scan_stats;
