@@ -75,6 +75,46 @@ def build_genome(torch, engine, workloads, revcomp_fn, genome_idx: int, records:
     return g, plants, host0
 
 
+def pipelined_passes(k, scratches, begin, end, chain=None, start_exchange=None, finish_exchange=None, pipeline=True,
+                     recv_slots=2):
+    """k passes of the hot path over `scratches` in rotation, pipelined the way the reference's worker pool +
+    collector are (internal/pipeline/pipeline.go:60-161): while the host waits for and joins pass i, the sweep of pass
+    i+1 is already queued (chain(cur, prev): behind pass i's on the device); with several GPUs the all-gather of pass
+    i's hit records runs under the following passes.  Invariants (tests/test_host_logic.py checks them with fakes):
+      * a scratch is begun again only after its previous pass has been ended AND the exchange that reads its device
+        hit buffer has finished;
+      * at most `recv_slots` exchanges are in flight (the exchanger has that many receive buffers);
+      * when the function returns every pass has been ended and every exchange finished.
+    Returns what end() returned for the last pass."""
+    n, works, ns = None, {}, len(scratches)   # works: pass -> exchange in flight (it reads that pass's scratch)
+    if k <= 0:
+        return n
+
+    def do_begin(j):
+        if finish_exchange is not None:
+            for jj in [q for q in works if q <= j - ns]:
+                finish_exchange(works.pop(jj))
+        if j > 0 and pipeline and chain is not None:
+            chain(scratches[j % ns], scratches[(j - 1) % ns])
+        begin(scratches[j % ns])
+
+    do_begin(0)
+    for i in range(k):
+        cur = scratches[i % ns]
+        if i + 1 < k and pipeline:
+            do_begin(i + 1)
+        n = end(i, cur)
+        if start_exchange is not None:
+            for jj in [q for q in works if q <= i - recv_slots]:
+                finish_exchange(works.pop(jj))
+            works[i] = start_exchange(cur)
+        if i + 1 < k and not pipeline:
+            do_begin(i + 1)
+    for jj in sorted(works):
+        finish_exchange(works.pop(jj))
+    return n
+
+
 def main() -> None:
     # HIP maps streams onto a few hardware queues (4 by default), in creation order.  This job has a dozen (three
     # scratches, the genome, torch, RCCL): when the sweep lane shares a queue with the collective's stream, every
@@ -145,50 +185,24 @@ def main() -> None:
         expect_products = n_
 
     def run_steps(k):
-        """k passes of the hot path, pipelined the way the reference's worker pool + collector are
-        (internal/pipeline/pipeline.go:60-161): while the host waits for / joins pass i, the kernels of
-        pass i+1 are already enqueued on the other scratch's stream; with several GPUs the all-gatherv
-        of pass i's hit records (RCCL) runs under pass i+1 too.  Every pass is complete (filter ->
-        verify -> hits -> match lists -> join -> products, hits exchanged) when run_steps returns."""
-        fms, n = [], 0
-        xt = [0.0, 0.0, 0]
-        works = {}                        # pass -> exchange in flight (it reads that pass's scratch on the device)
-        if k <= 0:
-            return fms, n
-        ns = len(scs)
+        """k passes of the hot path (see pipelined_passes); returns (filter ms per pass, products of the last pass)"""
+        fms = []
 
-        def begin(j):
-            # the all-gather of pass j-ns read the device hit buffer of the scratch pass j is about to reuse
-            for jj in [q for q in works if q <= j - ns]:
-                xchg.finish(works.pop(jj))
-            if j > 0 and not args.no_pipeline and not os.environ.get("IPCR_BENCH_NO_CHAIN"):
-                scs[j % ns].chain_after(scs[(j - 1) % ns])        # device: pass j's sweep behind pass j-1's
-            eng.ScanGenomeBegin(genome, cp, scs[j % ns])
-
-        begin(0)
-        for i in range(k):
-            cur = scs[i % ns]
-            if i + 1 < k and not args.no_pipeline:
-                begin(i + 1)
+        def end(i, cur):
             n = eng.ScanGenomeEndCount(genome, cp, cur)          # this rank's partition of the join: its records
             if n != expect_products:                             # every pass is checked, not only the last one
                 raise SystemExit(f"pass {i}: {n} products, the set-up scan found {expect_products}")
             fms.append(cur.stats().filter_ms)
-            if multi:
-                tq = time.perf_counter()
-                for jj in [q for q in works if q <= i - 2]:      # two receive slots
-                    xchg.finish(works.pop(jj))
-                tr = time.perf_counter()
-                works[i] = xchg.start_scratch(cur, nrec)         # all-gatherv of hit records, async, out of the device hit buffer
-                xt[0] += tr - tq
-                xt[1] += time.perf_counter() - tr
-                xt[2] += 1
-            if i + 1 < k and args.no_pipeline:
-                begin(i + 1)
-        for jj in sorted(works):
-            xchg.finish(works.pop(jj))
-        if multi and xt[2] and os.environ.get("IPCR_DEBUG_TIMES"):
-            print("exchange host time per pass: finish %.1f us, start %.1f us" % (1e6 * xt[0] / xt[2], 1e6 * xt[1] / xt[2]), file=sys.stderr)
+            return n
+
+        n = pipelined_passes(
+            k, scs,
+            begin=lambda cur: eng.ScanGenomeBegin(genome, cp, cur),
+            end=end,
+            chain=None if (args.no_pipeline or os.environ.get("IPCR_BENCH_NO_CHAIN")) else (lambda cur, prev: cur.chain_after(prev)),
+            start_exchange=(lambda cur: xchg.start_scratch(cur, nrec)) if multi else None,   # all-gatherv of hit records, async
+            finish_exchange=xchg.finish if multi else None,
+            pipeline=not args.no_pipeline)
         return fms, n
 
     # part of the untimed set-up: the first ~50 sweeps after idle run 15-25 % slower (clock ramp, DESIGN.md section 5);

@@ -244,3 +244,59 @@ def test_workload_primers_match_reference_generator():  # performance_benchmark_
     for idx in (0, 1, 2, 3, 77, 2047):
         assert workloads.bench_primer(idx) == O.bench_primer(idx, 20)
     assert len(workloads.c4_pairs(1024)) == 1024 + 2048
+
+
+@pytest.mark.parametrize("ns,pipeline,exchange", [(3, True, True), (2, True, True), (3, False, True), (3, True, False), (1, False, True), (4, True, True)])
+def test_pipelined_pass_schedule_invariants(ns, pipeline, exchange):
+    """bench.pipelined_passes with fake scratches and a fake exchanger: no scratch is begun while its previous pass
+    is open or while an exchange still reads its device hit buffer, at most two exchanges are in flight, everything
+    is finished at the end -- the hazards of the multi-GPU loop that no single-GPU run can show"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    class Scr:
+        def __init__(self, name):
+            self.name, self.open, self.read_by = name, False, None
+    scs = [Scr(i) for i in range(ns)]
+    log, inflight, ended = [], set(), []
+
+    def begin(cur):
+        assert not cur.open, "scan begun while the previous one on this scratch is still open"
+        assert cur.read_by is None, "scan begun while exchange %s still reads this scratch's hit buffer" % cur.read_by
+        cur.open = True
+        log.append(("begin", cur.name))
+
+    def end(i, cur):
+        assert cur.open
+        cur.open = False
+        ended.append(i)
+        return i * 10
+
+    def chain(cur, prev):
+        assert cur is not prev and not cur.open
+
+    def start(cur):
+        assert not cur.open and cur.read_by is None
+        h = ("x", len(log))
+        cur.read_by = h
+        inflight.add(h)
+        assert len(inflight) <= 2, "more exchanges in flight than receive slots"
+        log.append(("start", cur.name))
+        return (h, cur)
+
+    def finish(w):
+        h, cur = w
+        assert h in inflight
+        inflight.discard(h)
+        cur.read_by = None
+
+    if ns == 1 and pipeline:
+        return
+    k = 17
+    last = bench.pipelined_passes(k, scs, begin, end, chain=chain if pipeline else None,
+                                  start_exchange=start if exchange else None, finish_exchange=finish if exchange else None,
+                                  pipeline=pipeline)
+    assert last == (k - 1) * 10 and ended == list(range(k)) and not inflight
+    assert all(not s.open and s.read_by is None for s in scs)
+    assert bench.pipelined_passes(0, scs, begin, end) is None
