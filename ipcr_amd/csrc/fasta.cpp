@@ -56,6 +56,10 @@ extern ipcr_status ipcr_internal_fail(ipcr_status st, const char *fmt, ...);
 // host.cpp: pack a record that already lies in device memory (16-byte aligned) and remember its ID
 extern ipcr_status ipcr_internal_genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len, const char *id);
 extern hipStream_t ipcr_internal_genome_stream(ipcr_genome *g);
+// host.cpp: records lying anywhere in one device buffer, packed by one launch (d_tmp: room for the record table)
+extern ipcr_status ipcr_internal_genome_add_batch(ipcr_genome *g, const uint8_t *dbase, const uint64_t *offs, const uint64_t *lens,
+                                                  const std::string *ids, size_t n, void *d_tmp, size_t tmp_bytes);
+extern size_t ipcr_internal_batch_table_bytes(size_t n);
 
 namespace {
 
@@ -161,7 +165,12 @@ struct FastaLoader {
     std::vector<ipcr_fasta_range> ranges;
     bool at_line_start = true, lead_open = true;
     bool have_id = false;
+    bool open_in_slab = false; // the open record began in the slab being processed (its bytes are all in d_out so far)
     std::string id, ids;
+    std::vector<uint64_t> b_off, b_len; // records that begin and end inside the current slab: one pack launch for all
+    std::vector<std::string> b_id;
+    void *d_tab = nullptr;
+    size_t tab_cap = 0;
     uint32_t n_added = 0;
     double t_read = 0, t_host = 0, t_decode = 0, t_pack = 0;
 
@@ -177,6 +186,7 @@ struct FastaLoader {
         if (d_counts) (void)hipFree(d_counts);
         if (d_hdr_off) (void)hipFree(d_hdr_off);
         if (d_hdr) (void)hipFree(d_hdr);
+        if (d_tab) (void)hipFree(d_tab);
     }
 
     ipcr_status open(ipcr_genome *genome, const char *path) {
@@ -255,13 +265,32 @@ struct FastaLoader {
         return IPCR_OK;
     }
 
+    void count_record() {
+        if (n_added) ids.push_back('\n');
+        ids += id;
+        ++n_added;
+    }
+
+    ipcr_status flush_batch() {
+        const size_t n = b_off.size();
+        if (n == 0) return IPCR_OK;
+        const size_t need = ipcr_internal_batch_table_bytes(n);
+        if (need > tab_cap) {
+            if (d_tab) (void)hipFree(d_tab);
+            d_tab = nullptr;
+            tab_cap = need * 2;
+            FHIP(hipMalloc(&d_tab, tab_cap));
+        }
+        const ipcr_status s = ipcr_internal_genome_add_batch(g, d_out, b_off.data(), b_len.data(), b_id.data(), n, d_tab, tab_cap);
+        b_off.clear(); b_len.clear(); b_id.clear();
+        return s;
+    }
+
     ipcr_status finish_record() {
         if (!have_id) return IPCR_OK;
         const ipcr_status s = ipcr_internal_genome_add_device(g, d_rec ? d_rec : d_out, rec_len, id.c_str());
         if (s != IPCR_OK) return s;
-        if (n_added) ids.push_back('\n');
-        ids += id;
-        ++n_added;
+        count_record();
         have_id = false;
         rec_len = 0;
         return IPCR_OK;
@@ -383,19 +412,38 @@ struct FastaLoader {
             }
             const auto tp0 = std::chrono::steady_clock::now();
             t_decode += std::chrono::duration<double>(tp0 - td0).count();
-            // hand the compacted bytes to the records
+            // hand the compacted bytes to the records.  A record that begins and ends in this slab is packed straight
+            // out of d_out with all the others like it (one launch); the one that came in open and the one that stays
+            // open go through the record buffer
             uint64_t a = 0;
             for (uint32_t k = 0; k < nh; ++k) {
-                s = append(a, h_small[k]);
-                if (s == IPCR_OK) s = finish_record(); // path_ctx.go:164-170: a header flushes the open record
-                if (s != IPCR_OK) return s;
-                a = h_small[k];
+                const uint64_t b = h_small[k];
+                if (have_id && open_in_slab) {
+                    b_off.push_back(a); b_len.push_back(b - a); b_id.push_back(id);
+                    count_record();
+                    have_id = false;
+                } else {
+                    s = append(a, b);
+                    if (s == IPCR_OK) s = finish_record(); // path_ctx.go:164-170: a header flushes the open record
+                    if (s != IPCR_OK) return s;
+                }
+                a = b;
                 const std::string hdr((const char *)raw + ranges[k].start + 1, (size_t)(ranges[k].end - ranges[k].start - 1));
                 id = parse_header_id(hdr);
                 have_id = !id.empty(); // a header without an ID drops its record
+                open_in_slab = true;
                 rec_len = 0;
             }
-            s = append(a, total);
+            if (last && have_id && open_in_slab) { // the file ends here: the open record is complete too
+                b_off.push_back(a); b_len.push_back(total - a); b_id.push_back(id);
+                count_record();
+                have_id = false;
+            } else {
+                s = append(a, total);
+                if (s != IPCR_OK) return s;
+            }
+            open_in_slab = false; // whatever is still open continues in the record buffer
+            s = flush_batch();    // (waits for the stream: the record table is a host vector of that call)
             if (s != IPCR_OK) return s;
             FHIP(hipStreamSynchronize(st)); // d_out is reused by the next slab
             t_pack += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();

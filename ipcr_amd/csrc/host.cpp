@@ -716,16 +716,14 @@ ipcr_status genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len,
 
 // many records whose bytes lie in one device buffer (every one 16-byte aligned): one pack launch for all of them
 ipcr_status genome_add_device_batch(ipcr_genome *g, const uint8_t *dbase, const uint64_t *offs, const uint64_t *lens, size_t n,
-                                    void *d_tmp, size_t tmp_bytes) {
+                                    void *d_tmp, size_t tmp_bytes, const std::string *ids = nullptr) {
     if (n == 0) return IPCR_OK;
     if (g->rec_start.size() + n > g->max_records) return fail(IPCR_ERR_CAPACITY, "genome holds its maximum of %u records", g->max_records);
-    if ((reinterpret_cast<uintptr_t>(dbase) & 15u) != 0) return fail(IPCR_ERR_INVALID, "device sequence pointer must be 16-byte aligned");
     std::vector<ipcr_pack_rec> recs(n);
     std::vector<uint32_t> prefix(n + 1, 0);
     uint64_t col = g->next_col;
     const uint32_t first = (uint32_t)g->rec_start.size();
     for (size_t i = 0; i < n; ++i) {
-        if (offs[i] & 15u) return fail(IPCR_ERR_INVALID, "record %zu of the batch is not 16-byte aligned", i);
         const uint64_t cols = record_cols(lens[i]);
         recs[i] = ipcr_pack_rec{offs[i], lens[i], col, (uint32_t)cols, first + (uint32_t)i};
         prefix[i + 1] = prefix[i] + (uint32_t)(cols / 2u);
@@ -744,7 +742,7 @@ ipcr_status genome_add_device_batch(ipcr_genome *g, const uint8_t *dbase, const 
     for (size_t i = 0; i < n; ++i) {
         g->rec_start.push_back(recs[i].col0 * IPCR_COLUMN_BASES);
         g->rec_len.push_back(lens[i]);
-        g->ids.emplace_back();
+        g->ids.emplace_back(ids ? ids[i] : std::string());
         g->total_bases += lens[i];
     }
     g->next_col = col;
@@ -876,6 +874,11 @@ ipcr_status ipcr_internal_genome_add_device(ipcr_genome *g, const uint8_t *dseq,
     return st;
 }
 hipStream_t ipcr_internal_genome_stream(ipcr_genome *g) { return g->stream; }
+ipcr_status ipcr_internal_genome_add_batch(ipcr_genome *g, const uint8_t *dbase, const uint64_t *offs, const uint64_t *lens,
+                                           const std::string *ids, size_t n, void *d_tmp, size_t tmp_bytes) {
+    return genome_add_device_batch(g, dbase, offs, lens, n, d_tmp, tmp_bytes, ids);
+}
+size_t ipcr_internal_batch_table_bytes(size_t n) { return n * sizeof(ipcr_pack_rec) + (n + 1) * 4 + 64; }
 
 extern "C" {
 

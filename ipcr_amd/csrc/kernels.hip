@@ -36,6 +36,7 @@ __device__ __forceinline__ uint32_t swar_zero_bytes(uint32_t x) { // 0x80 in eve
     return ~(t | x) & 0x80808080u;
 }
 
+template <bool ALIGNED>
 __device__ __forceinline__ void pack_pair(const uint8_t *__restrict__ seq, uint64_t len, uint64_t col0, uint64_t ncol,
                                           uint64_t pairidx, uint32_t lane, uint32_t *mine,
                                           uint32_t *__restrict__ planes, uint32_t *__restrict__ rst,
@@ -47,7 +48,8 @@ __device__ __forceinline__ void pack_pair(const uint8_t *__restrict__ seq, uint6
         const uint64_t p0 = base + (uint64_t)idx * 16u;
         uint4 v;
         if (p0 + 16u <= len) {
-            v = *reinterpret_cast<const uint4 *>(seq + p0);
+            if (ALIGNED) v = *reinterpret_cast<const uint4 *>(seq + p0);
+            else __builtin_memcpy(&v, seq + p0, 16); // one global_load_dwordx4 at a byte address (records of a batch start anywhere)
         } else {
             uint32_t w[4] = {0x61616161u, 0x61616161u, 0x61616161u, 0x61616161u}; // 'a': inv = 1, rst = 0, code 0
             for (uint32_t t = 0; t < 16u; ++t)
@@ -105,10 +107,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t pairidx = (uint64_t)blockIdx.x * 4u + wv;
     if (pairidx * 2u >= ncol) return; // waves are independent (no workgroup barrier)
-    pack_pair(seq, len, col0, ncol, pairidx, lane, s_in[wv], planes, rst, rec_flags);
+    pack_pair<true>(seq, len, col0, ncol, pairidx, lane, s_in[wv], planes, rst, rec_flags);
 }
 
-// many records in one launch (a nested-PCR batch has thousands of short amplicons, one launch each costs ~17 us):
+// many records in one launch (a nested-PCR batch or a fragmented assembly has thousands of short records, one launch
+// each costs ~17 us); the records may start at any byte of `base`:
 // wave = one column pair of one record, found by binary search in the prefix of the records' pair counts
 __global__ __launch_bounds__(256) void pack_batch_kernel(const uint8_t *__restrict__ base, const ipcr_pack_rec *__restrict__ recs,
                                                          const uint32_t *__restrict__ pair_prefix, uint32_t nrec,
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const uint8_t *__restri
         if (pair_prefix[mid] <= gp) lo = mid; else hi = mid;
     }
     const ipcr_pack_rec r = recs[lo];
-    pack_pair(base + r.src_off, r.len, r.col0, r.ncol, gp - pair_prefix[lo], lane, s_in[wv], planes, rst, rec_flags + r.flag_idx);
+    pack_pair<false>(base + r.src_off, r.len, r.col0, r.ncol, gp - pair_prefix[lo], lane, s_in[wv], planes, rst, rec_flags + r.flag_idx);
 }
 
 // fill columns [col_begin, col_end) with padding (inv=1, everything else 0)
