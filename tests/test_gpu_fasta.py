@@ -165,3 +165,20 @@ def test_chunked_equals_unchunked_on_planted_records(tmp_path):
     for cs in (5000, 7777, 20000):
         chunked, _ = _cli(base + ["--chunk-size", str(cs), str(fa)])
         assert chunked == whole, cs
+
+
+def test_thousands_of_tiny_records_batched(tmp_path):
+    """a fragmented assembly: records that begin and end inside one slab are packed by ONE launch straight out of the
+    compacted slab, at whatever byte they start; records cut by a slab edge take the record-buffer path"""
+    rng = random.Random(2024)
+    parts = []
+    for r in range(3000):
+        n = rng.choice([0, 1, 15, 16, 17, 59, 60, 61, 128, 200, 1000])
+        seq = bytes(rng.choice(b"ACGTACGTACGTacgtN") for _ in range(n))
+        parts.append(b">c%d len=%d\n" % (r, n))
+        for i in range(0, n, 60):
+            parts.append(seq[i:i + 60] + b"\n")
+    p = tmp_path / "frag.fa"
+    p.write_bytes(b"".join(parts))
+    for slab in (None, 65536, 4096):
+        load_and_compare(str(p), slab)
