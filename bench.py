@@ -6,13 +6,16 @@ Workload (BASELINE.json configs[1], "C2"): one primer pair as `ipcr` scans it wi
 --terminal-window 5, --max-length 2000, --hit-cap 10000, over a synthetic 3.0 Gb genome
 (24 records x 125 Mb of the reference's benchDNA LCG, 1000 planted 180-bp amplicons:
 exact / 1 / 2 mismatches outside the 3' window).  One STEP = one pass of the hot path over the
-whole resident genome: bit-sliced filter kernel -> per-candidate verify kernel -> hit records to
-the host -> reference-order match lists -> amplicon join -> products.  Inputs (the 2-bit +
-invalid-bit tiles) are resident in HBM when the timed region starts.
+whole resident genome: the specialised sweep (block test, exact count, verification and hand-over
+in one kernel) -> hit records on the host -> reference-order match lists -> amplicon join ->
+products; the product count of EVERY pass is checked, all planted amplicons of the last one.
+Inputs (the 2-bit + invalid-bit tiles) are resident in HBM when the timed region starts.
+Passes are pipelined over three scratches (pipelined_passes); --no-pipeline runs them one by one.
 
 N > 1 (torchrun, one process per GPU): weak scaling -- every rank scans its own 3 Gb genome
-(seed + rank) with the same panel, hit records are exchanged by one all-gatherv over RCCL per
-step and joined on rank 0.
+(seed + rank) with the same panel and joins its own records; the hit records of every pass are
+exchanged by one all-gather over RCCL (straight out of the device hit buffer, two in flight), and
+rank 0 joins the whole job from the gathered records of the last pass as a check.
 
 Prints ONE JSON line on rank 0.
 """
