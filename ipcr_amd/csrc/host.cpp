@@ -25,6 +25,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "device_types.h"
@@ -1118,7 +1119,8 @@ ipcr_status wait_published(ipcr_scratch *s) {
     const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spin = 1;; ++spin) {
         if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == want) return IPCR_OK;
-        __builtin_ia32_pause();
+        if (spin < 0x10000u) __builtin_ia32_pause(); // the first millisecond (a sweep takes 0.2 ms): pure spin
+        else std::this_thread::yield();              // long scans (large panels, huge genomes): let other workers run
         if ((spin & 0xFFFFu) == 0) { // a fault on the stream would otherwise spin for ever
             const hipError_t q = hipStreamQuery(lane);
             if (q == hipSuccess) { // stream drained: the word is there, or device stores do not reach this host's pinned memory
