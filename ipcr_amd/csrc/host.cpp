@@ -1295,6 +1295,9 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             // some wave's survivor list was full and spilled to the queue (dense matches): run the
             // stand-alone verifier over the spilled words; it appends to the same hit buffer
             const PatternSet &set = p->set[pd.mode];
+            // the sweep may have run on another scratch's stream (chained scans) and has only published, not retired:
+            // its queue entries become visible to a later kernel on OUR stream when it has ended
+            if (pd.published) HIPCHK(hipEventSynchronize(s->ev[1]));
             const uint64_t qset = (uint64_t)IPCR_QUEUE_SHARDS * IPCR_QUEUE_COUNTER_STRIDE;
             unsigned long long *cnt = s->d_counts + 4u * pd.cset_used, *cnt_next = s->d_counts + 4u * (pd.cset_used ^ 1u);
             unsigned long long *qc = s->d_qcounts + qset * pd.cset_used, *qc_next = s->d_qcounts + qset * (pd.cset_used ^ 1u);
