@@ -118,11 +118,34 @@ def pipelined_passes(k, scratches, begin, end, chain=None, start_exchange=None, 
     return n
 
 
+def launch_plan(gpus: int, env, argv, python: str = sys.executable, script: str = os.path.abspath(__file__)):
+    """How `bench.py --gpus N` gets its N ranks (one process per GPU, internal/pipeline/pipeline.go:60-125 is the
+    reference's unit of parallelism: independent records over a pool of workers).
+      * RANK in the environment: this process IS a rank (torchrun or the driver started it) -> None = run here;
+        WORLD_SIZE must then equal --gpus when --gpus > 1 was given.
+      * no RANK and N > 1: this process only launches -- it returns the command of
+        `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`, which main() starts as a CHILD
+        process (never exec) before anything has touched the GPU, and whose exit code it returns.
+      * N <= 1: None."""
+    if "RANK" in env:
+        world = int(env.get("WORLD_SIZE", "1"))
+        if gpus > 1 and world != gpus:
+            raise SystemExit(f"bench.py: --gpus {gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                             f"(python bench.py --gpus {gpus} does it itself)")
+        return None
+    if gpus <= 1:
+        return None
+    port = env.get("MASTER_PORT") or str(29500 + (os.getpid() % 400))
+    return [python, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", port, script] + list(argv)
+
+
 def main() -> None:
     # HIP maps streams onto a few hardware queues (4 by default), in creation order.  This job has a dozen (three
     # scratches, the genome, torch, RCCL): when the sweep lane shares a queue with the collective's stream, every
     # all-gather is serialised between two sweeps (+25 us per step measured).  One queue per stream instead.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # one step is ~0.2 ms: the default region (about half a second) is long enough for the clocks to settle; the
@@ -136,6 +159,11 @@ def main() -> None:
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo to rehearse)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every pass before the next one is enqueued")
     args = ap.parse_args()
+
+    cmd = launch_plan(args.gpus, os.environ, sys.argv[1:])
+    if cmd is not None:   # launcher only: no torch import, no HIP call in this process
+        import subprocess
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ)))
 
     import numpy as np
     import torch

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IPCR_ABI_VERSION 1
+#define IPCR_ABI_VERSION 2
 #define IPCR_MAX_PRIMER_LEN 128 /* longest primer/probe the device path accepts */
 #define IPCR_MAX_MM 16          /* largest --mismatches the device path accepts */
 
@@ -113,6 +113,11 @@ typedef struct {
     double wait_ms;       /* host time waiting for the results (sequence word in pinned memory, or event / stream) */
     double sort_ms;       /* host: hit records -> (record, pattern, pos) order */
     double join_ms;       /* host: match lists + amplicon join */
+    /* in-kernel hand-over (specialised filter): hit records reach pinned host memory as two tagged 16-byte halves */
+    uint64_t handover_refetched;   /* scans whose records were fetched from device memory instead: a record's tags had
+                                      not both arrived within 2 ms */
+    uint64_t handover_checked;     /* IPCR_DEBUG_PUBLISH_CHECK=1: scans whose pinned records were compared with device memory */
+    uint64_t handover_check_diffs; /* ... records that differed (must be 0) */
 } ipcr_scan_stats;
 
 typedef struct ipcr_panel ipcr_panel;     /* engine.CompiledPanel + device tables */

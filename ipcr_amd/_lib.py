@@ -65,7 +65,9 @@ class ScanStats(C.Structure):
                 ("total_ms", C.c_double), ("bases", C.c_uint64), ("tile_bytes", C.c_uint64),
                 ("candidates", C.c_uint64), ("hits", C.c_uint64), ("products", C.c_uint64),
                 ("kernel_kind", C.c_int32), ("n_patterns", C.c_int32), ("enqueue_ms", C.c_double),
-                ("wait_ms", C.c_double), ("sort_ms", C.c_double), ("join_ms", C.c_double)]
+                ("wait_ms", C.c_double), ("sort_ms", C.c_double), ("join_ms", C.c_double),
+                ("handover_refetched", C.c_uint64), ("handover_checked", C.c_uint64),
+                ("handover_check_diffs", C.c_uint64)]
 
 
 EMIT_FN = C.CFUNCTYPE(C.c_int, C.POINTER(Product), C.c_void_p)

@@ -57,11 +57,25 @@ def split_chunk_suffix(seq_id: str):
     dash = suffix.find("-")
     if dash == -1:
         return seq_id, 0, False
-    try:
-        start = int(suffix[:dash])
-    except ValueError:
+    start = _atoi(suffix[:dash])
+    if start is None:
         return seq_id, 0, False
     return seq_id[:colon], start, True
+
+
+def _atoi(text: str):
+    """strconv.Atoi (ids.go:21): optional sign, then ASCII digits only, value inside int64 -- Python's int() also
+    takes surrounding blanks, '_' separators and non-ASCII digits, which would rebase IDs such as "x: 7-9" or
+    "x:1_0-5" that the reference leaves alone.  None where Atoi returns an error."""
+    body = text[1:] if text[:1] in ("+", "-") else text
+    if not body or not all("0" <= ch <= "9" for ch in body):
+        return None
+    v = int(body)
+    if text[:1] == "-":
+        v = -v
+    if v < -(1 << 63) or v > (1 << 63) - 1:
+        return None
+    return v
 
 
 def compute_overlap(max_len: int, max_primer_len: int) -> int:

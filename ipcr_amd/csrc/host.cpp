@@ -1186,6 +1186,10 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
                 v.seq = s->seq;
                 pd.published = true;
             }
+            {   // tests: IPCR_TEST_WITHHOLD_TAG=<slot+1>: that record's first half carries a stale tag (a torn record)
+                static const int withhold = getenv("IPCR_TEST_WITHHOLD_TAG") ? atoi(getenv("IPCR_TEST_WITHHOLD_TAG")) : 0;
+                v.withhold = withhold > 0 ? (uint32_t)withhold : 0u;
+            }
             HIPCHK(ipcr::jit_launch(set.jit[gi], lane, g->planes, nblocks, s->d_queue, s->qcap, qc, v,
                                     gi == 0 ? s->ev[0] : nullptr, gi + 1 == set.jit.size() ? s->ev[1] : nullptr));
         }
@@ -1344,27 +1348,34 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         raw.resize(nhit);
         uint64_t got = std::min<uint64_t>(nhit, pd.pre);
         if (pd.published && got) {
-            // the records were written to pinned memory by whichever wave found them; each carries this scan's tag in
-            // its last word, written last: wait for the ones still on their way (normally none), fetch them from device
-            // memory if that takes long
+            // The records were written to pinned memory by whichever wave found them, each as two 16-byte stores that
+            // nothing orders on their way to the host: each half carries this scan's tag (jit.cpp: publish) and a record
+            // is taken only when BOTH are there.  Wait for the ones still on their way (normally none); after 2 ms fetch
+            // the whole prefix from device memory, where the kernel has left the same records.
             const volatile ipcr_hit *vh = ph;
+            const uint64_t tag_pos = (uint64_t)(s->seq & 0xFFFFFFu);
+            const uint64_t tag_hi = (uint64_t)s->seq << 32;
             bool complete = true;
             const auto tw0 = std::chrono::steady_clock::now();
             for (uint64_t i = 0; i < got && complete; ++i) {
-                const uint64_t tag = ((uint64_t)s->seq << 32) | (uint32_t)i;
-                for (uint64_t spin = 1; vh[i].mm_mask[1] != tag; ++spin) {
+                for (uint64_t spin = 1; (vh[i].pos >> 40) != tag_pos || vh[i].mm_mask[1] != (tag_hi | (uint32_t)i); ++spin) {
                     __builtin_ia32_pause();
                     if ((spin & 0xFFFu) == 0 && ms_since(tw0) > 2.0) { complete = false; break; }
                 }
             }
             std::atomic_thread_fence(std::memory_order_acquire);
             if (!complete) {
+                ++s->stats.handover_refetched;
                 HIPCHK(hipEventSynchronize(s->ev[1]));
-                HIPCHK(hipMemcpyAsync(const_cast<ipcr_hit *>(ph), s->d_hits, got * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->cstream));
+                HIPCHK(hipMemcpyAsync(raw.data(), s->d_hits, got * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->cstream));
                 HIPCHK(hipStreamSynchronize(s->cstream));
+            } else {
+                memcpy(raw.data(), ph, got * sizeof(ipcr_hit));
+                for (uint64_t i = 0; i < got; ++i) { // strip the tags (patterns of the specialised filter are <= 32 nt: m1 is zero)
+                    raw[i].pos &= (1ull << 40) - 1ull;
+                    raw[i].mm_mask[1] = 0;
+                }
             }
-            memcpy(raw.data(), ph, got * sizeof(ipcr_hit));
-            for (uint64_t i = 0; i < got; ++i) raw[i].mm_mask[1] = 0; // patterns of the specialised filter are <= 32 nt
         } else if (got) {
             memcpy(raw.data(), ph, got * sizeof(ipcr_hit));
         }
@@ -1381,7 +1392,9 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             uint64_t diff = 0;
             for (uint64_t i = 0; i < got; ++i)
                 if (memcmp(&dev[i], &raw[i], sizeof(ipcr_hit)) != 0) ++diff;
-            if (diff) fprintf(stderr, "publish check: %llu of %llu hit records had not reached pinned memory when they were read\n",
+            s->stats.handover_check_diffs += diff;
+            ++s->stats.handover_checked;
+            if (diff) fprintf(stderr, "publish check: %llu of %llu hit records taken from pinned memory differ from device memory\n",
                               (unsigned long long)diff, (unsigned long long)got);
         }
         trace("retired", s);

@@ -440,6 +440,24 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
          "  const u64 idx = atomicAdd(qcount, 1ull);\n"
          "  if (idx < qcap) { qent e; e.key = (q << 48) | pos; e.bits = bits; e.pad = 0u; queue[idx] = e; }\n"
          "}\n";
+    // Hand-over of one hit record to the host's pinned buffer: stores of different waves (XCDs) reach host memory in
+    // no particular order relative to the last wave's sequence word, and the two 16-byte halves of a record are
+    // separate stores -- so EACH half carries the scan's tag and is written by ONE dwordx4 store:
+    //   half 0 = {pos | (seq & 0xFFFFFF) << 40, record, pattern}     (positions are < 2^40: 288 GB of HBM)
+    //   half 1 = {m0, slot | seq << 32}                               (m1 is zero for patterns <= 64 nt)
+    // The host takes a record only when both tags are this scan's (host.cpp: scan_collect) and strips them.
+    // withhold (tests only): slot + 1 of a record whose first half is published with a stale tag -- a torn record.
+    s << "__device__ __forceinline__ void publish(hitrec* __restrict__ pub_hits, u64 slot, u64 pos, u32 record, u32 pattern,\n"
+         "    u64 m0, u32 seq, u32 withhold) {\n"
+         "  const u32 tag0 = (withhold != 0u && slot + 1ull == (u64)withhold) ? (seq - 1u) : seq;\n"
+         "  const u64 tpos = pos | ((u64)(tag0 & 0xFFFFFFu) << 40);\n"
+         "  v4 a, b;\n"
+         "  a.x = (u32)tpos; a.y = (u32)(tpos >> 32); a.z = record; a.w = pattern;\n"
+         "  b.x = (u32)m0; b.y = (u32)(m0 >> 32); b.z = (u32)slot; b.w = seq;\n"
+         "  v4* dst = (v4*)(pub_hits + slot);\n"
+         "  dst[0] = a; // one global_store_dwordx4 each (checked in the ISA by csrc/jit_check.py)\n"
+         "  dst[1] = b;\n"
+         "}\n";
     // the patterns of this kernel as constant tables (the verifier's per-position masks: low 4 bits =
     // bases the primer position accepts, bit 4 = position inside the protected window)
     s << "#define NPAT " << pats.size() << "u\n#define QBASE " << qbase << "u\n";
@@ -458,7 +476,8 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
          "    const u64* __restrict__ rec_len, const u32* __restrict__ block_rec, u32 nrec, u32 max_mm, u32 check_rst,\n"
          "    hitrec* __restrict__ hits, u64 hcap,\n"
          "    u64* __restrict__ counts, u64* __restrict__ next_counts, u64* __restrict__ next_qcount,\n"
-         "    u32* __restrict__ tickets, u64* __restrict__ pub, hitrec* __restrict__ pub_hits, u32 pre, u32* __restrict__ pub_seq, u32 seq) {\n";
+         "    u32* __restrict__ tickets, u64* __restrict__ pub, hitrec* __restrict__ pub_hits, u32 pre, u32* __restrict__ pub_seq, u32 seq,\n"
+         "    u32 withhold) {\n";
     s << "  const u32 lane = threadIdx.x & 63u;\n";
     s << "  const u32 wv = threadIdx.x >> 6;\n";
     s << "  const u64 block = (u64)blockIdx.x * " << WPG << "u + wv;\n";
@@ -554,10 +573,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
          "          const u64 slot = atomicAdd(counts + 1, 1ull);\n"
          "          hitrec h; h.pos = local; h.record = r; h.pattern = gid | (flag << 31); h.m0 = (u64)mm; h.m1 = 0ull;\n"
          "          if (slot < hcap) hits[slot] = h;\n"
-         "          if (pub_hits && slot < pre) { // the first hits also go straight to the host's pinned buffer, tagged with the\n"
-         "            h.m1 = ((u64)seq << 32) | (u32)slot; // scan: stores of different XCDs are not ordered with the last wave's\n"
-         "            pub_hits[slot] = h;                  // sequence word, so the host checks that every record has arrived\n"
-         "          }\n"
+         "          if (pub_hits && slot < pre) publish(pub_hits, slot, h.pos, h.record, h.pattern, h.m0, seq, withhold); // the first hits also go straight to the host\n"
          "        }\n"
          "      }\n"
          "      nl = 0u; // done\n"
@@ -596,7 +612,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
          "        const u64 slot = atomicAdd(counts + 1, 1ull);\n"
          "        hitrec h; h.pos = local; h.record = lo; h.pattern = gid | (flag << 31); h.m0 = mm; h.m1 = 0ull;\n"
          "        if (slot < hcap) hits[slot] = h;\n"
-         "        if (pub_hits && slot < pre) { h.m1 = ((u64)seq << 32) | (u32)slot; pub_hits[slot] = h; }\n"
+         "        if (pub_hits && slot < pre) publish(pub_hits, slot, h.pos, h.record, h.pattern, h.m0, seq, withhold);\n"
          "      }\n"
          "    }\n"
          "  }\n"
@@ -668,15 +684,20 @@ bool compile_group(const std::string &src, const std::string &arch, std::vector<
         const auto it = cc.map.find(key);
         if (it != cc.map.end()) { code = it->second; return true; }
     }
-    // IPCR_JIT_CACHE_DIR: code objects also persist on disk (a CLI that is run again with the same primers
-    // skips hiprtc); file name = 64-bit FNV-1a of (arch, source) + source length
-    std::string disk;
+    // IPCR_JIT_CACHE_DIR: code objects also persist on disk (a CLI that is run again with the same primers skips
+    // hiprtc).  File name = 64-bit FNV-1a of the key; the file STORES its key (arch, hiprtc version, source) in front
+    // of the code object and is used only when that key is byte-identical: a hash collision or a code object built
+    // by another ROCm release is compiled afresh, never loaded silently.
+    std::string disk, fullkey;
     if (const char *dir = getenv("IPCR_JIT_CACHE_DIR")) {
         if (*dir) {
+            int vmaj = 0, vmin = 0;
+            (void)hiprtcVersion(&vmaj, &vmin);
+            fullkey = "hiprtc " + std::to_string(vmaj) + "." + std::to_string(vmin) + "\n" + key;
             unsigned long long h = 1469598103934665603ull;
-            for (const unsigned char ch : key) { h ^= ch; h *= 1099511628211ull; }
+            for (const unsigned char ch : fullkey) { h ^= ch; h *= 1099511628211ull; }
             char name[64];
-            snprintf(name, sizeof name, "/ipcr_%016llx_%zu.hsaco", h, key.size());
+            snprintf(name, sizeof name, "/ipcr_%016llx.jit", h);
             disk = std::string(dir) + name;
             if (FILE *fh = fopen(disk.c_str(), "rb")) {
                 std::vector<char> buf;
@@ -684,7 +705,12 @@ bool compile_group(const std::string &src, const std::string &arch, std::vector<
                 size_t n;
                 while ((n = fread(tmp, 1, sizeof tmp, fh)) > 0) buf.insert(buf.end(), tmp, tmp + n);
                 fclose(fh);
-                if (buf.size() > 64 && memcmp(buf.data(), "\177ELF", 4) == 0) code.swap(buf);
+                // layout: "IPCRJIT1" | u64 key length | key | code object
+                unsigned long long klen = 0;
+                if (buf.size() > 16 && memcmp(buf.data(), "IPCRJIT1", 8) == 0) memcpy(&klen, buf.data() + 8, 8);
+                if (klen == fullkey.size() && buf.size() > 16 + klen + 64 && memcmp(buf.data() + 16, fullkey.data(), klen) == 0 &&
+                    memcmp(buf.data() + 16 + klen, "\177ELF", 4) == 0)
+                    code.assign(buf.begin() + 16 + (long)klen, buf.end());
             }
         }
     }
@@ -693,8 +719,11 @@ bool compile_group(const std::string &src, const std::string &arch, std::vector<
         if (!disk.empty()) { // write next to the target, then rename: readers never see a partial file
             const std::string tmpname = disk + ".tmp" + std::to_string((unsigned long long)getpid());
             if (FILE *fh = fopen(tmpname.c_str(), "wb")) {
-                const bool ok = fwrite(code.data(), 1, code.size(), fh) == code.size();
-                fclose(fh);
+                const unsigned long long klen = fullkey.size();
+                bool ok = fwrite("IPCRJIT1", 1, 8, fh) == 8 && fwrite(&klen, 1, 8, fh) == 8 &&
+                          fwrite(fullkey.data(), 1, fullkey.size(), fh) == fullkey.size() &&
+                          fwrite(code.data(), 1, code.size(), fh) == code.size();
+                ok = (fclose(fh) == 0) && ok;
                 if (!ok || rename(tmpname.c_str(), disk.c_str()) != 0) (void)remove(tmpname.c_str());
             }
         }
@@ -1047,7 +1076,7 @@ hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint
                     (void *)&a.rst, (void *)&a.pats, (void *)&a.rec_start, (void *)&a.rec_len, (void *)&a.block_rec, (void *)&a.nrec,
                     (void *)&a.max_mm, (void *)&a.check_rst, (void *)&a.hits, (void *)&a.hcap, (void *)&a.counts,
                     (void *)&a.next_counts, (void *)&a.next_qcount, (void *)&a.tickets, (void *)&a.pub,
-                    (void *)&a.pub_hits, (void *)&a.pre, (void *)&a.pub_seq, (void *)&a.seq};
+                    (void *)&a.pub_hits, (void *)&a.pre, (void *)&a.pub_seq, (void *)&a.seq, (void *)&a.withhold};
     const unsigned wpg = f->waves_per_group, threads = wpg * 64u;
     const unsigned grid = (unsigned)((nblocks + wpg - 1) / wpg);
     // start/stop are attached to this dispatch itself (its begin/end timestamps)

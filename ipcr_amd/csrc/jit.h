@@ -36,10 +36,11 @@ struct JitVerify {
     uint64_t hcap = 0;
     unsigned long long *counts = nullptr, *next_counts = nullptr, *next_qcount = nullptr;
     // hand-over: every kernel also writes the first `pre` hit records to pub_hits (pinned host memory) as they are
-    // found, with (seq << 32 | slot) in the upper mask word (always zero for patterns <= 64 nt): stores of waves on
-    // different XCDs are not ordered with the last wave's sequence word -- with several processes on the GPU the host
-    // saw it before 40 % of the records -- so the host checks the tag of every record it takes and waits for
-    // stragglers.  In the last kernel of a scan (pub != null) the last wave to finish writes the counter set to
+    // found.  Stores of waves on different XCDs are not ordered with the last wave's sequence word -- with several
+    // processes on the GPU the host saw it before 40 % of the records -- and the two 16-byte halves of a record are
+    // separate stores, so EACH half carries the scan's tag (seq in bits 40..63 of pos; slot | seq << 32 in the upper
+    // mask word, which is zero for patterns <= 64 nt) and is one dwordx4 store; the host takes a record only when both
+    // tags are there, waits for stragglers and strips the tags.  In the last kernel of a scan (pub != null) the last wave to finish writes the counter set to
     // pub[0..3] and then `seq` to *pub_seq (one wave, system fence in between).
     // tickets: 65 zeroed counters, 32 words apart, left zeroed again (+ one statistics counter next to each).
     uint32_t *tickets = nullptr;
@@ -48,6 +49,7 @@ struct JitVerify {
     uint32_t pre = 0;
     uint32_t *pub_seq = nullptr;
     uint32_t seq = 0;
+    uint32_t withhold = 0; // tests: slot + 1 of a record published with a stale tag in its first half (a torn record)
 };
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,
                       uint64_t qcap, unsigned long long *qcount, const JitVerify &v, hipEvent_t start, hipEvent_t stop);

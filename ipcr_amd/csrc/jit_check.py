@@ -28,6 +28,15 @@ def main() -> None:
             subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-c", path,
                                    "-o", path[:-4] + ".o"])
         cp.close()
+    # the hand-over relies on each 16-byte half of a published hit record being ONE store instruction (each half
+    # carries the scan's tag): check the ISA of the C2 kernel for the dwordx4 pairs of hits[] and publish()
+    path = os.path.join(outdir, "filter_c2_m0.hip")
+    asm = subprocess.check_output(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only",
+                                   "-o", "-", path], stderr=subprocess.DEVNULL).decode()
+    lines = asm.splitlines()
+    pairs16 = sum(1 for a, b in zip(lines, lines[1:]) if "global_store_dwordx4" in a and "global_store_dwordx4" in b
+                  and b.rstrip().endswith("offset:16"))
+    assert pairs16 >= 4, f"hit records are no longer stored as two dwordx4 halves ({pairs16} pairs found)"
     # seed-index filter of a large panel (config C4)
     from ipcr_amd.workloads import c4_pairs
     cp = engine.New(engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)).CompilePanel(c4_pairs(64))

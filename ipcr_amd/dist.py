@@ -124,9 +124,15 @@ def allgather_record_meta(lens: Sequence[int], flags: Sequence[int], device=None
 
 class HitExchanger:
     """Persistent buffers for the per-step all-gatherv of hit records: ONE collective per step
-    (a max-padded all-gather whose first 32-byte slot carries this rank's hit and record counts);
-    a second, larger round happens only when some rank overflows the current capacity, and every
-    rank takes that decision from the same gathered header, so they stay in lock step."""
+    (a max-padded all-gather whose header carries this rank's hit and record counts).
+
+    Lock step: no rank ever decides alone.  A rank whose hits exceed the current capacity still enters
+    the collective (header with the true count + the first `cap` records); after the gather EVERY rank
+    reads the same headers, sees the same overflow, and all of them regrow and redo that exchange
+    together (`finish` for the overlapped forms, the loop in `allgather` for the synchronous one).
+    A rank whose scratch's device hit buffer is smaller than the exchange capacity sends through a
+    device staging buffer of the agreed size instead of the zero-copy view -- the collective's shape
+    never depends on a local condition."""
 
     def __init__(self, device=None, cap_hits: int = 4096, group=None):
         import torch
@@ -138,7 +144,9 @@ class HitExchanger:
         self.rank = dist.get_rank(group) if self.active else 0
         self.device = device if device is not None else torch.device("cpu")
         self.cap = 0
+        self.redone = 0                      # exchanges repeated because some rank overflowed the capacity
         self.device_path = self.device.type == "cuda"
+        self._rec_counts = [0] * self.world
         self._alloc(cap_hits)
 
     def _alloc(self, cap: int) -> None:
@@ -148,45 +156,54 @@ class HitExchanger:
         pin = self.device.type == "cuda"
         self.h_send = torch.zeros(n, dtype=torch.uint8, pin_memory=pin)
         self.h_recv = torch.zeros(self.world * n, dtype=torch.uint8, pin_memory=pin)
-        self._views, self._from_device, self._nrec_local, self._host_work = {}, False, 0, None
+        self._views, self._host_work, self._last = {}, None, None
         if self.device.type == "cuda":
+            nb = 64 + cap * 32
             self.d_send = torch.zeros(n, dtype=torch.uint8, device=self.device)
             self.d_recv = torch.zeros(self.world * n, dtype=torch.uint8, device=self.device)
-            self.d_recv_dev = [torch.zeros(self.world * (64 + cap * 32), dtype=torch.uint8, device=self.device) for _ in range(2)]
-            self._slot, self._done_slot = 0, 0
-            self.h_recv_dev = torch.zeros(self.world * (64 + cap * 32), dtype=torch.uint8, pin_memory=True)
+            self.d_stage = torch.zeros(nb, dtype=torch.uint8, device=self.device)
+            # two receive slots (+ the pinned copy of their headers): up to two exchanges may be in flight
+            self.d_recv_dev = [torch.zeros(self.world * nb, dtype=torch.uint8, device=self.device) for _ in range(2)]
+            self.h_hdr = [torch.zeros(self.world * 64, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self._slot = 0
+            self.h_recv_dev = torch.zeros(self.world * nb, dtype=torch.uint8, pin_memory=True)
         else:
             self.d_send, self.d_recv = self.h_send, self.h_recv
 
     # -- overlapped form: the collective runs while the host joins this rank's own records --------
     def start(self, local: np.ndarray, n_local_records: int):
         """Enqueue the all-gatherv of this step's hit records (H2D of the local records + one
-        RCCL all-gather) and return at once.  Capacity must already fit (it does after one
-        synchronous `allgather`, which regrows it on every rank consistently)."""
+        all-gather) and return at once.  More records than the capacity: the first `cap` go out with
+        the true count in the header, and `finish` redoes the exchange on every rank."""
         assert local.dtype == HIT_DTYPE
         if not self.active:
             return None
-        if len(local) > self.cap:
-            raise RuntimeError(f"{len(local)} hit records exceed the exchange capacity {self.cap}; "
-                               "call allgather() once first so every rank regrows it together")
-        self._from_device = False
         if self._host_work is not None:               # one send buffer: the previous host-path exchange must be done
             self._host_work.wait()
-        n = len(local)
+        n = min(len(local), self.cap)
         hs = self.h_send.numpy()
-        hs[:16].view(np.int64)[:] = (n, n_local_records)
+        hs[:16].view(np.int64)[:] = (len(local), n_local_records)
         if n:
-            hs[32:32 + n * 32] = local.view(np.uint8).reshape(-1)
+            hs[32:32 + n * 32] = local[:n].view(np.uint8).reshape(-1)
         if self.d_send is not self.h_send:
             self.d_send.copy_(self.h_send, non_blocking=True)
         self._host_work = self.dist.all_gather_into_tensor(self.d_recv, self.d_send, group=self.group, async_op=True)
-        return self._host_work
+        return ("host", self._host_work, local, n_local_records, self.cap)
 
     # -- device form (RCCL): the hit records never visit the host on the sending side ---------------
     class _DevView:
         """zero-copy torch view of a raw device range (__cuda_array_interface__)"""
         def __init__(self, ptr: int, nbytes: int):
             self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    def _view(self, ptr: int, nbytes: int):
+        key = (ptr, nbytes)
+        view = self._views.get(key)
+        if view is None:
+            view = self.torch.as_tensor(self._DevView(ptr, nbytes), device=self.device)
+            self._views = {k: v for k, v in self._views.items() if k[0] != ptr}
+            self._views[key] = view
+        return view
 
     def agree_on_device_path(self, scratch) -> bool:
         """Every rank tries the zero-copy view of its scratch's device hit buffer (the one step of the device
@@ -196,10 +213,9 @@ class HitExchanger:
         if self.active and self.device.type == "cuda" and not os.environ.get("IPCR_EXCHANGE_HOST"):
             try:
                 ptr, _, cap = scratch.device_hits()
-                if cap >= self.cap:
-                    nbytes = 64 + self.cap * 32
-                    view = self.torch.as_tensor(self._DevView(ptr, nbytes), device=self.device)
-                    ok = int(view.numel() == nbytes and view.data_ptr() == ptr)
+                nbytes = 64 + min(cap, self.cap) * 32
+                view = self.torch.as_tensor(self._DevView(ptr, nbytes), device=self.device)
+                ok = int(view.numel() == nbytes and view.data_ptr() == ptr)
             except Exception:
                 ok = 0
         if self.active:
@@ -218,62 +234,82 @@ class HitExchanger:
         if self.device.type != "cuda" or not self.device_path:
             return self.start(hits_from_scratch(scratch), n_local_records)
         ptr, n, cap = scratch.device_hits()
-        if n > self.cap or cap < self.cap:
-            raise RuntimeError(f"{n} hit records / device capacity {cap} do not fit the exchange capacity {self.cap}; "
-                               "call allgather() once first so every rank regrows it together")
         nbytes = 64 + self.cap * 32
-        key = (ptr, nbytes)
-        view = self._views.get(key)
-        if view is None:
-            view = self.torch.as_tensor(self._DevView(ptr, nbytes), device=self.device)
-            self._views = {k: v for k, v in self._views.items() if k[0] != ptr}
-            self._views[key] = view
-        self._nrec_local = n_local_records
-        self._from_device = True
-        # two receive slots: up to two exchanges may be in flight (three scratches in rotation), and the
-        # host later waits for ONE of them (its own event), not for the whole stream
+        if cap >= self.cap:
+            send = self._view(ptr, nbytes)
+        else:   # this rank's buffer is smaller than the agreed shape: same bytes through a staging buffer
+            m = 64 + cap * 32
+            self.d_stage[:m].copy_(self._view(ptr, m), non_blocking=True)
+            send = self.d_stage
         slot = self._slot = (self._slot + 1) & 1
-        work = self.dist.all_gather_into_tensor(self.d_recv_dev[slot][: self.world * nbytes], view, group=self.group, async_op=True)
+        recv, hdr = self.d_recv_dev[slot], self.h_hdr[slot]
+        work = self.dist.all_gather_into_tensor(recv[: self.world * nbytes], send, group=self.group, async_op=True)
         work.wait()                                   # current stream waits (no host block) ...
+        hdr.view(self.world, 64).copy_(recv.view(self.world, nbytes)[:, :64], non_blocking=True)  # every rank's counters
         ev = self.torch.cuda.Event()
-        ev.record()                                   # ... so this event completes exactly when the all-gather has
-        return (work, ev, slot)
+        ev.record()                                   # ... so this event completes exactly when gather + header copy have
+        return ("dev", work, ev, recv, hdr, self.cap, scratch, n_local_records)
+
+    @staticmethod
+    def _device_counts(hdr_bytes: np.ndarray, world: int) -> np.ndarray:
+        hdr = hdr_bytes.reshape(world, 64).view(np.uint64).reshape(world, 8)
+        return np.maximum(hdr[:, 1], hdr[:, 5]).astype(np.int64)   # the counter set of the last scan is the non-zero one
 
     def finish(self, work) -> None:
-        """Wait until every rank's hit records of this step are resident in this rank's memory
-        (`d_recv`: world x (header + cap records)); `gathered()` brings them to the host."""
+        """Wait until every rank's hit records of this step are resident in this rank's memory.  If the
+        gathered headers show that some rank had more hits than the capacity, every rank (all read the
+        same headers) regrows and repeats that exchange synchronously; `gathered()` then returns the
+        complete result."""
         if work is None:
             return
-        if isinstance(work, tuple):
-            work[1].synchronize()
-            self._done_slot = work[2]
+        if work[0] == "dev":
+            _, _, ev, recv, hdr, cap, scratch, nrec = work
+            ev.synchronize()
+            counts = self._device_counts(hdr.numpy(), self.world)
+            if int(counts.max()) > cap:
+                self.redone += 1
+                self._last = ("full",) + tuple(self.allgather(hits_from_scratch(scratch), nrec))
+            else:
+                self._last = ("dev", recv, cap, counts)
             return
-        work.wait()
+        _, w, local, nrec, cap = work
+        w.wait()
+        if self._host_work is w:
+            self._host_work = None
         if self.device.type == "cuda":
+            self.h_recv.copy_(self.d_recv, non_blocking=True)
             self.torch.cuda.current_stream(self.device).synchronize()
+        hr = self.h_recv.numpy().reshape(self.world, (cap + 1) * 32)
+        meta = hr[:, :16].copy().view(np.int64).reshape(self.world, 2)
+        if int(meta[:, 0].max()) > cap:
+            self.redone += 1
+            self._last = ("full",) + tuple(self.allgather(local, nrec))
+        else:
+            self._last = ("full",) + tuple(self._unpack(hr, meta))
 
     def gathered(self):
-        """Host copy of the last gathered buffer -> same triple as allgather()."""
+        """Result of the exchange most recently finished -> same triple as allgather()."""
         if not self.active:
             raise RuntimeError("no exchange in a single-process job")
-        if self._from_device:
-            self.h_recv_dev.copy_(self.d_recv_dev[self._done_slot])
-            return self._unpack_device()
-        if self.d_recv is not self.h_recv:
-            self.h_recv.copy_(self.d_recv)
-        return self._unpack()
+        if self._last is None:
+            raise RuntimeError("no finished exchange")
+        if self._last[0] == "full":
+            return self._last[1:]
+        _, recv, cap, counts = self._last
+        nbytes = 64 + cap * 32
+        host = self.h_recv_dev if self.h_recv_dev.numel() == recv.numel() else self.torch.empty(recv.numel(), dtype=self.torch.uint8, pin_memory=True)
+        host.copy_(recv)
+        return self._unpack_device(host.numpy().reshape(self.world, nbytes), cap, counts)
 
     def set_record_counts(self, counts) -> None:
         """records per rank (static for a job; the device form does not resend them every step)"""
         self._rec_counts = [int(c) for c in counts]
 
-    def _unpack_device(self):
-        nbytes = 64 + self.cap * 32
-        hr = self.h_recv_dev.numpy().reshape(self.world, nbytes)
-        hdr = hr[:, :64].copy().view(np.uint64).reshape(self.world, 8)
+    def _unpack_device(self, hr: np.ndarray, cap: int, counts: np.ndarray):
         parts, ranges, offsets, off, pos = [], [], [], 0, 0
         for r in range(self.world):
-            cnt = int(max(hdr[r, 1], hdr[r, 5]))     # the counter set of the last scan is the non-zero one
+            cnt = int(counts[r])
+            assert cnt <= cap, f"rank {r} sent {cnt} hits through an exchange of capacity {cap}"
             part = hr[r, 64:64 + cnt * 32].copy().view(HIT_DTYPE)
             part["record"] += np.uint32(off)
             parts.append(part)
@@ -283,9 +319,7 @@ class HitExchanger:
             off += self._rec_counts[r]
         return np.concatenate(parts), ranges, offsets
 
-    def _unpack(self):
-        hr = self.h_recv.numpy().reshape(self.world, (self.cap + 1) * 32)
-        meta = hr[:, :16].copy().view(np.int64).reshape(self.world, 2)
+    def _unpack(self, hr: np.ndarray, meta: np.ndarray):
         parts, ranges, offsets, off, pos = [], [], [], 0, 0
         for r in range(self.world):
             cnt, nrec = int(meta[r, 0]), int(meta[r, 1])
@@ -304,6 +338,9 @@ class HitExchanger:
         if not self.active:
             return local, [(0, len(local))], [0]
         torch = self.torch
+        if self._host_work is not None:
+            self._host_work.wait()
+            self._host_work = None
         while True:
             n = min(len(local), self.cap)
             hs = self.h_send.numpy()
@@ -325,15 +362,9 @@ class HitExchanger:
             cap = self.cap
             while cap < need:
                 cap *= 2
+            rc = self._rec_counts
             self._alloc(cap)  # identical on every rank: all saw the same header
-        parts, ranges, offsets, off, pos = [], [], [], 0, 0
-        for r in range(self.world):
-            cnt, nrec = int(meta[r, 0]), int(meta[r, 1])
-            part = hr[r, 32:32 + cnt * 32].copy().view(HIT_DTYPE)
-            part["record"] += np.uint32(off)
-            parts.append(part)
-            ranges.append((pos, pos + cnt))
-            offsets.append(off)
-            pos += cnt
-            off += nrec
-        return np.concatenate(parts), ranges, offsets
+            self._rec_counts = rc
+        out = self._unpack(hr, meta)
+        self._last = ("full",) + tuple(out)
+        return out

@@ -229,6 +229,39 @@ static int upper_bound_pos(const or_matches *ms, int pos) {
     return lo;
 }
 
+/* test hook for core/engine/match_search_test.go:8-31: sortMatchesByPos + lower/upperBoundMatchPos on bare positions */
+void or_sort_and_bounds(const int32_t *pos, int n, int query, int32_t *sorted_out, int *lo, int *hi) {
+    or_matches ms;
+    ms.v = (or_match *)calloc((size_t)(n > 0 ? n : 1), sizeof(or_match));
+    ms.n = n; ms.cap = n;
+    for (int i = 0; i < n; i++) { ms.v[i].pos = pos[i]; ms.v[i].mm = i; } /* mm carries the input order: stability is visible */
+    sort_matches_by_pos(&ms);
+    for (int i = 0; i < n; i++) { sorted_out[2 * i] = ms.v[i].pos; sorted_out[2 * i + 1] = ms.v[i].mm; }
+    *lo = lower_bound_pos(&ms, query);
+    *hi = upper_bound_pos(&ms, query);
+    free(ms.v);
+}
+
+/* core/primer/validate.go:12-37 : Normalize (drop white space and quotes, upper-case) then accept only
+ * ACGTRYSWKMBDHVN ('U' is rejected at the input boundary).  Returns the normalised length (>= 1), 0 for an empty
+ * primer, or -(1-based position) of the first unsupported character.  ASCII input (the reference walks runes:
+ * multi-byte white space / letters do not occur in primer TSVs and are reported as unsupported here). */
+int or_validate_primer(const char *raw, char *out, int cap) {
+    int n = 0;
+    for (const unsigned char *q = (const unsigned char *)raw; *q; ++q) {
+        unsigned char ch = *q;
+        if (ch == ' ' || (ch >= 9 && ch <= 13) || ch == '\'' || ch == '"') continue; /* unicode.IsSpace on ASCII: \t \n \v \f \r space */
+        if (ch >= 'a' && ch <= 'z') ch = (unsigned char)(ch - 32);
+        if (n + 1 < cap) out[n] = (char)ch;
+        n++;
+    }
+    if (n < cap) out[n] = 0; else if (cap > 0) out[cap - 1] = 0;
+    if (n == 0) return 0;
+    for (int i = 0; i < n && i + 1 < cap; i++)
+        if (!strchr("ACGTRYSWKMBDHVN", out[i]) || out[i] == 0) return -(i + 1);
+    return n;
+}
+
 /* One direction of engine.go:108-404.  `left` are the forward-strand hits of the
  * left primer (fwdA, or fwdB), `right` the rc hits of the other primer (revB, or
  * revA); rlen is the right primer length; type 0 forward / 1 revcomp. */

@@ -77,6 +77,10 @@ int or_mismatch_count(const uint8_t *g, const uint8_t *p, int n); /* mismatch.go
 void or_find_matches(const uint8_t *seq, int n, const uint8_t *primer, int pl,
                      int max_mm, int cap_hits, int tw, or_matches *out); /* match.go:30-90 */
 void or_matches_free(or_matches *m);
+/* engine.go:70-93 on bare positions (match_search_test.go:8-31): sorted_out gets (pos, input index) pairs */
+void or_sort_and_bounds(const int32_t *pos, int n, int query, int32_t *sorted_out, int *lo, int *hi);
+/* core/primer/validate.go:12-37: normalised length, 0 = empty, -(1-based position) = unsupported character */
+int or_validate_primer(const char *raw, char *out, int cap);
 
 /* ---- core/engine ---- */
 void or_products_free(or_products *p);

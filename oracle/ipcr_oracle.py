@@ -67,6 +67,10 @@ def lib():
         L.or_find_matches.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.POINTER(_Matches)]
         L.or_matches_free.argtypes = [C.POINTER(_Matches)]
+        L.or_sort_and_bounds.restype = None
+        L.or_sort_and_bounds.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.or_validate_primer.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         L.or_products_free.argtypes = [C.POINTER(_Products)]
         L.or_simulate_bruteforce.restype = None
         L.or_simulate_bruteforce.argtypes = [C.POINTER(_Config), C.c_char_p, C.c_int, C.c_int,
@@ -224,6 +228,28 @@ def find_matches(seq, primer, max_mm: int, cap_hits: int, tw: int) -> List[Match
     ms = _Matches()
     lib().or_find_matches(seq, len(seq), primer, len(primer), max_mm, cap_hits, tw, C.byref(ms))
     return _matches_out(ms)
+
+
+def sort_and_bounds(positions: Sequence[int], query: int):
+    """sortMatchesByPos + lowerBoundMatchPos / upperBoundMatchPos -- core/engine/engine.go:70-93.
+    -> (sorted positions, their input indices (stability), lo, hi)"""
+    n = len(positions)
+    arr = (C.c_int32 * max(n, 1))(*positions)
+    out = (C.c_int32 * max(2 * n, 1))()
+    lo, hi = C.c_int(), C.c_int()
+    lib().or_sort_and_bounds(arr, n, query, out, C.byref(lo), C.byref(hi))
+    return [out[2 * i] for i in range(n)], [out[2 * i + 1] for i in range(n)], lo.value, hi.value
+
+
+def validate_primer(raw: str) -> str:
+    """primer.Validate -- core/primer/validate.go:27-37; ValueError where the reference returns an error."""
+    buf = C.create_string_buffer(len(raw.encode()) + 2)
+    r = lib().or_validate_primer(raw.encode(), buf, len(buf))
+    if r == 0:
+        raise ValueError("empty primer")
+    if r < 0:
+        raise ValueError("invalid primer base at position %d" % -r)
+    return buf.value.decode()
 
 
 def simulate_bruteforce(cfg: Config, seq, pairs: Sequence[Pair]) -> List[Product]:

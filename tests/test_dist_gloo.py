@@ -52,6 +52,18 @@ work = xchg.start(local_hits, len(lens))                   # overlapped form: en
 xchg.finish(work)
 x3, r3, o3 = xchg.gathered()
 assert np.array_equal(x3, all_hits) and r3 == x_ranges and o3 == offsets
+# overflow on ONE rank of two in the overlapped form: nobody raises before the collective, nobody hangs; every rank
+# sees the overflow in the gathered headers and they regrow + redo together (ADVICE r1: lock-step overflow handling)
+lens_by_rank = [b - a for a, b in x_ranges]
+small = dist.HitExchanger(cap_hits=min(lens_by_rank) if min(lens_by_rank) < max(lens_by_rank) else max(lens_by_rank) - 1)
+assert small.cap < max(lens_by_rank)
+w = small.start(local_hits, len(lens))
+small.finish(w)
+x4, r4, o4 = small.gathered()
+assert small.redone == 1 and small.cap >= max(lens_by_rank)
+assert np.array_equal(x4, all_hits) and r4 == x_ranges and o4 == offsets
+w = small.start(local_hits, len(lens)); small.finish(w)       # steady state again: fits, one collective
+assert small.redone == 1 and np.array_equal(small.gathered()[0], all_hits)
 all_lens, all_flags = dist.allgather_record_meta(lens, flags)
 assert offsets == [0, 3] and all_lens == [4000] * 5 and len(all_flags) == 5
 sc = engine.SimulationScratch(cp, host_only=True)

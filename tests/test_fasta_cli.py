@@ -73,6 +73,13 @@ def test_split_chunk_suffix():  # internal/common/ids.go:11-27
     assert cli.split_chunk_suffix("a:b:7-9") == ("a:b", 7, True)
     assert cli.split_chunk_suffix("x:") == ("x:", 0, False)
     assert cli.split_chunk_suffix("x:ab-3") == ("x:ab-3", 0, False)
+    # strconv.Atoi (ids.go:21), not Python's int(): no blanks, no '_' separators, no non-ASCII digits, int64 range
+    for odd in ("x: 7-9", "x:1_0-2", "x:7 -9", "x:\u0667-9", "x:-9", "x:--7-9", "x:99999999999999999999-3", "x:+-1-2"):
+        assert cli.split_chunk_suffix(odd) == (odd, 0, False), odd
+    assert cli.split_chunk_suffix("x:+7-9") == ("x", 7, True)
+    assert cli.split_chunk_suffix("x:007-9") == ("x", 7, True)
+    assert cli.split_chunk_suffix("x:9223372036854775807-1") == ("x", 9223372036854775807, True)
+    assert cli.split_chunk_suffix("x:9223372036854775808-1") == ("x:9223372036854775808-1", 0, False)
 
 
 def test_row_format_and_order():  # internal/output/rows.go:21-29, internal/common/sort.go:34-78

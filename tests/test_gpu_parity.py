@@ -724,6 +724,17 @@ def test_device_hit_exchange_one_rank_rccl(hip, monkeypatch):
         flags = [g.record_flags(r) for r in range(g.num_records)]
         prods = eng.JoinHits(cp, host, hits, lens, flags)
         assert [p.sig() for p in prods] == want_products
+        # more hits than the exchange capacity: the rank still enters the collective (first `cap` records, true count
+        # in the header), finish() sees the overflow in the gathered header, regrows and redoes the exchange
+        x2 = dist.HitExchanger(device=dev, cap_hits=max(1, len(local) // 2))
+        x2.set_record_counts([g.num_records])
+        eng.ScanGenomeHits(g, cp, scs[0])
+        x2.finish(x2.start_scratch(scs[0], g.num_records))
+        h2, r2, _ = x2.gathered()
+        assert x2.redone == 1 and x2.cap >= len(local) and r2 == [(0, len(local))]
+        assert np.array_equal(key(np.unique(h2)), key(local))
+        x2.finish(x2.start_scratch(scs[0], g.num_records))            # now it fits: device form, nothing redone
+        assert x2.redone == 1 and np.array_equal(key(np.unique(x2.gathered()[0])), key(local))
     finally:
         if started_here and tdist.is_initialized():
             tdist.destroy_process_group()
@@ -773,9 +784,19 @@ def test_jit_disk_cache(hip, tmp_path, monkeypatch):
     cfg = E.Config(MaxMM=1, TerminalWindow=2, MaxLen=500, HitCap=100, SeedLen=12)
     first = check(hip, cfg, seq, pairs)
     files = sorted(f.name for f in tmp_path.iterdir())
-    assert len(files) >= 1 and all(f.endswith(".hsaco") for f in files)
+    assert len(files) >= 1 and all(f.endswith(".jit") for f in files)
     again = check(hip, cfg, seq, pairs)          # served from memory or disk, same answer
     assert [p.sig() for p in again] == [p.sig() for p in first] and sorted(f.name for f in tmp_path.iterdir()) == files
+    # every file carries its own key (hiprtc version, arch, source) in front of the code object; a file whose stored
+    # key differs (hash collision, another ROCm release) is ignored and rebuilt, not loaded
+    raw = (tmp_path / files[0]).read_bytes()
+    klen = int.from_bytes(raw[8:16], "little")
+    assert raw[:8] == b"IPCRJIT1" and raw[16:23] == b"hiprtc " and b"ipcr_filter" in raw[16:16 + klen]
+    assert raw[16 + klen:16 + klen + 4] == b"\x7fELF"
+    (tmp_path / files[0]).write_bytes(raw[:16] + bytes([raw[16] ^ 1]) + raw[17:])   # stored key no longer matches
+    pairs2 = [P("disk2", "ACGTTGCAAGGCTTAA", "TTGGCCAATTGGAACC", 0, 0)]             # same source, new panel object
+    third = check(hip, cfg, seq, pairs2)
+    assert [p.sig()[1:] for p in third] == [p.sig()[1:] for p in first]
 
 
 def test_fallback_when_hand_over_does_not_arrive(tmp_path):
@@ -804,3 +825,78 @@ def test_fallback_when_hand_over_does_not_arrive(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK 1" in r.stdout, (r.stdout, r.stderr)
     assert "using the copy path" in r.stderr
+
+
+_HANDOVER_CHILD = """
+    import sys, random
+    sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+    import ipcr_oracle as O
+    from ipcr_amd import engine, primer, workloads
+    from test_host_logic import rand_seq, plant
+    rng = random.Random(11)
+    pair = workloads.bench_pair(0)
+    pairs = primer.AddSelfPairs([pair])
+    cfg = engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12)
+    ocfg = O.Config(max_mm=2, terminal_window=5, max_len=2000, hit_cap=10000, seed_len=12)
+    opairs = [O.Pair(p.ID, p.Forward, p.Reverse, p.MinProduct, p.MaxProduct) for p in pairs]
+    seqs = []
+    for r in range(4):
+        s = rand_seq(rng, 300000, junk=False)
+        for t in range(12):
+            a = 1000 + t * 20000 + rng.randrange(500)
+            plant(rng, s, pair.Forward, a, rng.choice([0, 1, 2]))
+            plant(rng, s, O.revcomp(pair.Reverse).decode(), a + 160, 0)
+        seqs.append("".join(s).encode())
+    g = engine.Genome(sum(map(len, seqs)) + 65536, max_records=8)
+    for r, s in enumerate(seqs):
+        g.add_record("chr%%d" %% r, s)
+    eng = engine.New(cfg); cp = eng.CompilePanel(pairs)
+    op = O.Panel(ocfg, opairs)
+    want = []
+    for r, s in enumerate(seqs):
+        want += [("chr%%d" %% r,) + w.sig() for w in op.scan(s)]
+    scs = [eng.NewSimulationScratch(cp) for _ in range(3)]
+    refetched = checked = diffs = 0
+    for i in range(6):                                   # plain scans
+        got = eng.ScanGenome(g, cp, scs[i %% 3])
+        assert [(p.SequenceID,) + p.sig() for p in got] == want and len(want) >= 40, i
+        st = scs[i %% 3].stats()
+        assert st.kernel_kind == 1
+        refetched += st.handover_refetched; checked += st.handover_checked; diffs += st.handover_check_diffs
+    eng.ScanGenomeBegin(g, cp, scs[0])                    # chained sweeps, as bench.py runs them
+    for i in range(9):
+        if i + 1 < 9:
+            scs[(i + 1) %% 3].chain_after(scs[i %% 3])
+            eng.ScanGenomeBegin(g, cp, scs[(i + 1) %% 3])
+        assert eng.ScanGenomeEndCount(g, cp, scs[i %% 3]) == len(want), i
+        assert [(p.SequenceID,) + p.sig() for p in scs[i %% 3].products(g.ids)] == want
+        st = scs[i %% 3].stats()
+        refetched += st.handover_refetched; checked += st.handover_checked; diffs += st.handover_check_diffs
+    print("OK refetched=%%d checked=%%d diffs=%%d hits=%%d" %% (refetched, checked, diffs, scs[0].stats().hits))
+"""
+
+
+def _run_handover_child(extra_env):
+    import subprocess, sys, os, textwrap, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(_HANDOVER_CHILD % (root, os.path.join(root, "oracle"), os.path.join(root, "tests")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra_env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK refetched=" in r.stdout, (r.stdout, r.stderr[-3000:])
+    m = re.search(r"OK refetched=(\d+) checked=(\d+) diffs=(\d+) hits=(\d+)", r.stdout)
+    return tuple(int(x) for x in m.groups()), r.stderr
+
+
+def test_handover_torn_record_is_not_accepted():
+    """A hit record reaches pinned host memory as two 16-byte stores that nothing orders.  Simulated tear: the first
+    half of record 2 carries a stale tag while its second half (the one the round-1 host looked at) is current.
+    The host must not take it: it waits 2 ms, fetches the prefix from device memory instead (the straggler branch of
+    scan_collect), and every result still equals the oracle's.  Child process: the knob is read once per process."""
+    (refetched, _, _, hits), _ = _run_handover_child({"IPCR_TEST_WITHHOLD_TAG": "3"})
+    assert refetched == 15 and hits >= 40          # every one of the 15 scans had to take the device copy
+
+
+def test_handover_matches_device_memory():
+    """IPCR_DEBUG_PUBLISH_CHECK=1: after every scan the records the host took from pinned memory are compared with
+    what the kernel left in device memory -- zero differences, nothing refetched, plain and chained sweeps."""
+    (refetched, checked, diffs, hits), err = _run_handover_child({"IPCR_DEBUG_PUBLISH_CHECK": "1"})
+    assert checked == 15 and diffs == 0 and refetched == 0 and hits >= 40, err[-2000:]

@@ -300,3 +300,32 @@ def test_pipelined_pass_schedule_invariants(ns, pipeline, exchange):
     assert last == (k - 1) * 10 and ended == list(range(k)) and not inflight
     assert all(not s.open and s.read_by is None for s in scs)
     assert bench.pipelined_passes(0, scs, begin, end) is None
+
+
+def test_bench_launch_decision(monkeypatch):
+    """`python bench.py --gpus N` must become N ranks: without RANK in the environment the process only launches
+    torch.distributed.run as a child (fake launcher here) and returns its exit code; a process that already is a rank
+    runs in place and refuses a --gpus that contradicts WORLD_SIZE"""
+    import os, subprocess, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert bench.launch_plan(8, {"RANK": "3", "WORLD_SIZE": "8"}, ["--gpus", "8"]) is None
+    assert bench.launch_plan(1, {}, []) is None
+    assert bench.launch_plan(1, {"RANK": "0", "WORLD_SIZE": "2"}, []) is None     # torchrun without --gpus: env decides
+    cmd = bench.launch_plan(8, {}, ["--gpus", "8", "--steps", "5"], python="py", script="/x/bench.py")
+    assert cmd[:3] == ["py", "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == ["/x/bench.py", "--gpus", "8", "--steps", "5"]
+    with pytest.raises(SystemExit):
+        bench.launch_plan(8, {"RANK": "0", "WORLD_SIZE": "2"}, [])
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append(cmd) or 7)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(v, raising=False)
+    torch_loaded = "torch" in sys.modules
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7 and len(calls) == 1
+    assert calls[0][-4:] == ["--gpus", "4", "--steps", "3"] and calls[0][calls[0].index("--nproc-per-node") + 1] == "4"
+    assert ("torch" in sys.modules) == torch_loaded, "the launcher process must not import torch"

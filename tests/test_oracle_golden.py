@@ -288,3 +288,27 @@ def test_best_hit():  # core/oligo/oligo_test.go:5-21, core/probe/annotate_test.
     h = O.best_hit("AAAGACCC", "GAY", 0)
     assert (h.found, h.strand, h.pos, h.site) == (True, "+", 3, "GAC")
     assert not O.best_hit("ACGT", "  ", 0).found
+
+
+def test_sort_matches_by_pos_and_bounds():  # core/engine/match_search_test.go:8-31
+    pos, order, lo, hi = O.sort_and_bounds([8, 2, 5, 5], 5)
+    assert pos == [2, 5, 5, 8]
+    assert (lo, hi) == (1, 3)
+    assert order == [1, 2, 3, 0]          # sort.SliceStable (engine.go:80-83): the two 5s keep their input order
+    assert O.sort_and_bounds([1, 2, 3], 0)[2:] == (0, 0) and O.sort_and_bounds([1, 2, 3], 9)[2:] == (3, 3)
+    assert O.sort_and_bounds([], 4) == ([], [], 0, 0)
+
+
+def test_validate_primer():  # core/primer/validate_test.go:5-25
+    assert O.validate_primer(" acgtry swkmbdhvn ") == "ACGTRYSWKMBDHVN"
+    with pytest.raises(ValueError):
+        O.validate_primer("ACGX")
+    with pytest.raises(ValueError):
+        O.validate_primer("ACGU")          # :21 -- U is rejected at the input boundary, although iupacMask knows it
+    with pytest.raises(ValueError):
+        O.validate_primer(" '\" ")
+    from ipcr_amd import primer            # the host mirror the CLI uses follows the same rule
+    assert primer.Validate(" acgtry swkmbdhvn ") == "ACGTRYSWKMBDHVN"
+    for bad in ("ACGX", "ACGU", ""):
+        with pytest.raises(ValueError):
+            primer.Validate(bad)
