@@ -44,10 +44,20 @@ struct ipcr_probe_rec { // layout-identical to ipcr_probe_hit
     int32_t found, strand, pos, mm;
 };
 
-// ---- seed-index filter for large panels (kernels.hip: filter_index_kernel) ----
+// ---- seed-index filter for large panels (jit.cpp: jit_index_source) ----
 // One shape = one exact "key" every window of a pattern group must contain if it is to match
-// with <= k mismatches: the protected terminal bases plus one of k+1 pigeonhole blocks, both
-// relative to the anchored end of the window.  Keys are read out of a rolling 2-bit k-mer.
+// with <= k mismatches: protected terminal bases plus one of k+1 pigeonhole blocks, both
+// relative to the anchored end of the window.  Keys are read out of a rolling 2-bit k-mer
+// (newest base in bits 1:0).  Right-anchored groups (A/B orientations, 3' window at the window end)
+// are tested when their window ENDS at the newest base; left-anchored groups (rc orientations) when
+// their window STARTED `dl` bases ago, dl = longest left pattern - 1, so that the whole window is
+// already in the k-mer.
+//   key = ((kmer >> tw_shift) & tw_mask) | (((kmer >> blk_shift) & blk_mask) << tw_bits)      (<= 16 bits)
+// A shape's keys are a 64-Kbit bitmap in LDS, addressed as 1024 64-bit words: word key >> 6, bit
+// key & 63.  In a FAST group the low six key bits (three protected bases next to the anchor) are
+// common to all its shapes and the word index of shape j is the same k-mer field `delay` steps
+// earlier: one index per base step fetches the words of all shapes, words wait in a register
+// ring for their delay, and ONE bit test of their OR answers "some shape of the group hits".
 struct ipcr_index_shape {
     uint8_t left;       // 1: anchored at the window start (rc orientations), 0: at its end
     uint8_t tw_shift;   // k-mer bit offset of the protected part
@@ -55,25 +65,28 @@ struct ipcr_index_shape {
     uint8_t tw_bits;    // 2 * bases of the protected part used in the key
     uint32_t tw_mask;   // (1 << tw_bits) - 1
     uint32_t blk_mask;  // (1 << 2*b) - 1
-    uint32_t reserved;
-    uint64_t valid_mask; // even bits of the k-mer positions the key reads (must all be valid bases)
+    uint8_t group;      // shapes of one (anchored end, protected length) share a group
+    uint8_t delay;      // fast groups: base steps between fetching this shape's word and testing it
+    uint8_t fast;       // group evaluated by the delayed-OR scheme (else one probe per shape)
+    uint8_t dl;         // left shapes: the window start lies dl bases behind the newest base
+    uint64_t valid_mask; // even bits of the k-mer positions the key reads
 };
 
 struct ipcr_index_entry { // 64 B; entry r belongs to the r-th distinct (shape, key) in sorted order
     uint32_t next;    // further pattern with the same key (index into the same array), 0xFFFFFFFF = none
     uint32_t pattern; // set-local pattern index
-    uint64_t ok[4];   // IUPAC masks as four position sets: even bit 2*(L-1-j) of ok[b] set when base b
-                      // (A,C,G,T) is allowed at pattern position j -- pure ACGT primers are the one-hot case
+    uint64_t seq2;    // pure ACGT patterns: the primer as 2-bit codes, position j in bits 2*(L-1-j)+1 : 2*(L-1-j)
     uint64_t prot2;   // even bit 2*(L-1-j) set when position j is protected
     uint32_t len;
-    uint32_t left;
-    uint64_t pad;
+    uint32_t flags;   // bit 0: left-anchored, bit 1: pure ACGT (seq2 valid: the first 32 bytes suffice for the check)
+    uint64_t ok[4];   // IUPAC masks as four position sets: even bit 2*(L-1-j) of ok[b] set when base b
+                      // (A,C,G,T) is allowed at pattern position j -- pure ACGT primers are the one-hot case
 };
 static_assert(sizeof(ipcr_index_entry) == 64, "index entries are read as four 16-byte loads");
 
-#define IPCR_INDEX_MAX_SHAPES 16
+#define IPCR_INDEX_MAX_SHAPES 12
 #define IPCR_INDEX_BITMAP_WORDS 2048u // 65536 bits per shape
-#define IPCR_INDEX_GROUPS 256u        // rank prefix per 256 bitmap bits (8 words)
+#define IPCR_INDEX_GROUPS 1024u       // rank prefix (uint16) per 64 bitmap bits
 
 // raw byte range [start, end) of one FASTA header line (its '\n' included) inside a slab
 struct ipcr_fasta_range {

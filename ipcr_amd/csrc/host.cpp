@@ -171,12 +171,23 @@ struct PatternDef {
     bool seeded;
 };
 
-// seed index over the pure-ACGT patterns of a set (large panels; kernels.hip: filter_index_kernel)
+// seed index over the keyable patterns of a set (large panels; jit.cpp: jit_index_source)
 struct IndexPlan {
     bool built = false, usable = false;
+    bool all_acgt = true; // no keyed pattern holds an IUPAC code: entries are checked from their first 32 bytes
+    int dl = 0;        // left-anchored windows are tested dl bases after their start
+    int max_right = 0; // longest right-anchored pattern served
+    int uniform_len = 0; // length shared by every served pattern (0: mixed)
+    ipcr::IndexGeom geom() const {
+        ipcr::IndexGeom g;
+        g.tail_rows = std::max(max_right - 1, dl);
+        g.all_acgt = all_acgt;
+        g.uniform_len = uniform_len;
+        return g;
+    }
     std::vector<ipcr_index_shape> shapes;
     // per shape: 2048 bitmap words (one bit per 16-bit key), then for all shapes the rank of the first key of
-    // every 256-bit group (uint16, relative to the shape's first entry), then the shapes' first entries
+    // every 64-bit bitmap word (uint16, relative to the shape's first entry), then the shapes' first entries
     std::vector<uint32_t> lds_image;
     std::vector<ipcr_index_entry> table; // entry r = first pattern of the r-th distinct (shape, key); more patterns of a key are chained
     std::vector<uint32_t> leftover;      // set-local patterns the index cannot serve (> 32 nt, too degenerate, ...)
@@ -256,20 +267,44 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     }
     std::vector<std::pair<uint32_t, uint32_t>> ents; // (tag, pattern)
     std::vector<char> dropped(P, 0);
+    // left-anchored windows are tested when their start lies DL bases behind the newest base: the longest left
+    // pattern then ends exactly at the newest base (31 for a 32-nt pattern)
+    int DL = 0;
+    for (const Group &g : groups)
+        if (g.left)
+            for (uint32_t q : g.members) DL = std::max(DL, pats[q].len - 1);
+    ix.dl = DL;
+    uint8_t next_group = 0;
+    unsigned ring_regs = 0; // VGPRs the fast groups' delay rings will need (2 per delayed word)
     for (Group &g : groups) {
-        const int t = std::min(g.t, g.lmin), tu = std::min(t, 8);
+        const int t = std::min(g.t, g.lmin);
         const int bf = (t >= g.lmin) ? 0 : (g.lmin - t) / (k + 1);
-        const int b = (tu >= 8) ? 0 : std::min(8 - tu, bf);
+        // With k >= 1 and at least three protected bases the key is "3 protected bases next to the anchor + 5 block
+        // bases" for every block: the protected part is then the low six key bits of all the group's shapes, which
+        // is what the delayed-OR evaluation needs (device_types.h).  Otherwise: as many protected bases as fit.
+        const bool tri = k >= 1 && t >= 3 && bf >= 1;
+        const int tu = tri ? 3 : std::min(t, 8);
+        const int b = tri ? std::min(5, bf) : ((tu >= 8) ? 0 : std::min(8 - tu, bf));
         const int ns = b > 0 ? k + 1 : 1;
         if ((tu == 0 && b == 0) || ix.shapes.size() + (size_t)ns > IPCR_INDEX_MAX_SHAPES) { // nothing exact to key on
             for (uint32_t q : g.members) dropped[q] = 1;
             continue;
+        }
+        bool fast = (ns > 1 && tu == 3) || (ns == 1 && b == 0 && tu >= 3);
+        if (fast && ns > 1) { // the rings (bf slots of 64 bits per delayed shape) must stay in registers, the unrolled body within reason
+            const unsigned regs = 2u * (unsigned)((ns - 1) * bf);
+            const unsigned unroll = 4u / std::__gcd(4u, (unsigned)bf) * (unsigned)bf;
+            if (unroll > 40 || ring_regs + regs > 48) fast = false;
+            else ring_regs += regs;
         }
         const size_t ents_before = ents.size();
         const size_t shapes_before = ix.shapes.size();
         for (int j = 0; j < ns; ++j) {
             ipcr_index_shape sh{};
             sh.left = g.left ? 1 : 0;
+            sh.group = next_group;
+            sh.fast = fast ? 1 : 0;
+            sh.dl = (uint8_t)(g.left ? DL : 0);
             sh.tw_bits = (uint8_t)(2 * tu);
             sh.tw_mask = tu ? (uint32_t)((1ull << (2 * tu)) - 1ull) : 0u;
             sh.blk_mask = b ? (uint32_t)((1ull << (2 * b)) - 1ull) : 0u;
@@ -277,13 +312,15 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
             if (!g.left) { // anchored at the window end = lowest bits of the k-mer
                 sh.tw_shift = 0;
                 sh.blk_shift = (uint8_t)(2 * (t + j * bf));
+                sh.delay = (uint8_t)(j * bf);
                 for (int u = 0; u < tu; ++u) vm |= 1ull << (2 * u);
                 for (int u = 0; u < b; ++u) vm |= 1ull << (2 * (t + j * bf + u));
-            } else {       // anchored at the window start = top of the 32-base k-mer
-                sh.tw_shift = (uint8_t)(tu ? 64 - 2 * tu : 0);
-                sh.blk_shift = (uint8_t)(b ? 64 - 2 * (t + j * bf + b) : 0);
-                for (int u = 0; u < tu; ++u) vm |= 1ull << (2 * (31 - u));
-                for (int u = 0; u < b; ++u) vm |= 1ull << (2 * (31 - (t + j * bf + u)));
+            } else {       // anchored at the window start = base DL of the k-mer, the pattern runs towards base 0
+                sh.tw_shift = (uint8_t)(tu ? 2 * (DL + 1 - tu) : 0);
+                sh.blk_shift = (uint8_t)(b ? 2 * (DL + 1 - (t + j * bf + b)) : 0);
+                sh.delay = (uint8_t)((ns - 1 - j) * bf);
+                for (int u = 0; u < tu; ++u) vm |= 1ull << (2 * (DL - u));
+                for (int u = 0; u < b; ++u) vm |= 1ull << (2 * (DL - (t + j * bf + u)));
             }
             sh.valid_mask = vm;
             const uint32_t s = (uint32_t)ix.shapes.size();
@@ -292,7 +329,7 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
                 if (dropped[q]) continue;
                 const Pat &pt = pats[q];
                 const int L = pt.len;
-                const int up = g.left ? 64 - 2 * L : 0; // pattern bit -> k-mer bit
+                const int up = g.left ? 2 * (DL + 1 - L) : 0; // pattern bit -> k-mer bit
                 // key positions of this shape, in pattern (right-aligned) bit coordinates, and the
                 // bases each may take: IUPAC codes expand into every concrete key (capped)
                 std::vector<int> kb;
@@ -306,7 +343,6 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
                     if (combos > 64) break;
                 }
                 if (combos == 0 || combos > 64) { dropped[q] = 1; continue; } // too degenerate to key
-                std::vector<int> choice(kb.size(), 0);
                 for (uint64_t it = 0; it < combos; ++it) {
                     uint64_t km = 0, rem = it;
                     for (size_t z = 0; z < kb.size(); ++z) {
@@ -331,7 +367,16 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         bool any = false;
         for (uint32_t q : g.members) any |= !dropped[q];
         if (!any) ix.shapes.resize(shapes_before);
+        else ++next_group;
     }
+    ix.max_right = 0; // longest right-anchored pattern the index serves
+    ix.uniform_len = -1;
+    for (uint32_t q = 0; q < P; ++q) {
+        if (dropped[q] || pats[q].len <= 0) continue;
+        if (!pats[q].left) ix.max_right = std::max(ix.max_right, pats[q].len);
+        ix.uniform_len = (ix.uniform_len == -1 || ix.uniform_len == pats[q].len) ? pats[q].len : 0;
+    }
+    if (ix.uniform_len < 0) ix.uniform_len = 0;
     for (uint32_t q = 0; q < P; ++q)
         if (dropped[q]) ix.leftover.push_back(q);
     std::sort(ents.begin(), ents.end());
@@ -340,7 +385,7 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     // the set bits IS the index of its entry -- one entry load per hit, no tag compare, no probing.  The rank
     // comes from a per-256-bit-group prefix (uint16, LDS) plus popcounts inside the group.
     const size_t NS = ix.shapes.size();
-    const size_t img_words = NS * IPCR_INDEX_BITMAP_WORDS + NS * (IPCR_INDEX_GROUPS / 2) + NS;
+    const size_t img_words = NS * IPCR_INDEX_BITMAP_WORDS + NS * (IPCR_INDEX_GROUPS / 2) + NS + 2 * NS;
     ix.lds_image.assign(std::max<size_t>(1, img_words), 0u);
     uint16_t *prefix = reinterpret_cast<uint16_t *>(ix.lds_image.data() + NS * IPCR_INDEX_BITMAP_WORDS);
     uint32_t *base = ix.lds_image.data() + NS * IPCR_INDEX_BITMAP_WORDS + NS * (IPCR_INDEX_GROUPS / 2);
@@ -355,7 +400,14 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         for (int bb = 0; bb < 4; ++bb) en.ok[bb] = pats[q].ok[bb];
         en.prot2 = pats[q].prot2;
         en.len = (uint32_t)pats[q].len;
-        en.left = pats[q].left ? 1u : 0u;
+        const uint64_t E = 0x5555555555555555ull;
+        const uint64_t wm = pats[q].len >= 32 ? E : (((1ull << (2 * pats[q].len)) - 1ull) & E);
+        const uint64_t a = pats[q].ok[0], c = pats[q].ok[1], g = pats[q].ok[2], t = pats[q].ok[3];
+        // exactly one base allowed at every position?
+        const bool acgt = ((a ^ c ^ g ^ t) == wm) && ((a & c) | (a & g) | (a & t) | (c & g) | (c & t) | (g & t)) == 0;
+        en.seq2 = acgt ? ((c | t) | ((g | t) << 1)) : 0ull;
+        en.flags = (pats[q].left ? 1u : 0u) | (acgt ? 2u : 0u);
+        if (!acgt) ix.all_acgt = false;
     };
     std::vector<uint32_t> shape_count(NS + 1, 0);
     size_t r = 0;
@@ -378,11 +430,19 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     for (size_t sidx = 0; sidx < NS; ++sidx) {
         base[sidx] = run;
         uint32_t within = 0;
-        for (uint32_t g = 0; g < IPCR_INDEX_GROUPS; ++g) {
-            prefix[sidx * IPCR_INDEX_GROUPS + g] = (uint16_t)within; // < 65536: a shape has at most 65536 keys, the last group starts below that
-            for (uint32_t w = 0; w < 8; ++w) within += (uint32_t)__builtin_popcount(ix.lds_image[sidx * IPCR_INDEX_BITMAP_WORDS + g * 8 + w]);
+        for (uint32_t g = 0; g < IPCR_INDEX_GROUPS; ++g) { // one prefix per 64-bit word of the bitmap
+            prefix[sidx * IPCR_INDEX_GROUPS + g] = (uint16_t)within; // < 65536: a shape has at most 65536 keys, the last word starts below that
+            for (uint32_t w = 0; w < 2; ++w) within += (uint32_t)__builtin_popcount(ix.lds_image[sidx * IPCR_INDEX_BITMAP_WORDS + g * 2 + w]);
         }
         run += shape_count[sidx];
+    }
+    // the shapes' constants for the drain, which handles a hit's shape as a run-time value:
+    // {tw_shift | blk_shift << 8 | tw_bits << 16 | left << 24 | dl << 25, tw_mask | blk_mask << 16}
+    for (size_t sidx = 0; sidx < NS; ++sidx) {
+        const ipcr_index_shape &sh = ix.shapes[sidx];
+        base[NS + 2 * sidx] = (uint32_t)sh.tw_shift | ((uint32_t)sh.blk_shift << 8) | ((uint32_t)sh.tw_bits << 16) |
+                              ((uint32_t)sh.left << 24) | ((uint32_t)sh.dl << 25);
+        base[NS + 2 * sidx + 1] = (sh.tw_mask & 0xFFFFu) | ((sh.blk_mask & 0xFFFFu) << 16);
     }
     std::sort(ix.leftover.begin(), ix.leftover.end());
     ix.usable = !ix.shapes.empty() && !ents.empty();
@@ -584,7 +644,7 @@ ipcr_status ipcr_panel_filter_source(const ipcr_panel *p, int32_t mode, char *ou
         std::lock_guard<std::mutex> lock(mp->mu);
         PatternSet &ps = mp->set[mode - 2];
         if (!ps.index.built) build_index(*mp, ps);
-        const std::string isrc = ps.index.usable ? ipcr::jit_index_source(ps.index.shapes) : std::string();
+        const std::string isrc = ps.index.usable ? ipcr::jit_index_source(ps.index.shapes, ps.index.geom()) : std::string();
         if (needed) *needed = isrc.size() + 1;
         if (out && cap) {
             const size_t n = std::min(cap - 1, isrc.size());
@@ -1011,7 +1071,7 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode) {
         IndexPlan &ix = s.index;
         if (ix.usable) {
             std::string jerr;
-            ix.jit = ipcr::jit_build_index(ix.shapes, jerr);
+            ix.jit = ipcr::jit_build_index(ix.shapes, ix.geom(), jerr);
             if (!ix.jit) {
                 ix.usable = false; // no hiprtc: the table-driven kernel serves
                 return IPCR_OK;

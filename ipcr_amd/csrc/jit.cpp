@@ -837,18 +837,79 @@ std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, in
     return out;
 }
 
-// ---- seed-index filter with the panel's key shapes baked in (same algorithm as
-// kernels.hip: filter_index_kernel; constants let the compiler turn every variable 64-bit shift
-// and mask into a 32-bit bitfield extract)
-std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes) {
+// ---- seed-index filter with the panel's key shapes baked in (device_types.h: ipcr_index_shape).
+// One thread per strand walks its 128 rows plus `tail_rows` rows of the next strand with a rolling 2-bit k-mer.
+// Per base step:
+//  * FAST groups (three protected bases + one block per key): one table index per group fetches the 64-bit bitmap
+//    words of all the group's shapes; the words of the delayed shapes wait in a register ring (the unrolled body's
+//    length is a multiple of every delay, so ring slots are plain registers); the OR of the words that are due is
+//    tested ONCE at the bit the three protected bases select -- "some shape of this group has this key";
+//  * other groups: one bitmap probe per shape.
+//  No validity test here: a window with <= k mismatches has a key whose bases are all valid and exact, so invalid
+//  bases (code A in the k-mer) can only add candidates, which the exact check below rejects.
+//  * hits go to a per-wave LDS queue (k-mer, invalid flags, where, groups) -- ballot + mbcnt slots, no atomics -- and
+//    are drained 64 at a time: each lane looks its hit up in every shape of the hit groups, ranks the key among the
+//    shape's keys (prefix per 64-bit word + popcount), loads the entry and checks the pattern exactly against the k-mer.
+#define IPCR_INDEX_WAVES 16u // one 1024-thread workgroup per CU: the LDS image is staged once per CU, 4 waves per SIMD
+static unsigned index_image_bytes(unsigned nshapes) { // bitmaps + per-word rank prefixes + first entries + shape constants (build_index)
+    const unsigned image = nshapes * (IPCR_INDEX_BITMAP_WORDS * 4u + IPCR_INDEX_GROUPS * 2u + 4u + 8u);
+    return (image + 15u) & ~15u;
+}
+static unsigned index_queue_entries(unsigned nshapes) { // per-wave hit queue: what the image leaves of the 160 KiB, in rounds of 64
+    const unsigned left = 160u * 1024u - index_image_bytes(nshapes);
+    unsigned q = left / (IPCR_INDEX_WAVES * 16u) / 64u * 64u;
+    return q < 128u ? 128u : (q > 448u ? 448u : q);
+}
+
+std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom) {
+    const int tail_rows = geom.tail_rows;
+    const bool all_acgt = geom.all_acgt;
     const size_t NS = shapes.size();
+    struct Grp { bool fast = false; std::vector<int> sh; int c_off = 0, v_off = 0, v_bits = 0; unsigned bf = 1; };
+    std::vector<Grp> groups;
+    for (size_t i = 0; i < NS; ++i) {
+        if (shapes[i].group >= groups.size()) groups.resize((size_t)shapes[i].group + 1);
+        groups[shapes[i].group].sh.push_back((int)i);
+        groups[shapes[i].group].fast = shapes[i].fast != 0;
+    }
+    unsigned U = 4;
+    for (Grp &g : groups) {
+        if (!g.fast || g.sh.empty()) continue;
+        const ipcr_index_shape &a = shapes[(size_t)g.sh[0]];
+        g.c_off = a.tw_shift;
+        if (g.sh.size() == 1) { // the key is one contiguous field of protected bases: low 6 bits select the bit, the rest the word
+            g.v_off = a.tw_shift + 6;
+            g.v_bits = a.tw_bits - 6;
+        } else {
+            std::sort(g.sh.begin(), g.sh.end(), [&](int x, int y) { return shapes[(size_t)x].delay < shapes[(size_t)y].delay; });
+            g.v_off = shapes[(size_t)g.sh[0]].blk_shift;   // the delay-0 shape's block field
+            g.v_bits = __builtin_popcount(a.blk_mask);
+            g.bf = shapes[(size_t)g.sh[1]].delay;           // delays are 0, bf, 2 bf, ... (host.cpp: build_index)
+            U = U / std::__gcd(U, g.bf) * g.bf;
+        }
+    }
+    while (U < 8) U *= 2;
+    const int RT = 128 + (tail_rows < 0 ? 0 : tail_rows);
+    const unsigned NQ = (unsigned)(RT + 3) / 4;        // row quads walked
+    const unsigned NB = NQ * 4 / U;                    // full unrolled bodies
+    const unsigned TAILSTEPS = NQ * 4 - NB * U;        // a shorter copy of the body finishes the walk
+    const unsigned QCAP = index_queue_entries((unsigned)NS);
+
     std::ostringstream s;
-    s << "// generated by ipcr_amd/csrc/jit.cpp: seed-index filter, " << NS << " key shapes\n";
+    s << "// generated by ipcr_amd/csrc/jit.cpp: seed-index filter, " << NS << " key shapes in " << groups.size() << " groups, "
+      << RT << " rows per strand, body of " << U << " steps\n";
     s << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
     s << "typedef unsigned int u32;\ntypedef unsigned long long u64;\n";
     s << "typedef u32 v4 __attribute__((ext_vector_type(4)));\n";
     s << "struct qent { u64 key; u32 bits; u32 pad; };\n";
     s << "#define NS " << NS << "\n";
+    s << "#define QCAP " << QCAP << "u // per-wave queue of hits (16-byte entries), drained in rounds of 64 at full lane occupancy\n";
+    s << "#define ALL_ACGT " << (all_acgt ? "true" : "false") << " // no indexed pattern holds an IUPAC code\n";
+    s << "#define ULEN " << geom.uniform_len << "u // length of every indexed pattern (0: mixed)\n";
+    bool aligned = geom.uniform_len > 0; // ... and left-anchored windows are tested exactly when they end: no shift in the check
+    for (const ipcr_index_shape &x : shapes)
+        if (x.left && (int)x.dl != geom.uniform_len - 1) aligned = false;
+    s << "#define WINDOW_AT_NEWEST " << (aligned ? "true" : "false") << "\n";
     auto arr = [&](const char *type, const char *name, auto get) {
         s << "__device__ constexpr " << type << " " << name << "[NS] = {";
         for (size_t i = 0; i < NS; ++i) s << (i ? ", " : "") << get(shapes[i]);
@@ -859,173 +920,214 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes) {
     arr("u32", "TW_BITS", [](const ipcr_index_shape &x) { return std::to_string(x.tw_bits) + "u"; });
     arr("u32", "TW_MASK", [](const ipcr_index_shape &x) { return std::to_string(x.tw_mask) + "u"; });
     arr("u32", "BLK_MASK", [](const ipcr_index_shape &x) { return std::to_string(x.blk_mask) + "u"; });
-    arr("u32", "VALID32", [](const ipcr_index_shape &x) { // one bit per base (bit u = u bases before the newest) instead of two
-        uint32_t m = 0;
-        for (int u = 0; u < 32; ++u)
-            if (x.valid_mask & (1ull << (2 * u))) m |= 1u << u;
-        return std::to_string(m) + "u";
-    });
     s << R"SRC(
 template <int S> struct key_of {
   static __device__ __forceinline__ u32 get(u64 km) {
     return ((u32)(km >> TW_SHIFT[S]) & TW_MASK[S]) | (((u32)(km >> BLK_SHIFT[S]) & BLK_MASK[S]) << TW_BITS[S]);
   }
 };
-// all shapes' bitmap words are read unconditionally and together (independent LDS reads, one wait); a read placed
-// behind the validity test costs a divergent branch and an exposed LDS round trip per shape and base
-template <int S> __device__ __forceinline__ void read_all(u64 km, const u32* lds, u32* keys, u32* words) {
-  if constexpr (S < NS) {
-    const u32 k = key_of<S>::get(km);
-    keys[S] = k;
-    words[S] = lds[S * 2048 + (k >> 5)];
-    read_all<S + 1>(km, lds, keys, words);
-  }
-}
-template <int S> __device__ __forceinline__ void test_all(u32 bad, const u32* keys, const u32* words, u32& hitmask) {
-  if constexpr (S < NS) {
-    const u32 bit = __builtin_amdgcn_ubfe(words[S], keys[S] & 31u, 1u);
-    hitmask |= ((bad & VALID32[S]) == 0u ? bit : 0u) << S;
-    test_all<S + 1>(bad, keys, words, hitmask);
-  }
-}
-template <int S> __device__ __forceinline__ u32 key_at(u32 s, u64 km) { // key of shape s (run-time index) from a stored k-mer
-  if constexpr (S + 1 < NS) return s == (u32)S ? key_of<S>::get(km) : key_at<S + 1>(s, km);
-  else return key_of<S>::get(km);
-}
-// LDS image (host.cpp: build_index): NS bitmaps of 2048 words | NS x 256 uint16 group prefixes | NS first-entry indices
+// LDS image (host.cpp: build_index): NS bitmaps of 1024 64-bit words | NS x 1024 uint16 rank prefixes | NS first-entry
+// indices | NS x 2 words of shape constants
 #define PREFIX_WORD0 (NS * 2048u)
-#define BASE_WORD0 (NS * 2048u + NS * 128u)
-#define LDS_WORDS (NS * 2048u + NS * 128u + NS)
-#define QCAP 128u   // per-wave queue of key hits (20-byte entries), flushed at full lane occupancy
-#define QWORDS 5u
-extern "C" __global__ void __launch_bounds__(512) ipcr_index_filter(const u32* __restrict__ planes, u64 ncolpairs,
-    const u32* __restrict__ lds_image, const v4* __restrict__ table, u32 max_mm,
-    qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {
-  extern __shared__ u32 lds[];
-  for (u32 i = threadIdx.x; i < LDS_WORDS; i += blockDim.x) lds[i] = lds_image[i];
-  __syncthreads();
-  const unsigned short* prefix = reinterpret_cast<const unsigned short*>(lds + PREFIX_WORD0);
-  const u32 lane = threadIdx.x & 63u, half = lane >> 5, bit = lane & 31u;
-  u32* wq = lds + ((LDS_WORDS + 3u) & ~3u) + (threadIdx.x >> 6) * (QCAP * QWORDS); // this wave's hit queue
-  u32 qn = 0; // entries queued (wave-uniform)
-  const u64 wave0 = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);
-  for (u64 cp = wave0; cp < ncolpairs; cp += nwaves) {
-    // A key hit means: look the patterns of that key up and compare them with the k-mer.  Doing that where the
-    // hit occurs keeps ~10 of 64 lanes busy at EVERY base step (some lane always hits with thousands of keys), and
-    // the step then costs twice the instructions plus an L2 round trip.  So hits are queued (k-mer, key, where) and
-    // the queue is drained 64 at a time: every lane one hit, 64 independent entry loads in flight.
-    auto flush = [&]() __attribute__((always_inline)) {
-      for (u32 base = 0; base < qn; base += 64u) {
-        const u32 i = base + lane;
-        if (i < qn) {
-          const u32* e = wq + i * QWORDS;
-          const u64 km = ((u64)e[1] << 32) | e[0], im = ((u64)e[3] << 32) | e[2];
-          const u32 where = e[4];
-          const u32 ol = where & 63u;
-          const int erow = (int)((where >> 6) & 0xFFu);
-          const u64 strand_base = ((((cp * 2u + (ol >> 5)) << 5) + (ol & 31u)) << 7);
-          for (u32 smask = where >> 14; smask; smask &= smask - 1u) { // the shapes whose key hit at this base (usually one)
-          const u32 s = (u32)__builtin_ctz(smask);
-          const u32 key = key_at<0>(s, km);
-          // the key is in the panel; its rank among the shape's keys is the index of its entry
-          const u32 grp = key >> 8, wi = (key >> 5) & 7u, bi = key & 31u;
-          const v4* gw = reinterpret_cast<const v4*>(lds + s * 2048u + grp * 8u);
-          const v4 g0 = gw[0], g1 = gw[1];
-          const u32 gword[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-          u32 rank = lds[BASE_WORD0 + s] + (u32)prefix[s * 256u + grp];
-#pragma unroll
-          for (u32 j = 0; j < 8u; ++j) {
-            const u32 m = j < wi ? 0xFFFFFFFFu : (j == wi ? ((1u << bi) - 1u) : 0u);
-            rank += (u32)__builtin_popcount(gword[j] & m);
-          }
-          for (u32 idx = rank; idx != 0xFFFFFFFFu;) {
-            const v4 e0 = table[idx * 4u], e1 = table[idx * 4u + 1u], e2 = table[idx * 4u + 2u], e3 = table[idx * 4u + 3u];
-            const u64 okA = ((u64)e0.w << 32) | e0.z, okC = ((u64)e1.y << 32) | e1.x;
-            const u64 okG = ((u64)e1.w << 32) | e1.z, okT = ((u64)e2.y << 32) | e2.x;
-            const u64 prot2 = ((u64)e2.w << 32) | e2.z;
-            const u32 L = e3.x, left = e3.y;
-            const u32 sft = left ? 64u - 2u * L : 0u;
-            const u64 x = km >> sft, iv = im >> sft;
-            const u64 wm = (L >= 32u) ? ~0ull : ((1ull << (2u * L)) - 1ull);
-            const u64 E = 0x5555555555555555ull;
-            const u64 lo = x & E, hi = (x >> 1) & E;
-            const u64 match = (~lo & ~hi & okA) | (lo & ~hi & okC) | (~lo & hi & okG) | (lo & hi & okT);
-            const u64 mm2 = ((~match & E) | iv) & wm;
-            const int srow = left ? erow - 31 : erow - (int)L + 1;
-            if ((mm2 & prot2) == 0ull && (u32)__popcll(mm2) <= max_mm && srow >= 0 && srow < 128) {
-              const u32 shard = (u32)cp & 255u;
-              const u64 qi = atomicAdd(qcount + shard * 16u, 1ull);
-              if (qi < qcap) { qent qe; qe.key = ((u64)e0.y << 48) | (strand_base + (u64)srow); qe.bits = 1u; qe.pad = 0u; queue[(u64)shard * qcap + qi] = qe; }
-            }
-            idx = e0.x; // further pattern with the same key (rare)
-          }
-          }
-        }
-      }
-      qn = 0;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // queue slots are rewritten by other lanes next
-    };
-    const u64 col = cp * 2u + half;
-    const u64 ncol = (bit == 31u) ? col + 1u : col;
-    const u32 nbit = (bit + 1u) & 31u;
-    u64 km = 0, im = 0x5555555555555555ull;
-    u32 bad = 0xFFFFFFFFu; // the same invalid-base flags, one bit per base: the per-shape key tests are 32-bit
-    // row quads: 32 of my strand, then 8 of the next one; quad rq+1 is loaded while quad rq is processed
-    auto quad_addr = [&](u32 rq) {
-      const u64 c = rq >= 32u ? ncol : col;
-      return planes + ((((c >> 6) * 32u + (rq & 31u)) * 3u * 64u + (u32)(c & 63u)) << 2); // tile_layout.h: ipcr_plane_word
-    };
-    const u32* pa = quad_addr(0u);
-    v4 nlo = *reinterpret_cast<const v4*>(pa), nhi = *reinterpret_cast<const v4*>(pa + 256u), niv = *reinterpret_cast<const v4*>(pa + 512u);
-    for (u32 rq = 0; rq < 40u; ++rq) {
-      const u32 b = rq >= 32u ? nbit : bit;
-      const v4 qlo = nlo, qhi = nhi, qiv = niv;
-      if (rq + 1u < 40u) {
-        pa = quad_addr(rq + 1u);
-        nlo = *reinterpret_cast<const v4*>(pa); nhi = *reinterpret_cast<const v4*>(pa + 256u); niv = *reinterpret_cast<const v4*>(pa + 512u);
-      }
-#pragma unroll
-      for (u32 t = 0; t < 4u; ++t) {
-        const u32 code = ((qlo[t] >> b) & 1u) | (((qhi[t] >> b) & 1u) << 1);
-        km = (km << 2) | code;
-        const u32 inv = (qiv[t] >> b) & 1u;
-        im = (im << 2) | inv;
-        bad = (bad << 1) | inv;
-        const u32 erow = rq * 4u + t;
-        u32 keys[NS], words[NS];
-        u32 hitmask = 0;
-        read_all<0>(km, lds, keys, words);
-        test_all<0>(bad, keys, words, hitmask);
-        const u64 bal = __ballot(hitmask != 0u);
-        if (bal != 0ull) { // one queue entry per lane whatever the number of shapes that hit: (k-mer, shapes, where)
-          const u32 n = (u32)__popcll(bal);
-          if (qn + n > QCAP) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); flush(); }
-          if (hitmask != 0u) {
-            const u32 slot = qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-            u32* e = wq + slot * QWORDS;
-            e[0] = (u32)km; e[1] = (u32)(km >> 32); e[2] = (u32)im; e[3] = (u32)(im >> 32);
-            e[4] = lane | (erow << 6) | (hitmask << 14);
-          }
-          qn += n;
-          if (qn >= 64u) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); flush(); }
-        }
-      }
+#define BASE_WORD0 (NS * 2048u + NS * 512u)
+#define SHAPE_WORD0 (BASE_WORD0 + NS)
+#define LDS_WORDS (SHAPE_WORD0 + 2u * NS)
+// invalid-base flags, one bit per base -> the even bits of a 2-bit-per-base word
+__device__ __forceinline__ u64 spread2(u32 v) {
+  u64 x = v;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+// exact check of the patterns filed under one key (entry `idx` and its chain) against the k-mer of a hit.
+// Entry (device_types.h: ipcr_index_entry): {next, pattern, seq2 | prot2, len, flags | okA, okC | okG, okT}
+__device__ __forceinline__ void check_chain(u32 idx, u64 km, u32 bad, int erow, u64 strand_base, u32 left, u32 dl,
+    u32 shard, const v4* __restrict__ table, u32 max_mm, qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {
+  while (idx != 0xFFFFFFFFu) {
+    const v4 e0 = table[idx * 4u], e1 = table[idx * 4u + 1u];
+    const u64 seq2 = ((u64)e0.w << 32) | e0.z, prot2 = ((u64)e1.y << 32) | e1.x;
+    const u32 L = ULEN ? ULEN : e1.z;                 // one length for the whole panel: every shift and mask below is a constant
+    const u32 sft = WINDOW_AT_NEWEST ? 0u : (left ? 2u * (dl + 1u - L) : 0u); // the window's last base sits sft / 2 bases behind the newest
+    const u64 x = km >> sft;
+    const u64 E = 0x5555555555555555ull;
+    const u64 wmE = ((L >= 32u) ? ~0ull : ((1ull << (2u * L)) - 1ull)) & E;
+    u64 mm2;
+    if (ALL_ACGT || (e1.w & 2u)) {                     // one base per position: XOR against the primer's 2-bit codes
+      const u64 d = x ^ seq2;
+      mm2 = (d | (d >> 1)) & wmE;
+    } else {                                           // IUPAC codes: four sets of allowed positions
+      const v4 e2 = table[idx * 4u + 2u], e3 = table[idx * 4u + 3u];
+      const u64 okA = ((u64)e2.y << 32) | e2.x, okC = ((u64)e2.w << 32) | e2.z;
+      const u64 okG = ((u64)e3.y << 32) | e3.x, okT = ((u64)e3.w << 32) | e3.z;
+      const u64 lo = x & E, hi = (x >> 1) & E;
+      const u64 match = (~lo & ~hi & okA) | (lo & ~hi & okC) | (~lo & hi & okG) | (lo & hi & okT);
+      mm2 = ~match & wmE;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    flush(); // `where` is relative to this column pair
+    const u32 bw = (bad >> (sft >> 1)) & ((L >= 32u) ? 0xFFFFFFFFu : ((1u << L) - 1u));
+    if (bw) mm2 |= spread2(bw);                        // rare: the window holds an invalid base
+    const int srow = left ? erow - (int)dl : erow - (int)L + 1;
+    if ((mm2 & prot2) == 0ull && (u32)__popcll(mm2) <= max_mm && srow >= 0 && srow < 128) {
+      const u64 qi = atomicAdd(qcount + shard * 16u, 1ull);
+      if (qi < qcap) { qent qe; qe.key = ((u64)e0.y << 48) | (strand_base + (u64)srow); qe.bits = 1u; qe.pad = 0u; queue[(u64)shard * qcap + qi] = qe; }
+    }
+    idx = e0.x; // further pattern with the same key (rare)
   }
 }
 )SRC";
+    s << "extern \"C\" __global__ void __launch_bounds__(" << IPCR_INDEX_WAVES * 64u << ", " << IPCR_INDEX_WAVES / 4u << ") ipcr_index_filter(const u32* __restrict__ planes, u64 ncolpairs,\n"
+         "    const u32* __restrict__ lds_image, const v4* __restrict__ table, u32 max_mm,\n"
+         "    qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {\n"
+         "  __shared__ u32 lds[((LDS_WORDS + 3u) & ~3u) + " << IPCR_INDEX_WAVES << "u * QCAP * 4u]; // static: every LDS address is a compile-time offset\n"
+         "  for (u32 i = threadIdx.x; i < LDS_WORDS; i += blockDim.x) lds[i] = lds_image[i];\n"
+         "  __syncthreads();\n"
+         "  const u64* T64 = reinterpret_cast<const u64*>(lds);\n"
+         "  const unsigned short* prefix = reinterpret_cast<const unsigned short*>(lds + PREFIX_WORD0);\n"
+         "  const u32 lane = threadIdx.x & 63u, half = lane >> 5, bit = lane & 31u;\n"
+         "  u32* wq = lds + ((LDS_WORDS + 3u) & ~3u) + (threadIdx.x >> 6) * (QCAP * 4u); // this wave's hit queue\n"
+         "  u32 qn = 0; // entries queued (wave-uniform)\n"
+         "  const u64 wave0 = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);\n"
+         "  const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);\n"
+         "  for (u64 cp = wave0; cp < ncolpairs; cp += nwaves) {\n";
+    // ---- drain of the hit queue: 64 hits per round, one per lane.  First every lane probes the bitmaps of all shapes
+    // of its hit's groups (the base step only knew "some shape of the group"); then ONE convergent round ranks the
+    // key, loads the entry and checks the pattern -- the shape is a run-time value there (constants from LDS), so that
+    // lanes whose hits belong to different shapes share one trip to the entry table.  A key that is filed under a
+    // second shape as well costs another round (rare).
+    s << "    auto flush = [&]() __attribute__((always_inline)) {\n"
+         "      for (u32 qb = 0; qb < qn; qb += 64u) {\n"
+         "        const u32 i = qb + lane;\n"
+         "        u64 hkm = 0ull; u32 hbad = 0u, where = 0u, pend = 0u;\n"
+         "        if (i < qn) {\n"
+         "          const v4 e = *reinterpret_cast<const v4*>(wq + i * 4u);\n"
+         "          hkm = ((u64)e.y << 32) | e.x; hbad = e.z; where = e.w;\n"
+         "          const u32 gm = where >> 14;\n";
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const Grp &g = groups[gi];
+        if (g.sh.empty()) continue;
+        s << "          if (gm & " << (1u << gi) << "u) {\n";
+        if (g.fast) { // key = six common bits + the shape's word index: one shift serves all shapes of the group
+            s << "            const u32 c = (u32)(hkm >> " << g.c_off << "u) & 63u;\n";
+            for (int si : g.sh) {
+                const ipcr_index_shape &sh = shapes[(size_t)si];
+                const unsigned off = g.sh.size() == 1 ? (unsigned)g.v_off : (unsigned)sh.blk_shift;
+                const unsigned vmask = g.v_bits > 0 ? ((1u << g.v_bits) - 1u) : 0u;
+                s << "            pend |= ((u32)(T64[" << si * 1024 << "u + ((u32)(hkm >> " << off << "u) & " << vmask << "u)] >> c) & 1u) << " << si << ";\n";
+            }
+        } else {
+            for (int si : g.sh)
+                s << "            { const u32 key = key_of<" << si << ">::get(hkm); pend |= ((u32)(T64[" << si * 1024 << "u + (key >> 6)] >> (key & 63u)) & 1u) << " << si << "; }\n";
+        }
+        s << "          }\n";
+    }
+    s << "        }\n"
+         "        const u32 ol = where & 63u;\n"
+         "        const int erow = (int)((where >> 6) & 0xFFu);\n"
+         "        const u64 strand_base = ((((cp * 2u + (ol >> 5)) << 5) + (ol & 31u)) << 7);\n"
+         "        const u32 shard = (u32)cp & 255u;\n"
+         "        while (__ballot(pend != 0u) != 0ull) {\n"
+         "          if (pend != 0u) {\n"
+         "            const u32 sidx = (u32)__builtin_ctz(pend);\n"
+         "            pend &= pend - 1u;\n"
+         "            const u32 c0 = lds[SHAPE_WORD0 + 2u * sidx], c1 = lds[SHAPE_WORD0 + 2u * sidx + 1u];\n"
+         "            const u32 key = ((u32)(hkm >> (c0 & 63u)) & (c1 & 0xFFFFu)) | (((u32)(hkm >> ((c0 >> 8) & 63u)) & (c1 >> 16)) << ((c0 >> 16) & 31u));\n"
+         "            const u64 w = T64[sidx * 1024u + (key >> 6)];\n"
+         "            // the key is in the panel; its rank among the shape's keys is the index of its entry\n"
+         "            const u32 rank = lds[BASE_WORD0 + sidx] + (u32)prefix[sidx * 1024u + (key >> 6)] + (u32)__popcll((w << (63u - (key & 63u))) << 1);\n"
+         "            check_chain(rank, hkm, hbad, erow, strand_base, (c0 >> 24) & 1u, c0 >> 25, shard, table, max_mm, queue, qcap, qcount);\n"
+         "          }\n"
+         "        }\n"
+         "      }\n"
+         "      qn = 0;\n"
+         "      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // queue slots are rewritten by other lanes next\n"
+         "    };\n";
+    s << "    const u64 col = cp * 2u + half;\n"
+         "    const u64 ncol = (bit == 31u) ? col + 1u : col;\n"
+         "    const u32 nbit = (bit + 1u) & 31u;\n"
+         "    u64 km = 0;\n"
+         "    u32 bad = 0xFFFFFFFFu; // invalid-base flags of the last 32 bases, one bit per base\n";
+    // delay rings of the fast groups.  Shapes sorted by delay (0, bf, 2 bf, ...): X_last = W_last,
+    // X_i(r) = W_i(r) | X_{i+1}(r - bf), and X_0(r) is the OR of every shape's word that is due at step r.
+    // One ring of bf slots per level i >= 1 (the body length is a multiple of bf: slots are plain registers).
+    for (size_t gi = 0; gi < groups.size(); ++gi)
+        if (groups[gi].fast)
+            for (size_t lv = 1; lv < groups[gi].sh.size(); ++lv)
+                for (unsigned i = 0; i < groups[gi].bf; ++i) s << "    u64 x" << gi << "_" << lv << "_" << i << " = 0ull;\n";
+    s << "    auto quad_addr = [&](u32 rq) { // row quads: 32 of my strand, then those of the next one\n"
+         "      const u64 c = rq >= 32u ? ncol : col;\n"
+         "      return planes + ((((c >> 6) * 32u + (rq & 31u)) * 3u * 64u + (u32)(c & 63u)) << 2); // tile_layout.h: ipcr_plane_word\n"
+         "    };\n"
+         "    const u32* pa = quad_addr(0u);\n"
+         "    v4 nlo = *reinterpret_cast<const v4*>(pa), nhi = *reinterpret_cast<const v4*>(pa + 256u), niv = *reinterpret_cast<const v4*>(pa + 512u);\n"
+         "    v4 qlo, qhi, qiv;\n"
+         "    u32 b = bit;\n";
+    // The walk is ONE copy of the U-step body inside a loop; the last pass stops after TAILSTEPS steps.  Every step is
+    // guarded by the (wave-uniform) step counter, so that the queue drain exists once in the code, not once per
+    // step: a step that fills the queue marks the counter, the remaining guards fall through (two scalar
+    // instructions each), the drain runs at the end of the pass and the next pass resumes behind that step.
+    // All ring slots are still addressed statically.
+    s << "    u32 it = 0u, u = 0u;\n"
+         "    bool done = false;\n"
+         "    while (!done) {\n";
+    const std::string rq0 = "(it * " + std::to_string(U / 4) + "u)";
+    for (unsigned k = 0; k < U; ++k) {
+        const unsigned t = k & 3u;
+        s << "      if (u == " << k << "u) {\n";
+        if (t == 0) {
+            s << "        { const u32 rq = " << rq0 << " + " << k / 4 << "u;\n"
+              << "          b = rq >= 32u ? nbit : bit;\n"
+              << "          qlo = nlo; qhi = nhi; qiv = niv;\n"
+              << "          if (rq + 1u < " << NQ << "u) { pa = quad_addr(rq + 1u); nlo = *reinterpret_cast<const v4*>(pa); nhi = *reinterpret_cast<const v4*>(pa + 256u); niv = *reinterpret_cast<const v4*>(pa + 512u); }\n"
+              << "        }\n";
+        }
+        s << "        km = (km << 2) | (u64)(__builtin_amdgcn_ubfe(qlo[" << t << "], b, 1u) | (__builtin_amdgcn_ubfe(qhi[" << t << "], b, 1u) << 1));\n"
+          << "        bad = (bad << 1) | __builtin_amdgcn_ubfe(qiv[" << t << "], b, 1u);\n"
+          << "        u32 hm = 0u;\n";
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const Grp &g = groups[gi];
+            if (g.sh.empty()) continue;
+            if (g.fast) {
+                const unsigned vmask = g.v_bits > 0 ? ((1u << g.v_bits) - 1u) : 0u;
+                s << "        { const u32 v = " << (g.v_bits > 0 ? "(u32)(km >> " + std::to_string(g.v_off) + "u) & " + std::to_string(vmask) + "u" : std::string("0u")) << ";\n";
+                for (int si : g.sh) s << "          const u64 w" << si << " = T64[" << si * 1024 << "u + v];\n";
+                const size_t nl = g.sh.size();
+                auto slot = [&](size_t lv) { return "x" + std::to_string(gi) + "_" + std::to_string(lv) + "_" + std::to_string(k % g.bf); };
+                // level lv's slot holds X_lv of bf steps ago: read it (for level lv - 1), then overwrite it with X_lv of this step
+                s << "          const u64 acc = w" << g.sh[0] << (nl > 1 ? " | " + slot(1) : std::string()) << ";\n";
+                for (size_t lv = 1; lv < nl; ++lv)
+                    s << "          " << slot(lv) << " = w" << g.sh[lv] << (lv + 1 < nl ? " | " + slot(lv + 1) : std::string()) << ";\n";
+                s << "          hm |= ((u32)(acc >> ((u32)(km >> " << g.c_off << "u) & 63u)) & 1u) << " << gi << ";\n        }\n";
+            } else {
+                for (int si : g.sh)
+                    s << "        { const u32 key = key_of<" << si << ">::get(km); const u32 w = lds[" << si * 2048 << "u + (key >> 5)]; hm |= ((w >> (key & 31u)) & 1u) << " << gi << "; }\n";
+            }
+        }
+        // qn <= QCAP - 64 on entry (a fuller queue is drained before the next step runs) and a step adds at most 64: no overflow
+        s << "        const u64 bal = __ballot(hm != 0u);\n"
+             "        if (bal != 0ull) { // one queue entry per lane whatever the number of groups that hit: (k-mer, invalid flags, where, groups)\n"
+             "          if (hm != 0u) {\n"
+             "            const u32 slot = qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));\n"
+             "            v4 e; e.x = (u32)km; e.y = (u32)(km >> 32); e.z = bad; e.w = lane | ((" << rq0 << " * 4u + " << k << "u) << 6) | (hm << 14);\n"
+             "            *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
+             "          }\n"
+             "          qn += (u32)__popcll(bal);\n"
+             "        }\n";
+        s << "        u = " << k + 1 << "u;\n";
+        if (TAILSTEPS && k + 1 == TAILSTEPS) s << "        if (it == " << NB << "u) { done = true; u = 255u; } // the last pass ends here\n";
+        s << "        if (qn > QCAP - 64u) u |= 256u;\n      }\n";
+    }
+    s << "      const bool full = (u & 256u) != 0u;\n"
+         "      u &= 255u;\n"
+         "      if (u == " << U << "u) { u = 0u; ++it;" << (TAILSTEPS == 0 ? " if (it == " + std::to_string(NB) + "u) done = true;" : std::string()) << " }\n"
+         "      if (full || done) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); flush(); }\n"
+         "    }\n";
+    s << "  }\n}\n"; // (`where` is relative to the column pair: the queue is always empty when a pair ends)
     return s.str();
 }
 
-static unsigned index_lds_bytes(unsigned nshapes) { // bitmaps + group prefixes + first-entry indices (build_index) + 8 hit queues
-    const unsigned image = nshapes * (IPCR_INDEX_BITMAP_WORDS * 4u + IPCR_INDEX_GROUPS * 2u + 4u);
-    return ((image + 15u) & ~15u) + 8u * 128u * 20u;
-}
-
-JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, std::string &err) {
+JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom, std::string &err) {
     if (shapes.empty() || shapes.size() > IPCR_INDEX_MAX_SHAPES) { err = "no index shapes"; return nullptr; }
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1037,35 +1139,29 @@ JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, std::str
         if (colon != std::string::npos) arch = arch.substr(0, colon);
     }
     std::vector<char> code;
-    if (!compile_group(jit_index_source(shapes), arch, code, err)) return nullptr;
+    if (!compile_group(jit_index_source(shapes, geom), arch, code, err)) return nullptr;
     JitFilter *f = new JitFilter;
-    f->waves_per_group = 8;
+    f->waves_per_group = IPCR_INDEX_WAVES;
     if (hipModuleLoadData(&f->module, code.data()) != hipSuccess ||
         hipModuleGetFunction(&f->fn, f->module, "ipcr_index_filter") != hipSuccess) {
         err = "hipModuleLoadData/GetFunction failed for the specialised index filter";
         jit_destroy(f);
         return nullptr;
     }
-    const unsigned lds = index_lds_bytes((unsigned)shapes.size());
-    if (lds > 48u * 1024u) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(f->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    return f;
+    return f; // the kernel's LDS (image + hit queues, up to 160 KiB) is static: nothing to request at launch
 }
 
-hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint32_t nshapes,
+hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint32_t /*nshapes*/,
                             const uint32_t *lds_image, const void *table, uint32_t max_mm, void *queue,
                             uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0) return hipSuccess;
     uint64_t ncolpairs = nblocks * 32u;
-    const unsigned lds = index_lds_bytes(nshapes);
-    // persistent 8-wave workgroups: the bitmaps are staged into LDS once per workgroup; as many
-    // workgroups per CU as the 160 KiB of LDS admit (at most 4 = all 32 wave slots)
-    unsigned per_cu = (160u * 1024u) / (lds ? lds : 1u);
-    per_cu = per_cu < 1u ? 1u : (per_cu > 4u ? 4u : per_cu);
-    uint64_t grid = 256ull * per_cu;
-    if (grid * 8u > ncolpairs) grid = (ncolpairs + 7u) / 8u;
+    // one persistent 16-wave workgroup per CU: the bitmaps are staged into LDS once per CU
+    uint64_t grid = 256ull;
+    if (grid * IPCR_INDEX_WAVES > ncolpairs) grid = (ncolpairs + IPCR_INDEX_WAVES - 1u) / IPCR_INDEX_WAVES;
     void *args[] = {(void *)&planes, (void *)&ncolpairs, (void *)&lds_image, (void *)&table,
                     (void *)&max_mm, (void *)&queue, (void *)&qcap, (void *)&qcount};
-    return hipExtModuleLaunchKernel(f->fn, (unsigned)grid * 512u, 1, 1, 512, 1, 1, lds, st, args, nullptr, start, stop, 0);
+    return hipExtModuleLaunchKernel(f->fn, (unsigned)grid * IPCR_INDEX_WAVES * 64u, 1, 1, IPCR_INDEX_WAVES * 64u, 1, 1, 0, st, args, nullptr, start, stop, 0);
 }
 
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,

@@ -54,8 +54,13 @@ struct JitVerify {
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,
                       uint64_t qcap, unsigned long long *qcount, const JitVerify &v, hipEvent_t start, hipEvent_t stop);
 // seed-index filter for large panels, with the panel's key shapes baked in (host.cpp: build_index)
-std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes);
-JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, std::string &err);
+struct IndexGeom {
+    int tail_rows = 0;     // rows of the following strand a window that starts in this one can reach
+    bool all_acgt = false; // no indexed pattern holds an IUPAC code (the exact check then needs half an entry)
+    int uniform_len = 0;   // every indexed pattern has this length (0: mixed); shifts and masks of the check become constants
+};
+std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom);
+JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom, std::string &err);
 hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint32_t nshapes,
                             const uint32_t *lds_image, const void *table, uint32_t max_mm, void *queue,
                             uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop);
