@@ -189,55 +189,94 @@ std::string count_code(int B, int k, int *cost) {
         th << "            f |= u" << (k + 1) << ";\n";
         ++th_cost;
     }
+    // Carry-save adder tree.  gfx950 has v_bitop3_b32 (any function of three words in one instruction), so a full
+    // adder is TWO instructions (xor3, majority) and a half adder two (xor, and); outputs that do not reach the verdict
+    // are neither emitted nor counted.  Example, "more than 3 of 5 flags": maj(e0,e1,e2) & maj(e3,e4,e0^e1^e2), 4 ops.
     std::ostringstream cs;
     int cs_cost = 0;
     {
+        struct Node { std::string name, expr; std::vector<int> deps; bool live = false; };
+        std::vector<Node> nodes;
+        auto leaf_or_node = [&](const std::string &nm) { // index of the node that defines nm, -1 for an input flag
+            for (size_t i = 0; i < nodes.size(); ++i)
+                if (nodes[i].name == nm) return (int)i;
+            return -1;
+        };
+        auto add = [&](const std::string &expr, const std::vector<std::string> &in) {
+            Node n;
+            n.name = "x" + std::to_string(nodes.size());
+            n.expr = expr;
+            for (const auto &i : in) { const int d = leaf_or_node(i); if (d >= 0) n.deps.push_back(d); }
+            nodes.push_back(n);
+            return nodes.back().name;
+        };
         int wmax = 0;
         while ((2 << wmax) <= k) ++wmax; // top weight whose bit can be set in a value <= k
         std::vector<std::vector<std::string>> planes((size_t)wmax + 2);
         for (int i = 0; i < B; ++i) planes[0].push_back("e" + std::to_string(i));
         std::vector<std::string> ovf;
-        int tmp = 0;
         for (int w = 0; w <= wmax; ++w) {
             auto &pl = planes[(size_t)w];
             while (pl.size() >= 2) {
-                const std::string a = pl[0], b = pl[1];
-                const std::string t = "x" + std::to_string(tmp++), sum = "x" + std::to_string(tmp++), cy = "x" + std::to_string(tmp++);
+                std::string sum, cy;
                 if (pl.size() >= 3) {
-                    const std::string c = pl[2];
-                    cs << "            const u32 " << t << " = " << a << " ^ " << b << ", " << sum << " = " << t << " ^ " << c << ", "
-                       << cy << " = (" << t << " & " << c << ") | (~" << t << " & " << a << ");\n";
+                    const std::string a = pl[0], b = pl[1], c = pl[2];
+                    sum = add(a + " ^ " + b + " ^ " + c, {a, b, c});
+                    cy = add("(" + a + " & " + b + ") | (" + c + " & (" + a + " | " + b + "))", {a, b, c});
                     pl.erase(pl.begin(), pl.begin() + 3);
-                    cs_cost += 3;
                 } else {
-                    cs << "            const u32 " << sum << " = " << a << " ^ " << b << ", " << cy << " = " << a << " & " << b << ";\n";
+                    const std::string a = pl[0], b = pl[1];
+                    sum = add(a + " ^ " + b, {a, b});
+                    cy = add(a + " & " + b, {a, b});
                     pl.erase(pl.begin(), pl.begin() + 2);
-                    cs_cost += 2;
                 }
                 pl.push_back(sum);
                 if (w == wmax) ovf.push_back(cy); else planes[(size_t)w + 1].push_back(cy);
             }
         }
         // value = sum of planes[w][0] << w  (w <= wmax); fail = overflow | value > k
+        std::vector<std::string> used = ovf;
         std::string gt, eq;
+        int cmp_cost = 0;
         for (int w = wmax; w >= 0; --w) {
             const std::string bw = planes[(size_t)w].empty() ? std::string("0u") : planes[(size_t)w][0];
             if (((k >> w) & 1) == 0) {
                 const std::string term = eq.empty() ? bw : "(" + eq + " & " + bw + ")";
                 gt = gt.empty() ? term : gt + " | " + term;
                 eq = eq.empty() ? "~" + bw : eq + " & ~" + bw;
-                cs_cost += 2;
+                used.push_back(bw);
+                cmp_cost += 2;
             } else {
+                bool lower_zero = false; // a set bit of k only matters if some lower bit of k is clear
+                for (int v = w - 1; v >= 0; --v) lower_zero |= ((k >> v) & 1) == 0;
+                if (!lower_zero) continue;
                 eq = eq.empty() ? bw : eq + " & " + bw;
-                cs_cost += 1;
+                used.push_back(bw);
+                cmp_cost += 1;
             }
         }
+        if (gt.empty()) cmp_cost = 0; // nothing can exceed k below the overflow weight
+        for (const auto &u : (gt.empty() ? ovf : used)) {
+            std::vector<int> stack;
+            const int d = leaf_or_node(u);
+            if (d >= 0) stack.push_back(d);
+            while (!stack.empty()) {
+                const int n = stack.back();
+                stack.pop_back();
+                if (nodes[(size_t)n].live) continue;
+                nodes[(size_t)n].live = true;
+                for (int dd : nodes[(size_t)n].deps) stack.push_back(dd);
+            }
+        }
+        for (const Node &n : nodes)
+            if (n.live) { cs << "            const u32 " << n.name << " = " << n.expr << ";\n"; ++cs_cost; }
         cs << "            f |= ";
         bool first = true;
-        for (const auto &o : ovf) { cs << (first ? "" : " | ") << o; first = false; ++cs_cost; }
+        for (const auto &o : ovf) { cs << (first ? "" : " | ") << o; first = false; }
         if (!gt.empty()) { cs << (first ? "" : " | ") << gt; first = false; }
         if (first) cs << "0u";
         cs << ";\n";
+        cs_cost += cmp_cost + (int)(ovf.size() + 1) / 2; // the final ORs, three inputs per instruction
     }
     const int force = env_int("IPCR_JIT_COUNTER", 0, 0, 2); // 1 = thermometer, 2 = adder tree
     const bool use_cs = force == 2 || (force == 0 && cs_cost < th_cost);
@@ -245,11 +284,29 @@ std::string count_code(int B, int k, int *cost) {
     return use_cs ? cs.str() : th.str();
 }
 
-std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigned qbase) {
-    if (pats.empty() || pats.size() > 48) return "";
+std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, unsigned qbase) {
+    if (full_pats.empty() || full_pats.size() > 48) return "";
+    // The register window is the kernel's budget (W rows x 4 planes), and the filter only has to be SOUND: a window
+    // with <= k mismatches has <= k mismatches at any subset of its positions.  So a pattern longer than LF is
+    // filtered by its LF positions next to the protected end (the others are left to the exact verifier, which reads
+    // the tiles): 20-row windows leave registers for two row-quads of prefetch whatever the primer lengths.
+    // off = positions dropped at the window's start: the filter then sees the window `off` rows late.
+    const int LF = env_int("IPCR_JIT_FILTER_LEN", 20, 8, 32);
+    std::vector<ipcr_dev_pattern> pats = full_pats;
+    std::vector<int> offs(pats.size(), 0);
     int Lmax = 0;
-    for (const auto &p : pats) {
+    for (size_t q = 0; q < pats.size(); ++q) {
+        ipcr_dev_pattern &p = pats[q];
         if (p.len == 0 || p.len > 32) return "";
+        if ((int)p.len > LF) {
+            const int drop = (int)p.len - LF;
+            if (p.mask[p.len - 1] & 16u) { // protected 3' window at the right end (or everything protected): keep the right end
+                for (int j = 0; j < LF; ++j) p.mask[j] = p.mask[j + drop];
+                offs[q] = drop;
+            }
+            for (int j = LF; j < (int)p.len; ++j) p.mask[j] = 0;
+            p.len = (uint16_t)LF;
+        }
         Lmax = std::max<int>(Lmax, p.len);
     }
     const int W = (Lmax + 3) / 4 * 4;        // window rows, multiple of the row-quad
@@ -340,7 +397,12 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
                 b << count_code((int)U, k);
                 b << "              }\n";
             }
-            b << "              if (f != 0xFFFFFFFFu) push(" << (qbase + q) << "ull, pos, ~f, lcnt, lkey, lbits, queue, qcap, qcount, counts);\n";
+            if (offs[q] == 0)
+                b << "              if (f != 0xFFFFFFFFu) push(" << (qbase + q) << "ull, pos, ~f, lcnt, lkey, lbits, queue, qcap, qcount, counts);\n";
+            else // the window starts offs[q] rows before the filtered part: in the previous strand (= the previous bit) when that crosses row 0
+                b << "              if (f != 0xFFFFFFFFu) { u64 wp = pos; u32 wm = ~f; if (wp >= " << offs[q] << "ull) wp -= " << offs[q]
+                  << "ull; else { wp += " << 128 - offs[q] << "ull; wm >>= 1; } if (wm) push(" << (qbase + q)
+                  << "ull, wp, wm, lcnt, lkey, lbits, queue, qcap, qcount, counts); }\n";
             b << "            }\n";
         }
         b << "          }\n        }\n      }\n";
@@ -462,11 +524,11 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
     // bases the primer position accepts, bit 4 = position inside the protected window)
     s << "#define NPAT " << pats.size() << "u\n#define QBASE " << qbase << "u\n";
     s << "__device__ const unsigned char __attribute__((aligned(16))) PMASK[NPAT * 32u] = {";
-    for (size_t q = 0; q < pats.size(); ++q)
-        for (int j = 0; j < 32; ++j) s << (q || j ? "," : "") << (j < pats[q].len ? (unsigned)pats[q].mask[j] : 0u);
+    for (size_t q = 0; q < full_pats.size(); ++q)
+        for (int j = 0; j < 32; ++j) s << (q || j ? "," : "") << (j < full_pats[q].len ? (unsigned)full_pats[q].mask[j] : 0u);
     s << "};\n__device__ const u32 PINFO[NPAT * 4u] = {"; // len, seed_off, seed_len, global_id
-    for (size_t q = 0; q < pats.size(); ++q)
-        s << (q ? "," : "") << pats[q].len << "u," << pats[q].seed_off << "u," << pats[q].seed_len << "u," << pats[q].global_id << "u";
+    for (size_t q = 0; q < full_pats.size(); ++q)
+        s << (q ? "," : "") << full_pats[q].len << "u," << full_pats[q].seed_off << "u," << full_pats[q].seed_len << "u," << full_pats[q].global_id << "u";
     s << "};\n";
     s << "#define CAND_CAP " << CAND_CAP << "u\n";
     s << "// IPCR_WAVES_PER_GROUP " << WPG << "\n";
@@ -565,7 +627,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
          "        const u64 local = P - rs;\n"
          "        const u32 mm = (u32)(__ballot(mis) >> (half * 32u));\n"
          "        const u32 pv = (u32)(__ballot(prot) >> (half * 32u));\n"
-         "        const bool ok = live && pv == 0u && (u32)__builtin_popcount(mm) <= max_mm && local + L <= rl;\n"
+         "        const bool ok = live && pv == 0u && (u32)__builtin_popcount(mm) <= max_mm && P >= rs && local + L <= rl; // P < rs: a shifted window start in the padding in front of the record\n"
          "        u32 flag = 0u;\n"
          "        if (check_rst) flag = ((u32)(__ballot(ok && j < slen && rst_bit(rst, P + soff + j)) >> (half * 32u))) != 0u ? 1u : 0u;\n"
          "        if (__ballot(ok) != 0ull) wrote = true;\n"
@@ -595,7 +657,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int k, unsigne
          "      u32 lo = 0u, hi = nrec; // last record with start <= P\n"
          "      while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (rec_start[mid] <= P) lo = mid; else hi = mid; }\n"
          "      const u64 local = P - rec_start[lo];\n"
-         "      if (local + L > rec_len[lo]) continue; // window must stay inside the record (ac.go:188-190)\n"
+         "      if (P < rec_start[lo] || local + L > rec_len[lo]) continue; // window must stay inside the record (ac.go:188-190)\n"
          "      bool mis = false, prot = false;\n"
          "      if (lane < L) {\n"
          "        const u32 g = base_bits(planes32, P + lane);\n"

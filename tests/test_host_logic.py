@@ -329,3 +329,66 @@ def test_bench_launch_decision(monkeypatch):
     assert e.value.code == 7 and len(calls) == 1
     assert calls[0][-4:] == ["--gpus", "4", "--steps", "3"] and calls[0][calls[0].index("--nproc-per-node") + 1] == "4"
     assert ("torch" in sys.modules) == torch_loaded, "the launcher process must not import torch"
+
+
+def _counter_blocks(src):
+    """(number of flags, statements) of every block counter in a generated filter: the lines between a pattern's
+    last `const u32 eN = ...;` and its `f |= ...;`"""
+    out, flags, stmts, in_pat = [], 0, [], False
+    for line in src.splitlines():
+        t = line.strip()
+        if t.startswith("{ // pattern") or t == "{":
+            flags, stmts, in_pat = 0, [], True
+            continue
+        if not in_pat:
+            continue
+        m = re.match(r"const u32 e(\d+) = ", t)
+        if m:
+            flags, stmts = int(m.group(1)) + 1, []
+            continue
+        if re.match(r"(const u32 x\d+|u32 u\d+|u\d+ \|?=) ", t) or re.match(r"const u32 x\d+ = .*, x\d+ = ", t):
+            stmts.append(t)
+            continue
+        if t.startswith("f |= ") and flags:
+            out.append((flags, stmts + [t]))
+            flags, stmts, in_pat = 0, [], False
+    return out
+
+
+@pytest.mark.parametrize("k,tw,primers", [
+    (1, 3, ("ACGTTGCATGCAAGCTAGCT", "GGCCTTAAGGCCATATGGCA")),
+    (2, 5, ("ACGTTGCATGCAAGCTAGCT", "GGCCTTAAGGCCATATGGCA")),
+    (3, 3, ("AGAGTTTGATCMTGGCTCAG", "TACGGYTACCTTGTTAYGACTT")),
+    (3, 0, ("ACGTTGCATGCAAGCTAGCTAGGATC", "GGCCTTAAGGCCATATGGCATTACGGA")),
+    (4, 2, ("ACGTTGCATGCAAGCTAGCTAGGATCAA", "GGCCTTAAGGCCATATGGCATTACGGAT")),
+    (5, 0, ("ACGTTGCATGCAAGCTAGCTAGGATCAATT", "GGCCTTAAGGCCATATGGCATTACGGATCC")),
+])
+def test_generated_block_counters_are_exact(k, tw, primers, monkeypatch):
+    """the "more than k of the B block flags are set" circuits the generator emits (thermometer or carry-save adder
+    tree, whichever is cheaper on v_bitop3) evaluated for EVERY combination of flags, main test and exact stage"""
+    for force in ("0", "1", "2"):
+        monkeypatch.setenv("IPCR_JIT_COUNTER", force)
+        cp = engine.New(engine.Config(MaxMM=k, TerminalWindow=tw, MaxLen=2000)).CompilePanel(
+            [primer.Pair("p", primers[0], primers[1], 0, 0)])
+        src = cp.filter_source(0)
+        cp.close()
+        blocks = _counter_blocks(src)
+        assert blocks, "no counter found in the generated source"
+        seen = set()
+        for flags, stmts in blocks:
+            key = (flags, tuple(stmts))
+            if key in seen or flags > 16:
+                continue
+            seen.add(key)
+            n = 1 << flags
+            full = (1 << n) - 1
+            env = {"f": 0, "FULL": full}
+            for i in range(flags):     # flag i as a truth-table column over all 2^flags assignments
+                env["e%d" % i] = sum(1 << a for a in range(n) if (a >> i) & 1)
+            for st in stmts:
+                st = st.rstrip(";").replace("const u32 ", "").replace("u32 ", "").replace("0u", "0")
+                for part in re.split(r",\s*(?=x\d+ = )", st):
+                    part = re.sub(r"~(\w+)", r"(FULL ^ \1)", part)
+                    exec(part, {}, env)
+            want = sum(1 << a for a in range(n) if bin(a).count("1") > k)
+            assert env["f"] & full == want, (k, flags, force, stmts)

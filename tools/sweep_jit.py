@@ -18,15 +18,19 @@ if which == "c2":
 else:
     cfg, pairs = E.Config(MaxMM=3, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12, Circular=True), workloads.c3_pairs()
 eng = E.New(cfg)
+for kv in os.environ.get("SWEEP_ENV", "").split():   # extra generator knobs for the whole sweep: "IPCR_JIT_FILTER_LEN=16 ..."
+    k_, v_ = kv.split("=", 1)
+    os.environ[k_] = v_
 configs = [tuple(int(x) for x in c.split(',')) for c in os.environ['SWEEP_CONFIGS'].split(';')] if os.environ.get('SWEEP_CONFIGS') else [(2, 2, 4), (3, 2, 4), (1, 2, 4), (2, 2, 2), (3, 2, 2), (2, 3, 2), (3, 3, 2), (2, 3, 1), (4, 1, 4), (3, 1, 4), (2, 2, 1), (3, 2, 1)]
 for (d, w, wg) in configs:
     os.environ["IPCR_JIT_DEPTH"], os.environ["IPCR_JIT_WAVES"], os.environ["IPCR_JIT_WG"] = str(d), str(w), str(wg)
     cp = eng.CompilePanel(pairs)
     sc = eng.NewSimulationScratch(cp)
     ts = []
-    for i in range(12):
+    warm = int(os.environ.get("SWEEP_WARM", "150"))   # the first ~50 sweeps after idle run 15-25 % slower (clock ramp)
+    for i in range(warm + 40):
         eng.ScanGenomeCount(g, cp, sc)
-        if i >= 3:
+        if i >= warm:
             ts.append(sc.stats().filter_ms)
     st = sc.stats()
     med = statistics.median(ts)
