@@ -221,8 +221,8 @@ std::string count_code(int B, int k, int *cost) {
                 std::string sum, cy;
                 if (pl.size() >= 3) {
                     const std::string a = pl[0], b = pl[1], c = pl[2];
-                    sum = add(a + " ^ " + b + " ^ " + c, {a, b, c});
-                    cy = add("(" + a + " & " + b + ") | (" + c + " & (" + a + " | " + b + "))", {a, b, c});
+                    sum = add("XOR3(" + a + ", " + b + ", " + c + ")", {a, b, c});
+                    cy = add("MAJ3(" + a + ", " + b + ", " + c + ")", {a, b, c});
                     pl.erase(pl.begin(), pl.begin() + 3);
                 } else {
                     const std::string a = pl[0], b = pl[1];
@@ -335,21 +335,50 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
         for (size_t q = 0; q < pats.size(); ++q) {
             const Plan &pl = plans[q];
             const auto &p = pats[q];
+            // OR over the mismatch planes of a set of positions, written as explicit three-input instructions
+            // (v_bitop3_b32 / v_or3_b32): left to itself the compiler shares sub-expressions between the OR trees and
+            // the adders behind them and ends up with two-input chains, a third more instructions.  A position whose
+            // IUPAC code allows two or three bases is the AND of that many planes.
+            int tmpn = 0;
             auto orchain = [&](const std::vector<int> &js) {
-                std::string e;
-                for (size_t i = 0; i < js.size(); ++i) {
-                    if (i) e += " | ";
-                    e += plane_expr(p.mask[js[i]], (sr + js[i]) % W, uses_n);
+                std::vector<std::string> singles;
+                std::vector<std::vector<std::string>> ands;
+                for (int j : js) {
+                    const uint8_t m = p.mask[j] & 15u;
+                    const std::string sl = std::to_string((sr + j) % W);
+                    if (m == 15u) { uses_n = true; singles.push_back("n" + sl); continue; }
+                    if (m == 0u) return std::string("0xFFFFFFFFu"); // matches nothing
+                    std::vector<std::string> t;
+                    for (int b = 0; b < 4; ++b)
+                        if (m & (1u << b)) t.push_back(std::string(1, "acgt"[b]) + sl);
+                    if (t.size() == 1) singles.push_back(t[0]); else ands.push_back(t);
                 }
-                return e.empty() ? std::string("0u") : e;
+                auto tmp = [&](const std::string &expr) {
+                    const std::string nm = "o" + std::to_string(q) + "_" + std::to_string(tmpn++);
+                    o << "            const u32 " << nm << " = " << expr << ";\n";
+                    return nm;
+                };
+                for (const auto &t : ands) {
+                    if (t.size() == 3) singles.push_back(tmp("AND3(" + t[0] + ", " + t[1] + ", " + t[2] + ")"));
+                    else if (!singles.empty()) { const std::string x = singles.back(); singles.pop_back(); singles.push_back(tmp("ANDOR(" + t[0] + ", " + t[1] + ", " + x + ")")); }
+                    else singles.push_back(tmp(t[0] + " & " + t[1]));
+                }
+                while (singles.size() > 3) {
+                    const std::string a = singles[0], b = singles[1], c = singles[2];
+                    singles.erase(singles.begin(), singles.begin() + 3);
+                    singles.push_back(tmp("OR3(" + a + ", " + b + ", " + c + ")"));
+                }
+                if (singles.empty()) return std::string("0u");
+                if (singles.size() == 1) return singles[0];
+                if (singles.size() == 2) return singles[0] + " | " + singles[1];
+                return "OR3(" + singles[0] + ", " + singles[1] + ", " + singles[2] + ")";
             };
             o << "          { // pattern " << q << ": len " << pl.L << ", " << pl.prot.size() << " protected, "
               << pl.blocks.size() << " blocks\n";
-            o << "            u32 f = " << orchain(pl.prot) << ";\n";
+            { const std::string e = orchain(pl.prot); o << "            u32 f = " << e << ";\n"; }
             if (pl.counted) {
                 const int B = (int)pl.blocks.size();
-                for (int i = 0; i < B; ++i)
-                    o << "            const u32 e" << i << " = " << orchain(pl.blocks[(size_t)i]) << ";\n";
+                for (int i = 0; i < B; ++i) { const std::string e = orchain(pl.blocks[(size_t)i]); o << "            const u32 e" << i << " = " << e << ";\n"; }
                 o << count_code(B, k);
             }
             o << "            f" << q << " = f;\n          }\n";
@@ -363,9 +392,8 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
         const std::string sl = std::to_string(slot);
         b << "      { // window slot " << slot << "\n";
         b << "        const u32 lo = clo." << comp << ", hi = chi." << comp << ", iv = civ." << comp << ";\n";
-        b << "        const u32 nlo = ~lo, nhi = ~hi;\n";
-        b << "        a" << sl << " = lo | hi | iv; c" << sl << " = nlo | hi | iv; g" << sl << " = lo | nhi | iv; t"
-          << sl << " = nlo | nhi | iv; n" << sl << " = iv;\n";
+        b << "        a" << sl << " = OR3(lo, hi, iv); c" << sl << " = __builtin_amdgcn_bitop3_b32(lo, hi, iv, 0xEF); g" << sl
+          << " = __builtin_amdgcn_bitop3_b32(lo, hi, iv, 0xFB); t" << sl << " = __builtin_amdgcn_bitop3_b32(lo, hi, iv, 0xBF); n" << sl << " = iv;\n";
         if (guard == "never") { b << "      }\n"; return b.str(); }
         if (!guard.empty()) b << "        if (" << guard << ")\n";
         b << "        {\n          u32 ";
@@ -475,6 +503,12 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     s << "typedef u32 v4 __attribute__((ext_vector_type(4)));\n";
     s << "struct qent { u64 key; u32 bits; u32 pad; };\n";
     s << "struct hitrec { u64 pos; u32 record; u32 pattern; u64 m0, m1; };\n";
+    // three-input logic as single instructions (v_bitop3_b32; truth table over the masks a = 0xF0, b = 0xCC, c = 0xAA)
+    s << "#define OR3(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE)\n"
+         "#define AND3(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0x80)\n"
+         "#define ANDOR(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA) /* (a & b) | c */\n"
+         "#define XOR3(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0x96)\n"
+         "#define MAJ3(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8)\n";
     s << "struct dpat { unsigned short len, seed_off, seed_len, reserved; u32 global_id; unsigned char mask[128]; };\n";
     s << "#define LIST_CAP " << LIST_CAP << "u\n";
     // position -> (block, row, lane, bit) of the strand-major tiles (tile_layout.h)

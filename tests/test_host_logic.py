@@ -382,7 +382,7 @@ def test_generated_block_counters_are_exact(k, tw, primers, monkeypatch):
             seen.add(key)
             n = 1 << flags
             full = (1 << n) - 1
-            env = {"f": 0, "FULL": full}
+            env = {"f": 0, "FULL": full, "XOR3": lambda a, b, c: a ^ b ^ c, "MAJ3": lambda a, b, c: (a & b) | (c & (a | b))}
             for i in range(flags):     # flag i as a truth-table column over all 2^flags assignments
                 env["e%d" % i] = sum(1 << a for a in range(n) if (a >> i) & 1)
             for st in stmts:
