@@ -1,23 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X-native ipcr primer scan.
+"""bench.py -- benchmark of the MI355X-native ipcr primer scan.  Prints ONE JSON line on rank 0.
 
-Workload (BASELINE.json configs[1], "C2"): one primer pair as `ipcr` scans it with the default
---self (3 pairs / 12 orientation slots / 4 distinct patterns), --mismatches 2,
---terminal-window 5, --max-length 2000, --hit-cap 10000, over a synthetic 3.0 Gb genome
-(24 records x 125 Mb of the reference's benchDNA LCG, 1000 planted 180-bp amplicons:
-exact / 1 / 2 mismatches outside the 3' window).  One STEP = one pass of the hot path over the
-whole resident genome: the specialised sweep (block test, exact count, verification and hand-over
-in one kernel) -> hit records on the host -> reference-order match lists -> amplicon join ->
-products; the product count of EVERY pass is checked, all planted amplicons of the last one.
-Inputs (the 2-bit + invalid-bit tiles) are resident in HBM when the timed region starts.
-Passes are pipelined over three scratches (pipelined_passes); --no-pipeline runs them one by one.
+    python bench.py                          # 1 GPU, workload C2 (the headline), other workloads in config.other_workloads
+    python bench.py --gpus 8                 # starts 8 ranks itself (torch.distributed.run as a child process)
+    python bench.py --workload c4            # the 1024-row multiplex panel as the main line
 
-N > 1 (torchrun, one process per GPU): weak scaling -- every rank scans its own 3 Gb genome
-(seed + rank) with the same panel and joins its own records; the hit records of every pass are
-exchanged by one all-gather over RCCL (straight out of the device hit buffer, two in flight), and
-rank 0 joins the whole job from the gathered records of the last pass as a check.
+Workloads (BASELINE.json configs[1..4]; synthetic 3.0 Gb genome per GPU = 24 records x 125 Mb
+of the reference's benchDNA LCG, resident in HBM as 2-bit + invalid-bit tiles when the timed region starts):
+  c2  one primer pair as `ipcr` scans it with the default --self (12 orientation slots, 4 distinct patterns), k=2,
+      3'-window 5, hit-cap 10000, max-length 2000; 1000 planted 180-bp amplicons (exact / 1 / 2 mismatches)
+  c3  27F/1492R (IUPAC M/Y), k=3, 3'-window 3, --circular; 480 planted amplicons + one origin-spanning per record
+  c4  1024-row ipcr-multiplex panel (3072 pairs / 4096 distinct patterns), k=2, 3'-window 3: seed-index filter
+  c5  c2's pair + an internal probe (ipcr-probe): scan + batched probe rescan of every product
+One STEP = one pass of the hot path over the whole resident genome: sweep (filter, exact verification and hand-over)
+-> hit records on the host -> reference-order match lists -> amplicon join -> products (c5: + probe rescan); the
+product count of EVERY pass is checked, every planted amplicon of the last one.  Passes are pipelined over three
+scratches (pipelined_passes); --no-pipeline runs them one by one.
 
-Prints ONE JSON line on rank 0.
+N > 1 (one process per GPU): weak scaling -- every rank scans its own genome (seed + rank) with the same panel and
+joins its own records; the hit records of every pass are exchanged by one all-gather over RCCL straight out of the
+device hit buffer (two in flight); rank 0 joins the whole job from the gathered records of the last pass as a check.
 """
 from __future__ import annotations
 
@@ -31,51 +33,36 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
-BYTES_PER_BASE = 0.375         # lo + hi + inv planes: the encoded tile the filter reads once
+BYTES_PER_BASE = 0.375         # lo + hi + inv planes: the encoded tile a filter kernel reads once
 RECORDS = 24
 RECORD_LEN = 125_000_000
 N_PLANTS = 1000
 PRODUCT_LEN = 180
+MIN_WARM_PASSES = {"c2": 300, "c3": 300, "c5": 300, "c4": 12}   # the first ~50 sweeps after idle run 15-25 % slower (clock ramp)
+PROBE = "TGGACCTTAGCAGGTCATTCAG"
 
 
-def build_genome(torch, engine, workloads, revcomp_fn, genome_idx: int, records: int, record_len: int,
-                 keep_host_record0: bool):
-    """Synthetic genome of SURVEY.md 8(d): LCG stream seed 0x5eed1234+g cut into records, amplicons
-    planted as makeEngineBenchFixture does (performance_benchmark_test.go:47-62)."""
-    from ipcr_amd import workloads as W
-    g = engine.Genome(records * record_len, records)
-    pair = W.bench_pair(0)
-    fwd = pair.Forward
-    rc_rev = revcomp_fn(pair.Reverse)
-    buf = torch.empty(record_len, dtype=torch.uint8, device="cuda")
-    plants = []  # (record, start, n_mismatches)
-    per_rec = (N_PLANTS + records - 1) // records
-    stride = max((record_len - 4096) // (per_rec + 1), 400)
-    host0 = None
-    for r in range(records):
-        engine.lcg_fill_device(buf.data_ptr(), record_len, 0x5eed1234 + genome_idx, r * record_len)
-        for t in range(per_rec):
-            gidx = t * records + r
-            if gidx >= N_PLANTS:
-                break
-            start = 2048 + t * stride
-            if start + PRODUCT_LEN + 64 > record_len:
-                break
-            nm = gidx % 3
-            site = list(fwd)
-            if nm >= 1:
-                site[10] = W.different_base(site[10])
-            if nm >= 2:
-                site[3] = W.different_base(site[3])
-            buf[start:start + 20] = torch.tensor(list("".join(site).encode()), dtype=torch.uint8)
-            buf[start + PRODUCT_LEN - 20:start + PRODUCT_LEN] = torch.tensor(list(rc_rev), dtype=torch.uint8)
-            plants.append((r, start, nm))
-        torch.cuda.synchronize()
-        if keep_host_record0 and r == 0:
-            host0 = buf.cpu().numpy().copy()
-        g.add_record_device("chr%d" % (r + 1), buf.data_ptr(), record_len)
-    del buf
-    return g, plants, host0
+# ----------------------------------------------------------------------------------------------- launch
+def launch_plan(gpus: int, env, argv, python: str = sys.executable, script: str = os.path.abspath(__file__)):
+    """How `bench.py --gpus N` gets its N ranks (one process per GPU, internal/pipeline/pipeline.go:60-125 is the
+    reference's unit of parallelism: independent records over a pool of workers).
+      * RANK in the environment: this process IS a rank (torchrun or the driver started it) -> None = run here;
+        WORLD_SIZE must then equal --gpus when --gpus > 1 was given.
+      * no RANK and N > 1: this process only launches -- it returns the command of
+        `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`, which main() starts as a CHILD
+        process (never exec) before anything has touched the GPU, and whose exit code it returns.
+      * N <= 1: None."""
+    if "RANK" in env:
+        world = int(env.get("WORLD_SIZE", "1"))
+        if gpus > 1 and world != gpus:
+            raise SystemExit(f"bench.py: --gpus {gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                             f"(python bench.py --gpus {gpus} does it itself)")
+        return None
+    if gpus <= 1:
+        return None
+    port = env.get("MASTER_PORT") or str(29500 + (os.getpid() % 400))
+    return [python, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", port, script] + list(argv)
 
 
 def pipelined_passes(k, scratches, begin, end, chain=None, start_exchange=None, finish_exchange=None, pipeline=True,
@@ -118,111 +105,224 @@ def pipelined_passes(k, scratches, begin, end, chain=None, start_exchange=None, 
     return n
 
 
-def launch_plan(gpus: int, env, argv, python: str = sys.executable, script: str = os.path.abspath(__file__)):
-    """How `bench.py --gpus N` gets its N ranks (one process per GPU, internal/pipeline/pipeline.go:60-125 is the
-    reference's unit of parallelism: independent records over a pool of workers).
-      * RANK in the environment: this process IS a rank (torchrun or the driver started it) -> None = run here;
-        WORLD_SIZE must then equal --gpus when --gpus > 1 was given.
-      * no RANK and N > 1: this process only launches -- it returns the command of
-        `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`, which main() starts as a CHILD
-        process (never exec) before anything has touched the GPU, and whose exit code it returns.
-      * N <= 1: None."""
-    if "RANK" in env:
-        world = int(env.get("WORLD_SIZE", "1"))
-        if gpus > 1 and world != gpus:
-            raise SystemExit(f"bench.py: --gpus {gpus} but WORLD_SIZE={world}: start one rank per GPU "
-                             f"(python bench.py --gpus {gpus} does it itself)")
-        return None
-    if gpus <= 1:
-        return None
-    port = env.get("MASTER_PORT") or str(29500 + (os.getpid() % 400))
-    return [python, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
-            "--master-addr", "127.0.0.1", "--master-port", port, script] + list(argv)
+# ----------------------------------------------------------------------------------------------- genomes
+class Ctx:
+    """everything a workload run needs: modules, rank layout, the exchanger's device, arguments"""
+    pass
 
 
-def main() -> None:
-    # HIP maps streams onto a few hardware queues (4 by default), in creation order.  This job has a dozen (three
-    # scratches, the genome, torch, RCCL): when the sweep lane shares a queue with the collective's stream, every
-    # all-gather is serialised between two sweeps (+25 us per step measured).  One queue per stream instead.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    # one step is ~0.2 ms: the default region (about half a second) is long enough for the clocks to settle; the
-    # first ~50 steps after idle run 15-25 % slower (see DESIGN.md section 5)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--records", type=int, default=RECORDS)
-    ap.add_argument("--record-len", type=int, default=RECORD_LEN)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo to rehearse)")
-    ap.add_argument("--no-pipeline", action="store_true", help="finish every pass before the next one is enqueued")
-    args = ap.parse_args()
+def _put(torch, buf, pos, text):
+    b = text if isinstance(text, (bytes, bytearray)) else text.encode()
+    buf[pos:pos + len(b)] = torch.tensor(list(b), dtype=torch.uint8)
 
-    cmd = launch_plan(args.gpus, os.environ, sys.argv[1:])
-    if cmd is not None:   # launcher only: no torch import, no HIP call in this process
-        import subprocess
-        raise SystemExit(subprocess.call(cmd, env=dict(os.environ)))
 
-    import numpy as np
-    import torch
-    from ipcr_amd import _lib, dist, engine, workloads
+def plant_stride(records: int, record_len: int) -> int:
+    per_rec = (N_PLANTS + records - 1) // records
+    return max((record_len - 4096) // (per_rec + 1), 400)
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the ipcr_amd scan path has no CPU fallback")
-    if os.environ.get("IPCR_BENCH_ONE_DEVICE"):  # rehearsal: several ranks share GPU 0 (gloo collectives)
-        os.environ["LOCAL_RANK"] = "0"
-    rank, world, local, backend = dist.init_process_group(args.backend)
-    torch.cuda.set_device(local)
-    _lib.check(_lib.lib().ipcr_set_device(local))
-    dev = torch.device("cuda", local)
-    cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective payloads live
-    import torch.distributed as tdist
-    multi = world > 1 or bool(os.environ.get("IPCR_EXCHANGE_SELFTEST"))  # selftest: one rank runs the RCCL exchange too
 
-    def revcomp(s: str) -> bytes:
-        from ipcr_amd import primer
-        return primer.RevComp(s)
+def build_genome(torch, engine, workloads, revcomp_fn, genome_idx: int, records: int, record_len: int,
+                 keep_host_record0: bool, probe: str = ""):
+    """C2 / C4 / C5 genome of SURVEY.md 8(d): LCG stream seed 0x5eed1234+g cut into records, amplicons of pair 0
+    planted as makeEngineBenchFixture does (performance_benchmark_test.go:47-62); with `probe` (C5) every amplicon
+    also carries the probe at offset 60: as is, reverse-complemented, with 1 or 2 substitutions, or not at all."""
+    from ipcr_amd import workloads as W
+    g = engine.Genome(records * record_len, records)
+    pair = W.bench_pair(0)
+    fwd = pair.Forward
+    rc_rev = revcomp_fn(pair.Reverse)
+    rc_probe = revcomp_fn(probe) if probe else b""
+    buf = torch.empty(record_len, dtype=torch.uint8, device="cuda")
+    plants = []  # (record, start, n_mismatches)
+    per_rec = (N_PLANTS + records - 1) // records
+    stride = plant_stride(records, record_len)
+    host0 = None
+    for r in range(records):
+        engine.lcg_fill_device(buf.data_ptr(), record_len, 0x5eed1234 + genome_idx, r * record_len)
+        for t in range(per_rec):
+            gidx = t * records + r
+            if gidx >= N_PLANTS:
+                break
+            start = 2048 + t * stride
+            if start + PRODUCT_LEN + 64 > record_len:
+                break
+            nm = gidx % 3
+            site = list(fwd)
+            if nm >= 1:
+                site[10] = W.different_base(site[10])
+            if nm >= 2:
+                site[3] = W.different_base(site[3])
+            _put(torch, buf, start, "".join(site))
+            _put(torch, buf, start + PRODUCT_LEN - 20, rc_rev)
+            if probe:
+                kind = gidx % 5          # 0 '+', 1 '-', 2 one substitution, 3 two, 4 no probe site
+                ps = list(probe)
+                if kind in (2, 3):
+                    ps[5] = W.different_base(ps[5])
+                if kind == 3:
+                    ps[15] = W.different_base(ps[15])
+                if kind != 4:
+                    _put(torch, buf, start + 60, rc_probe if kind == 1 else "".join(ps))
+            plants.append((r, start, nm))
+        torch.cuda.synchronize()
+        if keep_host_record0 and r == 0:
+            host0 = buf.cpu().numpy().copy()
+        g.add_record_device("chr%d" % (r + 1), buf.data_ptr(), record_len)
+    del buf
+    return g, plants, host0
 
-    cfg = engine.Config(MaxMM=2, TerminalWindow=5, MinLen=0, MaxLen=2000, HitCap=10000, SeedLen=12)
-    pairs = workloads.c2_pairs()
-    eng = engine.New(cfg)
-    cp = eng.CompilePanel(pairs)
-    sc = eng.NewSimulationScratch(cp)
 
-    want_cpu = (not args.no_cpu_baseline) and rank == 0 and world == 1
-    genome, plants, host0 = build_genome(torch, engine, workloads, revcomp, rank, args.records, args.record_len, want_cpu)
-    nrec = genome.num_records
-    lens = [genome.record_len(r) for r in range(nrec)]
-    flags = [genome.record_flags(r) for r in range(nrec)]
-    all_lens, all_flags = dist.allgather_record_meta(lens, flags, device=cdev) if multi else (lens, flags)
-    host_sc = engine.SimulationScratch(cp, host_only=True) if multi else None
-    xchg = dist.HitExchanger(device=cdev) if multi else None
-    rec_off = 0
-    if multi:  # one synchronous exchange: sizes the buffers on every rank, yields this rank's record offset
-        eng.ScanGenomeHits(genome, cp, sc)
-        _, _, offs = xchg.allgather(dist.hits_from_scratch(sc), nrec)
-        rec_off = offs[rank]
-        xchg.agree_on_device_path(sc)   # zero-copy view of the device hit buffer on every rank, or the host copy on all
+def build_genome_c3(torch, engine, workloads, revcomp_fn, genome_idx: int, records: int, record_len: int):
+    """C3 genome: LCG records (seed 0x5eed3333 + g), 27F / rc(1492R) planted 400 bp apart with concrete bases for the
+    IUPAC codes (M -> A/C, Y -> C/T alternating) and 0..3 substitutions outside the 3' window; one amplicon per record
+    spans the origin (forward site near the end, reverse site near the start: found in --circular mode only)."""
+    from ipcr_amd import workloads as W
+    pair = W.c3_pairs()[0]
+    fwd, rev = pair.Forward, pair.Reverse
+    rc_rev = revcomp_fn(rev).decode()
+    opts = {"A": "A", "C": "C", "G": "G", "T": "T", "M": "AC", "Y": "CT", "R": "AG", "K": "GT"}
 
+    def concrete(s, salt):
+        return "".join(opts[ch][(salt + i) % len(opts[ch])] for i, ch in enumerate(s))
+
+    g = engine.Genome(records * record_len, records)
+    buf = torch.empty(record_len, dtype=torch.uint8, device="cuda")
+    plants = []  # (record, start, mismatch idx tuple)
+    per_rec = 20
+    stride = max((record_len - 2_000_000) // (per_rec + 1), 1000)
+    for r in range(records):
+        engine.lcg_fill_device(buf.data_ptr(), record_len, 0x5eed3333 + genome_idx, r * record_len)
+        for t in range(per_rec):
+            start = 1_000_000 + t * stride
+            if start + 464 > record_len - 1000:
+                break
+            site = list(concrete(fwd, r + t))
+            want = [j for j in ((2, 7, 12)[: (r + t) % 4]) if fwd[j] in "ACGT"]     # 0..3 substitutions, 3' window clean
+            for j in want:
+                site[j] = W.different_base(site[j])
+            _put(torch, buf, start, "".join(site))
+            _put(torch, buf, start + 400 - len(rc_rev), concrete(rc_rev, r))
+            plants.append((r, start, tuple(want)))
+        if record_len > 4000:
+            _put(torch, buf, record_len - 150, concrete(fwd, r))
+            _put(torch, buf, 100, concrete(rc_rev, r))
+        torch.cuda.synchronize()
+        g.add_record_device("chr%d" % (r + 1), buf.data_ptr(), record_len)
+    del buf
+    return g, plants
+
+
+# ----------------------------------------------------------------------------------------------- one workload
+def workload_spec(name, engine, workloads):
+    E = engine
+    if name == "c2":
+        return dict(cfg=E.Config(MaxMM=2, TerminalWindow=5, MinLen=0, MaxLen=2000, HitCap=10000, SeedLen=12),
+                    pairs=workloads.c2_pairs(), genome="c2", kernel="ipcr_filter",
+                    text="C2: 1 primer pair (+self pairs: 12 orientation slots, 4 distinct patterns), k=2, 3'-window=5, "
+                         "hit-cap 10000, max-length 2000")
+    if name == "c3":
+        return dict(cfg=E.Config(MaxMM=3, TerminalWindow=3, MinLen=0, MaxLen=2000, HitCap=10000, SeedLen=12, Circular=True),
+                    pairs=workloads.c3_pairs(), genome="c3", kernel="ipcr_filter",
+                    text="C3: 27F/1492R with IUPAC codes M/Y (+self pairs: 4 distinct patterns of 20 and 22 nt), k=3, "
+                         "3'-window=3, --circular, hit-cap 10000, max-length 2000")
+    if name == "c4":
+        return dict(cfg=E.Config(MaxMM=2, TerminalWindow=3, MinLen=0, MaxLen=2000, HitCap=10000, SeedLen=12),
+                    pairs=workloads.c4_pairs(1024), genome="c2", kernel="ipcr_index_filter",
+                    text="C4: 1024-row ipcr-multiplex panel (unique self pairs added: 3072 pairs, 4096 distinct patterns), "
+                         "k=2, 3'-window=3, hit-cap 10000, max-length 2000")
+    if name == "c5":
+        return dict(cfg=E.Config(MaxMM=2, TerminalWindow=5, MinLen=0, MaxLen=2000, HitCap=10000, SeedLen=12),
+                    pairs=workloads.c2_pairs(), genome="c5", kernel="ipcr_filter", probe=PROBE,
+                    text="C5: ipcr-probe = C2's pair + internal probe %s (--probe-max-mm 2): scan, then the batched probe "
+                         "rescan of every product" % PROBE)
+    raise SystemExit("unknown workload " + name)
+
+
+def get_genome(ctx, key):
+    """genomes are built once per process and shared by the workloads that scan them"""
+    if key in ctx.genomes:
+        return ctx.genomes[key]
+    torch, engine, workloads = ctx.torch, ctx.engine, ctx.workloads
+    a = ctx.args
+    if key == "c3":
+        g, plants = build_genome_c3(torch, engine, workloads, ctx.revcomp, ctx.rank, a.records, a.record_len)
+        host0 = None
+    else:
+        want_host = key == "c2" and ctx.want_cpu
+        g, plants, host0 = build_genome(torch, engine, workloads, ctx.revcomp, ctx.rank, a.records, a.record_len,
+                                        want_host, probe=PROBE if key == "c5" else "")
+    nrec = g.num_records
+    lens = [g.record_len(r) for r in range(nrec)]
+    flags = [g.record_flags(r) for r in range(nrec)]
+    all_lens, all_flags = ctx.dist.allgather_record_meta(lens, flags, device=ctx.cdev) if ctx.multi else (lens, flags)
+    ctx.genomes[key] = dict(g=g, plants=plants, host0=host0, nrec=nrec, all_lens=all_lens, all_flags=all_flags)
+    return ctx.genomes[key]
+
+
+def check_products(name, prods, plants):
+    """every planted amplicon of rank 0's genome must come back exactly (coordinates, mismatch counts and positions)"""
+    if name in ("c2", "c4", "c5"):
+        found = {(p.Record, p.Start): p for p in prods
+                 if p.ExperimentID == "bench_000" and p.Type == "forward" and p.Length == PRODUCT_LEN}
+        for (r, start, nm) in plants:
+            p = found.get((r, start))
+            assert p is not None, f"{name}: planted amplicon missing: record {r} start {start}"
+            want_idx = () if nm == 0 else ((10,) if nm == 1 else (3, 10))
+            assert p.FwdMM == nm and p.FwdMismatchIdx == want_idx and p.RevMM == 0, (name, p, nm)
+    else:
+        found = {(p.Record, p.Start): p for p in prods if p.ExperimentID == "16S" and p.Type == "forward" and p.Length == 400}
+        for (r, start, idx) in plants:
+            p = found.get((r, start))
+            assert p is not None, f"c3: planted amplicon missing: record {r} start {start}"
+            assert (p.FwdMM, p.FwdMismatchIdx, p.RevMM) == (len(idx), idx, 0), (p, idx)
+        wraps = [p for p in prods if p.ExperimentID == "16S" and p.Type == "forward" and p.Start > p.End]
+        recs = {r for (r, _, _) in plants}
+        assert {p.Record for p in wraps} >= recs, "c3: an origin-spanning amplicon is missing (circular join)"
+
+
+def run_workload(ctx, name, steps, warmup):
+    """Set up workload `name`, run `warmup` untimed and `steps` timed passes (barrier + synchronize on both sides,
+    MAX over ranks), verify the last pass.  Returns a dict of measurements."""
+    torch, engine, dist, tdist = ctx.torch, ctx.engine, ctx.dist, ctx.tdist
+    _lib = ctx._lib
+    spec = workload_spec(name, engine, ctx.workloads)
+    G = get_genome(ctx, spec["genome"])
+    genome, nrec = G["g"], G["nrec"]
+    t_setup = time.perf_counter()
+    eng = engine.New(spec["cfg"])
+    cp = eng.CompilePanel(spec["pairs"])
     # three scratches in rotation: one being swept, one being joined on the host, one whose hit buffer the
     # all-gather of the pass before may still be reading (several GPUs); two would do on one GPU
-    scs = [sc, eng.NewSimulationScratch(cp), eng.NewSimulationScratch(cp)]
-    expect_products = None
+    scs = [eng.NewSimulationScratch(cp) for _ in range(3)]
+    multi = ctx.multi
+    xchg, host_sc = None, None
+    if multi:
+        host_sc = engine.SimulationScratch(cp, host_only=True)
+        xchg = dist.HitExchanger(device=ctx.cdev)
+        eng.ScanGenomeHits(genome, cp, scs[0])      # one synchronous exchange: sizes the buffers on every rank
+        xchg.allgather(dist.hits_from_scratch(scs[0]), nrec)
+        xchg.agree_on_device_path(scs[0])           # zero-copy view of the device hit buffer on every rank, or the host copy on all
+    expect = None
     for s_ in scs:  # untimed set-up: kernel specialisation (hiprtc) and buffer sizing happen here
         n_ = eng.ScanGenomeCount(genome, cp, s_)
-        assert expect_products in (None, n_)
-        expect_products = n_
+        assert expect in (None, n_)
+        expect = n_
+    setup_s = time.perf_counter() - t_setup
+    probe = spec.get("probe")
+    probe_out = (_lib.ProbeHit * max(expect, 1))() if probe else None
+    probe_ms = []
 
     def run_steps(k):
-        """k passes of the hot path (see pipelined_passes); returns (filter ms per pass, products of the last pass)"""
         fms = []
 
         def end(i, cur):
             n = eng.ScanGenomeEndCount(genome, cp, cur)          # this rank's partition of the join: its records
-            if n != expect_products:                             # every pass is checked, not only the last one
-                raise SystemExit(f"pass {i}: {n} products, the set-up scan found {expect_products}")
+            if n != expect:                                      # every pass is checked, not only the last one
+                raise SystemExit(f"{name} pass {i}: {n} products, the set-up scan found {expect}")
+            if probe:                                            # ipcr-probe: rescan every product's amplicon (internal/visitors/probe.go:18-33)
+                t0 = time.perf_counter()
+                _lib.check(_lib.lib().ipcr_probe_products(cur._h, genome._h, probe.encode(), 2, probe_out, n))
+                probe_ms.append((time.perf_counter() - t0) * 1e3)
             fms.append(cur.stats().filter_ms)
             return n
 
@@ -230,142 +330,245 @@ def main() -> None:
             k, scs,
             begin=lambda cur: eng.ScanGenomeBegin(genome, cp, cur),
             end=end,
-            chain=None if (args.no_pipeline or os.environ.get("IPCR_BENCH_NO_CHAIN")) else (lambda cur, prev: cur.chain_after(prev)),
+            chain=None if (ctx.args.no_pipeline or os.environ.get("IPCR_BENCH_NO_CHAIN")) else (lambda cur, prev: cur.chain_after(prev)),
             start_exchange=(lambda cur: xchg.start_scratch(cur, nrec)) if multi else None,   # all-gatherv of hit records, async
             finish_exchange=xchg.finish if multi else None,
-            pipeline=not args.no_pipeline)
+            pipeline=not ctx.args.no_pipeline)
         return fms, n
 
-    # part of the untimed set-up: the first ~50 sweeps after idle run 15-25 % slower (clock ramp);
-    # whatever --warmup the caller picks, the device has done at least 300 passes before the timed region
-    run_steps(max(0, 300 - max(args.warmup, 0)))
-    run_steps(max(args.warmup, 0))
-
+    # whatever --warmup the caller picks, the device has done at least MIN_WARM_PASSES before the timed region
+    # (reported as warmup_actual): the first ~50 sweeps after idle run 15-25 % slower (clock ramp)
+    hidden = max(0, MIN_WARM_PASSES[name] - max(warmup, 0))
+    run_steps(hidden)
+    run_steps(max(warmup, 0))
     if multi:
         tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    filter_ms, nprod = run_steps(args.steps)
+    filter_ms, nprod = run_steps(steps)
     torch.cuda.synchronize()
     if multi:
         tdist.barrier()
     elapsed = time.perf_counter() - t0
     if multi:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.cdev)
         tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        ptot = torch.tensor([nprod], dtype=torch.int64, device=cdev)
+        ptot = torch.tensor([nprod], dtype=torch.int64, device=ctx.cdev)
         tdist.all_reduce(ptot, op=tdist.ReduceOp.SUM)
         nprod = int(ptot.item())
-    last = scs[(args.steps - 1) % len(scs)]   # scratch holding the last pass
-
-    # ---- correctness outside the timed region: every planted amplicon must come back exactly ----
+    last = scs[(steps - 1) % len(scs)]   # scratch holding the last pass
+    # ---- correctness outside the timed region ----
     if not multi:
         prods = last.products(genome.ids)
     else:  # rank 0 joins the WHOLE job from the gathered hits and checks its own genome's plants
         allhits, _, _ = xchg.gathered()                     # what the last step's all-gatherv left on every rank
-        prods = eng.JoinHits(cp, host_sc, allhits, all_lens, all_flags) if rank == 0 else []
-        if rank == 0:
-            assert len(prods) == nprod, f"whole-job join on rank 0 found {len(prods)} products, partitioned join {nprod}"
-    if rank == 0:
-        found = {(p.Record, p.Start): p for p in prods if p.ExperimentID == "bench_000" and p.Type == "forward" and p.Length == PRODUCT_LEN}
-        for (r, start, nm) in plants:           # rank 0's own genome occupies records [0, nrec)
-            p = found.get((r, start))
-            assert p is not None, f"planted amplicon missing: record {r} start {start}"
-            want_idx = () if nm == 0 else ((10,) if nm == 1 else (3, 10))
-            assert p.FwdMM == nm and p.FwdMismatchIdx == want_idx and p.RevMM == 0, (p, nm)
-
-    total_bases = genome.total_bases * world
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = total_bases * args.steps / elapsed / 1e9
+        prods = eng.JoinHits(cp, host_sc, allhits, G["all_lens"], G["all_flags"]) if ctx.rank == 0 else []
+        if ctx.rank == 0:
+            assert len(prods) == nprod, f"{name}: whole-job join on rank 0 found {len(prods)} products, partitioned join {nprod}"
+    if ctx.rank == 0:
+        check_products(name, prods, G["plants"])            # rank 0's own genome occupies records [0, nrec)
+        if probe and not multi:
+            kinds = {0: ("+", 0), 1: ("-", 0), 2: ("+", 1), 3: ("+", 2)}
+            byplant = {(p.Record, p.Start): i for i, p in enumerate(prods)
+                       if p.ExperimentID == "bench_000" and p.Type == "forward" and p.Length == PRODUCT_LEN}
+            stride = plant_stride(nrec, ctx.args.record_len)
+            for (r, start, _nm) in G["plants"]:
+                kind = (((start - 2048) // stride) * nrec + r) % 5
+                h = probe_out[byplant[(r, start)]]
+                if kind == 4:
+                    continue    # no planted probe site: whatever the background holds
+                assert h.found and (chr(h.strand), h.pos, h.mm) == (kinds[kind][0], 60, kinds[kind][1]), (r, start, kind, h.found, h.pos, h.mm)
+    st = last.stats()
+    total_bases = genome.total_bases * ctx.world
     fms_avg = sum(filter_ms) / len(filter_ms)
-    alg_bytes = genome.total_bases * BYTES_PER_BASE
-    achieved = alg_bytes / (fms_avg * 1e-3) / 1e9
-    traffic = None
-    import glob
-    pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_filter_pmc.json")))   # latest round's PMC passes
-    tfile = pmc_files[-1] if pmc_files else ""
-    if tfile and os.path.exists(tfile):
-        try:
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    res = dict(
+        name=name, text=spec["text"], kernel=spec["kernel"], steps=steps, warmup=warmup, warmup_actual=hidden + max(warmup, 0),
+        elapsed=elapsed, ms_per_step=elapsed * 1e3 / steps, value=total_bases * steps / elapsed / 1e9,
+        filter_ms=fms_avg, nprod=int(nprod), hits=int(st.hits), candidates=int(st.candidates), kernel_kind=int(st.kernel_kind),
+        n_patterns=int(st.n_patterns), setup_s=setup_s, bases_per_gpu=genome.total_bases, nrec=nrec, plants=len(G["plants"]),
+        pack_ms=genome.pack_ms, breakdown={k: round(getattr(st, k), 4) for k in
+                                           ("filter_ms", "verify_ms", "enqueue_ms", "wait_ms", "sort_ms", "join_ms", "total_ms")},
+        device_path=bool(xchg.device_path) if multi else None, exchange_redone=xchg.redone if multi else 0,
+        probe_ms=(sum(probe_ms[-steps:]) / max(1, len(probe_ms[-steps:]))) if probe_ms else None,
+        prods=prods)
+    for s_ in scs:
+        s_.close()
+    if host_sc is not None:
+        host_sc.close()
+    cp.close()
+    return res
 
+
+def roofline_of(res, traffic_file=None):
+    alg_bytes = res["bases_per_gpu"] * BYTES_PER_BASE
+    achieved = alg_bytes / (res["filter_ms"] * 1e-3) / 1e9
     out = {
-        "metric": "genome Gbases scanned/sec (k=2)",
-        "value": round(value, 2),
-        "unit": "Gbases/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u32",
-        "data": "synthetic",
-        "config": {
-            "workload": "C2: 1 primer pair (+self pairs: 12 orientation slots, 4 distinct patterns), k=2, "
-                        "3'-window=5, hit-cap 10000, max-length 2000, synthetic %.2f Gb genome per GPU "
-                        "(%d x %d b LCG records, %d planted amplicons)" % (genome.total_bases / 1e9, nrec, args.record_len, len(plants)),
-            "input": "2-bit + invalid-bit tiles resident in HBM (0.375 B/base); pack kernel timed separately",
-            "products_per_step": int(nprod),
-            "hits_per_step_rank0": int(last.stats().hits),
-            "filter_candidates_rank0": int(last.stats().candidates),
-            "filter_kernel": "panel-specialised (hiprtc)" if last.stats().kernel_kind == 1 else "table-driven",
-            "pipelining": "off" if args.no_pipeline else
-                          "pass i+1's sweep is queued behind pass i's on one in-order stream (two scratches) while the host "
-                          "waits for, sorts and joins pass i; each sweep verifies its own survivors and its last wave "
-                          "publishes counters + hits to pinned memory (no verify kernel, no copy operation)",
-            "pack_ms_per_genome": round(genome.pack_ms, 3),
-            "gbases_per_s_incl_pack": round(genome.total_bases * world / ((genome.pack_ms + ms_per_step) * 1e-3) / 1e9, 1),
-            "step_breakdown_ms_rank0": {k: round(getattr(last.stats(), k), 4) for k in
-                                        ("filter_ms", "verify_ms", "enqueue_ms", "wait_ms", "sort_ms", "join_ms", "total_ms")},
-            "parallelism": ("1 genome per GPU, one all-gatherv of hit records per step (%s, %s), join partitioned by record"
-                            % (backend, "out of the device hit buffer" if xchg.device_path else "host copy of the hits"))
-                           if multi else "single GPU",
-        },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "ipcr_filter",
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": int(alg_bytes),
-            "frac_of_copy_peak": round(achieved / 6290.0, 4),  # 6.29 TB/s: what a float4 copy reaches (MI355X_MICROARCH.md)
-            "avg_launch_ms": round(fms_avg, 4),
-            "gbases_per_s_kernel": round(genome.total_bases / (fms_avg * 1e-3) / 1e9, 1),
-        },
+        "bound": "hbm",
+        "kernel": res["kernel"],
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "algorithmic_bytes_per_launch": int(alg_bytes),
+        "frac_of_copy_peak": round(achieved / 6290.0, 4),  # 6.29 TB/s: what a float4 copy reaches (MI355X_MICROARCH.md)
+        "avg_launch_ms": round(res["filter_ms"], 4),
+        "gbases_per_s_kernel": round(res["bases_per_gpu"] / (res["filter_ms"] * 1e-3) / 1e9, 1),
     }
+    # HBM traffic needs a rocprofv3 --pmc pass, which this process cannot run on itself: the number below is what the
+    # PMC passes of the SAME command measured when profiles/ was last collected, and is labelled as such
+    if traffic_file and os.path.exists(traffic_file):
+        try:
+            d = json.load(open(traffic_file))
+            if d.get("kernel") == res["kernel"] and d.get("hbm_bytes_per_launch"):
+                out["traffic"] = d["hbm_bytes_per_launch"]
+                out["traffic_source"] = ("%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command when profiles/ "
+                                         "was collected (FETCH_SIZE doubled, MI355X_MICROARCH.md HBM); not measured by this run"
+                                         % os.path.relpath(traffic_file, ROOT))
+        except Exception:
+            pass
+    if res["kernel"] == "ipcr_index_filter":
+        out["limiter"] = ("not HBM: six random 8-byte LDS bitmap lookups per base step (SQ_LDS_IDX_ACTIVE ~77 %, 57 % of it "
+                          "bank conflicts) + the drain of ~0.17 key hits per lane and step; see DESIGN.md section 4.3")
+    return out
 
-    if want_cpu:
-        out["cpu_baseline"] = cpu_baseline(host0, args.cpu_seconds, prods)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if multi:
-        tdist.barrier()
-        tdist.destroy_process_group()
+
+# ----------------------------------------------------------------------------------------------- other measurements
+def scan_chunk_rates(ctx, record_bases=125_000_000, chunk=4_000_000, overlap=2000):
+    """Drop-in entry point (what the cgo shim binds): ipcr_scan_chunk on host ASCII under the reference's worker model
+    (internal/pipeline/pipeline.go:60-125): W threads, one scratch each, one shared panel, rolling chunks of one
+    record from a queue.  PCIe-inclusive; reported next to the raw pinned H2D rate; never `value`."""
+    import queue
+    import threading
+    torch, engine = ctx.torch, ctx.engine
+    n = min(record_bases, ctx.args.record_len)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+    engine.lcg_fill_device(buf.data_ptr(), n, 0x5eed1234)
+    seq = buf.cpu().numpy().tobytes()
+    h = torch.empty(256 << 20, dtype=torch.uint8, pin_memory=True)
+    d = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    h2d = 0.0
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d.copy_(h, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d = max(h2d, h.numel() / (time.perf_counter() - t0) / 1e9)
+    del buf, h, d
+    spec = workload_spec("c2", engine, ctx.workloads)
+    eng = engine.New(spec["cfg"])
+    cp = eng.CompilePanel(spec["pairs"])
+    view = memoryview(seq)
+    starts = list(range(0, n, chunk - overlap)) if n > chunk else [0]
+    chunks = [bytes(view[s:s + chunk]) for s in starts]   # each job owns its bytes (core/fasta/path_ctx.go:117)
+    out = {"pinned_h2d_GBps": round(h2d, 1), "record_bases": n, "chunk_bases": chunk, "chunks": len(chunks)}
+    for workers in (1, 8):
+        scs = [eng.NewSimulationScratch(cp) for _ in range(workers)]
+        for sc in scs:
+            eng.SimulateCompiledWithScratch("w", chunks[0], cp, sc)
+        best = 0.0
+        for _ in range(3):
+            q = queue.Queue()
+            for i, c in enumerate(chunks):
+                q.put((i, c))
+
+            def work(sc):
+                while True:
+                    try:
+                        i, c = q.get_nowait()
+                    except queue.Empty:
+                        return
+                    eng.SimulateCompiledWithScratch("chr1:%d-%d" % (starts[i], starts[i] + len(c)), c, cp, sc)
+
+            ths = [threading.Thread(target=work, args=(sc,)) for sc in scs]
+            t0 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            best = max(best, sum(len(c) for c in chunks) / (time.perf_counter() - t0) / 1e9)
+        out["gbases_per_s_%d_worker%s" % (workers, "" if workers == 1 else "s")] = round(best, 2)
+        for sc in scs:
+            sc.close()
+    sc = eng.NewSimulationScratch(cp)
+    best = 0.0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        eng.SimulateCompiledWithScratch("chr1", seq, cp, sc)
+        best = max(best, n / (time.perf_counter() - t0) / 1e9)
+    out["gbases_per_s_whole_record"] = round(best, 2)
+    sc.close()
+    cp.close()
+    return out
 
 
-def _join_count(eng, cp, host_sc, hits, lens, flags) -> int:
-    """join without materialising Python objects per product"""
-    import ctypes as C
-    from ipcr_amd import _lib
-    n, nrec = len(hits), len(lens)
-    lens_c = (C.c_uint64 * max(nrec, 1))(*lens)
-    flags_c = (C.c_uint8 * max(nrec, 1))(*flags)
-    ptr = C.c_void_p(hits.ctypes.data) if n else None
-    _lib.check(_lib.lib().ipcr_join_hits(cp._h, host_sc._h, ptr, n, lens_c, flags_c, nrec, None, None))
-    return host_sc.num_products()
+def fasta_to_tsv(ctx, records=8):
+    """FASTA file (80-column lines, page cache) -> resident tiles -> scan -> sorted TSV rows, C2 panel."""
+    import io
+    import tempfile
+    import numpy as np
+    engine = ctx.engine
+    from ipcr_amd import cli
+    G = get_genome(ctx, "c2")
+    genome = G["g"]
+    records = min(records, G["nrec"])
+    path = os.path.join(os.environ.get("TMPDIR", tempfile.gettempdir()), "ipcr_bench_%d.fa" % os.getpid())
+    try:
+        with open(path, "wb") as fh:
+            for r in range(records):
+                n = genome.record_len(r)
+                seq = np.frombuffer(genome.read(r, 0, n), dtype=np.uint8)
+                fh.write(b">chr%d synthetic LCG record\n" % (r + 1))
+                full = (n // 80) * 80
+                body = np.empty((full // 80, 81), dtype=np.uint8)
+                body[:, :80] = seq[:full].reshape(-1, 80)
+                body[:, 80] = 10
+                fh.write(body.tobytes())
+                if full < n:
+                    fh.write(seq[full:].tobytes() + b"\n")
+        fsize = os.path.getsize(path)
+        spec = workload_spec("c2", engine, ctx.workloads)
+        eng = engine.New(spec["cfg"])
+        cp = eng.CompilePanel(spec["pairs"])
+        sc = eng.NewSimulationScratch(cp)
+        eng.ScanGenomeCount(genome, cp, sc)                      # kernel build outside the timed stages
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            g = engine.Genome(sum(genome.record_len(r) for r in range(records)) + (1 << 20), max_records=records + 4)
+            g.add_fasta(path)
+            t1 = time.perf_counter()
+            prods = eng.ScanGenome(g, cp, sc)
+            t2 = time.perf_counter()
+            rows = sorted(((path, p) for p in prods), key=lambda t: cli.product_sort_key(t[0], t[1]))
+            out = io.StringIO()
+            out.write(cli.TSV_HEADER + "\n")
+            for f, p in rows:
+                out.write(cli.format_row(f, p) + "\n")
+            t3 = time.perf_counter()
+            found = {(p.Record, p.Start) for p in prods if p.ExperimentID == "bench_000" and p.Type == "forward"}
+            assert all((r, s) in found for (r, s, _) in G["plants"] if r < records), "planted amplicon missing after the FASTA round trip"
+            cur = {"file_GB": round(fsize / 1e9, 3), "bases": g.total_bases, "load_s": round(t1 - t0, 4),
+                   "scan_ms": round((t2 - t1) * 1e3, 3), "sort_format_ms": round((t3 - t2) * 1e3, 3),
+                   "total_s": round(t3 - t0, 4), "gbases_per_s": round(g.total_bases / (t3 - t0) / 1e9, 2),
+                   "products": len(prods), "host_threads": len(os.sched_getaffinity(0))}
+            g.close()
+            if best is None or cur["total_s"] < best["total_s"]:
+                best = cur
+        sc.close()
+        cp.close()
+        return best
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
 
 
 def cpu_baseline(host0, budget_s: float, gpu_products):
-    """Reference algorithm restated in C (oracle/: approximate-seed Aho-Corasick scan + verify +
-    join, one worker per rolling chunk like internal/pipeline/pipeline.go:60-125) timed on this
-    box's host cores over a bounded sample: record 0 of the same genome, repeated to fill the
-    budget.  Checker/baseline only -- never on the product path."""
+    """Reference algorithm restated in C (oracle/: approximate-seed Aho-Corasick scan + verify + join, one worker per
+    rolling chunk like internal/pipeline/pipeline.go:60-125) timed on this box's host cores over a bounded sample:
+    record 0 of the same genome, several passes queued to ONE worker pool so that every thread has chunks to scan
+    (at least four per thread).  Checker/baseline only -- never on the product path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ipcr_oracle as O
     from ipcr_amd import workloads
@@ -374,24 +577,171 @@ def cpu_baseline(host0, budget_s: float, gpu_products):
     panel = O.Panel(O.Config(max_mm=2, terminal_window=5, min_len=0, max_len=2000, hit_cap=10000, seed_len=12), pairs)
     n = int(host0.shape[0])
     ptr = host0.ctypes.data
-    passes, t0, nprod = 0, time.perf_counter(), 0
-    while True:
-        nprod = panel.baseline_scan_mt(ptr, n, 4_000_000, 2000, cores)
-        passes += 1
+    chunk, overlap = 4_000_000, 2000
+    nch = max(1, -(-max(n - overlap, 1) // (chunk - overlap)))
+    passes = max(1, -(-4 * cores // nch))                       # >= 4 chunks per thread
+    t0 = time.perf_counter()
+    nprod, busy, nch = panel.baseline_scan_pool(ptr, n, chunk, overlap, cores, passes)     # calibration round
+    el = time.perf_counter() - t0
+    rate = n * passes / el
+    if el < budget_s * 0.6:                                     # fill the budget with ONE longer pool run
+        passes2 = max(passes, int(passes * (budget_s / max(el, 1e-3)) * 0.8))
+        t0 = time.perf_counter()
+        nprod, busy, nch = panel.baseline_scan_pool(ptr, n, chunk, overlap, cores, passes2)
         el = time.perf_counter() - t0
-        if el >= budget_s or passes >= 4096:
-            break
+        rate, passes = n * passes2 / el, passes2
     gpu_rec0 = len([p for p in gpu_products if p.Record == 0])
     assert nprod == gpu_rec0, f"CPU baseline found {nprod} products in record 0, GPU path {gpu_rec0}"
     return {
-        "value": round(n * passes / el / 1e9, 4),
+        "value": round(rate / 1e9, 4),
         "unit": "Gbases/s",
         "cores": cores,
+        "threads_busy": int(busy),
         "kind": "port",
-        "sample": "record 0 (%d bases) of the same genome, %d passes, chunk 4 Mb / overlap 2000, %d threads; "
-                  "C restatement of the reference's seeded AC scan + verify + join (not the Go binary)" % (n, passes, cores),
+        "sample": "record 0 (%d bases) of the same genome, %d passes queued to one pool of %d threads (%d chunks of 4 Mb, "
+                  "overlap 2000, per pass = %d chunks in all, %.1f s); C restatement of the reference's seeded AC scan + "
+                  "verify + join (not the Go binary)" % (n, passes, cores, nch, nch * passes, el),
         "products_in_sample": int(nprod),
     }
+
+
+# ----------------------------------------------------------------------------------------------- main
+def main() -> None:
+    # HIP maps streams onto a few hardware queues (4 by default), in creation order.  This job has a dozen (three
+    # scratches, the genome, torch, RCCL): when the sweep lane shares a queue with the collective's stream, every
+    # all-gather is serialised between two sweeps (+25 us per step measured).  One queue per stream instead.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    # one C2 step is ~0.2 ms: the default region (about half a second) is long enough for the clocks to settle
+    ap.add_argument("--steps", type=int, default=None, help="timed passes (default 2000; 40 for c4)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed passes before them (default 200; 5 for c4)")
+    ap.add_argument("--records", type=int, default=RECORDS)
+    ap.add_argument("--record-len", type=int, default=RECORD_LEN)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip config.other_workloads")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo to rehearse)")
+    ap.add_argument("--no-pipeline", action="store_true", help="finish every pass before the next one is enqueued")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 40 if args.workload == "c4" else 2000
+    if args.warmup is None:
+        args.warmup = 5 if args.workload == "c4" else 200
+
+    cmd = launch_plan(args.gpus, os.environ, sys.argv[1:])
+    if cmd is not None:   # launcher only: no torch import, no HIP call in this process
+        import subprocess
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ)))
+
+    import glob
+    import torch
+    from ipcr_amd import _lib, dist, engine, workloads, primer
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the ipcr_amd scan path has no CPU fallback")
+    if os.environ.get("IPCR_BENCH_ONE_DEVICE"):  # rehearsal: several ranks share GPU 0 (gloo collectives)
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local, backend = dist.init_process_group(args.backend)
+    torch.cuda.set_device(local)
+    _lib.check(_lib.lib().ipcr_set_device(local))
+    import torch.distributed as tdist
+
+    ctx = Ctx()
+    ctx.torch, ctx.engine, ctx.workloads, ctx.dist, ctx.tdist, ctx._lib = torch, engine, workloads, dist, tdist, _lib
+    ctx.args, ctx.rank, ctx.world, ctx.local, ctx.backend = args, rank, world, local, backend
+    ctx.dev = torch.device("cuda", local)
+    ctx.cdev = ctx.dev if backend == "nccl" else torch.device("cpu")  # where collective payloads live
+    ctx.multi = world > 1 or bool(os.environ.get("IPCR_EXCHANGE_SELFTEST"))  # selftest: one rank runs the RCCL exchange too
+    ctx.revcomp = primer.RevComp
+    ctx.genomes = {}
+    ctx.want_cpu = (not args.no_cpu_baseline) and rank == 0 and world == 1 and args.workload == "c2"
+
+    res = run_workload(ctx, args.workload, args.steps, args.warmup)
+
+    others = {}
+    if not args.no_others:
+        if world == 1 and not ctx.multi:
+            for nm, st, wu in (("c3", 400, 100), ("c4", 30, 5), ("c5", 300, 50)):
+                if nm == args.workload:
+                    continue
+                r = run_workload(ctx, nm, st, wu)
+                rf = roofline_of(r)
+                others[nm] = {"workload": r["text"], "ms_per_step": round(r["ms_per_step"], 4), "gbases_per_s": round(r["value"], 1),
+                              "sweep_ms": round(r["filter_ms"], 4), "kernel": r["kernel"], "roofline_frac": rf["frac"],
+                              "steps": r["steps"], "warmup_actual": r["warmup_actual"], "products_per_step": r["nprod"],
+                              "hits_per_step": r["hits"], "planted_amplicons_verified": r["plants"],
+                              "step_breakdown_ms": r["breakdown"]}
+                if r["probe_ms"] is not None:
+                    others[nm]["probe_rescan_ms"] = round(r["probe_ms"], 4)
+                if "limiter" in rf:
+                    others[nm]["limiter"] = rf["limiter"]
+                r["prods"] = None
+            others["scan_chunk"] = scan_chunk_rates(ctx)
+            others["fasta_to_tsv"] = fasta_to_tsv(ctx)
+        elif args.workload != "c4":   # several GPUs: the scaling target north_star names rides along
+            r = run_workload(ctx, "c4", 30, 5)
+            others["c4"] = {"workload": r["text"], "ms_per_step": round(r["ms_per_step"], 4), "gbases_per_s": round(r["value"], 1),
+                            "sweep_ms_rank0": round(r["filter_ms"], 4), "kernel": r["kernel"], "n_gpus": world, "scaling": "weak",
+                            "steps": r["steps"], "warmup_actual": r["warmup_actual"], "products_per_step": r["nprod"],
+                            "device_path": r["device_path"], "exchange_redone": r["exchange_redone"]}
+            r["prods"] = None
+
+    genome_bases = res["bases_per_gpu"]
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_pmc.json" % ("filter" if args.workload == "c2" else args.workload))))
+    out = {
+        "metric": "genome Gbases scanned/sec (k=%d)" % (3 if args.workload == "c3" else 2),
+        "value": round(res["value"], 2),
+        "unit": "Gbases/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "warmup_actual": res["warmup_actual"],
+        "ms_per_step": round(res["ms_per_step"], 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s, synthetic %.2f Gb genome per GPU (%d x %d b LCG records, %d planted amplicons verified)"
+                        % (res["text"], genome_bases / 1e9, res["nrec"], args.record_len, res["plants"]),
+            "input": "2-bit + invalid-bit tiles resident in HBM (0.375 B/base); pack kernel timed separately",
+            "products_per_step": res["nprod"],
+            "hits_per_step_rank0": res["hits"],
+            "filter_candidates_rank0": res["candidates"],
+            "filter_kernel": {1: "panel-specialised (hiprtc)", 2: "table-driven", 3: "seed-index (hiprtc)"}.get(res["kernel_kind"], "?"),
+            "n_patterns": res["n_patterns"],
+            "pipelining": "off" if args.no_pipeline else
+                          "pass i+1's sweep is queued behind pass i's on one in-order stream while the host waits for, sorts "
+                          "and joins pass i; the specialised sweep verifies its own survivors and its last wave publishes "
+                          "counters + hits to pinned memory (no verify kernel, no copy operation)",
+            "pack_ms_per_genome": round(res["pack_ms"], 3),
+            "gbases_per_s_incl_pack": round(genome_bases * world / ((res["pack_ms"] + res["ms_per_step"]) * 1e-3) / 1e9, 1),
+            "step_breakdown_ms_rank0": res["breakdown"],
+            "rccl_ranks": world if ctx.multi else 0,
+            "backend": backend if ctx.multi else None,
+            "device_path": res["device_path"],
+            "parallelism": ("1 genome per GPU (weak scaling); one all-gatherv of hit records per step (%s, %s; %d exchanges redone "
+                            "after an overflow); every rank joins its own records inside the step, the gathered records are "
+                            "joined whole on rank 0 once after the timed region as a check"
+                            % (backend, "out of the device hit buffer" if res["device_path"] else "host copy of the hits",
+                               res["exchange_redone"])) if ctx.multi else "single GPU",
+            "other_workloads": others,
+        },
+        "roofline": roofline_of(res, pmc[-1] if pmc else None),
+    }
+    if res["probe_ms"] is not None:
+        out["config"]["probe_rescan_ms"] = round(res["probe_ms"], 4)
+    if ctx.want_cpu:
+        out["cpu_baseline"] = cpu_baseline(ctx.genomes["c2"]["host0"], args.cpu_seconds, res["prods"])
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if ctx.multi and tdist.is_initialized():
+        tdist.barrier()
+        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

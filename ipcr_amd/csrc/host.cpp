@@ -223,6 +223,8 @@ struct ipcr_panel {
     bool specialize = true;
     int device = -1;
     mutable std::mutex mu;
+    // device scratches alive = workers scanning with this panel (shared: a scratch may outlive its panel object)
+    std::shared_ptr<std::atomic<int>> live_scratches = std::make_shared<std::atomic<int>>(0);
 };
 
 namespace {
@@ -1038,6 +1040,12 @@ struct ipcr_scratch {
     std::vector<uint64_t> last_rec_start;
     ipcr_scan_stats stats{};
     ipcr_genome *chunk = nullptr; // private genome of ipcr_scan_chunk
+    // ipcr_scan_chunk with several workers: the caller's (pageable) bytes go through two pinned slices of this
+    // scratch -- the CPU copy of slice i+1 runs under the DMA of slice i, and workers do not meet in the runtime's
+    // own pageable-copy path
+    uint8_t *h_stage[2] = {nullptr, nullptr};
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    std::shared_ptr<std::atomic<int>> counted_in; // the panel's worker count this scratch is part of
     // probe buffers
     uint8_t *d_amps = nullptr; uint64_t amps_cap = 0;
     ipcr_genome *nest = nullptr; // amplicons of a nested-PCR batch, one record each (ipcr_nested_windows)
@@ -1752,6 +1760,8 @@ ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out) {
         memset(raw->pinned, 0, 64 + PREFIX_HITS * sizeof(ipcr_hit) + 64);
         HIPCHK(hipMalloc((void **)&raw->d_tickets, 65 * 128));
         HIPCHK(hipMemset(raw->d_tickets, 0, 65 * 128));
+        raw->counted_in = p->live_scratches;
+        raw->counted_in->fetch_add(1);
         return IPCR_OK;
     };
     ipcr_status st = build();
@@ -1773,6 +1783,11 @@ void ipcr_scratch_destroy(ipcr_scratch *s) {
     if (s->stream) { // a scan left in flight still reads and writes the buffers freed below
         if (s->pend.active && s->lane_used) (void)hipStreamSynchronize(s->lane_used->s);
         (void)hipStreamSynchronize(s->stream);
+    }
+    if (s->counted_in) s->counted_in->fetch_sub(1);
+    for (int h = 0; h < 2; ++h) {
+        if (s->h_stage[h]) (void)hipHostFree(s->h_stage[h]);
+        if (s->ev_stage[h]) (void)hipEventDestroy(s->ev_stage[h]);
     }
     if (s->chunk) ipcr_genome_destroy(s->chunk);
     if (s->nest) ipcr_genome_destroy(s->nest);
@@ -1919,7 +1934,31 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         g->staging_cap = len + 16 + (len >> 3);
         HIPCHK(hipMalloc((void **)&g->staging, g->staging_cap));
     }
-    if (len) HIPCHK(hipMemcpyAsync(g->staging, seq, len, hipMemcpyHostToDevice, g->stream));
+    if (len) {
+        // One worker: the runtime's pageable copy (it pins the caller's pages in place) runs at the link rate.  Several
+        // workers calling it at once serialise inside the runtime (8 workers x 4 Mb chunks: 12 Gbases/s in all, a single
+        // worker 22): then every worker stages through its own pinned slices instead.  IPCR_CHUNK_STAGING=0/1 forces.
+        static const int force = getenv("IPCR_CHUNK_STAGING") ? atoi(getenv("IPCR_CHUNK_STAGING")) : -1;
+        const bool staged = force >= 0 ? force != 0 : p->live_scratches->load(std::memory_order_relaxed) > 1;
+        if (!staged) {
+            HIPCHK(hipMemcpyAsync(g->staging, seq, len, hipMemcpyHostToDevice, g->stream));
+        } else {
+            constexpr uint64_t SLICE = 8ull << 20;
+            for (int h = 0; h < 2; ++h) {
+                if (!s->h_stage[h]) HIPCHK(hipHostMalloc((void **)&s->h_stage[h], SLICE, hipHostMallocDefault));
+                if (!s->ev_stage[h]) HIPCHK(hipEventCreateWithFlags(&s->ev_stage[h], hipEventDisableTiming));
+            }
+            uint64_t i = 0;
+            for (uint64_t off = 0; off < len; off += SLICE, ++i) {
+                const int h = (int)(i & 1u);
+                const uint64_t n = std::min<uint64_t>(SLICE, len - off);
+                if (i >= 2) HIPCHK(hipEventSynchronize(s->ev_stage[h])); // the DMA that read this slice has finished
+                memcpy(s->h_stage[h], seq + off, n);
+                HIPCHK(hipMemcpyAsync(g->staging + off, s->h_stage[h], n, hipMemcpyHostToDevice, g->stream));
+                HIPCHK(hipEventRecord(s->ev_stage[h], g->stream));
+            }
+        }
+    }
     st = genome_add_device(g, g->staging, len, false);
     if (st != IPCR_OK) return st;
     st = scan_enqueue(p, s, g, true);

@@ -1247,21 +1247,26 @@ typedef struct { int64_t gs, ge; int32_t type, pair; } pkey;
 typedef struct {
     const or_panel *p; const uint8_t *seq;
     const chunk_t *chunks; int nchunks;
-    int next; pthread_mutex_t mu;
+    int64_t njobs;   /* passes x nchunks: every pass of the record is queued at once, one pool serves them all */
+    int64_t next; pthread_mutex_t mu;
     pkey *keys; int64_t nkeys, capkeys;
+    int busy;        /* workers that got at least one chunk */
 } mt_ctx;
 
 static void *mt_worker(void *arg) {
     mt_ctx *c = arg;
+    int mine = 0;
     for (;;) {
         pthread_mutex_lock(&c->mu);
-        int i = c->next++;
+        int64_t job = c->next++;
+        if (job < c->njobs && mine++ == 0) c->busy++;
         pthread_mutex_unlock(&c->mu);
-        if (i >= c->nchunks) break;
+        if (job >= c->njobs) break;
+        const int i = (int)(job % c->nchunks);
         or_products ps = {0};
         int64_t off = c->chunks[i].start;
         or_panel_scan(c->p, c->seq + off, (int)(c->chunks[i].end - off), &ps);
-        if (ps.n > 0) {
+        if (ps.n > 0 && job < c->nchunks) { /* the products of the first pass are the answer; later passes only cost time */
             pthread_mutex_lock(&c->mu);
             if (c->nkeys + ps.n > c->capkeys) {
                 while (c->nkeys + ps.n > c->capkeys) c->capkeys = c->capkeys ? c->capkeys * 2 : 1024;
@@ -1279,6 +1284,9 @@ static void *mt_worker(void *arg) {
     return NULL;
 }
 
+int64_t or_baseline_scan_pool(const or_panel *p, const uint8_t *seq, int64_t n, int chunk_size, int overlap,
+                              int threads, int passes, int *busy, int *nchunks_out);
+
 static int pkey_cmp(const void *a, const void *b) {
     const pkey *x = a, *y = b;
     if (x->gs != y->gs) return x->gs < y->gs ? -1 : 1;
@@ -1290,6 +1298,14 @@ static int pkey_cmp(const void *a, const void *b) {
 
 int64_t or_baseline_scan_mt(const or_panel *p, const uint8_t *seq, int64_t n,
                             int chunk_size, int overlap, int threads) {
+    return or_baseline_scan_pool(p, seq, n, chunk_size, overlap, threads, 1, NULL, NULL);
+}
+
+/* `passes` passes over the record served by ONE pool of `threads` workers (all chunks of all passes queued together,
+ * the way internal/pipeline/pipeline.go:60-125 feeds its workers from one job channel): the pool stays busy when one
+ * pass alone has fewer chunks than there are threads.  *busy = workers that scanned at least one chunk. */
+int64_t or_baseline_scan_pool(const or_panel *p, const uint8_t *seq, int64_t n, int chunk_size, int overlap,
+                              int threads, int passes, int *busy, int *nchunks_out) {
     /* core/fasta/path_ctx.go:83-179 chunk schedule for one record of n bases */
     int64_t step = (int64_t)chunk_size - overlap;
     chunk_t *chunks = NULL; int nch = 0, cap = 0;
@@ -1306,6 +1322,7 @@ int64_t or_baseline_scan_mt(const or_panel *p, const uint8_t *seq, int64_t n,
     mt_ctx c;
     memset(&c, 0, sizeof c);
     c.p = p; c.seq = seq; c.chunks = chunks; c.nchunks = nch;
+    c.njobs = (int64_t)nch * (passes < 1 ? 1 : passes);
     pthread_mutex_init(&c.mu, NULL);
     pthread_t *th = xmalloc((size_t)threads * sizeof(pthread_t));
     for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, mt_worker, &c);
@@ -1321,5 +1338,7 @@ int64_t or_baseline_scan_mt(const or_panel *p, const uint8_t *seq, int64_t n,
     }
     free(c.keys);
     free(chunks);
+    if (busy) *busy = c.busy;
+    if (nchunks_out) *nchunks_out = nch;
     return uniq;
 }

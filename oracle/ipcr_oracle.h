@@ -137,6 +137,9 @@ int64_t or_make_bench_fixture(int pair_count, int64_t genome_len, int mutate_for
  * instead of the bounded LRU). */
 int64_t or_baseline_scan_mt(const or_panel *p, const uint8_t *seq, int64_t n,
                             int chunk_size, int overlap, int threads);
+/* the same with `passes` passes over the record queued to one worker pool; *busy = workers that got a chunk */
+int64_t or_baseline_scan_pool(const or_panel *p, const uint8_t *seq, int64_t n, int chunk_size, int overlap,
+                              int threads, int passes, int *busy, int *nchunks_out);
 
 #ifdef __cplusplus
 }

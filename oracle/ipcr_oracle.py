@@ -110,6 +110,9 @@ def lib():
                                             C.c_char_p, C.c_char_p]
         L.or_baseline_scan_mt.restype = C.c_int64
         L.or_baseline_scan_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]
+        L.or_baseline_scan_pool.restype = C.c_int64
+        L.or_baseline_scan_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -318,6 +321,14 @@ class Panel:
         ms = _Matches()
         lib().or_panel_scan_matches(self._h, seq, len(seq), pair, which.encode(), C.byref(ms))
         return _matches_out(ms)
+
+    def baseline_scan_pool(self, ptr: int, n: int, chunk_size: int, overlap: int, threads: int, passes: int):
+        """`passes` passes over one record served by one pool of worker threads -> (distinct products of a pass,
+        workers that scanned at least one chunk, chunks per pass)"""
+        busy, nch = C.c_int(), C.c_int()
+        uniq = lib().or_baseline_scan_pool(self._h, C.c_void_p(ptr), n, chunk_size, overlap, threads, passes,
+                                           C.byref(busy), C.byref(nch))
+        return int(uniq), busy.value, nch.value
 
     def baseline_scan_mt(self, ptr: int, n: int, chunk_size: int, overlap: int, threads: int) -> int:
         return lib().or_baseline_scan_mt(self._h, C.c_void_p(ptr), n, chunk_size, overlap, threads)
