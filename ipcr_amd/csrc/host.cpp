@@ -854,7 +854,7 @@ ipcr_status genome_finalize(ipcr_genome *g) {
 
 // chunk path (one record, the scratch's own stream): same preparation without waiting for anything; the
 // record's reset-byte flag arrives in *pinned_flag when the stream has passed this point
-ipcr_status genome_finalize_async(ipcr_genome *g, uint32_t *pinned_flag) {
+ipcr_status genome_finalize_async(ipcr_genome *g, uint32_t *pinned_flag, uint64_t *pinned_tables) {
     const uint64_t need = (g->next_col + 63) / 64 * 64 + 64;
     if (g->padded_until < need) {
         const uint64_t from = std::max(g->next_col, g->padded_until);
@@ -862,8 +862,12 @@ ipcr_status genome_finalize_async(ipcr_genome *g, uint32_t *pinned_flag) {
         g->padded_until = need;
     }
     if (g->tables_dirty && !g->rec_start.empty()) {
-        HIPCHK(hipMemcpyAsync(g->d_rec_start, g->rec_start.data(), g->rec_start.size() * 8ull, hipMemcpyHostToDevice, g->stream));
-        HIPCHK(hipMemcpyAsync(g->d_rec_len, g->rec_len.data(), g->rec_len.size() * 8ull, hipMemcpyHostToDevice, g->stream));
+        // the one record's start and length go through the scratch's PINNED words: a copy out of pageable memory (the
+        // vectors) takes the runtime's staging lock, where the workers of a pool would meet on every chunk
+        pinned_tables[0] = g->rec_start[0];
+        pinned_tables[1] = g->rec_len[0];
+        HIPCHK(hipMemcpyAsync(g->d_rec_start, pinned_tables, 8, hipMemcpyHostToDevice, g->stream));
+        HIPCHK(hipMemcpyAsync(g->d_rec_len, pinned_tables + 1, 8, hipMemcpyHostToDevice, g->stream));
         const uint64_t nb = (g->next_col + 63) / 64 + 1;
         HIPCHK(hipMemsetAsync(g->d_block_rec, 0, nb * 4ull, g->stream)); // one record: every block belongs to record 0
         g->tables_dirty = false;
@@ -1312,7 +1316,7 @@ ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g, b
     // chunk path: nothing is waited for before the sweep is enqueued.  Whether the record holds a reset byte is
     // only known afterwards, so it is scanned the way a genome with such records is (rc patterns unprotected,
     // the host applies the 5' window): right for both kinds of record, as in a resident genome that mixes them
-    ipcr_status st = chunk ? genome_finalize_async(g, pinned_seq(s) + 4) : genome_finalize(g);
+    ipcr_status st = chunk ? genome_finalize_async(g, pinned_seq(s) + 4, reinterpret_cast<uint64_t *>(pinned_seq(s) + 8)) : genome_finalize(g);
     if (st != IPCR_OK) return st;
     trace("finalized", s);
     s->last_rec_len = g->rec_len;
@@ -1943,9 +1947,13 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         if (!staged) {
             HIPCHK(hipMemcpyAsync(g->staging, seq, len, hipMemcpyHostToDevice, g->stream));
         } else {
-            constexpr uint64_t SLICE = 8ull << 20;
+            constexpr uint64_t SLICE_MAX = 8ull << 20;
+            static const uint64_t slice_env = getenv("IPCR_CHUNK_SLICE") ? strtoull(getenv("IPCR_CHUNK_SLICE"), nullptr, 10) : 0;
+            // 8 MiB slices: a 4 Mb chunk is one CPU copy + one DMA (finer slices were measured slower: 0.5 MiB 37.6,
+            // 1 MiB 42.7, 2 MiB 44.6, whole chunk 44.7 Gbases/s for 8 workers); a whole chromosome is double-buffered
+            const uint64_t SLICE = slice_env ? std::min<uint64_t>(std::max<uint64_t>(slice_env, 65536), SLICE_MAX) : SLICE_MAX;
             for (int h = 0; h < 2; ++h) {
-                if (!s->h_stage[h]) HIPCHK(hipHostMalloc((void **)&s->h_stage[h], SLICE, hipHostMallocDefault));
+                if (!s->h_stage[h]) HIPCHK(hipHostMalloc((void **)&s->h_stage[h], SLICE_MAX, hipHostMallocDefault));
                 if (!s->ev_stage[h]) HIPCHK(hipEventCreateWithFlags(&s->ev_stage[h], hipEventDisableTiming));
             }
             uint64_t i = 0;

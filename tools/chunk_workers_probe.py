@@ -35,10 +35,12 @@ def run(seq, chunk, overlap, workers, eng, cp, passes=3):
     chunks = [bytes(view[s:s + chunk]) for s in starts]   # the jobs own private copies, as fasta/path_ctx.go:117 makes them
     best = 0.0
     nprod = 0
+    reps = max(1, -(-16 * workers // len(chunks)))      # >= 16 chunks per worker in a timed pass
     for _ in range(passes):
         q = queue.Queue()
-        for i, c in enumerate(chunks):
-            q.put((i, c))
+        for rep in range(reps):                         # enough jobs per worker that thread start-up does not show
+            for i, c in enumerate(chunks):
+                q.put((i, c))
         counts = [0] * workers
 
         def work(w):
@@ -57,8 +59,8 @@ def run(seq, chunk, overlap, workers, eng, cp, passes=3):
         for t in ths:
             t.join()
         dt = time.perf_counter() - t0
-        best = max(best, sum(len(c) for c in chunks) / dt / 1e9)
-        nprod = sum(counts)
+        best = max(best, reps * sum(len(c) for c in chunks) / dt / 1e9)
+        nprod = sum(counts) // reps
     for sc in scs:
         sc.close()
     return best, nprod, len(chunks)
