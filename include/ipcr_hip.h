@@ -146,6 +146,15 @@ int32_t ipcr_panel_max_primer_len(const ipcr_panel *p);
 int32_t ipcr_panel_have(const ipcr_panel *p, int32_t pair, char which);
 /* 0 = table-driven filter only, 1 = allow the panel-specialised filter (default) */
 ipcr_status ipcr_panel_set_specialize(ipcr_panel *p, int32_t enable);
+/* Pattern-axis sharding (one genome x a huge panel over several GPUs): this panel object scans only
+ * every count-th distinct pattern of its scanned-pattern list, starting at `index` (the orientations of a pair are
+ * independent until the per-pair join, core/engine/compiled.go:192-207,260-265).  Call before the first scan.  The
+ * hits keep the panel-wide pattern ids, so the hit lists of all shards over the SAME records, concatenated (e.g. by
+ * the all-gatherv), joined with ipcr_join_hits give exactly the products of the unsharded scan. */
+ipcr_status ipcr_panel_set_shard(ipcr_panel *p, int32_t index, int32_t count);
+/* distinct-pattern ids this panel object scans in `mode` (as in ipcr_panel_filter_source: 0 / 1), ascending; returns
+ * their number, fills at most cap */
+int32_t ipcr_panel_scanned_patterns(const ipcr_panel *p, int32_t mode, int32_t *out, int32_t cap);
 /* HIP source of the panel-specialised filter kernel (what hiprtc compiles at first scan);
  * mode 0 = records without non-ACGT bytes, 1 = with; 2 / 3 = the seed-index filter's source (the
  * kernel large panels use) for mode 0 / 1.  Writes at most cap bytes (NUL-terminated),

@@ -88,6 +88,8 @@ SYMBOLS = {
     "ipcr_panel_max_primer_len": (C.c_int32, [C.c_void_p]),
     "ipcr_panel_have": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char]),
     "ipcr_panel_set_specialize": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ipcr_panel_set_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "ipcr_panel_scanned_patterns": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "ipcr_panel_filter_source": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ipcr_panel_num_patterns_total": (C.c_int32, [C.c_void_p]),
     "ipcr_panel_pattern_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

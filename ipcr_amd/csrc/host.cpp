@@ -221,6 +221,7 @@ struct ipcr_panel {
     bool modes_equal = true;
     int max_len = 0;
     bool specialize = true;
+    int32_t shard_index = 0, shard_count = 1; // ipcr_panel_set_shard: this panel object scans every count-th pattern
     int device = -1;
     mutable std::mutex mu;
     // device scratches alive = workers scanning with this panel (shared: a scratch may outlive its panel object)
@@ -665,6 +666,35 @@ ipcr_status ipcr_panel_filter_source(const ipcr_panel *p, int32_t mode, char *ou
         out[n] = 0;
     }
     return IPCR_OK;
+}
+
+ipcr_status ipcr_panel_set_shard(ipcr_panel *p, int32_t index, int32_t count) {
+    if (!p || count < 1 || index < 0 || index >= count) return fail(IPCR_ERR_INVALID, "ipcr_panel_set_shard: need 0 <= index < count");
+    std::lock_guard<std::mutex> lock(p->mu);
+    for (int mode = 0; mode < 2; ++mode) {
+        PatternSet &s = p->set[mode];
+        if (s.dev || s.jit_tried || s.index.built) return fail(IPCR_ERR_INVALID, "ipcr_panel_set_shard: the panel has already been scanned with");
+        if (p->shard_count != 1) return fail(IPCR_ERR_INVALID, "ipcr_panel_set_shard: the panel is already a shard");
+    }
+    for (int mode = 0; mode < 2; ++mode) { // every count-th distinct pattern of the scanned list, starting at index
+        PatternSet &s = p->set[mode];
+        std::vector<uint32_t> ids;
+        std::vector<ipcr_dev_pattern> host;
+        for (size_t i = 0; i < s.ids.size(); ++i)
+            if ((int32_t)(i % (size_t)count) == index) { ids.push_back(s.ids[i]); host.push_back(s.host[i]); }
+        s.ids.swap(ids);
+        s.host.swap(host);
+    }
+    p->shard_index = index;
+    p->shard_count = count;
+    return IPCR_OK;
+}
+
+int32_t ipcr_panel_scanned_patterns(const ipcr_panel *p, int32_t mode, int32_t *out, int32_t cap) {
+    if (!p || mode < 0 || mode > 1) return 0;
+    const std::vector<uint32_t> &ids = p->set[mode].ids;
+    for (size_t i = 0; i < ids.size() && out && (int32_t)i < cap; ++i) out[i] = (int32_t)ids[i];
+    return (int32_t)ids.size();
 }
 
 ipcr_status ipcr_panel_set_specialize(ipcr_panel *p, int32_t enable) {

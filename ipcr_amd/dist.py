@@ -61,9 +61,23 @@ def hits_from_scratch(scratch) -> np.ndarray:
     return np.frombuffer(buf, dtype=HIT_DTYPE, count=n).copy()
 
 
-def allgather_hits(local: np.ndarray, n_local_records: int, device=None, group=None):
+def pattern_shard(cp, rank: Optional[int] = None, world: Optional[int] = None):
+    """Pattern-axis sharding (one genome x a huge panel): this rank's panel object scans every world-th
+    distinct pattern; all ranks scan the SAME records.  Gather the hits with `allgather_hits(..., same_records=True)`
+    (or HitExchanger(same_records=True)) and join them with a full panel: the orientations of a pair are
+    independent until the per-pair join (core/engine/compiled.go:192-207,260-265)."""
+    r, w, _ = env_rank()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    if world > 1:
+        cp.set_shard(rank, world)
+    return cp
+
+
+def allgather_hits(local: np.ndarray, n_local_records: int, device=None, group=None, same_records: bool = False):
     """All-gatherv of hit records.  Returns (hits, record_offset_per_rank): every rank's hits
-    concatenated in rank order with `record` rebased to a job-global record index."""
+    concatenated in rank order with `record` rebased to a job-global record index (genome-parallel
+    jobs), or left as it is when every rank scanned the same records (same_records: pattern shards)."""
     import torch
     import torch.distributed as dist
     assert local.dtype == HIT_DTYPE
@@ -90,7 +104,8 @@ def allgather_hits(local: np.ndarray, n_local_records: int, device=None, group=N
         part = recv[r, :counts[r] * 32].copy().view(HIT_DTYPE)
         part["record"] += np.uint32(off)
         parts.append(part)
-        off += nrecs[r]
+        if not same_records:
+            off += nrecs[r]
     return (np.concatenate(parts) if parts else np.zeros(0, dtype=HIT_DTYPE)), offsets
 
 
@@ -134,10 +149,11 @@ class HitExchanger:
     device staging buffer of the agreed size instead of the zero-copy view -- the collective's shape
     never depends on a local condition."""
 
-    def __init__(self, device=None, cap_hits: int = 4096, group=None):
+    def __init__(self, device=None, cap_hits: int = 4096, group=None, same_records: bool = False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
+        self.same_records = same_records     # pattern shards: every rank scanned the same records, no index rebase
         self.active = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(group) > 1 or bool(os.environ.get("IPCR_EXCHANGE_SELFTEST")))
         self.world = dist.get_world_size(group) if self.active else 1
@@ -316,7 +332,8 @@ class HitExchanger:
             ranges.append((pos, pos + cnt))
             offsets.append(off)
             pos += cnt
-            off += self._rec_counts[r]
+            if not self.same_records:
+                off += self._rec_counts[r]
         return np.concatenate(parts), ranges, offsets
 
     def _unpack(self, hr: np.ndarray, meta: np.ndarray):
@@ -329,7 +346,8 @@ class HitExchanger:
             ranges.append((pos, pos + cnt))
             offsets.append(off)
             pos += cnt
-            off += nrec
+            if not self.same_records:
+                off += nrec
         return np.concatenate(parts), ranges, offsets
 
     def allgather(self, local: np.ndarray, n_local_records: int):

@@ -140,6 +140,17 @@ class CompiledPanel:
         _lib.check(_lib.lib().ipcr_panel_filter_source(self._h, mode, buf, need.value, None))
         return buf.value.decode()
 
+    def set_shard(self, index: int, count: int) -> None:
+        """Pattern-axis sharding: this panel object scans every count-th distinct pattern only (before the first scan);
+        hits keep panel-wide pattern ids, so gathered hit lists join to the unsharded result (dist.py)."""
+        _lib.check(_lib.lib().ipcr_panel_set_shard(self._h, index, count))
+
+    def scanned_patterns(self, mode: int = 0) -> List[int]:
+        n = _lib.lib().ipcr_panel_scanned_patterns(self._h, mode, None, 0)
+        out = (C.c_int32 * max(n, 1))()
+        _lib.lib().ipcr_panel_scanned_patterns(self._h, mode, out, n)
+        return [out[i] for i in range(n)]
+
     def set_specialize(self, enable: bool) -> None:
         _lib.check(_lib.lib().ipcr_panel_set_specialize(self._h, 1 if enable else 0))
 

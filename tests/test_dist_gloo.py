@@ -99,3 +99,79 @@ def test_two_rank_gloo_allgather_and_join(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert f"RANK_OK {rank}" in out, out
+
+
+SHARD_WORKER = r'''
+import os, sys, random
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle")); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import torch.distributed as tdist
+import ipcr_oracle as O
+from ipcr_amd import dist, engine, primer
+from test_host_logic import synth_hits, rand_seq, plant
+
+rank, world, local, backend = dist.init_process_group("gloo")
+assert world == 2
+rng = random.Random(31)   # same stream on both ranks: same panel, same records
+rows = [primer.Pair("r%d" % i, "".join(rng.choice("ACGT") for _ in range(19)), "".join(rng.choice("ACGT") for _ in range(21)), 0, 0) for i in range(6)]
+pairs = primer.AddSelfPairsUnique(rows)
+cfg = engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=500, HitCap=10000, SeedLen=12)
+seqs = []
+for r in range(4):
+    s = rand_seq(rng, 5000, junk=(r == 2))
+    for i in range(6):
+        a = 100 + i * 780
+        plant(rng, s, rows[i].Forward, a, rng.choice([0, 1, 2]))
+        plant(rng, s, O.revcomp(rows[i].Reverse).decode(), a + rng.randint(60, 300), rng.choice([0, 1]))
+    seqs.append("".join(s).encode())
+eng = engine.New(cfg)
+full = eng.CompilePanel(pairs)
+mine = dist.pattern_shard(eng.CompilePanel(pairs))          # this rank's slice of the distinct-pattern list
+assert len(mine.scanned_patterns(0)) * 2 in (len(full.scanned_patterns(0)), len(full.scanned_patterns(0)) + 1, len(full.scanned_patterns(0)) - 1)
+reset = [any(ch not in b"ACGTacgt" for ch in s) for s in seqs]
+mode = 1 if any(reset) else 0
+local_hits = np.concatenate([synth_hits(mine, s, cfg.MaxMM, i, mode) for i, s in enumerate(seqs)])   # EVERY record, my patterns
+lens = [len(s) for s in seqs]
+flags = [(1 if reset[i] else 0) | (2 if mode else 0) for i in range(len(seqs))]
+all_hits, offsets = dist.allgather_hits(local_hits, len(seqs), same_records=True)
+assert offsets == [0, 0] and len(all_hits) > len(local_hits)
+x = dist.HitExchanger(cap_hits=8, same_records=True)          # the persistent form, with an agreed regrow on the way
+x_hits, _, x_off = x.allgather(local_hits, len(seqs))
+assert x_off == [0, 0] and np.array_equal(x_hits, all_hits)
+w = x.start(local_hits, len(seqs)); x.finish(w)
+assert np.array_equal(x.gathered()[0], all_hits)
+sc = engine.SimulationScratch(full, host_only=True)
+got = eng.JoinHits(full, sc, all_hits, lens, flags, ["rec%d" % r for r in range(len(seqs))])
+op = O.Panel(O.Config(max_mm=2, terminal_window=3, max_len=500, hit_cap=10000, seed_len=12),
+             [O.Pair(p.ID, p.Forward, p.Reverse, p.MinProduct, p.MaxProduct) for p in pairs])
+want = []
+for r, s in enumerate(seqs):
+    want += [("rec%d" % r,) + w_.sig() for w_ in op.scan(s)]
+assert [(g.SequenceID,) + g.sig() for g in got] == want and len(want) >= 12
+whole = np.concatenate([synth_hits(full, s, cfg.MaxMM, i, mode) for i, s in enumerate(seqs)])   # the single-rank scan
+single = eng.JoinHits(full, sc, whole, lens, flags, ["rec%d" % r for r in range(len(seqs))])
+assert [g.sig() for g in single] == [g.sig() for g in got]
+tdist.barrier()
+print("SHARD_OK", rank, len(got))
+'''
+
+
+def test_two_rank_gloo_pattern_shards(tmp_path):
+    """pattern-axis sharding (SURVEY 8e, north_star "primer x genome tiles"): two ranks scan the SAME records with
+    halves of the distinct-pattern list, all-gather the hits (no record rebase) and join with the full panel:
+    the product list equals the single-rank scan's and the oracle's"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER.format(root=ROOT))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f"SHARD_OK {rank}" in out, out

@@ -601,6 +601,53 @@ def test_concurrent_workers_share_one_panel(hip):
     for t in threads:
         t.join()
     assert not errors and got == want
+    # several scratches alive = several workers: ipcr_scan_chunk stages the caller's bytes through two pinned 8 MiB
+    # slices per scratch (CPU copy of slice i+1 under the DMA of slice i); a 20 Mb record takes three slices
+    s1, s2 = eng.NewSimulationScratch(cp), eng.NewSimulationScratch(cp)
+    big = bytearray(O.bench_dna(20_000_000, 4242))
+    big[5_000_000:5_000_003] = b"NNN"
+    for a in (100, 8_388_500, 16_777_100, 19_999_000):     # amplicons across both slice boundaries and at the ends
+        big[a:a + 16] = pairs[0].Forward.encode()
+        big[a + 200:a + 216] = O.revcomp(pairs[0].Reverse)
+    big = bytes(big)
+    want_big = [w.sig() for w in O.simulate_batch(ocfg(cfg), big, opairs(pairs))]
+    for sc in (s1, s2, s1):
+        assert [p.sig() for p in eng.SimulateCompiledWithScratch("big", big, cp, sc)] == want_big and len(want_big) >= 4
+    s1.close()
+    s2.close()
+
+
+@pytest.mark.parametrize("npairs,count,junk", [(6, 3, 0), (40, 2, 2), (40, 4, 0)])
+def test_pattern_shards_scan_and_join(hip, npairs, count, junk):
+    """ipcr_panel_set_shard on the device: `count` panel objects scan the same resident genome with slices of the
+    distinct-pattern list (specialised kernels for the small panel, the seed index for the 40-row one); the
+    concatenated hit lists joined with the full panel are the unsharded scan's products, which equal the oracle's"""
+    import numpy as np
+    from ipcr_amd import dist, workloads
+    rng = random.Random(700 + npairs + count)
+    pairs = workloads.c4_pairs(npairs)
+    g, seqs = build_planted_genome(hip, rng, 4, 400_003, pairs[:npairs], 0x5eed7777, junk_every=junk)
+    cfg = hip.engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)
+    eng, full, sc, want = scan_and_compare(hip, cfg, pairs, g, seqs)
+    parts, kinds = [], set()
+    for i in range(count):
+        sh = eng.CompilePanel(pairs)
+        sh.set_shard(i, count)
+        ssc = eng.NewSimulationScratch(sh)
+        eng.ScanGenomeHits(g, sh, ssc)
+        kinds.add(ssc.stats().kernel_kind)
+        part = dist.hits_from_scratch(ssc)
+        assert set(int(x) & 0x7FFFFFFF for x in part["pattern"]) <= set(sh.scanned_patterns(0)) | set(sh.scanned_patterns(1))
+        parts.append(part)
+        ssc.close()
+        sh.close()
+    host = hip.engine.SimulationScratch(full, host_only=True)
+    lens = [g.record_len(r) for r in range(g.num_records)]
+    flags = [g.record_flags(r) for r in range(g.num_records)]
+    got = eng.JoinHits(full, host, np.concatenate(parts[::-1]), lens, flags, g.ids)
+    assert [p.sig() for p in got] == [p.sig() for p in want] and len(want) >= 20
+    assert kinds <= {1, 3}
+    g.close()
 
 
 def test_index_large_iupac_panel(hip):

@@ -90,6 +90,7 @@ def synth_hits(cp, seq, k, record, mode):
     """What the device would report for one record: every distinct scanned pattern's verified
     matches (core/primer/match.go:30-90 semantics via the oracle), as ipcr_hit records."""
     used = {cp.slot_pattern(i, w, mode) for i in range(len(cp.Pairs)) for w in "ABab"}
+    used &= set(cp.scanned_patterns(mode))    # a pattern shard (ipcr_panel_set_shard) scans a slice of them
     rows = []
     for gid in sorted(used):
         pat, left, tw_dev, soff, slen = cp.pattern_info(gid)
@@ -392,3 +393,48 @@ def test_generated_block_counters_are_exact(k, tw, primers, monkeypatch):
                     exec(part, {}, env)
             want = sum(1 << a for a in range(n) if bin(a).count("1") > k)
             assert env["f"] & full == want, (k, flags, force, stmts)
+
+
+def test_pattern_shards_join_to_the_unsharded_result():
+    """ipcr_panel_set_shard: the distinct patterns are dealt round-robin over `count` panel objects; their hit lists
+    over the same records, concatenated in any order, join (full panel) to exactly the unsharded products -- the
+    orientations of a pair are independent until the per-pair join (core/engine/compiled.go:192-207,260-265)"""
+    rng = random.Random(4711)
+    pairs = primer.AddSelfPairsUnique([primer.Pair("p%d" % i, "".join(rng.choice("ACGT") for _ in range(18)),
+                                                   "".join(rng.choice("ACGT") for _ in range(20)), 0, 0) for i in range(5)])
+    cfg = engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=400, HitCap=50, SeedLen=12)
+    seqs = []
+    for r in range(3):
+        s = rand_seq(rng, 6000, junk=(r == 1))
+        for i in range(5):
+            a = 200 + i * 1000
+            plant(rng, s, pairs[i].Forward, a, rng.choice([0, 1, 2]))
+            plant(rng, s, O.revcomp(pairs[i].Reverse).decode(), a + 150, rng.choice([0, 1]))
+        seqs.append("".join(s).encode())
+    eng = engine.New(cfg)
+    full = eng.CompilePanel(pairs)
+    reset = [any(ch not in b"ACGTacgt" for ch in s) for s in seqs]
+    mode = 1 if any(reset) else 0
+    lens = [len(s) for s in seqs]
+    flags = [(1 if reset[i] else 0) | (2 if mode else 0) for i in range(3)]
+    whole = np.concatenate([synth_hits(full, s, cfg.MaxMM, i, mode) for i, s in enumerate(seqs)])
+    sc = engine.SimulationScratch(full, host_only=True)
+    want = [p.sig() for p in eng.JoinHits(full, sc, whole, lens, flags)]
+    assert len(want) >= 10
+    for count in (2, 3, 7):
+        shards = [eng.CompilePanel(pairs) for _ in range(count)]
+        for i, sh in enumerate(shards):
+            sh.set_shard(i, count)
+        lists = [sh.scanned_patterns(mode) for sh in shards]
+        assert sorted(sum(lists, [])) == full.scanned_patterns(mode)            # a partition of the pattern list
+        assert max(map(len, lists)) - min(map(len, lists)) <= 1                   # balanced
+        parts = [np.concatenate([synth_hits(sh, s, cfg.MaxMM, i, mode) for i, s in enumerate(seqs)]) for sh in shards]
+        rng.shuffle(parts)
+        got = [p.sig() for p in eng.JoinHits(full, sc, np.concatenate(parts), lens, flags)]
+        assert got == want, count
+        with pytest.raises(_lib.IpcrError):
+            shards[0].set_shard(0, 2)                                            # already a shard
+        for sh in shards:
+            sh.close()
+    with pytest.raises(_lib.IpcrError):
+        full.set_shard(3, 3)
