@@ -3,7 +3,7 @@
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB summed over the 8 XCDs; on gfx950 FETCH_SIZE counts a 16 B/lane
 coalesced stream at half its bytes (MI355X_MICROARCH.md, HBM section), so hbm_read = raw_kb * 1024 * 2; WRITE_SIZE is
-taken as is.
+taken as is.  SQ_* counters are summed over the chip; SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles.
 """
 import csv
 import glob
@@ -13,14 +13,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def short(name):
-    for key in ("ipcr_filter", "ipcr_index", "pack_kernel", "verify_kernel", "filter_generic", "filter_index",
-                "lcg_fill", "fill_pad"):
-        if key in name:
-            return key
-    return None
+KERNEL = {"c2": "ipcr_filter", "c3": "ipcr_filter", "c4": "ipcr_index_filter"}
 
 
 def newest(pattern):
@@ -29,21 +22,19 @@ def newest(pattern):
     return [max(files, key=os.path.getmtime)] if files else []
 
 
-def pmc(dirname, counter):
-    per = {}
+def counters(dirname, kernel):
+    """average per launch of every counter collected in `dirname` for dispatches of `kernel`"""
+    acc = {}
     for f in newest(os.path.join(dirname, "**", "*counter_collection.csv")):
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
-                if row["Counter_Name"] != counter:
-                    continue
-                k = short(row["Kernel_Name"])
-                if k:
-                    per.setdefault(k, []).append(float(row["Counter_Value"]))
-    return {k: {"launches": len(v), "avg_raw_kb": sum(v) / len(v)} for k, v in per.items()}
+                if kernel in row["Kernel_Name"] and not (kernel == "ipcr_filter" and "index" in row["Kernel_Name"]):
+                    acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    return {k: {"launches": len(v), "avg": sum(v) / len(v)} for k, v in acc.items()}
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     line = open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]
@@ -54,32 +45,33 @@ def main():
     if os.path.exists(serial):
         with open(os.path.join(dst, f"{tag}_bench_serial.json"), "w") as fh:
             fh.write(open(serial).read().strip().splitlines()[-1] + "\n")
-    stats = newest(os.path.join(src, "stats", "**", "*kernel_stats.csv"))
-    if stats:
-        shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
-    fetch = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
-    write = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE")
-    kernel = "ipcr_filter"
-    out = {
-        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py "
-                "--steps 4 --warmup 1 --no-cpu-baseline`; FETCH_SIZE is reported in KiB and, on gfx950, at half the "
-                "bytes of a 16 B/lane coalesced stream (MI355X_MICROARCH.md, HBM): hbm_read = raw_kb*1024*2; "
-                "WRITE_SIZE exact.",
-        "FETCH_SIZE": fetch, "WRITE_SIZE": write, "kernel": kernel,
-    }
-    if kernel in fetch and kernel in write:
-        rd = int(fetch[kernel]["avg_raw_kb"] * 1024 * 2)
-        wr = int(write[kernel]["avg_raw_kb"] * 1024)
-        out.update(hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
-                   algorithmic_bytes_per_launch=int(bench["roofline"].get("algorithmic_bytes_per_launch", 0)) or None)
-    with open(os.path.join(dst, f"{tag}_filter_pmc.json"), "w") as fh:
-        json.dump(out, fh, indent=1)
-    print(json.dumps({k: out.get(k) for k in ("hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch")}))
-    if stats:
-        with open(stats[0], newline="") as fh:
-            for row in csv.DictReader(fh):
-                if short(row.get("Name", "")):
-                    print(row["Name"][:40], row.get("Calls"), row.get("AverageNs"))
+    alg = int(bench["roofline"].get("algorithmic_bytes_per_launch", 0)) or None
+    for w, kernel in KERNEL.items():
+        stats = newest(os.path.join(src, f"stats_{w}", "**", "*kernel_stats.csv"))
+        if stats:
+            shutil.copy(stats[0], os.path.join(dst, f"{tag}_{w}_kernel_stats.csv"))
+            with open(stats[0], newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if kernel in row.get("Name", ""):
+                        print(w, row["Name"][:40], row.get("Calls"), row.get("AverageNs"))
+        out = {"workload": w, "kernel": kernel,
+               "note": "rocprofv3 --kernel-trace --pmc <set> (one set per pass, nothing else traced) over `python3 bench.py "
+                       "--workload %s --no-cpu-baseline --no-others --steps 3..4 --warmup 1`; averages per launch of %s. "
+                       "FETCH_SIZE is reported in KiB and, on gfx950, at half the bytes of a 16 B/lane coalesced stream "
+                       "(MI355X_MICROARCH.md, HBM): hbm_read = raw_kb*1024*2; WRITE_SIZE exact." % (w, kernel)}
+        for name in ("fetch", "write", "sq", "lds", "grbm"):
+            for k, v in counters(os.path.join(src, f"pmc_{name}_{w}"), kernel).items():
+                out[k] = v
+        if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+            rd = int(out["FETCH_SIZE"]["avg"] * 1024 * 2)
+            wr = int(out["WRITE_SIZE"]["avg"] * 1024)
+            out.update(hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
+                       algorithmic_bytes_per_launch=alg)
+        name = "filter" if w == "c2" else w
+        with open(os.path.join(dst, f"{tag}_{name}_pmc.json"), "w") as fh:
+            json.dump(out, fh, indent=1)
+        print(w, {k: out.get(k) for k in ("hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch")},
+              {k: round(v["avg"]) for k, v in out.items() if isinstance(v, dict) and k.startswith("SQ_")})
 
 
 if __name__ == "__main__":

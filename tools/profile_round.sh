@@ -1,21 +1,29 @@
 #!/bin/bash
 # Collects the evidence profiles/ holds for one round, on the GPU box:
-#   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r01'
-# then, back in the container:  python tools/collect_profiles.py r01
-# Separate passes: bench line (with cpu_baseline), rocprofv3 kernel trace + stats, then one --pmc pass per counter
-# (never mixed with other trace domains).
+#   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02'
+# then, back in the container:  python tools/collect_profiles.py r02
+# Separate passes: bench line (all workloads + cpu_baseline), then per workload a rocprofv3 kernel trace + stats and
+# one --pmc pass per counter set (never mixed with other trace domains).
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || { tail -5 "$out/bench.err"; exit 1; }
-tail -1 "$out/bench.json"
-python3 bench.py --no-pipeline --no-cpu-baseline > "$out/bench_serial.json" 2> "$out/bench_serial.err" || exit 1
-tail -1 "$out/bench_serial.json"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 400 --warmup 50 --no-cpu-baseline > "$out/stats.log" 2>&1 || { tail -5 "$out/stats.log"; exit 1; }
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1 || { tail -5 "$out/pmc_fetch.log"; exit 1; }
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > "$out/pmc_write.log" 2>&1 || { tail -5 "$out/pmc_write.log"; exit 1; }
+tail -c 600 "$out/bench.json"; echo
+python3 bench.py --no-pipeline --no-cpu-baseline --no-others > "$out/bench_serial.json" 2> "$out/bench_serial.err" || exit 1
+for w in c2 c3 c4; do
+  steps=400; warm=50; psteps=4
+  if [ $w = c4 ]; then steps=20; warm=3; psteps=3; fi
+  args="--workload $w --no-cpu-baseline --no-others"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_$w" -- python3 bench.py $args --steps $steps --warmup $warm > "$out/stats_$w.log" 2>&1 || { tail -5 "$out/stats_$w.log"; exit 1; }
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch_$w" -- python3 bench.py $args --steps $psteps --warmup 1 > "$out/pmc_fetch_$w.log" 2>&1 || { tail -5 "$out/pmc_fetch_$w.log"; exit 1; }
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write_$w" -- python3 bench.py $args --steps $psteps --warmup 1 > "$out/pmc_write_$w.log" 2>&1 || { tail -5 "$out/pmc_write_$w.log"; exit 1; }
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d "$out/pmc_sq_$w" -- python3 bench.py $args --steps $psteps --warmup 1 > "$out/pmc_sq_$w.log" 2>&1 || { tail -5 "$out/pmc_sq_$w.log"; exit 1; }
+  rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY --output-format csv -d "$out/pmc_lds_$w" -- python3 bench.py $args --steps $psteps --warmup 1 > "$out/pmc_lds_$w.log" 2>&1 || { tail -5 "$out/pmc_lds_$w.log"; exit 1; }
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc_grbm_$w" -- python3 bench.py $args --steps $psteps --warmup 1 > "$out/pmc_grbm_$w.log" 2>&1 || { tail -5 "$out/pmc_grbm_$w.log"; exit 1; }
+  echo "profiled $w"
+done
 # keep the merge-back small: the per-dispatch traces are not needed, the summaries are
-find "$out" -name "*kernel_trace.csv" -size +8M -delete
+find "$out" -name "*kernel_trace.csv" -size +4M -delete
 echo done
