@@ -158,8 +158,8 @@ int32_t ipcr_panel_scanned_patterns(const ipcr_panel *p, int32_t mode, int32_t *
 /* HIP source of the panel-specialised filter kernel (what hiprtc compiles at first scan);
  * mode 0 = records without non-ACGT bytes, 1 = with; 2 / 3 = the seed-index filter's source (the
  * kernel large panels use) for mode 0 / 1.  Writes at most cap bytes (NUL-terminated),
- * *needed = full length + 1; an empty string means the panel is not specialisable (a primer
- * longer than 32 nt).  Large panels are cut into groups of patterns, one kernel each; this
+ * *needed = full length + 1; an empty string means the panel is not specialisable (too many
+ * pattern groups).  Large panels are cut into groups of patterns, one kernel each; this
  * returns the first group's source. */
 ipcr_status ipcr_panel_filter_source(const ipcr_panel *p, int32_t mode, char *out, size_t cap, size_t *needed);
 

@@ -295,9 +295,11 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     std::vector<ipcr_dev_pattern> pats = full_pats;
     std::vector<int> offs(pats.size(), 0);
     int Lmax = 0;
+    bool long_pattern = false; // a primer of 33..128 nt: its survivors go to the stand-alone verifier (the wave's own takes <= 32 nt)
     for (size_t q = 0; q < pats.size(); ++q) {
         ipcr_dev_pattern &p = pats[q];
-        if (p.len == 0 || p.len > 32) return "";
+        if (p.len == 0 || p.len > 128) return "";
+        long_pattern |= p.len > 32;
         if ((int)p.len > LF) {
             const int drop = (int)p.len - LF;
             if (p.mask[p.len - 1] & 16u) { // protected 3' window at the right end (or everything protected): keep the right end
@@ -321,7 +323,9 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     const int QM = ((32 - D) / QPI) * QPI;   // quads done by the rolled main loop (its prefetch stays < 32)
     const int NFULL = QM / QPI;
     const int QW = (LM1 + 3) / 4;            // head quads stashed for the wrap phase
-    const int LIST_CAP = env_int("IPCR_JIT_LIST", 48, 1, 64);    // survivor words a wave keeps for its own verify pass
+    // survivor words a wave keeps for its own verify pass; 0 = every survivor spills to the global queue and the host
+    // runs the stand-alone verifier (kernels with a primer longer than 32 nt)
+    const int LIST_CAP = long_pattern ? 0 : env_int("IPCR_JIT_LIST", 48, 1, 64);
     const int CAND_CAP = env_int("IPCR_JIT_CANDS", 128, 2, 1024); // candidate windows verified two per load round
 
     // exact count in the rare branch (see row_code): emitted once per (row slot, pattern), so only for small kernels
@@ -583,8 +587,8 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
          "    for (u32 t = threadIdx.x; t < 256u; t += " << WPG * 64 << "u) next_qcount[t * 16u] = 0ull;\n"
          "  }\n";
     s << "  if (block >= nblocks) return;\n";
-    s << "  __shared__ u64 lkey_all[" << WPG << "][LIST_CAP];\n";
-    s << "  __shared__ u32 lbits_all[" << WPG << "][LIST_CAP];\n";
+    s << "  __shared__ u64 lkey_all[" << WPG << "][LIST_CAP + 1u];\n";
+    s << "  __shared__ u32 lbits_all[" << WPG << "][LIST_CAP + 1u];\n";
     s << "  __shared__ u32 lcnt_all[" << WPG << "];\n";
     s << "  __shared__ u64 candP_all[" << WPG << "][CAND_CAP];\n";
     s << "  __shared__ unsigned char candq_all[" << WPG << "][CAND_CAP];\n";
@@ -861,7 +865,7 @@ bool compile_group_uncached(const std::string &src, const std::string &arch, std
 
 size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats) {
     for (const auto &p : pats)
-        if (p.len == 0 || p.len > 32) return 0; // not specialisable: table-driven filter
+        if (p.len == 0 || p.len > 128) return 0; // not specialisable: table-driven filter
     if (pats.empty()) return 0;
     // the unrolled main loop of one kernel should stay inside the 64 KiB instruction cache:
     // ~200 B of hot code per pattern per row step, W row steps
@@ -879,7 +883,7 @@ size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats) {
 std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err) {
     std::vector<JitFilter *> out;
     const size_t G = jit_group_size(pats);
-    if (G == 0) { err = "panel not specialised (a primer longer than 32 nt, or more pattern groups than IPCR_JIT_MAX_GROUPS)"; return out; }
+    if (G == 0) { err = "panel not specialised (more pattern groups than IPCR_JIT_MAX_GROUPS)"; return out; }
     const size_t ngroups = (pats.size() + G - 1) / G;
     int dev = 0;
     (void)hipGetDevice(&dev);

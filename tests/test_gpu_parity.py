@@ -202,6 +202,47 @@ def test_random_differential(hip, spec, seed):
         check(hip, cfg, "".join(seq).encode(), pairs, specialize=spec)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_long_primers_take_the_specialised_filter(hip, seed):
+    """primers of 33..128 nt: the specialised kernel filters on the 20 positions next to the protected end, every
+    survivor goes through the global queue and the stand-alone verifier (the wave's own verifier takes <= 32 nt);
+    mixed with short primers in one panel; vs the oracle, and the kernel kind is checked"""
+    rng = random.Random(4100 + seed)
+    E, P = hip.engine, hip.primer.Pair
+    for it in range(3):
+        n = rng.choice([3000, 40000])
+        seq = rand_case(rng, n, with_junk=rng.random() < 0.5)
+        pairs = []
+        for i in range(rng.randint(1, 3)):
+            def mk(lo, hi):
+                L = rng.randint(lo, hi)
+                s = [rng.choice("ACGT") for _ in range(L)]
+                for _ in range(rng.choice([0, 1, 2])):
+                    s[rng.randrange(L)] = rng.choice("RYSWKMBDHVN")
+                return "".join(s)
+            pairs.append(P("p%d" % i, mk(33, 128), mk(*rng.choice([(33, 128), (16, 30), (65, 128)]))))
+        for p in pairs:
+            for _ in range(2):
+                a = rng.randrange(0, n - 700)
+                ln = rng.randint(len(p.Forward) + len(p.Reverse), 600)
+                plant(rng, seq, p.Forward, a, rng.choice([0, 1, 2, 3]))
+                rc = O.revcomp(p.Reverse).decode()
+                plant(rng, seq, rc, a + ln - len(rc), rng.choice([0, 1]))
+        cfg = E.Config(MaxMM=rng.choice([0, 1, 2, 3]), TerminalWindow=rng.choice([0, 3, 5]), MaxLen=rng.choice([0, 1000]),
+                       HitCap=rng.choice([0, 10000]), SeedLen=rng.choice([0, 12]), Circular=rng.random() < 0.3)
+        if rng.random() < 0.5:
+            pairs = hip.primer.AddSelfPairs(pairs)
+        b = "".join(seq).encode()
+        check(hip, cfg, b, pairs)
+        eng = E.New(cfg)
+        cp = eng.CompilePanel(pairs)
+        sc = eng.NewSimulationScratch(cp)
+        eng.SimulateCompiledWithScratch("s", b, cp, sc)
+        assert sc.stats().kernel_kind == 1, "a panel with long primers fell back to the table-driven filter"
+        sc.close()
+        cp.close()
+
+
 def test_hit_cap_quirks(hip):
     """HitCap truncation per orientation, incl. the reference's cap-before-5'-filter order on the
     FindMatches path (core/engine/compiled.go:249-256) with and without non-ACGT bytes."""

@@ -215,8 +215,13 @@ def test_filter_source_is_generated_for_the_headline_panels():
     assert "ipcr_filter" in mid.filter_source(0)  # 96 patterns: cut into 8 groups, one kernel each
     big = engine.New(engine.Config(MaxMM=2, TerminalWindow=3)).CompilePanel(workloads.c4_pairs(64))
     assert big.filter_source(0) == ""  # 256 patterns: too many kernels to compile, table-driven filter
-    long_p = "ACGT" * 9  # 36 nt > 32: table-driven filter (still on the device)
-    assert engine.New(engine.Config(MaxMM=1)).CompilePanel([primer.Pair("l", long_p, long_p)]).filter_source(0) == ""
+    long_p = "ACGT" * 9  # 36 nt: filtered on the 20 positions next to the protected end; survivors go to the stand-alone verifier
+    lsrc = engine.New(engine.Config(MaxMM=1, TerminalWindow=3)).CompilePanel([primer.Pair("l", long_p, long_p)]).filter_source(0)
+    assert "ipcr_filter" in lsrc and "#define LIST_CAP 0u" in lsrc and "len 20, 3 protected" in lsrc
+    assert "wp -= 16ull" in lsrc     # right-protected pattern: its window starts 16 rows before the filtered part
+    too_long = "ACGT" * 33           # 132 nt: beyond IPCR_MAX_PRIMER_LEN
+    with pytest.raises(_lib.IpcrError):
+        engine.New(engine.Config(MaxMM=1)).CompilePanel([primer.Pair("l", too_long, too_long)])
 
 
 def test_generated_filter_structure():
