@@ -723,7 +723,8 @@ struct ipcr_genome {
     mutable bool flags_valid = false;
     bool tables_dirty = true;
     uint64_t next_col = 0;
-    uint64_t padded_until = 0; // columns [next_col, padded_until) are known to be padding
+    uint64_t padded_until = 0; // columns [max(next_col, stale_until), padded_until) are known to be padding
+    uint64_t stale_until = 0;  // columns below hold the bases of records forgotten by genome_clear (chunk genome reuse)
     uint64_t total_bases = 0;
     uint8_t *staging = nullptr;
     uint64_t staging_cap = 0;
@@ -766,8 +767,9 @@ void genome_free_buffers(ipcr_genome *g) {
     g->d_rec_start = g->d_rec_len = nullptr;
 }
 
-void genome_clear(ipcr_genome *g) { // forget the records, keep the buffers
-    if (!g->rec_start.empty() && g->d_flags) (void)hipMemsetAsync(g->d_flags, 0, g->rec_start.size() * 4ull, g->stream);
+void genome_clear(ipcr_genome *g, bool flags_elsewhere = false) { // forget the records, keep the buffers (and what is known about padding)
+    if (!flags_elsewhere && !g->rec_start.empty() && g->d_flags) (void)hipMemsetAsync(g->d_flags, 0, g->rec_start.size() * 4ull, g->stream);
+    g->stale_until = std::max(g->stale_until, g->next_col);
     g->rec_start.clear();
     g->rec_len.clear();
     g->ids.clear();
@@ -775,11 +777,12 @@ void genome_clear(ipcr_genome *g) { // forget the records, keep the buffers
     g->flags_valid = false;
     g->tables_dirty = true;
     g->next_col = 0;
-    g->padded_until = 0;
     g->total_bases = 0;
 }
 
-ipcr_status genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len, bool wait = true) {
+// ext_flag: where the record's reset-byte flag goes instead of d_flags (the chunk path keeps it in pinned host memory);
+// with it the pack kernel also writes the record's start / length into the device tables (no copy operations)
+ipcr_status genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len, bool wait = true, uint32_t *ext_flag = nullptr) {
     const uint64_t cols = record_cols(len);
     if (g->rec_start.size() >= g->max_records) return fail(IPCR_ERR_CAPACITY, "genome holds its maximum of %u records", g->max_records);
     if (g->next_col + cols > g->cap_cols)
@@ -788,7 +791,8 @@ ipcr_status genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len,
     if ((reinterpret_cast<uintptr_t>(dseq) & 15u) != 0) return fail(IPCR_ERR_INVALID, "device sequence pointer must be 16-byte aligned");
     const uint32_t rec = (uint32_t)g->rec_start.size();
     HIPCHK(hipEventRecord(g->e0, g->stream));
-    HIPCHK(ipcr::launch_pack(g->stream, dseq, len, g->next_col, cols, g->planes, g->rst, g->d_flags + rec));
+    if (ext_flag) HIPCHK(ipcr::launch_pack(g->stream, dseq, len, g->next_col, cols, g->planes, g->rst, ext_flag, g->d_rec_start + rec, g->d_rec_len + rec));
+    else HIPCHK(ipcr::launch_pack(g->stream, dseq, len, g->next_col, cols, g->planes, g->rst, g->d_flags + rec));
     HIPCHK(hipEventRecord(g->e1, g->stream));
     if (wait) {
         HIPCHK(hipEventSynchronize(g->e1));
@@ -847,13 +851,25 @@ ipcr_status genome_add_device_batch(ipcr_genome *g, const uint8_t *dbase, const 
 
 // before a scan: the rest of the last block and one block beyond must be padding, and the
 // record tables must be on the device
-ipcr_status genome_finalize(ipcr_genome *g) {
+// the rest of the last block and one block beyond must be padding: fill what is not known to be
+ipcr_status genome_pad(ipcr_genome *g) {
     const uint64_t need = (g->next_col + 63) / 64 * 64 + 64;
+    const uint64_t lo = g->next_col; // first column that must be padding; known padding: [max(lo, stale_until), padded_until)
+    if (g->stale_until > lo) {       // bases of a forgotten, longer record follow the last one (a reused chunk genome)
+        HIPCHK(ipcr::launch_fill_pad(g->stream, g->planes, g->rst, lo, std::min(g->stale_until, need)));
+        if (g->stale_until > need) return IPCR_OK; // [lo, need) is padding now; what lies beyond stays marked stale
+        g->padded_until = std::max(g->padded_until, g->stale_until);
+        g->stale_until = lo;
+    }
     if (g->padded_until < need) {
-        const uint64_t from = std::max(g->next_col, g->padded_until);
-        HIPCHK(ipcr::launch_fill_pad(g->stream, g->planes, g->rst, from, need));
+        HIPCHK(ipcr::launch_fill_pad(g->stream, g->planes, g->rst, std::max(lo, g->padded_until), need));
         g->padded_until = need;
     }
+    return IPCR_OK;
+}
+
+ipcr_status genome_finalize(ipcr_genome *g) {
+    { const ipcr_status ps = genome_pad(g); if (ps != IPCR_OK) return ps; }
     if (g->tables_dirty && !g->rec_start.empty()) {
         HIPCHK(hipMemcpyAsync(g->d_rec_start, g->rec_start.data(), g->rec_start.size() * 8ull, hipMemcpyHostToDevice, g->stream));
         {
@@ -884,25 +900,13 @@ ipcr_status genome_finalize(ipcr_genome *g) {
 
 // chunk path (one record, the scratch's own stream): same preparation without waiting for anything; the
 // record's reset-byte flag arrives in *pinned_flag when the stream has passed this point
-ipcr_status genome_finalize_async(ipcr_genome *g, uint32_t *pinned_flag, uint64_t *pinned_tables) {
-    const uint64_t need = (g->next_col + 63) / 64 * 64 + 64;
-    if (g->padded_until < need) {
-        const uint64_t from = std::max(g->next_col, g->padded_until);
-        HIPCHK(ipcr::launch_fill_pad(g->stream, g->planes, g->rst, from, need));
-        g->padded_until = need;
-    }
-    if (g->tables_dirty && !g->rec_start.empty()) {
-        // the one record's start and length go through the scratch's PINNED words: a copy out of pageable memory (the
-        // vectors) takes the runtime's staging lock, where the workers of a pool would meet on every chunk
-        pinned_tables[0] = g->rec_start[0];
-        pinned_tables[1] = g->rec_len[0];
-        HIPCHK(hipMemcpyAsync(g->d_rec_start, pinned_tables, 8, hipMemcpyHostToDevice, g->stream));
-        HIPCHK(hipMemcpyAsync(g->d_rec_len, pinned_tables + 1, 8, hipMemcpyHostToDevice, g->stream));
-        const uint64_t nb = (g->next_col + 63) / 64 + 1;
-        HIPCHK(hipMemsetAsync(g->d_block_rec, 0, nb * 4ull, g->stream)); // one record: every block belongs to record 0
-        g->tables_dirty = false;
-    }
-    HIPCHK(hipMemcpyAsync(pinned_flag, g->d_flags, 4, hipMemcpyDeviceToHost, g->stream));
+// chunk path (one record, the scratch's own stream): nothing is copied and nothing waited for -- the pack kernel has
+// written the record's table entries and writes its reset-byte flag into pinned host memory; every block belongs to
+// record 0 (d_block_rec is zeroed once, when the chunk genome is created)
+ipcr_status genome_finalize_async(ipcr_genome *g) {
+    const ipcr_status ps = genome_pad(g);
+    if (ps != IPCR_OK) return ps;
+    g->tables_dirty = false;
     return IPCR_OK;
 }
 
@@ -1346,7 +1350,7 @@ ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g, b
     // chunk path: nothing is waited for before the sweep is enqueued.  Whether the record holds a reset byte is
     // only known afterwards, so it is scanned the way a genome with such records is (rc patterns unprotected,
     // the host applies the 5' window): right for both kinds of record, as in a resident genome that mixes them
-    ipcr_status st = chunk ? genome_finalize_async(g, pinned_seq(s) + 4, reinterpret_cast<uint64_t *>(pinned_seq(s) + 8)) : genome_finalize(g);
+    ipcr_status st = chunk ? genome_finalize_async(g) : genome_finalize(g);
     if (st != IPCR_OK) return st;
     trace("finalized", s);
     s->last_rec_len = g->rec_len;
@@ -1959,9 +1963,12 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         (void)hipStreamDestroy(s->chunk->stream);
         s->chunk->stream = s->stream;
         s->chunk->shared_stream = true;
+        HIPCHK(hipMemsetAsync(s->chunk->d_block_rec, 0, (s->chunk->cap_cols / 64 + 2) * 4ull, s->stream)); // one record: every block is record 0's
     }
     ipcr_genome *g = s->chunk;
-    genome_clear(g);
+    genome_clear(g, true);
+    uint32_t *pinned_flag = pinned_seq(s) + 4; // the pack kernel sets it when the record holds a byte outside ACGTacgt
+    *pinned_flag = 0u;
     if (len + 16 > g->staging_cap) {
         if (g->staging) (void)hipFree(g->staging);
         g->staging = nullptr;
@@ -1997,7 +2004,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
             }
         }
     }
-    st = genome_add_device(g, g->staging, len, false);
+    st = genome_add_device(g, g->staging, len, false, pinned_flag);
     if (st != IPCR_OK) return st;
     st = scan_enqueue(p, s, g, true);
     if (st == IPCR_OK) st = scan_collect(p, s, g);

@@ -95,16 +95,24 @@ __device__ __forceinline__ void pack_pair(const uint8_t *__restrict__ seq, uint6
         *reinterpret_cast<uint4 *>(rst + ipcr_rst_word(block, q * 4u, ln)) = make_uint4(ors[0], ors[1], ors[2], ors[3]);
     }
     const bool saw_rst = (ors[0] | ors[1] | ors[2] | ors[3]) != 0u;
-    if (__ballot(saw_rst) != 0ull && lane == 0u) atomicOr(rec_flags, 1u);
+    // bit 0 is the only bit a record's flag word ever gets: a plain store (idempotent, also right when the word lives
+    // in pinned host memory, where the chunk path keeps it -- no copy operation brings it back)
+    if (__ballot(saw_rst) != 0ull && lane == 0u) __hip_atomic_store(rec_flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ seq, uint64_t len,
                                                    uint64_t col0, uint64_t ncol,
                                                    uint32_t *__restrict__ planes,
                                                    uint32_t *__restrict__ rst,
-                                                   uint32_t *__restrict__ rec_flags) {
+                                                   uint32_t *__restrict__ rec_flags,
+                                                   uint64_t *__restrict__ rec_start_out,
+                                                   uint64_t *__restrict__ rec_len_out) {
     __shared__ uint32_t s_in[4][2048]; // per wave: 2 columns x 32 strands x 32 dwords
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (rec_start_out && blockIdx.x == 0 && threadIdx.x == 0) { // chunk path: the one record's table entries, no copy operation
+        rec_start_out[0] = col0 * IPCR_COLUMN_BASES;
+        rec_len_out[0] = len;
+    }
     const uint64_t pairidx = (uint64_t)blockIdx.x * 4u + wv;
     if (pairidx * 2u >= ncol) return; // waves are independent (no workgroup barrier)
     pack_pair<true>(seq, len, col0, ncol, pairidx, lane, s_in[wv], planes, rst, rec_flags);
@@ -488,11 +496,11 @@ __global__ __launch_bounds__(64) void probe_kernel(const uint8_t *__restrict__ a
 namespace ipcr {
 
 hipError_t launch_pack(hipStream_t st, const uint8_t *seq, uint64_t len, uint64_t col0, uint64_t ncol,
-                       uint32_t *planes, uint32_t *rst, uint32_t *rec_flags) {
+                       uint32_t *planes, uint32_t *rst, uint32_t *rec_flags, uint64_t *rec_start_out, uint64_t *rec_len_out) {
     const uint64_t pairs = (ncol + 1u) / 2u;
     const uint64_t grid = (pairs + 3u) / 4u;
     if (grid == 0) return hipSuccess;
-    pack_kernel<<<dim3((uint32_t)grid), dim3(256), 0, st>>>(seq, len, col0, ncol, planes, rst, rec_flags);
+    pack_kernel<<<dim3((uint32_t)grid), dim3(256), 0, st>>>(seq, len, col0, ncol, planes, rst, rec_flags, rec_start_out, rec_len_out);
     return hipGetLastError();
 }
 
