@@ -435,74 +435,22 @@ def roofline_of(res, traffic_file=None):
 
 
 # ----------------------------------------------------------------------------------------------- other measurements
-def scan_chunk_rates(ctx, record_bases=125_000_000, chunk=4_000_000, overlap=2000):
+def scan_chunk_rates(ctx, record_bases=125_000_000, chunk=4_000_000):
     """Drop-in entry point (what the cgo shim binds): ipcr_scan_chunk on host ASCII under the reference's worker model
     (internal/pipeline/pipeline.go:60-125): W threads, one scratch each, one shared panel, rolling chunks of one
-    record from a queue.  PCIe-inclusive; reported next to the raw pinned H2D rate; never `value`."""
-    import queue
-    import threading
-    torch, engine = ctx.torch, ctx.engine
+    record from a queue.  PCIe-inclusive; reported next to the raw pinned H2D rate; never `value`.  Measured by the
+    native driver ipcr_amd/chunk_workers (csrc/chunk_workers.cpp) in a child process: the call takes ~0.1 ms, and a
+    Python thread pool would add its own per-call interpreter work to it."""
+    import subprocess
+    exe = os.path.join(ROOT, "ipcr_amd", "chunk_workers")
+    if not os.path.exists(exe):
+        raise SystemExit(exe + " is missing: build first (python -c 'import __graft_entry__ as g; g.build()')")
     n = min(record_bases, ctx.args.record_len)
-    buf = torch.empty(n, dtype=torch.uint8, device="cuda")
-    engine.lcg_fill_device(buf.data_ptr(), n, 0x5eed1234)
-    seq = buf.cpu().numpy().tobytes()
-    h = torch.empty(256 << 20, dtype=torch.uint8, pin_memory=True)
-    d = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
-    h2d = 0.0
-    for _ in range(4):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        d.copy_(h, non_blocking=True)
-        torch.cuda.synchronize()
-        h2d = max(h2d, h.numel() / (time.perf_counter() - t0) / 1e9)
-    del buf, h, d
-    spec = workload_spec("c2", engine, ctx.workloads)
-    eng = engine.New(spec["cfg"])
-    cp = eng.CompilePanel(spec["pairs"])
-    view = memoryview(seq)
-    starts = list(range(0, n, chunk - overlap)) if n > chunk else [0]
-    chunks = [bytes(view[s:s + chunk]) for s in starts]   # each job owns its bytes (core/fasta/path_ctx.go:117)
-    out = {"pinned_h2d_GBps": round(h2d, 1), "record_bases": n, "chunk_bases": chunk, "chunks": len(chunks)}
-    for workers in (1, 8):
-        scs = [eng.NewSimulationScratch(cp) for _ in range(workers)]
-        for sc in scs:
-            eng.SimulateCompiledWithScratch("w", chunks[0], cp, sc)
-        best = 0.0
-        reps = max(1, -(-16 * workers // len(chunks)))    # >= 16 chunks per worker in a timed pass: thread start-up must not show
-        for _ in range(3):
-            q = queue.Queue()
-            for _rep in range(reps):
-                for i, c in enumerate(chunks):
-                    q.put((i, c))
-
-            def work(sc):
-                while True:
-                    try:
-                        i, c = q.get_nowait()
-                    except queue.Empty:
-                        return
-                    eng.SimulateCompiledWithScratch("chr1:%d-%d" % (starts[i], starts[i] + len(c)), c, cp, sc)
-
-            ths = [threading.Thread(target=work, args=(sc,)) for sc in scs]
-            t0 = time.perf_counter()
-            for t in ths:
-                t.start()
-            for t in ths:
-                t.join()
-            best = max(best, reps * sum(len(c) for c in chunks) / (time.perf_counter() - t0) / 1e9)
-        out["gbases_per_s_%d_worker%s" % (workers, "" if workers == 1 else "s")] = round(best, 2)
-        for sc in scs:
-            sc.close()
-    sc = eng.NewSimulationScratch(cp)
-    best = 0.0
-    for _ in range(3):
-        t0 = time.perf_counter()
-        eng.SimulateCompiledWithScratch("chr1", seq, cp, sc)
-        best = max(best, n / (time.perf_counter() - t0) / 1e9)
-    out["gbases_per_s_whole_record"] = round(best, 2)
-    sc.close()
-    cp.close()
-    return out
+    r = subprocess.run([exe, str(n), str(chunk), "1", "8", "16"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(ctx.local))))
+    if r.returncode != 0:
+        raise SystemExit("chunk_workers failed (%d): %s" % (r.returncode, r.stderr[-2000:]))
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def fasta_to_tsv(ctx, records=8):

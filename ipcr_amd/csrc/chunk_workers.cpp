@@ -1,0 +1,158 @@
+// chunk_workers -- the drop-in entry point under the reference's worker model, driven from native threads.
+//
+//   chunk_workers [record_bases] [chunk_bases] [workers ...]        (defaults: 125000000 4000000 1 8 16)
+//
+// internal/pipeline/pipeline.go:60-125: CompilePanel once, one scratch per worker, every worker pulls rolling chunks
+// (core/fasta/path_ctx.go:83-179: chunk size, overlap = max product length) of a record from one queue and calls
+// ForEachCompiledProduct = ipcr_scan_chunk on host ASCII.  Prints one JSON line: the pinned H2D rate of the link and
+// the aggregate PCIe-inclusive Gbases/s per worker count.  Workload C2 (benchPrimer pair 0 + self pairs, k=2,
+// 3'-window 5) over a benchDNA record with planted amplicons; the product count of every pass is checked.
+// bench.py runs this binary for config.other_workloads.scan_chunk: a Python thread pool adds its own per-call
+// interpreter work to what is a 0.1 ms call.
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ipcr_hip.h"
+
+static std::string bench_primer(unsigned idx, int n = 20) { // core/engine/performance_benchmark_test.go:78-93
+    unsigned x = 0x9e3779b9u ^ (idx * 0x45d9f3bu);
+    std::string s((size_t)n, 'A');
+    for (int i = 0; i < n; ++i) {
+        x = x * 1103515245u + 12345u + (unsigned)(i * 97);
+        s[(size_t)i] = "ACGT"[(x >> 29) & 3u];
+    }
+    s[0] = "ACGT"[idx & 3u];
+    s[1] = "ACGT"[(idx + 1) & 3u];
+    s[2] = "ACGT"[(idx + 2) & 3u];
+    s[(size_t)n - 1] = "ACGT"[(idx + 3) & 3u];
+    return s;
+}
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char **argv) {
+    const uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 10) : 125000000ull;
+    const uint64_t chunk = argc > 2 ? strtoull(argv[2], nullptr, 10) : 4000000ull;
+    std::vector<int> workers;
+    for (int i = 3; i < argc; ++i) workers.push_back(atoi(argv[i]));
+    if (workers.empty()) workers = {1, 8, 16};
+    const uint64_t overlap = 2000;
+    if (ipcr_device_count() < 1) { fprintf(stderr, "chunk_workers: no HIP device (the scan path has no CPU fallback)\n"); return 2; }
+
+    // the record: benchDNA (performance_benchmark_test.go:67-76) + an amplicon of pair 0 every 1 Mb
+    std::vector<uint8_t> seq(n);
+    unsigned x = 0x5eed1234u;
+    for (uint64_t i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; seq[i] = (uint8_t)"ACGT"[(x >> 30) & 3u]; }
+    const std::string fwd = bench_primer(0), rev = bench_primer(1);
+    std::string rc_rev(rev.size(), 'A');
+    ipcr_revcomp(rev.data(), rev.size(), &rc_rev[0]);
+    uint64_t planted = 0;
+    for (uint64_t a = 500000; a + 180 < n; a += 1000000, ++planted) {
+        memcpy(&seq[a], fwd.data(), 20);
+        memcpy(&seq[a + 160], rc_rev.data(), 20);
+    }
+
+    // the link: pinned host -> device, 256 MiB, best of 4
+    double h2d = 0;
+    {
+        const size_t bytes = 256u << 20;
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess || hipMalloc(&d, bytes) != hipSuccess) return 3;
+        memset(h, 1, bytes);
+        for (int r = 0; r < 4; ++r) {
+            (void)hipDeviceSynchronize();
+            const double t0 = now();
+            (void)hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, nullptr);
+            (void)hipDeviceSynchronize();
+            h2d = std::max(h2d, (double)bytes / (now() - t0) / 1e9);
+        }
+        (void)hipHostFree(h);
+        (void)hipFree(d);
+    }
+
+    // C2 as `ipcr` scans it: pair 0 + its self pairs (internal/common/primers.go:11-37)
+    ipcr_config cfg{};
+    cfg.max_mm = 2; cfg.terminal_window = 5; cfg.max_len = 2000; cfg.hit_cap = 10000; cfg.seed_len = 12;
+    const ipcr_pair pairs[3] = {{"bench_000", fwd.c_str(), rev.c_str(), 128, 212},
+                                {"bench_000+A:self", fwd.c_str(), fwd.c_str(), 128, 212},
+                                {"bench_000+B:self", rev.c_str(), rev.c_str(), 128, 212}};
+    ipcr_panel *panel = nullptr;
+    if (ipcr_panel_create(&cfg, pairs, 3, &panel) != IPCR_OK) { fprintf(stderr, "%s\n", ipcr_last_error()); return 4; }
+
+    std::vector<uint64_t> starts;
+    if (n > chunk) for (uint64_t s = 0; s < n; s += chunk - overlap) { starts.push_back(s); if (s + chunk >= n) break; }
+    else starts.push_back(0);
+    // every job owns a private copy of its bytes, as the FASTA layer hands them out (core/fasta/path_ctx.go:117)
+    std::vector<std::vector<uint8_t>> jobs;
+    for (uint64_t s : starts) jobs.emplace_back(seq.begin() + (long)s, seq.begin() + (long)std::min(n, s + chunk));
+
+    printf("{\"pinned_h2d_GBps\": %.1f, \"record_bases\": %llu, \"chunk_bases\": %llu, \"chunks\": %zu, \"planted\": %llu",
+           h2d, (unsigned long long)n, (unsigned long long)chunk, jobs.size(), (unsigned long long)planted);
+    int rc = 0;
+    for (int W : workers) {
+        std::vector<ipcr_scratch *> scs((size_t)W, nullptr);
+        for (auto &sc : scs)
+            if (ipcr_scratch_create(panel, &sc) != IPCR_OK) { fprintf(stderr, "%s\n", ipcr_last_error()); return 5; }
+        for (auto &sc : scs) (void)ipcr_scan_chunk(panel, sc, jobs[0].data(), jobs[0].size(), nullptr, nullptr); // kernel build, buffers
+        const size_t reps = std::max<size_t>(1, ((size_t)16 * (size_t)W + jobs.size() - 1) / jobs.size()); // >= 16 chunks per worker
+        double best = 0;
+        long long products = -1;
+        for (int pass = 0; pass < 3; ++pass) {
+            std::atomic<size_t> next{0};
+            std::atomic<long long> nprod{0};
+            std::atomic<int> failed{0};
+            const size_t total = reps * jobs.size();
+            auto work = [&](ipcr_scratch *sc) {
+                for (;;) {
+                    const size_t j = next.fetch_add(1);
+                    if (j >= total) break;
+                    const auto &job = jobs[j % jobs.size()];
+                    if (ipcr_scan_chunk(panel, sc, job.data(), job.size(), nullptr, nullptr) != IPCR_OK) { failed.store(1); break; }
+                    const ipcr_product *pr = nullptr;
+                    int64_t np = 0;
+                    (void)ipcr_scratch_products(sc, &pr, &np);
+                    nprod.fetch_add(np);
+                }
+            };
+            std::vector<std::thread> th;
+            const double t0 = now();
+            for (int w = 0; w < W; ++w) th.emplace_back(work, scs[(size_t)w]);
+            for (auto &t : th) t.join();
+            const double dt = now() - t0;
+            if (failed.load()) { fprintf(stderr, "scan failed: %s\n", ipcr_last_error()); rc = 6; }
+            uint64_t bases = 0;
+            for (const auto &j : jobs) bases += j.size();
+            best = std::max(best, (double)(bases * reps) / dt / 1e9);
+            const long long per_pass = nprod.load() / (long long)reps;
+            if (products >= 0 && per_pass != products) { fprintf(stderr, "product count changed between passes\n"); rc = 7; }
+            products = per_pass;
+        }
+        if (products < (long long)planted) { fprintf(stderr, "%lld products for %llu planted amplicons\n", products, (unsigned long long)planted); rc = 8; }
+        printf(", \"gbases_per_s_%d_worker%s\": %.2f", W, W == 1 ? "" : "s", best);
+        if (W == workers.back()) printf(", \"products_per_pass\": %lld", products);
+        for (auto &sc : scs) ipcr_scratch_destroy(sc);
+    }
+    {   // one worker, the whole record in one call
+        ipcr_scratch *sc = nullptr;
+        if (ipcr_scratch_create(panel, &sc) != IPCR_OK) return 5;
+        double best = 0;
+        for (int r = 0; r < 4; ++r) {
+            const double t0 = now();
+            if (ipcr_scan_chunk(panel, sc, seq.data(), n, nullptr, nullptr) != IPCR_OK) { rc = 6; break; }
+            if (r) best = std::max(best, (double)n / (now() - t0) / 1e9);
+        }
+        printf(", \"gbases_per_s_whole_record\": %.2f", best);
+        ipcr_scratch_destroy(sc);
+    }
+    printf("}\n");
+    ipcr_panel_destroy(panel);
+    return rc;
+}
