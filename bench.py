@@ -435,19 +435,21 @@ def roofline_of(res, traffic_file=None):
 
 
 # ----------------------------------------------------------------------------------------------- other measurements
-def scan_chunk_rates(ctx, record_bases=125_000_000, chunk=4_000_000):
+def scan_chunk_rates(args, local=0, record_bases=125_000_000, chunk=4_000_000):
     """Drop-in entry point (what the cgo shim binds): ipcr_scan_chunk on host ASCII under the reference's worker model
     (internal/pipeline/pipeline.go:60-125): W threads, one scratch each, one shared panel, rolling chunks of one
     record from a queue.  PCIe-inclusive; reported next to the raw pinned H2D rate; never `value`.  Measured by the
     native driver ipcr_amd/chunk_workers (csrc/chunk_workers.cpp) in a child process: the call takes ~0.1 ms, and a
-    Python thread pool would add its own per-call interpreter work to it."""
+    Python thread pool would add its own per-call interpreter work to it.  It runs BEFORE this process touches the GPU:
+    next to a second process that holds a context with a dozen hardware queues, 16 workers measured 31 Gbases/s
+    instead of 50."""
     import subprocess
     exe = os.path.join(ROOT, "ipcr_amd", "chunk_workers")
     if not os.path.exists(exe):
         raise SystemExit(exe + " is missing: build first (python -c 'import __graft_entry__ as g; g.build()')")
-    n = min(record_bases, ctx.args.record_len)
+    n = min(record_bases, args.record_len)
     r = subprocess.run([exe, str(n), str(chunk), "1", "8", "16"], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(ctx.local))))
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local))))
     if r.returncode != 0:
         raise SystemExit("chunk_workers failed (%d): %s" % (r.returncode, r.stderr[-2000:]))
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -586,6 +588,10 @@ def main() -> None:
         import subprocess
         raise SystemExit(subprocess.call(cmd, env=dict(os.environ)))
 
+    chunk_rates = None
+    if not args.no_others and "RANK" not in os.environ and args.gpus <= 1 and not os.environ.get("IPCR_EXCHANGE_SELFTEST"):
+        chunk_rates = scan_chunk_rates(args)      # child process, before anything here has initialised HIP
+
     import glob
     import torch
     from ipcr_amd import _lib, dist, engine, workloads, primer
@@ -629,7 +635,8 @@ def main() -> None:
                 if "limiter" in rf:
                     others[nm]["limiter"] = rf["limiter"]
                 r["prods"] = None
-            others["scan_chunk"] = scan_chunk_rates(ctx)
+            if chunk_rates is not None:
+                others["scan_chunk"] = chunk_rates
             others["fasta_to_tsv"] = fasta_to_tsv(ctx)
         elif args.workload != "c4":   # several GPUs: the scaling target north_star names rides along
             r = run_workload(ctx, "c4", 30, 5)
