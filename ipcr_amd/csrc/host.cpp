@@ -1473,6 +1473,9 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             if (!complete) {
                 ++s->stats.handover_refetched;
                 HIPCHK(hipEventSynchronize(s->ev[1]));
+                // a stream of its own (never waits behind a sweep), created on first use: every stream takes a turn in the
+                // runtime's stream -> hardware-queue mapping, and a worker pool should not pay for streams it never uses
+                if (!s->cstream) HIPCHK(hipStreamCreateWithFlags(&s->cstream, hipStreamNonBlocking));
                 HIPCHK(hipMemcpyAsync(raw.data(), s->d_hits, got * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->cstream));
                 HIPCHK(hipStreamSynchronize(s->cstream));
             } else {
@@ -1783,7 +1786,6 @@ ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out) {
             }
         }
         raw->stream = raw->own_lane->s;
-        HIPCHK(hipStreamCreateWithFlags(&raw->cstream, hipStreamNonBlocking));
         for (auto &e : raw->ev) HIPCHK(hipEventCreate(&e));
         raw->qcap = QCAP_INIT;
         raw->hcap = HCAP_INIT;
