@@ -440,16 +440,16 @@ def scan_chunk_rates(args, local=0, record_bases=125_000_000, chunk=4_000_000):
     (internal/pipeline/pipeline.go:60-125): W threads, one scratch each, one shared panel, rolling chunks of one
     record from a queue.  PCIe-inclusive; reported next to the raw pinned H2D rate; never `value`.  Measured by the
     native driver ipcr_amd/chunk_workers (csrc/chunk_workers.cpp) in a child process: the call takes ~0.1 ms, and a
-    Python thread pool would add its own per-call interpreter work to it.  It runs BEFORE this process touches the GPU:
-    next to a second process that holds a context with a dozen hardware queues, 16 workers measured 31 Gbases/s
-    instead of 50."""
+    Python thread pool would add its own per-call interpreter work to it.  It runs BEFORE this process touches the GPU
+    and with GPU_MAX_HW_QUEUES=8: with 16 queues per process a worker pool is fast or slow from run to run."""
     import subprocess
     exe = os.path.join(ROOT, "ipcr_amd", "chunk_workers")
     if not os.path.exists(exe):
         raise SystemExit(exe + " is missing: build first (python -c 'import __graft_entry__ as g; g.build()')")
     n = min(record_bases, args.record_len)
     r = subprocess.run([exe, str(n), str(chunk), "1", "8", "16"], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local))))
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local)),
+                                GPU_MAX_HW_QUEUES=os.environ.get("IPCR_CHUNK_HW_QUEUES", "8")))   # see chunk_workers.cpp
     if r.returncode != 0:
         raise SystemExit("chunk_workers failed (%d): %s" % (r.returncode, r.stderr[-2000:]))
     return json.loads(r.stdout.strip().splitlines()[-1])

@@ -45,9 +45,10 @@ int main(int argc, char **argv) {
     for (int i = 3; i < argc; ++i) workers.push_back(atoi(argv[i]));
     if (workers.empty()) workers = {1, 8, 16};
     const uint64_t overlap = 2000;
-    // one hardware queue per worker stream: HIP maps streams onto GPU_MAX_HW_QUEUES queues (default 4) in creation
-    // order, and workers whose streams share a queue run one after the other (16 workers: 27 instead of 50 Gbases/s)
-    setenv("GPU_MAX_HW_QUEUES", "32", 0);
+    // HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order.  Measured with 8 / 16 / 24
+    // workers, three runs each: 4 queues 44 / 27 / - Gbases/s; 8 queues 44 / 49 / 51, every run; 16 or 32 queues the
+    // same or 28 / 20 from run to run (more queues than the firmware keeps resident).  8 it is.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (ipcr_device_count() < 1) { fprintf(stderr, "chunk_workers: no HIP device (the scan path has no CPU fallback)\n"); return 2; }
 
     // the record: benchDNA (performance_benchmark_test.go:67-76) + an amplicon of pair 0 every 1 Mb
