@@ -297,7 +297,7 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         if (fast && ns > 1) { // the rings (bf slots of 64 bits per delayed shape) must stay in registers, the unrolled body within reason
             const unsigned regs = 2u * (unsigned)((ns - 1) * bf);
             const unsigned unroll = 4u / std::__gcd(4u, (unsigned)bf) * (unsigned)bf;
-            if (unroll > 40 || ring_regs + regs > 48) fast = false;
+            if (unroll > 40 || ring_regs + regs > 40) fast = false; // 40 ring registers: beyond, the kernel spills at four waves per SIMD (k = 3: two groups x 24)
             else ring_regs += regs;
         }
         const size_t ents_before = ents.size();

@@ -443,3 +443,36 @@ def test_pattern_shards_join_to_the_unsharded_result():
             sh.close()
     with pytest.raises(_lib.IpcrError):
         full.set_shard(3, 3)
+
+
+@pytest.mark.parametrize("k,tw,lens,iupac", [(2, 3, (20, 20), False), (1, 5, (18, 25), False), (3, 3, (22, 30), True),
+                                             (2, 0, (20, 24), False), (0, 3, (16, 21), False)])
+def test_seed_index_source_compiles_for_gfx950(k, tw, lens, iupac, tmp_path):
+    """the seed-index kernel is generated per panel (key shapes, delays, ring registers, queue size all baked in): its
+    source for panels of different k / window / primer lengths must compile for gfx950, keep its LDS within the CU's
+    160 KiB and its hot registers within four waves per SIMD (hipcc cross-compiles without a GPU)"""
+    import subprocess
+    rng = random.Random(k * 100 + tw * 10 + lens[0])
+    alphabet = "ACGT"
+    rows = []
+    for i in range(40):
+        def mk():
+            s = [rng.choice(alphabet) for _ in range(rng.randint(*lens))]
+            if iupac and rng.random() < 0.3:
+                s[rng.randrange(3, len(s) - 3)] = rng.choice("RYMK")
+            return "".join(s)
+        rows.append(primer.Pair("r%d" % i, mk(), mk(), 0, 0))
+    cp = engine.New(engine.Config(MaxMM=k, TerminalWindow=tw, MaxLen=2000)).CompilePanel(primer.AddSelfPairsUnique(rows))
+    src = cp.filter_source(2)
+    cp.close()
+    assert "ipcr_index_filter" in src
+    if tw >= 3 and k >= 1:
+        assert re.search(r"u64 x0_1_0 = 0ull;", src), "a panel with >= 3 protected bases must use the delayed-OR evaluation"
+    path = tmp_path / "index.hip"
+    path.write_text(src)
+    asm = subprocess.check_output(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", "-o", "-", str(path)],
+                                  stderr=subprocess.DEVNULL).decode()
+    lds = int(re.search(r"\.group_segment_fixed_size: (\d+)", asm).group(1))
+    vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", asm).group(1))
+    spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", asm).group(1))
+    assert lds <= 160 * 1024 and vgpr <= 128 and spill <= 16, (lds, vgpr, spill)
