@@ -300,7 +300,7 @@ def run_workload(ctx, name, steps, warmup):
         host_sc = engine.SimulationScratch(cp, host_only=True)
         xchg = dist.HitExchanger(device=ctx.cdev)
         eng.ScanGenomeHits(genome, cp, scs[0])      # one synchronous exchange: sizes the buffers on every rank
-        xchg.allgather(dist.hits_from_scratch(scs[0]), nrec)
+        xchg.allgather(dist.hits_from_scratch(scs[0]), nrec, size_hint=int(scs[0].device_hits()[1] * 1.25) + 64)
         xchg.agree_on_device_path(scs[0])           # zero-copy view of the device hit buffer on every rank, or the host copy on all
     expect = None
     for s_ in scs:  # untimed set-up: kernel specialisation (hiprtc) and buffer sizing happen here

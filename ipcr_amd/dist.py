@@ -350,8 +350,11 @@ class HitExchanger:
                 off += nrec
         return np.concatenate(parts), ranges, offsets
 
-    def allgather(self, local: np.ndarray, n_local_records: int):
-        """-> (all hits with job-global record index, per-rank (hit_start, hit_end), record offsets)"""
+    def allgather(self, local: np.ndarray, n_local_records: int, size_hint: int = 0):
+        """-> (all hits with job-global record index, per-rank (hit_start, hit_end), record offsets).
+        size_hint: a count the capacity should also cover on every rank, e.g. the number of records in the
+        scratch's DEVICE hit buffer (the seed-index filter leaves duplicates there that `local` no longer has):
+        the overlapped device form then fits without a redo."""
         assert local.dtype == HIT_DTYPE
         if not self.active:
             return local, [(0, len(local))], [0]
@@ -362,7 +365,7 @@ class HitExchanger:
         while True:
             n = min(len(local), self.cap)
             hs = self.h_send.numpy()
-            hs[:16].view(np.int64)[:] = (len(local), n_local_records)
+            hs[:24].view(np.int64)[:] = (len(local), n_local_records, max(int(size_hint), len(local)))
             if n:
                 hs[32:32 + n * 32] = local[:n].view(np.uint8).reshape(-1)
             if self.d_send is not self.h_send:
@@ -372,8 +375,9 @@ class HitExchanger:
                 self.h_recv.copy_(self.d_recv, non_blocking=True)
                 torch.cuda.current_stream(self.device).synchronize()
             hr = self.h_recv.numpy().reshape(self.world, (self.cap + 1) * 32)
-            meta = hr[:, :16].copy().view(np.int64).reshape(self.world, 2)
-            need = int(meta[:, 0].max())
+            meta3 = hr[:, :24].copy().view(np.int64).reshape(self.world, 3)
+            meta = np.ascontiguousarray(meta3[:, :2])
+            need = int(max(meta3[:, 0].max(), meta3[:, 2].max()))
             self._rec_counts = [int(c) for c in meta[:, 1]]
             if need <= self.cap:
                 break
