@@ -11,6 +11,7 @@
 // (ordering and HitCap rules included) and joins them.
 #include "ipcr_hip.h"
 
+#include <emmintrin.h>
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -790,10 +791,8 @@ ipcr_status genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len,
                     (unsigned long long)g->next_col, (unsigned long long)cols, (unsigned long long)g->cap_cols);
     if ((reinterpret_cast<uintptr_t>(dseq) & 15u) != 0) return fail(IPCR_ERR_INVALID, "device sequence pointer must be 16-byte aligned");
     const uint32_t rec = (uint32_t)g->rec_start.size();
-    HIPCHK(hipEventRecord(g->e0, g->stream));
-    if (ext_flag) HIPCHK(ipcr::launch_pack(g->stream, dseq, len, g->next_col, cols, g->planes, g->rst, ext_flag, g->d_rec_start + rec, g->d_rec_len + rec));
-    else HIPCHK(ipcr::launch_pack(g->stream, dseq, len, g->next_col, cols, g->planes, g->rst, g->d_flags + rec));
-    HIPCHK(hipEventRecord(g->e1, g->stream));
+    if (ext_flag) HIPCHK(ipcr::launch_pack(g->stream, dseq, len, g->next_col, cols, g->planes, g->rst, ext_flag, g->d_rec_start + rec, g->d_rec_len + rec, g->e0, g->e1));
+    else HIPCHK(ipcr::launch_pack(g->stream, dseq, len, g->next_col, cols, g->planes, g->rst, g->d_flags + rec, nullptr, nullptr, g->e0, g->e1));
     if (wait) {
         HIPCHK(hipEventSynchronize(g->e1));
         float ms = 0;
@@ -1944,6 +1943,28 @@ ipcr_status ipcr_join_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_hit 
     return join_sorted_hits(p, s, record_len, record_flags, n_records, emit, user);
 }
 
+// Caller's bytes -> a pinned slice (16-byte aligned) with non-temporal stores: the slice is read next by the DMA engine,
+// not by this core, and a plain memcpy's read-for-ownership of the destination lines costs a third of the memory
+// traffic (measured per 4 MB chunk with 8 threads copying at once: memcpy 0.27 ms, this 0.17 ms).
+static void stream_copy(uint8_t *dst, const uint8_t *src, uint64_t n) {
+    static const bool plain = getenv("IPCR_CHUNK_NTCOPY") && atoi(getenv("IPCR_CHUNK_NTCOPY")) == 0;
+    uint64_t i = 0;
+    if (!plain && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        for (; i + 64 <= n; i += 64) {
+            const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i));
+            const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 16));
+            const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 32));
+            const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 48));
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i), a);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i + 16), b);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i + 32), c);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i + 48), d);
+        }
+        _mm_sfence(); // the DMA descriptor written next must not overtake the streamed lines
+    }
+    if (i < n) memcpy(dst + i, src + i, n - i);
+}
+
 ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t *seq, uint64_t len,
                             ipcr_emit_fn emit, void *user) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -1971,6 +1992,13 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
     genome_clear(g, true);
     uint32_t *pinned_flag = pinned_seq(s) + 4; // the pack kernel sets it when the record holds a byte outside ACGTacgt
     *pinned_flag = 0u;
+    constexpr uint64_t SLICE_MAX = 8ull << 20;
+    // One worker: the runtime's pageable copy (it pins the caller's pages in place) runs at the link rate.  Several
+    // workers calling it at once serialise inside the runtime (8 workers x 4 Mb chunks: 12 Gbases/s in all, a single
+    // worker 22): then every worker stages through its own pinned slices instead.  IPCR_CHUNK_STAGING=0/1 forces.
+    static const int force = getenv("IPCR_CHUNK_STAGING") ? atoi(getenv("IPCR_CHUNK_STAGING")) : -1;
+    const bool staged = force >= 0 ? force != 0 : p->live_scratches->load(std::memory_order_relaxed) > 1;
+    const uint8_t *pack_src = nullptr;
     if (len + 16 > g->staging_cap) {
         if (g->staging) (void)hipFree(g->staging);
         g->staging = nullptr;
@@ -1978,19 +2006,18 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         HIPCHK(hipMalloc((void **)&g->staging, g->staging_cap));
     }
     if (len) {
-        // One worker: the runtime's pageable copy (it pins the caller's pages in place) runs at the link rate.  Several
-        // workers calling it at once serialise inside the runtime (8 workers x 4 Mb chunks: 12 Gbases/s in all, a single
-        // worker 22): then every worker stages through its own pinned slices instead.  IPCR_CHUNK_STAGING=0/1 forces.
-        static const int force = getenv("IPCR_CHUNK_STAGING") ? atoi(getenv("IPCR_CHUNK_STAGING")) : -1;
-        const bool staged = force >= 0 ? force != 0 : p->live_scratches->load(std::memory_order_relaxed) > 1;
+        pack_src = g->staging;
         if (!staged) {
             HIPCHK(hipMemcpyAsync(g->staging, seq, len, hipMemcpyHostToDevice, g->stream));
         } else {
-            constexpr uint64_t SLICE_MAX = 8ull << 20;
             static const uint64_t slice_env = getenv("IPCR_CHUNK_SLICE") ? strtoull(getenv("IPCR_CHUNK_SLICE"), nullptr, 10) : 0;
-            // 8 MiB slices: a 4 Mb chunk is one CPU copy + one DMA (finer slices were measured slower: 0.5 MiB 37.6,
-            // 1 MiB 42.7, 2 MiB 44.6, whole chunk 44.7 Gbases/s for 8 workers); a whole chromosome is double-buffered
-            const uint64_t SLICE = slice_env ? std::min<uint64_t>(std::max<uint64_t>(slice_env, 65536), SLICE_MAX) : SLICE_MAX;
+            // A chunk of up to 8 MiB goes in two halves: the DMA of the first runs under the CPU copy of the second, and
+            // two slices need no marker between them (8 workers x 4 Mb chunks: one slice 49.0, two 50.6, four 49.3
+            // Gbases/s; every further operation on the stream costs its own dispatch latency).  Anything larger -- a
+            // whole chromosome -- is double-buffered in 8 MiB slices.
+            const uint64_t halves = ((len + 1) / 2 + 4095) & ~4095ull;
+            const uint64_t SLICE = slice_env ? std::min<uint64_t>(std::max<uint64_t>(slice_env, 65536), SLICE_MAX)
+                                             : (len <= SLICE_MAX ? std::max<uint64_t>(halves, 65536) : SLICE_MAX);
             for (int h = 0; h < 2; ++h) {
                 if (!s->h_stage[h]) HIPCHK(hipHostMalloc((void **)&s->h_stage[h], SLICE_MAX, hipHostMallocDefault));
                 if (!s->ev_stage[h]) HIPCHK(hipEventCreateWithFlags(&s->ev_stage[h], hipEventDisableTiming));
@@ -2000,13 +2027,13 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
                 const int h = (int)(i & 1u);
                 const uint64_t n = std::min<uint64_t>(SLICE, len - off);
                 if (i >= 2) HIPCHK(hipEventSynchronize(s->ev_stage[h])); // the DMA that read this slice has finished
-                memcpy(s->h_stage[h], seq + off, n);
+                stream_copy(s->h_stage[h], seq + off, n);
                 HIPCHK(hipMemcpyAsync(g->staging + off, s->h_stage[h], n, hipMemcpyHostToDevice, g->stream));
-                HIPCHK(hipEventRecord(s->ev_stage[h], g->stream));
+                if (off + 2 * SLICE < len) HIPCHK(hipEventRecord(s->ev_stage[h], g->stream)); // slice i + 2 will wait for it; a chunk of one or two slices needs no marker
             }
         }
     }
-    st = genome_add_device(g, g->staging, len, false, pinned_flag);
+    st = genome_add_device(g, pack_src, len, false, pinned_flag);
     if (st != IPCR_OK) return st;
     st = scan_enqueue(p, s, g, true);
     if (st == IPCR_OK) st = scan_collect(p, s, g);

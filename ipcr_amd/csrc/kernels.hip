@@ -496,11 +496,14 @@ __global__ __launch_bounds__(64) void probe_kernel(const uint8_t *__restrict__ a
 namespace ipcr {
 
 hipError_t launch_pack(hipStream_t st, const uint8_t *seq, uint64_t len, uint64_t col0, uint64_t ncol,
-                       uint32_t *planes, uint32_t *rst, uint32_t *rec_flags, uint64_t *rec_start_out, uint64_t *rec_len_out) {
+                       uint32_t *planes, uint32_t *rst, uint32_t *rec_flags, uint64_t *rec_start_out, uint64_t *rec_len_out,
+                       hipEvent_t start, hipEvent_t stop) {
     const uint64_t pairs = (ncol + 1u) / 2u;
     const uint64_t grid = (pairs + 3u) / 4u;
     if (grid == 0) return hipSuccess;
-    pack_kernel<<<dim3((uint32_t)grid), dim3(256), 0, st>>>(seq, len, col0, ncol, planes, rst, rec_flags, rec_start_out, rec_len_out);
+    // start / stop ride on the dispatch itself (its begin and end timestamps): no marker packets around the kernel
+    hipExtLaunchKernelGGL(pack_kernel, dim3((uint32_t)grid), dim3(256), 0, st, start, stop, 0,
+                          seq, len, col0, ncol, planes, rst, rec_flags, rec_start_out, rec_len_out);
     return hipGetLastError();
 }
 

@@ -8,7 +8,8 @@
 namespace ipcr {
 hipError_t launch_pack(hipStream_t st, const uint8_t *seq, uint64_t len, uint64_t col0, uint64_t ncol,
                        uint32_t *planes, uint32_t *rst, uint32_t *rec_flags, uint64_t *rec_start_out = nullptr,
-                       uint64_t *rec_len_out = nullptr); // rec_*_out: the kernel also writes the record's table entries (chunk path)
+                       uint64_t *rec_len_out = nullptr, // rec_*_out: the kernel also writes the record's table entries (chunk path)
+                       hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t launch_pack_batch(hipStream_t st, const uint8_t *base, const ipcr_pack_rec *recs, const uint32_t *pair_prefix,
                              uint32_t nrec, uint64_t total_pairs, uint32_t *planes, uint32_t *rst, uint32_t *rec_flags);
 hipError_t launch_fill_pad(hipStream_t st, uint32_t *planes, uint32_t *rst, uint64_t col_begin, uint64_t col_end);
