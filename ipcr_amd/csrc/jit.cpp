@@ -1092,45 +1092,62 @@ __device__ __forceinline__ void check_chain(u32 idx, u64 km, u32 bad, int erow, 
          "  const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);\n"
          "  for (u64 cp = wave0; cp < ncolpairs; cp += nwaves) {\n";
     // ---- drain of the hit queue: 64 hits per round, one per lane.  First every lane probes the bitmaps of all shapes
-    // of its hit's groups (the base step only knew "some shape of the group"); then ONE convergent round ranks the
+    // of its hit's groups (the base step only knew "some shape of the group"); then ONE convergent step ranks the
     // key, loads the entry and checks the pattern -- the shape is a run-time value there (constants from LDS), so that
     // lanes whose hits belong to different shapes share one trip to the entry table.  A key that is filed under a
-    // second shape as well costs another round (rare).
+    // second shape as well (one hit in ten) does not hold the other 63 lanes for another trip: the lane hands the
+    // rest of its shapes back as a new entry (bit 31 of `where`: the shape bits are already known), written over
+    // slots this drain has consumed, and the next generation of rounds takes those at full occupancy again.
     s << "    auto flush = [&]() __attribute__((always_inline)) {\n"
-         "      for (u32 qb = 0; qb < qn; qb += 64u) {\n"
-         "        const u32 i = qb + lane;\n"
-         "        u64 hkm = 0ull; u32 hbad = 0u, where = 0u, pend = 0u;\n"
-         "        if (i < qn) {\n"
-         "          const v4 e = *reinterpret_cast<const v4*>(wq + i * 4u);\n"
-         "          hkm = ((u64)e.y << 32) | e.x; hbad = e.z; where = e.w;\n"
-         "          const u32 gm = where >> 14;\n";
+         "      u32 n = qn;\n"
+         "      while (n != 0u) {\n"
+         "        u32 nc = 0u; // entries handed back so far: slots [0, nc), always behind the round being read\n"
+         "        for (u32 qb = 0; qb < n; qb += 64u) {\n"
+         "          const u32 i = qb + lane;\n"
+         "          u64 hkm = 0ull; u32 hbad = 0u, where = 0u, pend = 0u;\n"
+         "          if (i < n) {\n"
+         "            const v4 e = *reinterpret_cast<const v4*>(wq + i * 4u);\n"
+         "            hkm = ((u64)e.y << 32) | e.x; hbad = e.z; where = e.w;\n"
+         "            const u32 gm = (where >> 14) & 0xFFFFu;\n"
+         "            if (where & 0x80000000u) pend = gm;\n"
+         "            else {\n";
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const Grp &g = groups[gi];
         if (g.sh.empty()) continue;
-        s << "          if (gm & " << (1u << gi) << "u) {\n";
+        s << "              if (gm & " << (1u << gi) << "u) {\n";
         if (g.fast) { // key = six common bits + the shape's word index: one shift serves all shapes of the group
-            s << "            const u32 c = (u32)(hkm >> " << g.c_off << "u) & 63u;\n";
+            s << "                const u32 c = (u32)(hkm >> " << g.c_off << "u) & 63u;\n";
             for (int si : g.sh) {
                 const ipcr_index_shape &sh = shapes[(size_t)si];
                 const unsigned off = g.sh.size() == 1 ? (unsigned)g.v_off : (unsigned)sh.blk_shift;
                 const unsigned vmask = g.v_bits > 0 ? ((1u << g.v_bits) - 1u) : 0u;
-                s << "            pend |= ((u32)(T64[" << si * 1024 << "u + ((u32)(hkm >> " << off << "u) & " << vmask << "u)] >> c) & 1u) << " << si << ";\n";
+                s << "                pend |= ((u32)(T64[" << si * 1024 << "u + ((u32)(hkm >> " << off << "u) & " << vmask << "u)] >> c) & 1u) << " << si << ";\n";
             }
         } else {
             for (int si : g.sh)
-                s << "            { const u32 key = key_of<" << si << ">::get(hkm); pend |= ((u32)(T64[" << si * 1024 << "u + (key >> 6)] >> (key & 63u)) & 1u) << " << si << "; }\n";
+                s << "                { const u32 key = key_of<" << si << ">::get(hkm); pend |= ((u32)(T64[" << si * 1024 << "u + (key >> 6)] >> (key & 63u)) & 1u) << " << si << "; }\n";
         }
-        s << "          }\n";
+        s << "              }\n";
     }
-    s << "        }\n"
-         "        const u32 ol = where & 63u;\n"
-         "        const int erow = (int)((where >> 6) & 0xFFu);\n"
-         "        const u64 strand_base = ((((cp * 2u + (ol >> 5)) << 5) + (ol & 31u)) << 7);\n"
-         "        const u32 shard = (u32)cp & 255u;\n"
-         "        while (__ballot(pend != 0u) != 0ull) {\n"
+    s << "            }\n"
+         "          }\n"
+         "          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // every lane has read its slot: slots up to qb + 63 may be rewritten\n"
+         "          const u32 rest = pend & (pend - 1u);\n"
+         "          const u64 rb = __ballot(rest != 0u);\n"
+         "          if (rb != 0ull) {\n"
+         "            if (rest != 0u) {\n"
+         "              const u32 slot = nc + __builtin_amdgcn_mbcnt_hi((u32)(rb >> 32), __builtin_amdgcn_mbcnt_lo((u32)rb, 0u));\n"
+         "              v4 e; e.x = (u32)hkm; e.y = (u32)(hkm >> 32); e.z = hbad; e.w = (where & 0x3FFFu) | (rest << 14) | 0x80000000u;\n"
+         "              *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
+         "            }\n"
+         "            nc += (u32)__popcll(rb);\n"
+         "          }\n"
          "          if (pend != 0u) {\n"
+         "            const u32 ol = where & 63u;\n"
+         "            const int erow = (int)((where >> 6) & 0xFFu);\n"
+         "            const u64 strand_base = ((((cp * 2u + (ol >> 5)) << 5) + (ol & 31u)) << 7);\n"
+         "            const u32 shard = (u32)cp & 255u;\n"
          "            const u32 sidx = (u32)__builtin_ctz(pend);\n"
-         "            pend &= pend - 1u;\n"
          "            const u32 c0 = lds[SHAPE_WORD0 + 2u * sidx], c1 = lds[SHAPE_WORD0 + 2u * sidx + 1u];\n"
          "            const u32 key = ((u32)(hkm >> (c0 & 63u)) & (c1 & 0xFFFFu)) | (((u32)(hkm >> ((c0 >> 8) & 63u)) & (c1 >> 16)) << ((c0 >> 16) & 31u));\n"
          "            const u64 w = T64[sidx * 1024u + (key >> 6)];\n"
@@ -1139,6 +1156,8 @@ __device__ __forceinline__ void check_chain(u32 idx, u64 km, u32 bad, int erow, 
          "            check_chain(rank, hkm, hbad, erow, strand_base, (c0 >> 24) & 1u, c0 >> 25, shard, table, max_mm, queue, qcap, qcount);\n"
          "          }\n"
          "        }\n"
+         "        n = nc;\n"
+         "        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // the entries handed back are read by other lanes next\n"
          "      }\n"
          "      qn = 0;\n"
          "      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // queue slots are rewritten by other lanes next\n"
