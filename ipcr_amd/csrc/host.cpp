@@ -184,6 +184,8 @@ struct IndexPlan {
         g.tail_rows = std::max(max_right - 1, dl);
         g.all_acgt = all_acgt;
         g.uniform_len = uniform_len;
+        g.dl = dl;
+        g.chain_carry = table.size() < (1u << 17);
         return g;
     }
     std::vector<ipcr_index_shape> shapes;

@@ -1010,6 +1010,8 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
     for (const ipcr_index_shape &x : shapes)
         if (x.left && (int)x.dl != geom.uniform_len - 1) aligned = false;
     s << "#define WINDOW_AT_NEWEST " << (aligned ? "true" : "false") << "\n";
+    s << "#define DL " << geom.dl << "u // left-anchored windows are tested DL bases after their start\n";
+    s << "#define CHAIN_CARRY " << (geom.chain_carry ? "true" : "false") << " // further patterns of a key are handed back to the queue (entry index in 17 bits)\n";
     auto arr = [&](const char *type, const char *name, auto get) {
         s << "__device__ constexpr " << type << " " << name << "[NS] = {";
         for (size_t i = 0; i < NS; ++i) s << (i ? ", " : "") << get(shapes[i]);
@@ -1042,39 +1044,40 @@ __device__ __forceinline__ u64 spread2(u32 v) {
   x = (x | (x << 1)) & 0x5555555555555555ull;
   return x;
 }
-// exact check of the patterns filed under one key (entry `idx` and its chain) against the k-mer of a hit.
+// exact check of ONE pattern filed under a key (entry `idx`) against the k-mer of a hit; returns the entry of the
+// next pattern with the same key (0xFFFFFFFF: none).
 // Entry (device_types.h: ipcr_index_entry): {next, pattern, seq2 | prot2, len, flags | okA, okC | okG, okT}
-__device__ __forceinline__ void check_chain(u32 idx, u64 km, u32 bad, int erow, u64 strand_base, u32 left, u32 dl,
+__device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u64 pair_base, u32 strand_off,
     u32 shard, const v4* __restrict__ table, u32 max_mm, qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {
-  while (idx != 0xFFFFFFFFu) {
-    const v4 e0 = table[idx * 4u], e1 = table[idx * 4u + 1u];
-    const u64 seq2 = ((u64)e0.w << 32) | e0.z, prot2 = ((u64)e1.y << 32) | e1.x;
-    const u32 L = ULEN ? ULEN : e1.z;                 // one length for the whole panel: every shift and mask below is a constant
-    const u32 sft = WINDOW_AT_NEWEST ? 0u : (left ? 2u * (dl + 1u - L) : 0u); // the window's last base sits sft / 2 bases behind the newest
-    const u64 x = km >> sft;
-    const u64 E = 0x5555555555555555ull;
-    const u64 wmE = ((L >= 32u) ? ~0ull : ((1ull << (2u * L)) - 1ull)) & E;
-    u64 mm2;
-    if (ALL_ACGT || (e1.w & 2u)) {                     // one base per position: XOR against the primer's 2-bit codes
-      const u64 d = x ^ seq2;
-      mm2 = (d | (d >> 1)) & wmE;
-    } else {                                           // IUPAC codes: four sets of allowed positions
-      const v4 e2 = table[idx * 4u + 2u], e3 = table[idx * 4u + 3u];
-      const u64 okA = ((u64)e2.y << 32) | e2.x, okC = ((u64)e2.w << 32) | e2.z;
-      const u64 okG = ((u64)e3.y << 32) | e3.x, okT = ((u64)e3.w << 32) | e3.z;
-      const u64 lo = x & E, hi = (x >> 1) & E;
-      const u64 match = (~lo & ~hi & okA) | (lo & ~hi & okC) | (~lo & hi & okG) | (lo & hi & okT);
-      mm2 = ~match & wmE;
-    }
-    const u32 bw = (bad >> (sft >> 1)) & ((L >= 32u) ? 0xFFFFFFFFu : ((1u << L) - 1u));
-    if (bw) mm2 |= spread2(bw);                        // rare: the window holds an invalid base
-    const int srow = left ? erow - (int)dl : erow - (int)L + 1;
-    if ((mm2 & prot2) == 0ull && (u32)__popcll(mm2) <= max_mm && srow >= 0 && srow < 128) {
-      const u64 qi = atomicAdd(qcount + shard * 16u, 1ull);
-      if (qi < qcap) { qent qe; qe.key = ((u64)e0.y << 48) | (strand_base + (u64)srow); qe.bits = 1u; qe.pad = 0u; queue[(u64)shard * qcap + qi] = qe; }
-    }
-    idx = e0.x; // further pattern with the same key (rare)
+  const v4 e0 = table[idx * 4u], e1 = table[idx * 4u + 1u];
+  const u64 seq2 = ((u64)e0.w << 32) | e0.z, prot2 = ((u64)e1.y << 32) | e1.x;
+  const u32 left = e1.w & 1u;
+  const u32 L = ULEN ? ULEN : e1.z;                 // one length for the whole panel: every shift and mask below is a constant
+  const u32 sft = WINDOW_AT_NEWEST ? 0u : (left ? 2u * (DL + 1u - L) : 0u); // the window's last base sits sft / 2 bases behind the newest
+  const u64 x = km >> sft;
+  const u64 E = 0x5555555555555555ull;
+  const u64 wmE = ((L >= 32u) ? ~0ull : ((1ull << (2u * L)) - 1ull)) & E;
+  u64 mm2;
+  if (ALL_ACGT || (e1.w & 2u)) {                     // one base per position: XOR against the primer's 2-bit codes
+    const u64 d = x ^ seq2;
+    mm2 = (d | (d >> 1)) & wmE;
+  } else {                                           // IUPAC codes: four sets of allowed positions
+    const v4 e2 = table[idx * 4u + 2u], e3 = table[idx * 4u + 3u];
+    const u64 okA = ((u64)e2.y << 32) | e2.x, okC = ((u64)e2.w << 32) | e2.z;
+    const u64 okG = ((u64)e3.y << 32) | e3.x, okT = ((u64)e3.w << 32) | e3.z;
+    const u64 lo = x & E, hi = (x >> 1) & E;
+    const u64 match = (~lo & ~hi & okA) | (lo & ~hi & okC) | (~lo & hi & okG) | (lo & hi & okT);
+    mm2 = ~match & wmE;
   }
+  const u32 bw = (bad >> (sft >> 1)) & ((L >= 32u) ? 0xFFFFFFFFu : ((1u << L) - 1u));
+  if (bw) mm2 |= spread2(bw);                        // rare: the window holds an invalid base
+  const int srow = left ? erow - (int)DL : erow - (int)L + 1;
+  if ((mm2 & prot2) == 0ull && (u32)__popcll(mm2) <= max_mm && srow >= 0 && srow < 128) {
+    const u64 qi = atomicAdd(qcount + shard * 16u, 1ull);
+    // position = (column pair * 64 + strand) * 128 + row: a scalar 64-bit base plus one 32-bit lane offset
+    if (qi < qcap) { qent qe; qe.key = ((u64)e0.y << 48) | (pair_base + (u64)(strand_off + (u32)srow)); qe.bits = 1u; qe.pad = 0u; queue[(u64)shard * qcap + qi] = qe; }
+  }
+  return e0.x;
 }
 )SRC";
     s << "extern \"C\" __global__ void __launch_bounds__(" << IPCR_INDEX_WAVES * 64u << ", " << IPCR_INDEX_WAVES / 4u << ") ipcr_index_filter(const u32* __restrict__ planes, u64 ncolpairs,\n"
@@ -1094,22 +1097,38 @@ __device__ __forceinline__ void check_chain(u32 idx, u64 km, u32 bad, int erow, 
     // ---- drain of the hit queue: 64 hits per round, one per lane.  First every lane probes the bitmaps of all shapes
     // of its hit's groups (the base step only knew "some shape of the group"); then ONE convergent step ranks the
     // key, loads the entry and checks the pattern -- the shape is a run-time value there (constants from LDS), so that
-    // lanes whose hits belong to different shapes share one trip to the entry table.  A key that is filed under a
-    // second shape as well (one hit in ten) does not hold the other 63 lanes for another trip: the lane hands the
-    // rest of its shapes back as a new entry (bit 31 of `where`: the shape bits are already known), written over
-    // slots this drain has consumed, and the next generation of rounds takes those at full occupancy again.
+    // lanes whose hits belong to different shapes share one trip to the entry table.  A lane never holds the other 63
+    // for a second trip: a key filed under a further shape as well (one hit in ten), or a further pattern filed under
+    // the same key (3 % of the keys of a 4096-pattern panel -- but some lane of nearly every round), goes back into
+    // the queue as a new entry, written over slots this drain has consumed, and the next generation of rounds takes
+    // those at full occupancy again.  `where` of such an entry: bit 31 = bits 14..30 are the entry index to check;
+    // else bit 30 = bits 14..29 are the shape bits (already probed).
     s << "    auto flush = [&]() __attribute__((always_inline)) {\n"
          "      u32 n = qn;\n"
+         "      const u64 pair_base = cp << 13; // first position of this column pair\n"
+         "      const u32 shard = (u32)cp & 255u;\n"
          "      while (n != 0u) {\n"
          "        u32 nc = 0u; // entries handed back so far: slots [0, nc), always behind the round being read\n"
+         "        auto hand_back = [&](bool mine, u64 hkm, u32 hbad, u32 w) __attribute__((always_inline)) {\n"
+         "          const u64 rb = __ballot(mine);\n"
+         "          if (rb != 0ull) {\n"
+         "            if (mine) {\n"
+         "              const u32 slot = nc + __builtin_amdgcn_mbcnt_hi((u32)(rb >> 32), __builtin_amdgcn_mbcnt_lo((u32)rb, 0u));\n"
+         "              v4 e; e.x = (u32)hkm; e.y = (u32)(hkm >> 32); e.z = hbad; e.w = w;\n"
+         "              *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
+         "            }\n"
+         "            nc += (u32)__popcll(rb);\n"
+         "          }\n"
+         "        };\n"
          "        for (u32 qb = 0; qb < n; qb += 64u) {\n"
          "          const u32 i = qb + lane;\n"
-         "          u64 hkm = 0ull; u32 hbad = 0u, where = 0u, pend = 0u;\n"
+         "          u64 hkm = 0ull; u32 hbad = 0u, where = 0u, pend = 0u, idx = 0xFFFFFFFFu;\n"
          "          if (i < n) {\n"
          "            const v4 e = *reinterpret_cast<const v4*>(wq + i * 4u);\n"
          "            hkm = ((u64)e.y << 32) | e.x; hbad = e.z; where = e.w;\n"
          "            const u32 gm = (where >> 14) & 0xFFFFu;\n"
-         "            if (where & 0x80000000u) pend = gm;\n"
+         "            if (where & 0x80000000u) idx = (where >> 14) & 0x1FFFFu;\n"
+         "            else if (where & 0x40000000u) pend = gm;\n"
          "            else {\n";
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const Grp &g = groups[gi];
@@ -1133,28 +1152,26 @@ __device__ __forceinline__ void check_chain(u32 idx, u64 km, u32 bad, int erow, 
          "          }\n"
          "          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // every lane has read its slot: slots up to qb + 63 may be rewritten\n"
          "          const u32 rest = pend & (pend - 1u);\n"
-         "          const u64 rb = __ballot(rest != 0u);\n"
-         "          if (rb != 0ull) {\n"
-         "            if (rest != 0u) {\n"
-         "              const u32 slot = nc + __builtin_amdgcn_mbcnt_hi((u32)(rb >> 32), __builtin_amdgcn_mbcnt_lo((u32)rb, 0u));\n"
-         "              v4 e; e.x = (u32)hkm; e.y = (u32)(hkm >> 32); e.z = hbad; e.w = (where & 0x3FFFu) | (rest << 14) | 0x80000000u;\n"
-         "              *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
-         "            }\n"
-         "            nc += (u32)__popcll(rb);\n"
-         "          }\n"
+         "          hand_back(rest != 0u, hkm, hbad, (where & 0x3FFFu) | (rest << 14) | 0x40000000u);\n"
          "          if (pend != 0u) {\n"
-         "            const u32 ol = where & 63u;\n"
-         "            const int erow = (int)((where >> 6) & 0xFFu);\n"
-         "            const u64 strand_base = ((((cp * 2u + (ol >> 5)) << 5) + (ol & 31u)) << 7);\n"
-         "            const u32 shard = (u32)cp & 255u;\n"
          "            const u32 sidx = (u32)__builtin_ctz(pend);\n"
          "            const u32 c0 = lds[SHAPE_WORD0 + 2u * sidx], c1 = lds[SHAPE_WORD0 + 2u * sidx + 1u];\n"
          "            const u32 key = ((u32)(hkm >> (c0 & 63u)) & (c1 & 0xFFFFu)) | (((u32)(hkm >> ((c0 >> 8) & 63u)) & (c1 >> 16)) << ((c0 >> 16) & 31u));\n"
          "            const u64 w = T64[sidx * 1024u + (key >> 6)];\n"
          "            // the key is in the panel; its rank among the shape's keys is the index of its entry\n"
-         "            const u32 rank = lds[BASE_WORD0 + sidx] + (u32)prefix[sidx * 1024u + (key >> 6)] + (u32)__popcll((w << (63u - (key & 63u))) << 1);\n"
-         "            check_chain(rank, hkm, hbad, erow, strand_base, (c0 >> 24) & 1u, c0 >> 25, shard, table, max_mm, queue, qcap, qcount);\n"
+         "            idx = lds[BASE_WORD0 + sidx] + (u32)prefix[sidx * 1024u + (key >> 6)] + (u32)__popcll((w << (63u - (key & 63u))) << 1);\n"
          "          }\n"
+         "          u32 next = 0xFFFFFFFFu;\n"
+         "          if (idx != 0xFFFFFFFFu) {\n"
+         "            const u32 strand_off = (where & 63u) << 7;\n"
+         "            const int erow = (int)((where >> 6) & 0xFFu);\n"
+         "            next = check_entry(idx, hkm, hbad, erow, pair_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
+         "            // a lane hands back at most ONE entry per round (so that slots [0, qb + 64) always hold them): one that\n"
+         "            // has done so for its shapes, or whose entry indices do not fit a queue entry, walks the chain here\n"
+         "            if (!CHAIN_CARRY || rest != 0u)\n"
+         "              while (next != 0xFFFFFFFFu) next = check_entry(next, hkm, hbad, erow, pair_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
+         "          }\n"
+         "          if (CHAIN_CARRY) hand_back(next != 0xFFFFFFFFu, hkm, hbad, (where & 0x3FFFu) | (next << 14) | 0x80000000u);\n"
          "        }\n"
          "        n = nc;\n"
          "        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // the entries handed back are read by other lanes next\n"

@@ -58,6 +58,8 @@ struct IndexGeom {
     int tail_rows = 0;     // rows of the following strand a window that starts in this one can reach
     bool all_acgt = false; // no indexed pattern holds an IUPAC code (the exact check then needs half an entry)
     int uniform_len = 0;   // every indexed pattern has this length (0: mixed); shifts and masks of the check become constants
+    int dl = 0;            // left-anchored windows are tested dl bases after their start (one value for the panel)
+    bool chain_carry = true; // entry indices fit the 17 bits a queue entry has for them: chained patterns of a key go back into the queue
 };
 std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom);
 JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom, std::string &err);
