@@ -714,6 +714,40 @@ def test_index_large_iupac_panel(hip):
     g.close()
 
 
+def test_index_drain_under_chains_and_crowded_rounds(hip, force_index):
+    """worst case for the seed-index drain: three families of 16 primers that differ only in two bases of one block
+    (every key of the other blocks is shared by the whole family: entry chains of 16; an exact site is filed under
+    all three shapes, and with k = 2 every site matches all 16 members) on a sequence
+    of period 128 = one strand, so that all 64 lanes of a wave hit in the same base step and every lane hands entries
+    back to the queue in every round; HitCap 0 keeps every match.  vs the oracle"""
+    rng = random.Random(77)
+    E, P = hip.engine, hip.primer.Pair
+    left, right = "ACGTTGCA", "GGATCCTAAC"          # 8 + 2 + 10 = 20 nt; the last 3 bases are protected at k = 2
+    fam = [left + a + b + right for a in "ACGT" for b in "ACGT"]
+    mids = [x[8:10] for x in fam]
+    rev = "TTGACCGTAGGCATTCAGGA"
+    pairs = [P("f%02d" % i, f, rev, 0, 0) for i, f in enumerate(fam)]
+    # two more families: the middle bases sit in another block, so other shapes carry the chains
+    for j, (l2, r2) in enumerate([("CATG", "ACCGTTAGCATCGG"), ("TGCATGCATGCAAT", "GTCA")]):
+        pairs += [P("g%d_%02d" % (j, i), l2 + m + r2, rev, 0, 0) for i, m in enumerate(mids)]
+    unit = list("".join(rng.choice("ACGT") for _ in range(128)))
+    unit[10:30] = fam[5]
+    unit[40:60] = list(pairs[20].Forward)
+    unit[70:90] = list(pairs[40].Forward)
+    rc = O.revcomp(rev.encode()).decode()
+    unit[100:120] = rc
+    seq = ("".join(unit) * 600).encode()            # 76 800 bases: 600 strands, each with the same sites
+    cfg = E.Config(MaxMM=2, TerminalWindow=3, MinLen=0, MaxLen=120, HitCap=0, SeedLen=12)
+    eng = E.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    sc = eng.NewSimulationScratch(cp)
+    got = eng.SimulateCompiledWithScratch("seq", seq, cp, sc)
+    assert sc.stats().kernel_kind == 3
+    want = O.simulate_batch(ocfg(cfg), seq, opairs(pairs))
+    assert len(want) >= 600 * 16 * 3
+    assert [g.sig() for g in got] == [w.sig() for w in want]
+
+
 def test_need_sites(hip):  # core/engine/engine.go:175-183 (FwdSite / RevSite for pretty text)
     E, P = hip.engine, hip.primer.Pair
     seq = b"TTTTCGTACAAAAGGTACCTTT"
