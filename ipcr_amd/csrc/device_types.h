@@ -52,25 +52,35 @@ struct ipcr_probe_rec { // layout-identical to ipcr_probe_hit
 // are tested when their window ENDS at the newest base; left-anchored groups (rc orientations) when
 // their window STARTED `dl` bases ago, dl = longest left pattern - 1, so that the whole window is
 // already in the k-mer.
-//   key = ((kmer >> tw_shift) & tw_mask) | (((kmer >> blk_shift) & blk_mask) << tw_bits)      (<= 16 bits)
-// A shape's keys are a 64-Kbit bitmap in LDS, addressed as 1024 64-bit words: word key >> 6, bit
-// key & 63.  In a FAST group the low six key bits (three protected bases next to the anchor) are
-// common to all its shapes and the word index of shape j is the same k-mer field `delay` steps
-// earlier: one index per base step fetches the words of all shapes, words wait in a register
-// ring for their delay, and ONE bit test of their OR answers "some shape of the group hits".
+//   key = ((kmer >> tw_shift) & tw_mask) | (((kmer >> blk_shift) & blk_mask) << tw_bits)      (<= 17 bits)
+// A shape's keys are a bitmap in LDS, addressed as 64-bit words: word key >> 6, bit key & 63 (2^(key bits - 6)
+// words, at least 16; the shapes' bitmaps lie one after the other: ipcr_index_words64).  Every shape is looked
+// up at the base step that completes its window -- all its fields are in the 32-base k-mer register by then.
+// In a FAST group the low six key bits (three protected bases next to the anchor) are common to all its
+// shapes: they are extracted once per step and select the bit, the shape's block field selects the word.
+// A block field is a run of bits, not of bases: with a spare base next to a five-base block the key takes one
+// bit of it too (11 block bits, half the false hits); no base ever feeds two blocks, which is all the
+// pigeonhole argument needs.
 struct ipcr_index_shape {
     uint8_t left;       // 1: anchored at the window start (rc orientations), 0: at its end
     uint8_t tw_shift;   // k-mer bit offset of the protected part
     uint8_t blk_shift;  // k-mer bit offset of the block part
     uint8_t tw_bits;    // 2 * bases of the protected part used in the key
     uint32_t tw_mask;   // (1 << tw_bits) - 1
-    uint32_t blk_mask;  // (1 << 2*b) - 1
+    uint32_t blk_mask;  // (1 << block bits) - 1
     uint8_t group;      // shapes of one (anchored end, protected length) share a group
-    uint8_t delay;      // fast groups: base steps between fetching this shape's word and testing it
-    uint8_t fast;       // group evaluated by the delayed-OR scheme (else one probe per shape)
+    uint8_t reserved0;
+    uint8_t fast;       // the group's shapes share their low six key bits (else the whole key is computed per shape)
     uint8_t dl;         // left shapes: the window start lies dl bases behind the newest base
-    uint64_t valid_mask; // even bits of the k-mer positions the key reads
+    uint64_t valid_mask; // even bits of the k-mer bases the key reads (a base that gives one bit counts)
 };
+
+static inline uint32_t ipcr_index_key_bits(const ipcr_index_shape &s) { return (uint32_t)s.tw_bits + (uint32_t)__builtin_popcount(s.blk_mask); }
+// 64-bit words of a shape's bitmap: never below 16 (so that word offsets fit the 11 bits the drain's constants have, in units of 16)
+static inline uint32_t ipcr_index_words64(const ipcr_index_shape &s) {
+    const uint32_t kb = ipcr_index_key_bits(s);
+    return kb <= 10u ? 16u : (1u << (kb - 6u));
+}
 
 struct ipcr_index_entry { // 64 B; entry r belongs to the r-th distinct (shape, key) in sorted order
     uint32_t next;    // further pattern with the same key (index into the same array), 0xFFFFFFFF = none
@@ -85,8 +95,7 @@ struct ipcr_index_entry { // 64 B; entry r belongs to the r-th distinct (shape, 
 static_assert(sizeof(ipcr_index_entry) == 64, "index entries are read as four 16-byte loads");
 
 #define IPCR_INDEX_MAX_SHAPES 12
-#define IPCR_INDEX_BITMAP_WORDS 2048u // 65536 bits per shape
-#define IPCR_INDEX_GROUPS 1024u       // rank prefix (uint16) per 64 bitmap bits
+#define IPCR_INDEX_MAX_KEY_BITS 17u
 
 // raw byte range [start, end) of one FASTA header line (its '\n' included) inside a slab
 struct ipcr_fasta_range {

@@ -189,8 +189,8 @@ struct IndexPlan {
         return g;
     }
     std::vector<ipcr_index_shape> shapes;
-    // per shape: 2048 bitmap words (one bit per 16-bit key), then for all shapes the rank of the first key of
-    // every 64-bit bitmap word (uint16, relative to the shape's first entry), then the shapes' first entries
+    // the shapes' bitmaps (one bit per key, 2^(key bits) bits each), then for every 64-bit bitmap word the rank of its
+    // first key (uint16, relative to the shape's first entry), then the shapes' first entries and constants
     std::vector<uint32_t> lds_image;
     std::vector<ipcr_index_entry> table; // entry r = first pattern of the r-th distinct (shape, key); more patterns of a key are chained
     std::vector<uint32_t> leftover;      // set-local patterns the index cannot serve (> 32 nt, too degenerate, ...)
@@ -233,11 +233,14 @@ struct ipcr_panel {
 
 namespace {
 
+bool env_flag(const char *name, bool dflt);
+
 // Pigeonhole keys for the seed-index filter.  Patterns are grouped by (anchored end, protected
 // length t); a group with shortest pattern Lmin uses blocks of bf = (Lmin - t) / (k+1) bases laid
 // next to the protected bases, so any window with <= k mismatches (none protected) has the
 // protected bases and at least one whole block exact.  A key = protected part + (a prefix of) one
-// block, at most 8 bases = 16 bits.
+// block, at most 8 bases = 16 bits -- 17 where a spare base next to a five-base block can lend one bit
+// (device_types.h) and the bitmaps still leave the waves their hit queues.
 void build_index(const ipcr_panel &p, PatternSet &set) {
     IndexPlan &ix = set.index;
     ix.built = true;
@@ -281,13 +284,16 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
             for (uint32_t q : g.members) DL = std::max(DL, pats[q].len - 1);
     ix.dl = DL;
     uint8_t next_group = 0;
-    unsigned ring_regs = 0; // VGPRs the fast groups' delay rings will need (2 per delayed word)
+    // LDS the bitmaps may take (8 B per 64 keys + 2 B of rank prefix): the 16 waves of a CU keep >= 192 queue entries each
+    const size_t lds_budget = 160u * 1024u - 16u * 192u * 16u - 256u;
+    size_t lds_used = 0;
+    auto shape_bytes = [](unsigned key_bits) { return (size_t)(key_bits <= 10 ? 16u : (1u << (key_bits - 6))) * 10u; };
     for (Group &g : groups) {
         const int t = std::min(g.t, g.lmin);
         const int bf = (t >= g.lmin) ? 0 : (g.lmin - t) / (k + 1);
         // With k >= 1 and at least three protected bases the key is "3 protected bases next to the anchor + 5 block
         // bases" for every block: the protected part is then the low six key bits of all the group's shapes, which
-        // is what the delayed-OR evaluation needs (device_types.h).  Otherwise: as many protected bases as fit.
+        // the kernel extracts once per step (device_types.h).  Otherwise: as many protected bases as fit.
         const bool tri = k >= 1 && t >= 3 && bf >= 1;
         const int tu = tri ? 3 : std::min(t, 8);
         const int b = tri ? std::min(5, bf) : ((tu >= 8) ? 0 : std::min(8 - tu, bf));
@@ -296,84 +302,140 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
             for (uint32_t q : g.members) dropped[q] = 1;
             continue;
         }
-        bool fast = (ns > 1 && tu == 3) || (ns == 1 && b == 0 && tu >= 3);
-        if (fast && ns > 1) { // the rings (bf slots of 64 bits per delayed shape) must stay in registers, the unrolled body within reason
-            const unsigned regs = 2u * (unsigned)((ns - 1) * bf);
-            const unsigned unroll = 4u / std::__gcd(4u, (unsigned)bf) * (unsigned)bf;
-            if (unroll > 40 || ring_regs + regs > 40) fast = false; // 40 ring registers: beyond, the kernel spills at four waves per SIMD (k = 3: two groups x 24)
-            else ring_regs += regs;
-        }
-        const size_t ents_before = ents.size();
-        const size_t shapes_before = ix.shapes.size();
-        for (int j = 0; j < ns; ++j) {
-            ipcr_index_shape sh{};
-            sh.left = g.left ? 1 : 0;
-            sh.group = next_group;
-            sh.fast = fast ? 1 : 0;
-            sh.dl = (uint8_t)(g.left ? DL : 0);
-            sh.tw_bits = (uint8_t)(2 * tu);
-            sh.tw_mask = tu ? (uint32_t)((1ull << (2 * tu)) - 1ull) : 0u;
-            sh.blk_mask = b ? (uint32_t)((1ull << (2 * b)) - 1ull) : 0u;
-            uint64_t vm = 0;
-            if (!g.left) { // anchored at the window end = lowest bits of the k-mer
-                sh.tw_shift = 0;
-                sh.blk_shift = (uint8_t)(2 * (t + j * bf));
-                sh.delay = (uint8_t)(j * bf);
-                for (int u = 0; u < tu; ++u) vm |= 1ull << (2 * u);
-                for (int u = 0; u < b; ++u) vm |= 1ull << (2 * (t + j * bf + u));
-            } else {       // anchored at the window start = base DL of the k-mer, the pattern runs towards base 0
-                sh.tw_shift = (uint8_t)(tu ? 2 * (DL + 1 - tu) : 0);
-                sh.blk_shift = (uint8_t)(b ? 2 * (DL + 1 - (t + j * bf + b)) : 0);
-                sh.delay = (uint8_t)((ns - 1 - j) * bf);
-                for (int u = 0; u < tu; ++u) vm |= 1ull << (2 * (DL - u));
-                for (int u = 0; u < b; ++u) vm |= 1ull << (2 * (DL - (t + j * bf + u)));
-            }
-            sh.valid_mask = vm;
-            const uint32_t s = (uint32_t)ix.shapes.size();
-            ix.shapes.push_back(sh);
-            for (uint32_t q : g.members) {
-                if (dropped[q]) continue;
-                const Pat &pt = pats[q];
-                const int L = pt.len;
-                const int up = g.left ? 2 * (DL + 1 - L) : 0; // pattern bit -> k-mer bit
-                // key positions of this shape, in pattern (right-aligned) bit coordinates, and the
-                // bases each may take: IUPAC codes expand into every concrete key (capped)
-                std::vector<int> kb;
-                for (int bit = 0; bit < 64; bit += 2)
-                    if (vm & (1ull << bit)) kb.push_back(bit - up);
-                uint64_t combos = 1;
-                for (int pb : kb) {
-                    int n = 0;
-                    for (int bb = 0; bb < 4; ++bb) n += (pt.ok[bb] >> pb) & 1;
-                    combos *= (uint64_t)n;
-                    if (combos > 64) break;
+        const bool fast = (ns > 1 && tu == 3) || (ns == 1 && b == 0 && tu >= 3);
+        // Where the k+1 blocks lie among the A = lmin - t bases behind the protected ones is free, as long as no base
+        // feeds two of them.  Candidates: blocks of b bases packed towards the anchor, spare bases at the far end --
+        // except that every block of a chosen subset owns a (b+1)-th base and reads one bit of it (11 block bits: half
+        // the false hits, twice the bitmap).  The layout is picked on the panel itself: its cost is the drain work one
+        // genome base causes, sum over shapes of (keys + 2 x further patterns chained under a key) / 2^(key bits) --
+        // e.g. the first bases of the reference's benchmark primers take only four values
+        // (performance_benchmark_test.go:78-93), and a block that ends on them files 2048 primers under 891 keys.
+        const int A = g.lmin - t;
+        std::vector<int> bits((size_t)ns, 2 * b), pos((size_t)ns, 0);
+        for (int j = 1; j < ns; ++j) pos[(size_t)j] = pos[(size_t)j - 1] + (b > 0 ? b : 0);
+        for (int j = 0; j < ns; ++j) lds_used += shape_bytes((unsigned)(2 * tu + bits[(size_t)j]));
+        // files the group's shapes and keys for one layout; returns its cost (see above)
+        auto emit = [&](const std::vector<int> &pos, const std::vector<int> &bits) -> double {
+            const size_t ents_before = ents.size();
+            const size_t shapes_before = ix.shapes.size();
+            for (int j = 0; j < ns; ++j) {
+                ipcr_index_shape sh{};
+                sh.left = g.left ? 1 : 0;
+                sh.group = next_group;
+                sh.fast = fast ? 1 : 0;
+                sh.dl = (uint8_t)(g.left ? DL : 0);
+                sh.tw_bits = (uint8_t)(2 * tu);
+                sh.tw_mask = tu ? (uint32_t)((1ull << (2 * tu)) - 1ull) : 0u;
+                const int nb = bits[(size_t)j], pj = pos[(size_t)j];
+                const int bases = (nb + 1) / 2; // bases the block field touches (the last one with one bit only when nb is odd)
+                sh.blk_mask = nb ? (uint32_t)((1ull << nb) - 1ull) : 0u;
+                uint64_t vm = 0;
+                if (!g.left) { // anchored at the window end = lowest bits of the k-mer; an odd field ends with the LOW bit of its last base
+                    sh.tw_shift = 0;
+                    sh.blk_shift = (uint8_t)(2 * (t + pj));
+                    for (int u = 0; u < tu; ++u) vm |= 1ull << (2 * u);
+                    for (int u = 0; u < bases; ++u) vm |= 1ull << (2 * (t + pj + u));
+                } else {       // anchored at the window start = base DL of the k-mer, the pattern runs towards base 0; an odd field starts with the HIGH bit of its last base
+                    sh.tw_shift = (uint8_t)(tu ? 2 * (DL + 1 - tu) : 0);
+                    sh.blk_shift = (uint8_t)(nb ? 2 * (DL + 1 - (t + pj)) - nb : 0);
+                    for (int u = 0; u < tu; ++u) vm |= 1ull << (2 * (DL - u));
+                    for (int u = 0; u < bases; ++u) vm |= 1ull << (2 * (DL - (t + pj + u)));
                 }
-                if (combos == 0 || combos > 64) { dropped[q] = 1; continue; } // too degenerate to key
-                for (uint64_t it = 0; it < combos; ++it) {
-                    uint64_t km = 0, rem = it;
-                    for (size_t z = 0; z < kb.size(); ++z) {
-                        int opts[4], n = 0;
-                        for (int bb = 0; bb < 4; ++bb)
-                            if ((pt.ok[bb] >> kb[z]) & 1) opts[n++] = bb;
-                        const int pick = opts[rem % (uint64_t)n];
-                        rem /= (uint64_t)n;
-                        km |= (uint64_t)pick << (kb[z] + up);
+                sh.valid_mask = vm;
+                const uint32_t s = (uint32_t)ix.shapes.size();
+                ix.shapes.push_back(sh);
+                for (uint32_t q : g.members) {
+                    if (dropped[q]) continue;
+                    const Pat &pt = pats[q];
+                    const int L = pt.len;
+                    const int up = g.left ? 2 * (DL + 1 - L) : 0; // pattern bit -> k-mer bit
+                    // key positions of this shape, in pattern (right-aligned) bit coordinates, and the
+                    // bases each may take: IUPAC codes expand into every concrete key (capped)
+                    std::vector<int> kb;
+                    for (int bit = 0; bit < 64; bit += 2)
+                        if (vm & (1ull << bit)) kb.push_back(bit - up);
+                    uint64_t combos = 1;
+                    for (int pb : kb) {
+                        int n = 0;
+                        for (int bb = 0; bb < 4; ++bb) n += (pt.ok[bb] >> pb) & 1;
+                        combos *= (uint64_t)n;
+                        if (combos > 64) break;
                     }
-                    const uint32_t key = ((uint32_t)(km >> sh.tw_shift) & sh.tw_mask) |
-                                         (((uint32_t)(km >> sh.blk_shift) & sh.blk_mask) << sh.tw_bits);
-                    ents.emplace_back((s << 16) | key, q);
+                    if (combos == 0 || combos > 64) { dropped[q] = 1; continue; } // too degenerate to key
+                    for (uint64_t it = 0; it < combos; ++it) {
+                        uint64_t km = 0, rem = it;
+                        for (size_t z = 0; z < kb.size(); ++z) {
+                            int opts[4], n = 0;
+                            for (int bb = 0; bb < 4; ++bb)
+                                if ((pt.ok[bb] >> kb[z]) & 1) opts[n++] = bb;
+                            const int pick = opts[rem % (uint64_t)n];
+                            rem /= (uint64_t)n;
+                            km |= (uint64_t)pick << (kb[z] + up);
+                        }
+                        const uint32_t key = ((uint32_t)(km >> sh.tw_shift) & sh.tw_mask) |
+                                             (((uint32_t)(km >> sh.blk_shift) & sh.blk_mask) << sh.tw_bits);
+                        ents.emplace_back((s << 20) | key, q);
+                    }
                 }
             }
+            // a pattern dropped in a later shape must lose the keys of the earlier ones too
+            size_t w = ents_before;
+            for (size_t i = ents_before; i < ents.size(); ++i)
+                if (!dropped[ents[i].second]) ents[w++] = ents[i];
+            ents.resize(w);
+            bool any = false;
+            for (uint32_t q : g.members) any |= !dropped[q];
+            if (!any) ix.shapes.resize(shapes_before);
+            else ++next_group;
+            double cost = 0;
+            {   // keys and chained patterns per shape (the group's entries are the tail of `ents`)
+                std::vector<std::pair<uint32_t, uint32_t>> mine(ents.begin() + (long)ents_before, ents.end());
+                std::sort(mine.begin(), mine.end());
+                mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
+                for (size_t i = 0; i < mine.size(); ++i) {
+                    const bool first = i == 0 || mine[i].first != mine[i - 1].first;
+                    const uint32_t sidx = mine[i].first >> 20;
+                    cost += (first ? 1.0 : 2.0) / (double)(1ull << ipcr_index_key_bits(ix.shapes[sidx]));
+                }
+            }
+            return cost;
+        };
+        if (tri && b == 5 && ns > 1) {
+            // Measured on the 4096-pattern panel (C4, 3 Gb): blocks of 11, 10, 11 bits are picked (cost 0.13 against 0.18
+            // for three 10-bit blocks) and a third fewer hits reach the drain -- but the bitmaps then leave the waves
+            // queues of 192 entries instead of 384, the drain's rounds run emptier, and the sweep takes 8.45 ms
+            // instead of 8.35.  Off unless asked for.
+            const bool half_bases = env_flag("IPCR_INDEX_HALF_BASES", false);
+            const int spare = A - b * ns;
+            double best = -1;
+            unsigned best_mask = 0;
+            const std::vector<char> dropped_keep = dropped;
+            const size_t ents_keep = ents.size(), shapes_keep = ix.shapes.size();
+            const uint8_t group_keep = next_group;
+            for (unsigned mask = 0; mask < (half_bases ? (1u << ns) : 1u); ++mask) {
+                if (__builtin_popcount(mask) > spare) continue;
+                if (lds_used + (size_t)__builtin_popcount(mask) * (shape_bytes(17) - shape_bytes(16)) > lds_budget) continue;
+                std::vector<int> cb(bits), cp(pos);
+                for (int j = 0; j < ns; ++j) {
+                    if (mask & (1u << j)) cb[(size_t)j] = 11;
+                    if (j) cp[(size_t)j] = cp[(size_t)j - 1] + ((mask & (1u << (j - 1))) ? b + 1 : b);
+                }
+                const double c = emit(cp, cb);
+                bool lost = false; // a layout that makes a pattern unkeyable (too many IUPAC expansions) only as a last resort
+                for (uint32_t q : g.members) lost |= dropped[q] && !dropped_keep[q];
+                const double score = c + (lost ? 1e3 : 0.0);
+                if (best < 0 || score < best) { best = score; best_mask = mask; }
+                dropped = dropped_keep; // roll back
+                ents.resize(ents_keep);
+                ix.shapes.resize(shapes_keep);
+                next_group = group_keep;
+            }
+            for (int j = 0; j < ns; ++j) {
+                if (best_mask & (1u << j)) { bits[(size_t)j] = 11; lds_used += shape_bytes(17) - shape_bytes(16); }
+                if (j) pos[(size_t)j] = pos[(size_t)j - 1] + ((best_mask & (1u << (j - 1))) ? b + 1 : b);
+            }
         }
-        // a pattern dropped in a later shape must lose the keys of the earlier ones too
-        size_t w = ents_before;
-        for (size_t i = ents_before; i < ents.size(); ++i)
-            if (!dropped[ents[i].second]) ents[w++] = ents[i];
-        ents.resize(w);
-        bool any = false;
-        for (uint32_t q : g.members) any |= !dropped[q];
-        if (!any) ix.shapes.resize(shapes_before);
-        else ++next_group;
+        (void)emit(pos, bits);
     }
     ix.max_right = 0; // longest right-anchored pattern the index serves
     ix.uniform_len = -1;
@@ -391,10 +453,15 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     // the set bits IS the index of its entry -- one entry load per hit, no tag compare, no probing.  The rank
     // comes from a per-256-bit-group prefix (uint16, LDS) plus popcounts inside the group.
     const size_t NS = ix.shapes.size();
-    const size_t img_words = NS * IPCR_INDEX_BITMAP_WORDS + NS * (IPCR_INDEX_GROUPS / 2) + NS + 2 * NS;
+    // LDS image: the shapes' bitmaps one after the other (64-bit words) | a uint16 rank prefix per bitmap word |
+    // NS first-entry indices | NS x 2 words of shape constants
+    std::vector<uint32_t> off64(NS + 1, 0);
+    for (size_t i = 0; i < NS; ++i) off64[i + 1] = off64[i] + ipcr_index_words64(ix.shapes[i]);
+    const size_t T64 = off64[NS];
+    const size_t img_words = T64 * 2 + T64 / 2 + NS + 2 * NS;
     ix.lds_image.assign(std::max<size_t>(1, img_words), 0u);
-    uint16_t *prefix = reinterpret_cast<uint16_t *>(ix.lds_image.data() + NS * IPCR_INDEX_BITMAP_WORDS);
-    uint32_t *base = ix.lds_image.data() + NS * IPCR_INDEX_BITMAP_WORDS + NS * (IPCR_INDEX_GROUPS / 2);
+    uint16_t *prefix = reinterpret_cast<uint16_t *>(ix.lds_image.data() + T64 * 2);
+    uint32_t *base = ix.lds_image.data() + T64 * 2 + T64 / 2;
     size_t ndistinct = 0;
     for (size_t i = 0; i < ents.size(); ++i)
         if (i == 0 || ents[i].first != ents[i - 1].first) ++ndistinct;
@@ -418,8 +485,8 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     std::vector<uint32_t> shape_count(NS + 1, 0);
     size_t r = 0;
     for (size_t i = 0; i < ents.size();) {
-        const uint32_t tag = ents[i].first, sidx = tag >> 16, key = tag & 0xFFFFu;
-        ix.lds_image[sidx * IPCR_INDEX_BITMAP_WORDS + (key >> 5)] |= 1u << (key & 31u);
+        const uint32_t tag = ents[i].first, sidx = tag >> 20, key = tag & 0xFFFFFu;
+        ix.lds_image[off64[sidx] * 2u + (key >> 5)] |= 1u << (key & 31u);
         ++shape_count[sidx];
         fill(ix.table[r], ents[i].second);
         uint32_t tail = (uint32_t)r;
@@ -433,25 +500,42 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         ++r;
     }
     uint32_t run = 0;
+    bool prefix_overflow = false;
     for (size_t sidx = 0; sidx < NS; ++sidx) {
         base[sidx] = run;
         uint32_t within = 0;
-        for (uint32_t g = 0; g < IPCR_INDEX_GROUPS; ++g) { // one prefix per 64-bit word of the bitmap
-            prefix[sidx * IPCR_INDEX_GROUPS + g] = (uint16_t)within; // < 65536: a shape has at most 65536 keys, the last word starts below that
-            for (uint32_t w = 0; w < 2; ++w) within += (uint32_t)__builtin_popcount(ix.lds_image[sidx * IPCR_INDEX_BITMAP_WORDS + g * 2 + w]);
+        for (uint32_t g = off64[sidx]; g < off64[sidx + 1]; ++g) { // one prefix per 64-bit word of the bitmap
+            prefix[g] = (uint16_t)within; // checked below: a shape files fewer than 65536 keys
+            for (uint32_t w = 0; w < 2; ++w) within += (uint32_t)__builtin_popcount(ix.lds_image[g * 2u + w]);
         }
+        if (within >= 65536u) prefix_overflow = true;
         run += shape_count[sidx];
     }
     // the shapes' constants for the drain, which handles a hit's shape as a run-time value:
-    // {tw_shift | blk_shift << 8 | tw_bits << 16 | left << 24 | dl << 25, tw_mask | blk_mask << 16}
+    // {tw_shift | blk_shift << 8 | tw_bits << 16 | (first bitmap word / 16) << 21, tw_mask | blk_mask << 16}
     for (size_t sidx = 0; sidx < NS; ++sidx) {
         const ipcr_index_shape &sh = ix.shapes[sidx];
-        base[NS + 2 * sidx] = (uint32_t)sh.tw_shift | ((uint32_t)sh.blk_shift << 8) | ((uint32_t)sh.tw_bits << 16) |
-                              ((uint32_t)sh.left << 24) | ((uint32_t)sh.dl << 25);
+        base[NS + 2 * sidx] = (uint32_t)sh.tw_shift | ((uint32_t)sh.blk_shift << 8) | ((uint32_t)sh.tw_bits << 16) | ((off64[sidx] / 16u) << 21);
         base[NS + 2 * sidx + 1] = (sh.tw_mask & 0xFFFFu) | ((sh.blk_mask & 0xFFFFu) << 16);
     }
+    static const bool debug = env_flag("IPCR_INDEX_DEBUG", false);
+    if (debug) { // per shape: key bits, distinct keys, filed patterns, longest chain
+        std::vector<uint32_t> ent_count(NS, 0), longest(NS, 0);
+        for (size_t i = 0; i < ents.size();) {
+            size_t j = i;
+            while (j < ents.size() && ents[j].first == ents[i].first) ++j;
+            const uint32_t sidx = ents[i].first >> 20;
+            ent_count[sidx] += (uint32_t)(j - i);
+            longest[sidx] = std::max(longest[sidx], (uint32_t)(j - i));
+            i = j;
+        }
+        for (size_t sidx = 0; sidx < NS; ++sidx)
+            fprintf(stderr, "ipcr index shape %zu: %s group %u, %u key bits (block shift %u, mask %#x), %u keys, %u patterns filed, longest chain %u\n",
+                    sidx, ix.shapes[sidx].left ? "left" : "right", ix.shapes[sidx].group, ipcr_index_key_bits(ix.shapes[sidx]),
+                    ix.shapes[sidx].blk_shift, ix.shapes[sidx].blk_mask, shape_count[sidx], ent_count[sidx], longest[sidx]);
+    }
     std::sort(ix.leftover.begin(), ix.leftover.end());
-    ix.usable = !ix.shapes.empty() && !ents.empty();
+    ix.usable = !ix.shapes.empty() && !ents.empty() && !prefix_overflow && T64 * 10 + 12 * NS + 16u * 128u * 16u <= 160u * 1024u;
 }
 
 void build_dev_pattern(const ipcr_panel &p, const PatternDef &d, uint32_t gid, ipcr_dev_pattern &o) {

@@ -939,24 +939,29 @@ std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, in
 
 // ---- seed-index filter with the panel's key shapes baked in (device_types.h: ipcr_index_shape).
 // One thread per strand walks its 128 rows plus `tail_rows` rows of the next strand with a rolling 2-bit k-mer.
-// Per base step:
-//  * FAST groups (three protected bases + one block per key): one table index per group fetches the 64-bit bitmap
-//    words of all the group's shapes; the words of the delayed shapes wait in a register ring (the unrolled body's
-//    length is a multiple of every delay, so ring slots are plain registers); the OR of the words that are due is
-//    tested ONCE at the bit the three protected bases select -- "some shape of this group has this key";
-//  * other groups: one bitmap probe per shape.
+// Per base step every shape is looked up in its LDS bitmap: the word index is the shape's block field of the k-mer,
+// the bit the protected bases (FAST groups extract those six bits once for all their shapes and read the 32-bit
+// half word that holds the bit; other groups compute the whole key per shape).  One ds_read_b32 per shape and step is
+// all the LDS traffic of a step without a hit -- the kernel is bound by LDS cycles and VALU issue together, no
+// registers are spent on delaying words, and the step knows WHICH shapes hit.
 //  No validity test here: a window with <= k mismatches has a key whose bases are all valid and exact, so invalid
 //  bases (code A in the k-mer) can only add candidates, which the exact check below rejects.
-//  * hits go to a per-wave LDS queue (k-mer, invalid flags, where, groups) -- ballot + mbcnt slots, no atomics -- and
-//    are drained 64 at a time: each lane looks its hit up in every shape of the hit groups, ranks the key among the
-//    shape's keys (prefix per 64-bit word + popcount), loads the entry and checks the pattern exactly against the k-mer.
-#define IPCR_INDEX_WAVES 16u // one 1024-thread workgroup per CU: the LDS image is staged once per CU, 4 waves per SIMD
-static unsigned index_image_bytes(unsigned nshapes) { // bitmaps + per-word rank prefixes + first entries + shape constants (build_index)
-    const unsigned image = nshapes * (IPCR_INDEX_BITMAP_WORDS * 4u + IPCR_INDEX_GROUPS * 2u + 4u + 8u);
+//  * hits go to a per-wave LDS queue (k-mer, invalid flags, where | shape bits) -- ballot + mbcnt slots, no atomics --
+//    and are drained 64 at a time: each lane ranks its hit's key among the shape's keys (prefix per 64-bit word +
+//    popcount), loads the entry and checks the pattern exactly against the k-mer.
+static unsigned index_waves() { return (unsigned)env_int("IPCR_INDEX_WAVES", 16, 4, 16) / 4u * 4u; } // one workgroup per CU (the LDS image is staged once per CU), 4 waves per SIMD unless the dev knob says otherwise
+#define IPCR_INDEX_WAVES index_waves()
+static unsigned index_words64(const std::vector<ipcr_index_shape> &shapes) {
+    unsigned t = 0;
+    for (const ipcr_index_shape &x : shapes) t += ipcr_index_words64(x);
+    return t;
+}
+static unsigned index_image_bytes(const std::vector<ipcr_index_shape> &shapes) { // bitmaps + per-word rank prefixes + first entries + shape constants (build_index)
+    const unsigned image = index_words64(shapes) * 10u + (unsigned)shapes.size() * 12u;
     return (image + 15u) & ~15u;
 }
-static unsigned index_queue_entries(unsigned nshapes) { // per-wave hit queue: what the image leaves of the 160 KiB, in rounds of 64
-    const unsigned left = 160u * 1024u - index_image_bytes(nshapes);
+static unsigned index_queue_entries(const std::vector<ipcr_index_shape> &shapes) { // per-wave hit queue: what the image leaves of the 160 KiB, in rounds of 64
+    const unsigned left = 160u * 1024u - std::min(160u * 1024u, index_image_bytes(shapes));
     unsigned q = left / (IPCR_INDEX_WAVES * 16u) / 64u * 64u;
     return q < 128u ? 128u : (q > 448u ? 448u : q);
 }
@@ -965,35 +970,23 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
     const int tail_rows = geom.tail_rows;
     const bool all_acgt = geom.all_acgt;
     const size_t NS = shapes.size();
-    struct Grp { bool fast = false; std::vector<int> sh; int c_off = 0, v_off = 0, v_bits = 0; unsigned bf = 1; };
+    struct Grp { bool fast = false; std::vector<int> sh; int c_off = 0; };
     std::vector<Grp> groups;
+    std::vector<unsigned> off64(NS + 1, 0); // first 64-bit word of every shape's bitmap
     for (size_t i = 0; i < NS; ++i) {
         if (shapes[i].group >= groups.size()) groups.resize((size_t)shapes[i].group + 1);
         groups[shapes[i].group].sh.push_back((int)i);
-        groups[shapes[i].group].fast = shapes[i].fast != 0;
+        groups[shapes[i].group].fast = shapes[i].fast != 0 && shapes[i].tw_bits >= 6;
+        groups[shapes[i].group].c_off = shapes[i].tw_shift;
+        off64[i + 1] = off64[i] + ipcr_index_words64(shapes[i]);
     }
-    unsigned U = 4;
-    for (Grp &g : groups) {
-        if (!g.fast || g.sh.empty()) continue;
-        const ipcr_index_shape &a = shapes[(size_t)g.sh[0]];
-        g.c_off = a.tw_shift;
-        if (g.sh.size() == 1) { // the key is one contiguous field of protected bases: low 6 bits select the bit, the rest the word
-            g.v_off = a.tw_shift + 6;
-            g.v_bits = a.tw_bits - 6;
-        } else {
-            std::sort(g.sh.begin(), g.sh.end(), [&](int x, int y) { return shapes[(size_t)x].delay < shapes[(size_t)y].delay; });
-            g.v_off = shapes[(size_t)g.sh[0]].blk_shift;   // the delay-0 shape's block field
-            g.v_bits = __builtin_popcount(a.blk_mask);
-            g.bf = shapes[(size_t)g.sh[1]].delay;           // delays are 0, bf, 2 bf, ... (host.cpp: build_index)
-            U = U / std::__gcd(U, g.bf) * g.bf;
-        }
-    }
-    while (U < 8) U *= 2;
+    const unsigned T64N = off64[NS];
+    const unsigned U = 8;                              // base steps per copy of the loop body
     const int RT = 128 + (tail_rows < 0 ? 0 : tail_rows);
     const unsigned NQ = (unsigned)(RT + 3) / 4;        // row quads walked
     const unsigned NB = NQ * 4 / U;                    // full unrolled bodies
     const unsigned TAILSTEPS = NQ * 4 - NB * U;        // a shorter copy of the body finishes the walk
-    const unsigned QCAP = index_queue_entries((unsigned)NS);
+    const unsigned QCAP = index_queue_entries(shapes);
 
     std::ostringstream s;
     s << "// generated by ipcr_amd/csrc/jit.cpp: seed-index filter, " << NS << " key shapes in " << groups.size() << " groups, "
@@ -1003,6 +996,7 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
     s << "typedef u32 v4 __attribute__((ext_vector_type(4)));\n";
     s << "struct qent { u64 key; u32 bits; u32 pad; };\n";
     s << "#define NS " << NS << "\n";
+    s << "#define T64N " << T64N << "u // 64-bit words of all bitmaps\n";
     s << "#define QCAP " << QCAP << "u // per-wave queue of hits (16-byte entries), drained in rounds of 64 at full lane occupancy\n";
     s << "#define ALL_ACGT " << (all_acgt ? "true" : "false") << " // no indexed pattern holds an IUPAC code\n";
     s << "#define ULEN " << geom.uniform_len << "u // length of every indexed pattern (0: mixed)\n";
@@ -1028,10 +1022,10 @@ template <int S> struct key_of {
     return ((u32)(km >> TW_SHIFT[S]) & TW_MASK[S]) | (((u32)(km >> BLK_SHIFT[S]) & BLK_MASK[S]) << TW_BITS[S]);
   }
 };
-// LDS image (host.cpp: build_index): NS bitmaps of 1024 64-bit words | NS x 1024 uint16 rank prefixes | NS first-entry
+// LDS image (host.cpp: build_index): the shapes' bitmaps, T64N 64-bit words | T64N uint16 rank prefixes | NS first-entry
 // indices | NS x 2 words of shape constants
-#define PREFIX_WORD0 (NS * 2048u)
-#define BASE_WORD0 (NS * 2048u + NS * 512u)
+#define PREFIX_WORD0 (T64N * 2u)
+#define BASE_WORD0 (T64N * 2u + T64N / 2u)
 #define SHAPE_WORD0 (BASE_WORD0 + NS)
 #define LDS_WORDS (SHAPE_WORD0 + 2u * NS)
 // invalid-base flags, one bit per base -> the even bits of a 2-bit-per-base word
@@ -1094,15 +1088,15 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "  const u64 wave0 = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);\n"
          "  const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);\n"
          "  for (u64 cp = wave0; cp < ncolpairs; cp += nwaves) {\n";
-    // ---- drain of the hit queue: 64 hits per round, one per lane.  First every lane probes the bitmaps of all shapes
-    // of its hit's groups (the base step only knew "some shape of the group"); then ONE convergent step ranks the
-    // key, loads the entry and checks the pattern -- the shape is a run-time value there (constants from LDS), so that
-    // lanes whose hits belong to different shapes share one trip to the entry table.  A lane never holds the other 63
-    // for a second trip: a key filed under a further shape as well (one hit in ten), or a further pattern filed under
-    // the same key (3 % of the keys of a 4096-pattern panel -- but some lane of nearly every round), goes back into
-    // the queue as a new entry, written over slots this drain has consumed, and the next generation of rounds takes
-    // those at full occupancy again.  `where` of such an entry: bit 31 = bits 14..30 are the entry index to check;
-    // else bit 30 = bits 14..29 are the shape bits (already probed).
+    // ---- drain of the hit queue: 64 entries per round, one per lane, ONE item of work per lane and round.
+    // `where` of an entry: lane | row << 6 | payload << 14; bit 31 clear: the payload (bits 14..25) is the set of shapes
+    // that filed the hit's key: rank the first one's key among the shape's keys, load that entry, check the pattern --
+    // the shape is a run-time value there (constants from LDS), so lanes whose hits belong to different shapes share one
+    // trip to the entry table.  A lane never holds the other 63 for a second trip: a key filed under a further shape as
+    // well (one hit in ten), or a further pattern filed under the same key (3 % of the keys of a 4096-pattern panel --
+    // but some lane of nearly every round), goes back into the queue as a new entry, written over slots this drain has
+    // consumed, and the next generation of rounds takes those at full occupancy again (bit 31 set: the payload, bits
+    // 14..30, is the index of the entry to check).
     s << "    auto flush = [&]() __attribute__((always_inline)) {\n"
          "      u32 n = qn;\n"
          "      const u64 pair_base = cp << 13; // first position of this column pair\n"
@@ -1126,40 +1120,20 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "          if (i < n) {\n"
          "            const v4 e = *reinterpret_cast<const v4*>(wq + i * 4u);\n"
          "            hkm = ((u64)e.y << 32) | e.x; hbad = e.z; where = e.w;\n"
-         "            const u32 gm = (where >> 14) & 0xFFFFu;\n"
          "            if (where & 0x80000000u) idx = (where >> 14) & 0x1FFFFu;\n"
-         "            else if (where & 0x40000000u) pend = gm;\n"
-         "            else {\n";
-    for (size_t gi = 0; gi < groups.size(); ++gi) {
-        const Grp &g = groups[gi];
-        if (g.sh.empty()) continue;
-        s << "              if (gm & " << (1u << gi) << "u) {\n";
-        if (g.fast) { // key = six common bits + the shape's word index: one shift serves all shapes of the group
-            s << "                const u32 c = (u32)(hkm >> " << g.c_off << "u) & 63u;\n";
-            for (int si : g.sh) {
-                const ipcr_index_shape &sh = shapes[(size_t)si];
-                const unsigned off = g.sh.size() == 1 ? (unsigned)g.v_off : (unsigned)sh.blk_shift;
-                const unsigned vmask = g.v_bits > 0 ? ((1u << g.v_bits) - 1u) : 0u;
-                s << "                pend |= ((u32)(T64[" << si * 1024 << "u + ((u32)(hkm >> " << off << "u) & " << vmask << "u)] >> c) & 1u) << " << si << ";\n";
-            }
-        } else {
-            for (int si : g.sh)
-                s << "                { const u32 key = key_of<" << si << ">::get(hkm); pend |= ((u32)(T64[" << si * 1024 << "u + (key >> 6)] >> (key & 63u)) & 1u) << " << si << "; }\n";
-        }
-        s << "              }\n";
-    }
-    s << "            }\n"
+         "            else pend = (where >> 14) & 0xFFFu;\n"
          "          }\n"
          "          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // every lane has read its slot: slots up to qb + 63 may be rewritten\n"
          "          const u32 rest = pend & (pend - 1u);\n"
-         "          hand_back(rest != 0u, hkm, hbad, (where & 0x3FFFu) | (rest << 14) | 0x40000000u);\n"
+         "          hand_back(rest != 0u, hkm, hbad, (where & 0x3FFFu) | (rest << 14));\n"
          "          if (pend != 0u) {\n"
          "            const u32 sidx = (u32)__builtin_ctz(pend);\n"
          "            const u32 c0 = lds[SHAPE_WORD0 + 2u * sidx], c1 = lds[SHAPE_WORD0 + 2u * sidx + 1u];\n"
          "            const u32 key = ((u32)(hkm >> (c0 & 63u)) & (c1 & 0xFFFFu)) | (((u32)(hkm >> ((c0 >> 8) & 63u)) & (c1 >> 16)) << ((c0 >> 16) & 31u));\n"
-         "            const u64 w = T64[sidx * 1024u + (key >> 6)];\n"
+         "            const u32 wi = (c0 >> 21) * 16u + (key >> 6); // the shape's bitmap word with this key\n"
+         "            const u64 w = T64[wi];\n"
          "            // the key is in the panel; its rank among the shape's keys is the index of its entry\n"
-         "            idx = lds[BASE_WORD0 + sidx] + (u32)prefix[sidx * 1024u + (key >> 6)] + (u32)__popcll((w << (63u - (key & 63u))) << 1);\n"
+         "            idx = lds[BASE_WORD0 + sidx] + (u32)prefix[wi] + (u32)__popcll((w << (63u - (key & 63u))) << 1);\n"
          "          }\n"
          "          u32 next = 0xFFFFFFFFu;\n"
          "          if (idx != 0xFFFFFFFFu) {\n"
@@ -1184,13 +1158,6 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "    const u32 nbit = (bit + 1u) & 31u;\n"
          "    u64 km = 0;\n"
          "    u32 bad = 0xFFFFFFFFu; // invalid-base flags of the last 32 bases, one bit per base\n";
-    // delay rings of the fast groups.  Shapes sorted by delay (0, bf, 2 bf, ...): X_last = W_last,
-    // X_i(r) = W_i(r) | X_{i+1}(r - bf), and X_0(r) is the OR of every shape's word that is due at step r.
-    // One ring of bf slots per level i >= 1 (the body length is a multiple of bf: slots are plain registers).
-    for (size_t gi = 0; gi < groups.size(); ++gi)
-        if (groups[gi].fast)
-            for (size_t lv = 1; lv < groups[gi].sh.size(); ++lv)
-                for (unsigned i = 0; i < groups[gi].bf; ++i) s << "    u64 x" << gi << "_" << lv << "_" << i << " = 0ull;\n";
     s << "    auto quad_addr = [&](u32 rq) { // row quads: 32 of my strand, then those of the next one\n"
          "      const u64 c = rq >= 32u ? ncol : col;\n"
          "      return planes + ((((c >> 6) * 32u + (rq & 31u)) * 3u * 64u + (u32)(c & 63u)) << 2); // tile_layout.h: ipcr_plane_word\n"
@@ -1203,7 +1170,6 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
     // guarded by the (wave-uniform) step counter, so that the queue drain exists once in the code, not once per
     // step: a step that fills the queue marks the counter, the remaining guards fall through (two scalar
     // instructions each), the drain runs at the end of the pass and the next pass resumes behind that step.
-    // All ring slots are still addressed statically.
     s << "    u32 it = 0u, u = 0u;\n"
          "    bool done = false;\n"
          "    while (!done) {\n";
@@ -1220,29 +1186,44 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
         }
         s << "        km = (km << 2) | (u64)(__builtin_amdgcn_ubfe(qlo[" << t << "], b, 1u) | (__builtin_amdgcn_ubfe(qhi[" << t << "], b, 1u) << 1));\n"
           << "        bad = (bad << 1) | __builtin_amdgcn_ubfe(qiv[" << t << "], b, 1u);\n"
-          << "        u32 hm = 0u;\n";
+          << "        u32 hm = 0u; // shapes that hold this step's key\n";
+        // dev knobs (tools/c4_knobs.sh): what one more LDS lookup / VALU instruction per base step costs -- which unit binds
+        const int xl = env_int("IPCR_INDEX_XLDS", 0, 0, 8), xv = env_int("IPCR_INDEX_XVALU", 0, 0, 64);
+        for (int x = 0; x < xl; ++x)
+            s << "        u32 dummy" << x << "; { const u32 da = (((u32)(km >> " << 8 + 2 * x << "u) & 1023u) << 3) + " << (x % 4) * 8192 << "u; asm volatile(\"ds_read_b32 %0, %1\" : \"=v\"(dummy" << x << ") : \"v\"(da) : \"memory\"); }\n";
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             const Grp &g = groups[gi];
             if (g.sh.empty()) continue;
             if (g.fast) {
-                const unsigned vmask = g.v_bits > 0 ? ((1u << g.v_bits) - 1u) : 0u;
-                s << "        { const u32 v = " << (g.v_bits > 0 ? "(u32)(km >> " + std::to_string(g.v_off) + "u) & " + std::to_string(vmask) + "u" : std::string("0u")) << ";\n";
-                for (int si : g.sh) s << "          const u64 w" << si << " = T64[" << si * 1024 << "u + v];\n";
-                const size_t nl = g.sh.size();
-                auto slot = [&](size_t lv) { return "x" + std::to_string(gi) + "_" + std::to_string(lv) + "_" + std::to_string(k % g.bf); };
-                // level lv's slot holds X_lv of bf steps ago: read it (for level lv - 1), then overwrite it with X_lv of this step
-                s << "          const u64 acc = w" << g.sh[0] << (nl > 1 ? " | " + slot(1) : std::string()) << ";\n";
-                for (size_t lv = 1; lv < nl; ++lv)
-                    s << "          " << slot(lv) << " = w" << g.sh[lv] << (lv + 1 < nl ? " | " + slot(lv + 1) : std::string()) << ";\n";
-                s << "          hm |= ((u32)(acc >> ((u32)(km >> " << g.c_off << "u) & 63u)) & 1u) << " << gi << ";\n        }\n";
+                // byte address of the 32-bit half word = (bitmap word index) * 8 + (bit 5 of c) * 4; the bit test takes c's low five bits
+                s << "        { const u32 c = (u32)(km >> " << g.c_off << "u) & 63u, ch = (c >> 3) & 4u;\n";
+                for (int si : g.sh) {
+                    const ipcr_index_shape &sh = shapes[(size_t)si];
+                    // a one-shape group keys on protected bases only: the word index is what follows the six bits of c
+                    const bool single = sh.blk_mask == 0;
+                    const unsigned off = single ? (unsigned)sh.tw_shift + 6u : (unsigned)sh.blk_shift;
+                    const unsigned vmask = single ? ((1u << (sh.tw_bits - 6)) - 1u) : sh.blk_mask;
+                    std::string a;
+                    if (vmask == 0) a = "ch";
+                    else if (off >= 3) a = "(((u32)(km >> " + std::to_string(off - 3) + "u) & " + std::to_string(vmask << 3) + "u) | ch)";
+                    else a = "((((u32)(km >> " + std::to_string(off) + "u) & " + std::to_string(vmask) + "u) << 3) | ch)";
+                    s << "          hm |= __builtin_amdgcn_ubfe(*reinterpret_cast<const u32*>(reinterpret_cast<const char*>(lds) + " << off64[(size_t)si] * 8u << "u + " << a << "), c & 31u, 1u) << " << si << ";\n";
+                }
+                s << "        }\n";
             } else {
                 for (int si : g.sh)
-                    s << "        { const u32 key = key_of<" << si << ">::get(km); const u32 w = lds[" << si * 2048 << "u + (key >> 5)]; hm |= ((w >> (key & 31u)) & 1u) << " << gi << "; }\n";
+                    s << "        { const u32 key = key_of<" << si << ">::get(km); const u32 w = lds[" << off64[(size_t)si] * 2u << "u + (key >> 5)]; hm |= ((w >> (key & 31u)) & 1u) << " << si << "; }\n";
             }
         }
+        if (xl) {
+            s << "        asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n";
+            for (int x = 0; x < xl; ++x) s << "        asm volatile(\"\" :: \"v\"(dummy" << x << "));\n";
+        }
+        for (int x = 0; x < xv; ++x)
+            s << "        { u32 dv; asm volatile(\"v_mov_b32 %0, %1\" : \"=v\"(dv) : \"v\"(bad)); asm volatile(\"\" :: \"v\"(dv)); }\n";
         // qn <= QCAP - 64 on entry (a fuller queue is drained before the next step runs) and a step adds at most 64: no overflow
         s << "        const u64 bal = __ballot(hm != 0u);\n"
-             "        if (bal != 0ull) { // one queue entry per lane whatever the number of groups that hit: (k-mer, invalid flags, where, groups)\n"
+             "        if (bal != 0ull) { // one queue entry per lane whatever the number of shapes that hit: (k-mer, invalid flags, where | shapes)\n"
              "          if (hm != 0u) {\n"
              "            const u32 slot = qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));\n"
              "            v4 e; e.x = (u32)km; e.y = (u32)(km >> 32); e.z = bad; e.w = lane | ((" << rq0 << " * 4u + " << k << "u) << 6) | (hm << 14);\n"

@@ -571,9 +571,12 @@ def test_index_filter_random(hip, force_index, seed):
     assert 3 in kinds
 
 
-def test_config_c4_large_panel_index(hip):
-    """256 TSV rows -> 768 pairs / 1024 distinct patterns: seed-index filter, vs the oracle"""
+@pytest.mark.parametrize("half_bases", [0, 1])
+def test_config_c4_large_panel_index(hip, monkeypatch, half_bases):
+    """256 TSV rows -> 768 pairs / 1024 distinct patterns: seed-index filter, vs the oracle; also with the 17-bit keys
+    (a block takes one bit of a spare sixth base: host.cpp build_index, off by default)"""
     from ipcr_amd import workloads
+    monkeypatch.setenv("IPCR_INDEX_HALF_BASES", str(half_bases))
     rng = random.Random(26)
     pairs = workloads.c4_pairs(256)
     g, seqs = build_planted_genome(hip, rng, 3, 400_000, pairs[:256], 0x5eed1239)

@@ -448,7 +448,7 @@ def test_pattern_shards_join_to_the_unsharded_result():
 @pytest.mark.parametrize("k,tw,lens,iupac", [(2, 3, (20, 20), False), (1, 5, (18, 25), False), (3, 3, (22, 30), True),
                                              (2, 0, (20, 24), False), (0, 3, (16, 21), False)])
 def test_seed_index_source_compiles_for_gfx950(k, tw, lens, iupac, tmp_path):
-    """the seed-index kernel is generated per panel (key shapes, delays, ring registers, queue size all baked in): its
+    """the seed-index kernel is generated per panel (key shapes, bitmap sizes, queue size all baked in): its
     source for panels of different k / window / primer lengths must compile for gfx950, keep its LDS within the CU's
     160 KiB and its hot registers within four waves per SIMD (hipcc cross-compiles without a GPU)"""
     import subprocess
@@ -467,7 +467,8 @@ def test_seed_index_source_compiles_for_gfx950(k, tw, lens, iupac, tmp_path):
     cp.close()
     assert "ipcr_index_filter" in src
     if tw >= 3 and k >= 1:
-        assert re.search(r"u64 x0_1_0 = 0ull;", src), "a panel with >= 3 protected bases must use the delayed-OR evaluation"
+        assert re.search(r"const u32 c = \(u32\)\(km >> \d+u\) & 63u, ch = ", src), \
+            "a panel with >= 3 protected bases must take its shapes' common six key bits once per step"
     path = tmp_path / "index.hip"
     path.write_text(src)
     asm = subprocess.check_output(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", "-o", "-", str(path)],
