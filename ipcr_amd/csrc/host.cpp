@@ -744,7 +744,7 @@ ipcr_status ipcr_panel_filter_source(const ipcr_panel *p, int32_t mode, char *ou
         return IPCR_OK;
     }
     const std::vector<ipcr_dev_pattern> &all = p->set[mode].host;
-    const size_t G = ipcr::jit_group_size(all); // source of the first pattern group
+    const size_t G = ipcr::jit_group_size(all, p->cfg.max_mm); // source of the first pattern group
     const std::string src = G ? ipcr::jit_source(std::vector<ipcr_dev_pattern>(all.begin(), all.begin() + (long)std::min(G, all.size())), p->cfg.max_mm) : std::string();
     if (needed) *needed = src.size() + 1;
     if (out && cap) {

@@ -863,7 +863,7 @@ bool compile_group_uncached(const std::string &src, const std::string &arch, std
 
 } // namespace
 
-size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats) {
+size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats, int max_mm) {
     for (const auto &p : pats)
         if (p.len == 0 || p.len > 128) return 0; // not specialisable: table-driven filter
     if (pats.empty()) return 0;
@@ -871,10 +871,12 @@ size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats) {
     // ~200 B of hot code per pattern per row step, W row steps
     const size_t G = (size_t)env_int("IPCR_JIT_GROUP", 12, 1, 48);
     const size_t ngroups = (pats.size() + G - 1) / G;
-    // every group is a separate hiprtc compile (seconds each, serialised inside hiprtc): beyond
-    // a few groups the table-driven filter is the better trade until the seed-index kernel for
-    // large panels exists
-    if (ngroups > (size_t)env_int("IPCR_JIT_MAX_GROUPS", 8, 1, 4096)) return 0;
+    // every group is a separate hiprtc compile (seconds each) and a sweep of its own: beyond 8 groups the
+    // seed-index kernel serves (one compile, one sweep of ~8 ms per 3 Gb whatever the panel) -- but it takes panels
+    // of k <= 3 only (host.cpp: panel_upload).  With more mismatches the alternative is the table-driven filter,
+    // ~4 ms per pattern and 3 Gb: there 32 groups (384 patterns; ~10 s of compiles, 32 sweeps of ~0.25 ms) are the
+    // better trade
+    if (ngroups > (size_t)env_int("IPCR_JIT_MAX_GROUPS", max_mm > 3 ? 32 : 8, 1, 4096)) return 0;
     return (pats.size() + ngroups - 1) / ngroups; // balanced
 }
 
@@ -882,7 +884,7 @@ size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats) {
 // streams the tiles once and appends to the same candidate queue).  Groups compile in parallel.
 std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err) {
     std::vector<JitFilter *> out;
-    const size_t G = jit_group_size(pats);
+    const size_t G = jit_group_size(pats, max_mm);
     if (G == 0) { err = "panel not specialised (more pattern groups than IPCR_JIT_MAX_GROUPS)"; return out; }
     const size_t ngroups = (pats.size() + G - 1) / G;
     int dev = 0;

@@ -17,7 +17,7 @@ struct JitFilter;
 // check); queue entries carry pattern index qbase + position in `pats`
 std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int max_mm, unsigned qbase = 0);
 // patterns per kernel for this panel; 0 = not specialisable (table-driven filter)
-size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats);
+size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats, int max_mm);
 // one kernel per pattern group, compiled in parallel; empty (and `err` set) when the panel
 // cannot be specialised or hiprtc fails
 std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err);

@@ -717,6 +717,21 @@ def test_index_large_iupac_panel(hip):
     g.close()
 
 
+def test_k4_medium_panel_is_specialised_in_groups(hip):
+    """k = 4 is beyond the seed index (five pigeonhole blocks of three bases key nothing): a 30-row panel (120
+    patterns, 10 groups) must still not fall to the table-driven filter -- the specialised filter takes it in up to
+    32 groups, one sweep each; vs the oracle"""
+    rng = random.Random(31)
+    P = hip.primer.Pair
+    rows = [P("row%03d" % i, "".join(rng.choice("ACGT") for _ in range(rng.randint(18, 24))),
+              "".join(rng.choice("ACGT") for _ in range(rng.randint(18, 24))), 0, 0) for i in range(30)]
+    g, seqs = build_planted_genome(hip, rng, 2, 150_000, rows, 0x5eed1240)
+    cfg = hip.engine.Config(MaxMM=4, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)
+    _, cp, sc, got = scan_and_compare(hip, cfg, rows, g, seqs)
+    assert sc.stats().n_patterns == 120 and sc.stats().kernel_kind == 1 and len(got) >= 4
+    g.close()
+
+
 def test_index_drain_under_chains_and_crowded_rounds(hip, force_index):
     """worst case for the seed-index drain: three families of 16 primers that differ only in two bases of one block
     (every key of the other blocks is shared by the whole family: entry chains of 16; an exact site is filed under
