@@ -429,8 +429,18 @@ def roofline_of(res, traffic_file=None):
         except Exception:
             pass
     if res["kernel"] == "ipcr_index_filter":
-        out["limiter"] = ("not HBM: six random 8-byte LDS bitmap lookups per base step (SQ_LDS_IDX_ACTIVE ~77 %, 57 % of it "
-                          "bank conflicts) + the drain of ~0.17 key hits per lane and step; see DESIGN.md section 4.3")
+        lim = ("not HBM: VALU issue and LDS cycles together (one random 4-byte LDS bitmap lookup per key shape and base step, "
+               "the queue entry and the drain of ~0.19 key hits per lane and step); see DESIGN.md section 4.3")
+        try:
+            dv = json.load(open(traffic_file)).get("derived")
+            if dv:
+                lim += ("; %s when profiles/ was collected: %.1f VALU instructions per base step = %.0f %% of the issue slots, "
+                        "LDS busy %.0f %% (%.0f %% of it bank conflicts)"
+                        % (os.path.relpath(traffic_file, ROOT), dv["valu_instructions_per_base_step"], 100 * dv["valu_issue_busy_frac"],
+                           100 * dv["lds_busy_frac"], 100 * dv["lds_bank_conflict_frac_of_busy"]))
+        except Exception:
+            pass
+        out["limiter"] = lim
     return out
 
 

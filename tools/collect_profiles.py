@@ -67,6 +67,23 @@ def main():
             wr = int(out["WRITE_SIZE"]["avg"] * 1024)
             out.update(hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
                        algorithmic_bytes_per_launch=alg)
+        if w == "c4" and all(k in out for k in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")):
+            # the index kernel is not HBM-bound: say what binds it, from the counters themselves
+            steps = 3.0e9 / 64.0 * 147.0 / 128.0   # wave-level base steps: 128 rows + 19 of the next strand
+            cu_cycles = 256.0 * out["GRBM_GUI_ACTIVE"]["avg"] / 8.0          # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            out["derived"] = {
+                "wave_base_steps_per_launch": round(steps),
+                "valu_instructions_per_base_step": round(out["SQ_INSTS_VALU"]["avg"] / steps, 1),
+                "lds_instructions_per_base_step": round(out["SQ_INSTS_LDS"]["avg"] / steps, 2) if "SQ_INSTS_LDS" in out else None,
+                "valu_issue_busy_frac": round(out["SQ_INSTS_VALU"]["avg"] * 4.0 / (4.0 * cu_cycles), 3),   # 4 cycles per wave instruction, 4 SIMDs per CU
+                "lds_busy_frac": round(out["SQ_LDS_IDX_ACTIVE"]["avg"] / cu_cycles, 3),
+                "lds_bank_conflict_frac_of_busy": round(out["SQ_LDS_BANK_CONFLICT"]["avg"] / out["SQ_LDS_IDX_ACTIVE"]["avg"], 3),
+            }
+            out["note"] += (" CAUTION for this kernel: the x2 rule is calibrated for 16 B/lane coalesced streams; the index filter's tile "
+                            "loads are two distinct 16-byte pieces per wave instruction (the 32 lanes of a half-wave share one "
+                            "word), an access width the guide calls uncalibrated, so hbm_read is an upper bound and the raw counter "
+                            "a lower one (1.15x the algorithmic bytes would be the 147 rows walked per 128-row strand). The kernel "
+                            "is bound by VALU issue and LDS cycles together either way: see `derived`.")
         name = "filter" if w == "c2" else w
         with open(os.path.join(dst, f"{tag}_{name}_pmc.json"), "w") as fh:
             json.dump(out, fh, indent=1)
