@@ -179,13 +179,14 @@ struct IndexPlan {
     int dl = 0;        // left-anchored windows are tested dl bases after their start
     int max_right = 0; // longest right-anchored pattern served
     int uniform_len = 0; // length shared by every served pattern (0: mixed)
-    ipcr::IndexGeom geom() const {
+    ipcr::IndexGeom geom(int strands = 2) const {
         ipcr::IndexGeom g;
+        g.strands = strands;
         g.tail_rows = std::max(max_right - 1, dl);
         g.all_acgt = all_acgt;
         g.uniform_len = uniform_len;
         g.dl = dl;
-        g.chain_carry = table.size() < (1u << 17);
+        g.table_entries = (uint32_t)table.size();
         return g;
     }
     std::vector<ipcr_index_shape> shapes;
@@ -197,7 +198,8 @@ struct IndexPlan {
     uint32_t *d_lds_image = nullptr;
     ipcr_index_entry *d_table = nullptr;
     uint32_t *d_leftover = nullptr;
-    ipcr::JitFilter *jit = nullptr; // the kernel, with the key shapes baked in (hiprtc)
+    ipcr::JitFilter *jit = nullptr; // the kernel, with the key shapes baked in (hiprtc): lanes walk two strands each
+    ipcr::JitFilter *jit_sw[2] = {nullptr, nullptr}; // ... one strand / four strands, built when a genome of that size class is first scanned
 };
 
 struct PatternSet {
@@ -681,6 +683,8 @@ void ipcr_panel_destroy(ipcr_panel *p) {
     if (!p) return;
     for (auto &s : p->set) {
         if (s.index.jit) ipcr::jit_destroy(s.index.jit);
+        for (ipcr::JitFilter *f : s.index.jit_sw)
+            if (f) ipcr::jit_destroy(f);
         if (s.index.d_lds_image) (void)hipFree(s.index.d_lds_image);
         if (s.index.d_table) (void)hipFree(s.index.d_table);
         if (s.index.d_leftover) (void)hipFree(s.index.d_leftover);
@@ -1324,6 +1328,25 @@ ipcr_status wait_published(ipcr_scratch *s) {
     }
 }
 
+// The seed-index kernel for a genome of `nblocks` blocks.  A lane walks 1, 2 or 4 consecutive strands before the tail
+// rows of the next one: (128 s + 19) / 128 s rows per base scanned -- 1.15, 1.07, 1.04 -- but a wave's unit of work
+// grows with s (64 s strands), and the sweep needs several units per wave to end evenly (3 Gb: 8.35 / 7.9 / 7.8 ms for
+// s = 1 / 2 / 4; s = 8: 8.0).  The two-strand kernel is built with the panel, the others on first use.
+ipcr::JitFilter *index_kernel(const ipcr_panel *cp, int mode, uint64_t nblocks) {
+    ipcr_panel *p = const_cast<ipcr_panel *>(cp);
+    IndexPlan &ix = p->set[mode].index;
+    const uint64_t waves = 256u * 16u, units1 = nblocks * 32u; // units of the one-strand kernel: column pairs
+    const int strands = units1 / 4u >= 8u * waves ? 4 : (units1 / 2u >= 2u * waves ? 2 : 1);
+    if (strands == 2) return ix.jit;
+    std::lock_guard<std::mutex> lock(p->mu);
+    ipcr::JitFilter *&f = ix.jit_sw[strands == 1 ? 0 : 1];
+    if (!f) {
+        std::string jerr;
+        f = ipcr::jit_build_index(ix.shapes, ix.geom(strands), jerr);
+    }
+    return f ? f : ix.jit;
+}
+
 // enqueue one attempt: the specialised filter alone (it verifies and publishes itself), or the seed-index /
 // table-driven filter + verify kernel + read-back of counters and first hits behind a marker event
 ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
@@ -1389,7 +1412,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     } else if (set.index.usable) {
         const IndexPlan &ix = set.index;
         const bool more = !ix.leftover.empty();
-        HIPCHK(ipcr::jit_launch_index(ix.jit, lane, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_lds_image, ix.d_table,
+        HIPCHK(ipcr::jit_launch_index(index_kernel(p, pd.mode, nblocks), lane, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_lds_image, ix.d_table,
                                       (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, qc, s->ev[0], more ? nullptr : s->ev[1]));
         if (more) // patterns the index cannot key
             HIPCHK(ipcr::launch_filter_generic(lane, g->planes, nblocks, set.dev, (uint32_t)ix.leftover.size(),

@@ -984,7 +984,15 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
     }
     const unsigned T64N = off64[NS];
     const unsigned U = 8;                              // base steps per copy of the loop body
-    const int RT = 128 + (tail_rows < 0 ? 0 : tail_rows);
+    // A lane walks SW consecutive strands and then the tail rows of the one after: the rows walked per base scanned
+    // are (128 SW + tail) / (128 SW) -- 1.15 for one strand and 19 tail rows, 1.07 for two.
+    unsigned SW = (unsigned)env_int("IPCR_INDEX_STRANDS", geom.strands, 1, 8); // (the env knob overrides the caller's choice: development)
+    while (SW & (SW - 1u)) --SW; // a power of two: a lane's strands are bits of ONE column's words
+    const int RT = 128 * (int)SW + (tail_rows < 0 ? 0 : tail_rows);
+    unsigned STEP_BITS = 8;
+    while ((1 << STEP_BITS) <= RT) ++STEP_BITS;
+    const unsigned PAY = 6u + STEP_BITS; // `where` of a queue entry: lane | row << 6 | payload << PAY
+    const bool chain_carry = geom.table_entries < (1u << (31u - PAY));
     const unsigned NQ = (unsigned)(RT + 3) / 4;        // row quads walked
     const unsigned NB = NQ * 4 / U;                    // full unrolled bodies
     const unsigned TAILSTEPS = NQ * 4 - NB * U;        // a shorter copy of the body finishes the walk
@@ -1007,7 +1015,9 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
         if (x.left && (int)x.dl != geom.uniform_len - 1) aligned = false;
     s << "#define WINDOW_AT_NEWEST " << (aligned ? "true" : "false") << "\n";
     s << "#define DL " << geom.dl << "u // left-anchored windows are tested DL bases after their start\n";
-    s << "#define CHAIN_CARRY " << (geom.chain_carry ? "true" : "false") << " // further patterns of a key are handed back to the queue (entry index in 17 bits)\n";
+    s << "#define CHAIN_CARRY " << (chain_carry ? "true" : "false") << " // further patterns of a key are handed back to the queue (entry index in " << 31u - PAY << " bits)\n";
+    s << "#define SW " << SW << "u // strands a lane walks before the tail rows\n";
+    s << "#define PAY " << PAY << "u // where = lane | row << 6 | payload << PAY\n";
     auto arr = [&](const char *type, const char *name, auto get) {
         s << "__device__ constexpr " << type << " " << name << "[NS] = {";
         for (size_t i = 0; i < NS; ++i) s << (i ? ", " : "") << get(shapes[i]);
@@ -1068,9 +1078,9 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
   const u32 bw = (bad >> (sft >> 1)) & ((L >= 32u) ? 0xFFFFFFFFu : ((1u << L) - 1u));
   if (bw) mm2 |= spread2(bw);                        // rare: the window holds an invalid base
   const int srow = left ? erow - (int)DL : erow - (int)L + 1;
-  if ((mm2 & prot2) == 0ull && (u32)__popcll(mm2) <= max_mm && srow >= 0 && srow < 128) {
+  if ((mm2 & prot2) == 0ull && (u32)__popcll(mm2) <= max_mm && srow >= 0 && srow < (int)(128u * SW)) {
     const u64 qi = atomicAdd(qcount + shard * 16u, 1ull);
-    // position = (column pair * 64 + strand) * 128 + row: a scalar 64-bit base plus one 32-bit lane offset
+    // position = (the wave's first strand + the lane's) * 128 + row: a scalar 64-bit base plus one 32-bit lane offset
     if (qi < qcap) { qent qe; qe.key = ((u64)e0.y << 48) | (pair_base + (u64)(strand_off + (u32)srow)); qe.bits = 1u; qe.pad = 0u; queue[(u64)shard * qcap + qi] = qe; }
   }
   return e0.x;
@@ -1084,24 +1094,25 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "  __syncthreads();\n"
          "  const u64* T64 = reinterpret_cast<const u64*>(lds);\n"
          "  const unsigned short* prefix = reinterpret_cast<const unsigned short*>(lds + PREFIX_WORD0);\n"
-         "  const u32 lane = threadIdx.x & 63u, half = lane >> 5, bit = lane & 31u;\n"
+         "  const u32 lane = threadIdx.x & 63u;\n"
+         "  const u32 bit = (lane * SW) & 31u; // my first strand's bit in its column's words\n"
          "  u32* wq = lds + ((LDS_WORDS + 3u) & ~3u) + (threadIdx.x >> 6) * (QCAP * 4u); // this wave's hit queue\n"
          "  u32 qn = 0; // entries queued (wave-uniform)\n"
          "  const u64 wave0 = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);\n"
          "  const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);\n"
-         "  for (u64 cp = wave0; cp < ncolpairs; cp += nwaves) {\n";
+         "  for (u64 cp = wave0; cp < ncolpairs / SW; cp += nwaves) { // one unit = 64 SW strands = 2 SW columns\n";
     // ---- drain of the hit queue: 64 entries per round, one per lane, ONE item of work per lane and round.
-    // `where` of an entry: lane | row << 6 | payload << 14; bit 31 clear: the payload (bits 14..25) is the set of shapes
+    // `where` of an entry: lane | row << 6 | payload << PAY; bit 31 clear: the payload (12 bits) is the set of shapes
     // that filed the hit's key: rank the first one's key among the shape's keys, load that entry, check the pattern --
     // the shape is a run-time value there (constants from LDS), so lanes whose hits belong to different shapes share one
     // trip to the entry table.  A lane never holds the other 63 for a second trip: a key filed under a further shape as
     // well (one hit in ten), or a further pattern filed under the same key (3 % of the keys of a 4096-pattern panel --
     // but some lane of nearly every round), goes back into the queue as a new entry, written over slots this drain has
-    // consumed, and the next generation of rounds takes those at full occupancy again (bit 31 set: the payload, bits
-    // 14..30, is the index of the entry to check).
+    // consumed, and the next generation of rounds takes those at full occupancy again (bit 31 set: the payload, up to
+    // bit 30, is the index of the entry to check).
     s << "    auto flush = [&]() __attribute__((always_inline)) {\n"
          "      u32 n = qn;\n"
-         "      const u64 pair_base = cp << 13; // first position of this column pair\n"
+         "      const u64 pair_base = cp * (8192u * SW); // first position of this unit\n"
          "      const u32 shard = (u32)cp & 255u;\n"
          "      while (n != 0u) {\n"
          "        u32 nc = 0u; // entries handed back so far: slots [0, nc), always behind the round being read\n"
@@ -1122,12 +1133,12 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "          if (i < n) {\n"
          "            const v4 e = *reinterpret_cast<const v4*>(wq + i * 4u);\n"
          "            hkm = ((u64)e.y << 32) | e.x; hbad = e.z; where = e.w;\n"
-         "            if (where & 0x80000000u) idx = (where >> 14) & 0x1FFFFu;\n"
-         "            else pend = (where >> 14) & 0xFFFu;\n"
+         "            if (where & 0x80000000u) idx = (where & 0x7FFFFFFFu) >> PAY;\n"
+         "            else pend = (where >> PAY) & 0xFFFu;\n"
          "          }\n"
          "          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // every lane has read its slot: slots up to qb + 63 may be rewritten\n"
          "          const u32 rest = pend & (pend - 1u);\n"
-         "          hand_back(rest != 0u, hkm, hbad, (where & 0x3FFFu) | (rest << 14));\n"
+         "          hand_back(rest != 0u, hkm, hbad, (where & ((1u << PAY) - 1u)) | (rest << PAY));\n"
          "          if (pend != 0u) {\n"
          "            const u32 sidx = (u32)__builtin_ctz(pend);\n"
          "            const u32 c0 = lds[SHAPE_WORD0 + 2u * sidx], c1 = lds[SHAPE_WORD0 + 2u * sidx + 1u];\n"
@@ -1139,15 +1150,15 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "          }\n"
          "          u32 next = 0xFFFFFFFFu;\n"
          "          if (idx != 0xFFFFFFFFu) {\n"
-         "            const u32 strand_off = (where & 63u) << 7;\n"
-         "            const int erow = (int)((where >> 6) & 0xFFu);\n"
+         "            const u32 strand_off = ((where & 63u) * SW) << 7;\n"
+         "            const int erow = (int)((where >> 6) & ((1u << (PAY - 6u)) - 1u));\n"
          "            next = check_entry(idx, hkm, hbad, erow, pair_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
          "            // a lane hands back at most ONE entry per round (so that slots [0, qb + 64) always hold them): one that\n"
          "            // has done so for its shapes, or whose entry indices do not fit a queue entry, walks the chain here\n"
          "            if (!CHAIN_CARRY || rest != 0u)\n"
          "              while (next != 0xFFFFFFFFu) next = check_entry(next, hkm, hbad, erow, pair_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
          "          }\n"
-         "          if (CHAIN_CARRY) hand_back(next != 0xFFFFFFFFu, hkm, hbad, (where & 0x3FFFu) | (next << 14) | 0x80000000u);\n"
+         "          if (CHAIN_CARRY) hand_back(next != 0xFFFFFFFFu, hkm, hbad, (where & ((1u << PAY) - 1u)) | (next << PAY) | 0x80000000u);\n"
          "        }\n"
          "        n = nc;\n"
          "        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // the entries handed back are read by other lanes next\n"
@@ -1155,13 +1166,13 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "      qn = 0;\n"
          "      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // queue slots are rewritten by other lanes next\n"
          "    };\n";
-    s << "    const u64 col = cp * 2u + half;\n"
-         "    const u64 ncol = (bit == 31u) ? col + 1u : col;\n"
-         "    const u32 nbit = (bit + 1u) & 31u;\n"
+    s << "    const u64 col = cp * (2u * SW) + ((lane * SW) >> 5);\n"
+         "    const u64 ncol = (bit + SW == 32u) ? col + 1u : col; // the strand after mine: where the tail rows are\n"
+         "    const u32 nbit = (bit + SW) & 31u;\n"
          "    u64 km = 0;\n"
          "    u32 bad = 0xFFFFFFFFu; // invalid-base flags of the last 32 bases, one bit per base\n";
     s << "    auto quad_addr = [&](u32 rq) { // row quads: 32 of my strand, then those of the next one\n"
-         "      const u64 c = rq >= 32u ? ncol : col;\n"
+         "      const u64 c = rq >= 32u * SW ? ncol : col;\n"
          "      return planes + ((((c >> 6) * 32u + (rq & 31u)) * 3u * 64u + (u32)(c & 63u)) << 2); // tile_layout.h: ipcr_plane_word\n"
          "    };\n"
          "    const u32* pa = quad_addr(0u);\n"
@@ -1181,7 +1192,7 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
         s << "      if (u == " << k << "u) {\n";
         if (t == 0) {
             s << "        { const u32 rq = " << rq0 << " + " << k / 4 << "u;\n"
-              << "          b = rq >= 32u ? nbit : bit;\n"
+              << "          b = rq >= 32u * SW ? nbit : bit + (rq >> 5);\n"
               << "          qlo = nlo; qhi = nhi; qiv = niv;\n"
               << "          if (rq + 1u < " << NQ << "u) { pa = quad_addr(rq + 1u); nlo = *reinterpret_cast<const v4*>(pa); nhi = *reinterpret_cast<const v4*>(pa + 256u); niv = *reinterpret_cast<const v4*>(pa + 512u); }\n"
               << "        }\n";
@@ -1228,7 +1239,7 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
              "        if (bal != 0ull) { // one queue entry per lane whatever the number of shapes that hit: (k-mer, invalid flags, where | shapes)\n"
              "          if (hm != 0u) {\n"
              "            const u32 slot = qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));\n"
-             "            v4 e; e.x = (u32)km; e.y = (u32)(km >> 32); e.z = bad; e.w = lane | ((" << rq0 << " * 4u + " << k << "u) << 6) | (hm << 14);\n"
+             "            v4 e; e.x = (u32)km; e.y = (u32)(km >> 32); e.z = bad; e.w = lane | ((" << rq0 << " * 4u + " << k << "u) << 6) | (hm << PAY);\n"
              "            *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
              "          }\n"
              "          qn += (u32)__popcll(bal);\n"

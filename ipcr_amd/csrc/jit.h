@@ -59,7 +59,8 @@ struct IndexGeom {
     bool all_acgt = false; // no indexed pattern holds an IUPAC code (the exact check then needs half an entry)
     int uniform_len = 0;   // every indexed pattern has this length (0: mixed); shifts and masks of the check become constants
     int dl = 0;            // left-anchored windows are tested dl bases after their start (one value for the panel)
-    bool chain_carry = true; // entry indices fit the 17 bits a queue entry has for them: chained patterns of a key go back into the queue
+    int strands = 2;       // consecutive strands a lane walks before the tail rows (1, 2 or 4): fewer tail rows per base, coarser work units
+    uint32_t table_entries = 0; // entries of the panel's table: chained patterns of a key go back into the queue when an entry index fits the bits a queue entry has for it
 };
 std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom);
 JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom, std::string &err);
