@@ -1171,9 +1171,12 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "    const u32 nbit = (bit + SW) & 31u;\n"
          "    u64 km = 0;\n"
          "    u32 bad = 0xFFFFFFFFu; // invalid-base flags of the last 32 bases, one bit per base\n";
-    s << "    auto quad_addr = [&](u32 rq) { // row quads: 32 of my strand, then those of the next one\n"
-         "      const u64 c = rq >= 32u * SW ? ncol : col;\n"
-         "      return planes + ((((c >> 6) * 32u + (rq & 31u)) * 3u * 64u + (u32)(c & 63u)) << 2); // tile_layout.h: ipcr_plane_word\n"
+    s << "    // tile_layout.h: ipcr_plane_word -- word ((block * 32 + row quad) * 3 planes * 64 + column in block) * 4: a per-lane base\n"
+         "    // per column and a wave-uniform offset per row quad (the full expression per quad was 29 VALU instructions of 64-bit math)\n"
+         "    const u32* const base_col = planes + (((col >> 6) * 6144u + (col & 63u)) << 2);\n"
+         "    const u32* const base_ncol = planes + (((ncol >> 6) * 6144u + (ncol & 63u)) << 2);\n"
+         "    auto quad_addr = [&](u32 rq) { // row quads: 32 per strand of mine, then those of the next one\n"
+         "      return (rq >= 32u * SW ? base_ncol : base_col) + (rq & 31u) * 768u;\n"
          "    };\n"
          "    const u32* pa = quad_addr(0u);\n"
          "    v4 nlo = *reinterpret_cast<const v4*>(pa), nhi = *reinterpret_cast<const v4*>(pa + 256u), niv = *reinterpret_cast<const v4*>(pa + 512u);\n"
