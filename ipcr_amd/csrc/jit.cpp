@@ -1179,8 +1179,9 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "      return (rq >= 32u * SW ? base_ncol : base_col) + (rq & 31u) * 768u;\n"
          "    };\n"
          "    const u32* pa = quad_addr(0u);\n"
-         "    v4 nlo = *reinterpret_cast<const v4*>(pa), nhi = *reinterpret_cast<const v4*>(pa + 256u), niv = *reinterpret_cast<const v4*>(pa + 512u);\n"
-         "    v4 qlo, qhi, qiv;\n"
+         "    // two register sets for the row quads: the body holds two quads, each reads one set while the other is being loaded\n"
+         "    v4 alo = *reinterpret_cast<const v4*>(pa), ahi = *reinterpret_cast<const v4*>(pa + 256u), aiv = *reinterpret_cast<const v4*>(pa + 512u);\n"
+         "    v4 blo, bhi, biv;\n"
          "    u32 b = bit;\n";
     // The walk is ONE copy of the U-step body inside a loop; the last pass stops after TAILSTEPS steps.  Every step is
     // guarded by the (wave-uniform) step counter, so that the queue drain exists once in the code, not once per
@@ -1193,43 +1194,45 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
     for (unsigned k = 0; k < U; ++k) {
         const unsigned t = k & 3u;
         s << "      if (u == " << k << "u) {\n";
+        const char cur = (k / 4) % 2 ? 'b' : 'a', nxt = (k / 4) % 2 ? 'a' : 'b'; // (U = 8: quad 0 of a body reads set a, quad 1 set b)
         if (t == 0) {
             s << "        { const u32 rq = " << rq0 << " + " << k / 4 << "u;\n"
               << "          b = rq >= 32u * SW ? nbit : bit + (rq >> 5);\n"
-              << "          qlo = nlo; qhi = nhi; qiv = niv;\n"
-              << "          if (rq + 1u < " << NQ << "u) { pa = quad_addr(rq + 1u); nlo = *reinterpret_cast<const v4*>(pa); nhi = *reinterpret_cast<const v4*>(pa + 256u); niv = *reinterpret_cast<const v4*>(pa + 512u); }\n"
+              << "          if (rq + 1u < " << NQ << "u) { pa = quad_addr(rq + 1u); " << nxt << "lo = *reinterpret_cast<const v4*>(pa); " << nxt << "hi = *reinterpret_cast<const v4*>(pa + 256u); " << nxt << "iv = *reinterpret_cast<const v4*>(pa + 512u); }\n"
               << "        }\n";
         }
-        s << "        km = (km << 2) | (u64)(__builtin_amdgcn_ubfe(qlo[" << t << "], b, 1u) | (__builtin_amdgcn_ubfe(qhi[" << t << "], b, 1u) << 1));\n"
-          << "        bad = (bad << 1) | __builtin_amdgcn_ubfe(qiv[" << t << "], b, 1u);\n"
-          << "        u32 hm = 0u; // shapes that hold this step's key\n";
+        s << "        km = (km << 2) | (u64)(__builtin_amdgcn_ubfe(" << cur << "lo[" << t << "], b, 1u) | (__builtin_amdgcn_ubfe(" << cur << "hi[" << t << "], b, 1u) << 1));\n"
+          << "        bad = (bad << 1) | __builtin_amdgcn_ubfe(" << cur << "iv[" << t << "], b, 1u);\n"
+          << "        u32 hm; // shapes that hold this step's key\n";
         // dev knobs (tools/c4_knobs.sh): what one more LDS lookup / VALU instruction per base step costs -- which unit binds
         const int xl = env_int("IPCR_INDEX_XLDS", 0, 0, 8), xv = env_int("IPCR_INDEX_XVALU", 0, 0, 64);
         for (int x = 0; x < xl; ++x)
             s << "        u32 dummy" << x << "; { const u32 da = (((u32)(km >> " << 8 + 2 * x << "u) & 1023u) << 3) + " << (x % 4) * 8192 << "u; asm volatile(\"ds_read_b32 %0, %1\" : \"=v\"(dummy" << x << ") : \"v\"(da) : \"memory\"); }\n";
-        for (size_t gi = 0; gi < groups.size(); ++gi) {
-            const Grp &g = groups[gi];
-            if (g.sh.empty()) continue;
-            if (g.fast) {
-                // byte address of the 32-bit half word = (bitmap word index) * 8 + (bit 5 of c) * 4; the bit test takes c's low five bits
-                s << "        { const u32 c = (u32)(km >> " << g.c_off << "u) & 63u, ch = (c >> 3) & 4u;\n";
-                for (int si : g.sh) {
-                    const ipcr_index_shape &sh = shapes[(size_t)si];
-                    // a one-shape group keys on protected bases only: the word index is what follows the six bits of c
-                    const bool single = sh.blk_mask == 0;
-                    const unsigned off = single ? (unsigned)sh.tw_shift + 6u : (unsigned)sh.blk_shift;
-                    const unsigned vmask = single ? ((1u << (sh.tw_bits - 6)) - 1u) : sh.blk_mask;
-                    std::string a;
-                    if (vmask == 0) a = "ch";
-                    else if (off >= 3) a = "(((u32)(km >> " + std::to_string(off - 3) + "u) & " + std::to_string(vmask << 3) + "u) | ch)";
-                    else a = "((((u32)(km >> " + std::to_string(off) + "u) & " + std::to_string(vmask) + "u) << 3) | ch)";
-                    s << "          hm |= __builtin_amdgcn_ubfe(*reinterpret_cast<const u32*>(reinterpret_cast<const char*>(lds) + " << off64[(size_t)si] * 8u << "u + " << a << "), c & 31u, 1u) << " << si << ";\n";
-                }
-                s << "        }\n";
+        // the shapes' bits are shifted into the mask from the highest shape down (one v_lshl_or each): bit s = shape s
+        for (size_t gi = 0; gi < groups.size(); ++gi)
+            if (groups[gi].fast && !groups[gi].sh.empty()) // the group's six protected-base bits: c selects the bit, ch the half word
+                s << "        const u32 c" << gi << " = (u32)(km >> " << groups[gi].c_off << "u) & 63u, ch" << gi << " = (c" << gi << " >> 3) & 4u;\n";
+        for (int si = (int)NS - 1; si >= 0; --si) {
+            const ipcr_index_shape &sh = shapes[(size_t)si];
+            const size_t gi = sh.group;
+            std::string bitx;
+            if (groups[gi].fast) {
+                // byte address of the 32-bit half word = (bitmap word index) * 8 + (bit 5 of c) * 4; the bit test takes c's low five bits.
+                // A one-shape group keys on protected bases only: the word index is what follows the six bits of c
+                const bool single = sh.blk_mask == 0;
+                const unsigned off = single ? (unsigned)sh.tw_shift + 6u : (unsigned)sh.blk_shift;
+                const unsigned vmask = single ? ((1u << (sh.tw_bits - 6)) - 1u) : sh.blk_mask;
+                const std::string ch = "ch" + std::to_string(gi);
+                std::string a;
+                if (vmask == 0) a = ch;
+                else if (off >= 3) a = "(((u32)(km >> " + std::to_string(off - 3) + "u) & " + std::to_string(vmask << 3) + "u) | " + ch + ")";
+                else a = "((((u32)(km >> " + std::to_string(off) + "u) & " + std::to_string(vmask) + "u) << 3) | " + ch + ")";
+                bitx = "__builtin_amdgcn_ubfe(*reinterpret_cast<const u32*>(reinterpret_cast<const char*>(lds) + " + std::to_string(off64[(size_t)si] * 8u) + "u + " + a + "), c" + std::to_string(gi) + " & 31u, 1u)";
             } else {
-                for (int si : g.sh)
-                    s << "        { const u32 key = key_of<" << si << ">::get(km); const u32 w = lds[" << off64[(size_t)si] * 2u << "u + (key >> 5)]; hm |= ((w >> (key & 31u)) & 1u) << " << si << "; }\n";
+                s << "        const u32 key" << si << " = key_of<" << si << ">::get(km);\n";
+                bitx = "__builtin_amdgcn_ubfe(lds[" + std::to_string(off64[(size_t)si] * 2u) + "u + (key" + std::to_string(si) + " >> 5)], key" + std::to_string(si) + " & 31u, 1u)";
             }
+            s << "        hm = " << (si == (int)NS - 1 ? std::string() : std::string("(hm << 1) | ")) << bitx << ";\n";
         }
         if (xl) {
             s << "        asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n";
