@@ -69,7 +69,7 @@ def main():
                        algorithmic_bytes_per_launch=alg)
         if w == "c4" and all(k in out for k in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")):
             # the index kernel is not HBM-bound: say what binds it, from the counters themselves
-            steps = 3.0e9 / 64.0 * 147.0 / 128.0   # wave-level base steps: 128 rows + 19 of the next strand
+            steps = 3.0e9 / 64.0 * 531.0 / 512.0   # wave-level base steps: a lane walks four strands (3 Gb: host.cpp index_kernel) + 19 rows of the next
             cu_cycles = 256.0 * out["GRBM_GUI_ACTIVE"]["avg"] / 8.0          # GRBM_GUI_ACTIVE is summed over the 8 XCDs
             out["derived"] = {
                 "wave_base_steps_per_launch": round(steps),
@@ -82,7 +82,10 @@ def main():
             out["note"] += (" CAUTION for this kernel: the x2 rule is calibrated for 16 B/lane coalesced streams; the index filter's tile "
                             "loads are two distinct 16-byte pieces per wave instruction (the 32 lanes of a half-wave share one "
                             "word), an access width the guide calls uncalibrated, so hbm_read is an upper bound and the raw counter "
-                            "a lower one (1.15x the algorithmic bytes would be the 147 rows walked per 128-row strand). The kernel "
+                            "a lower one.  A lane walks four strands of one column (3 Gb), i.e. the column's words four times, 128 base steps "
+                            "apart: 192 KB of rows per CU are live, more than a CU's share of the L2, so most re-reads miss it and are "
+                            "counted here although the 256 MB Infinity Cache serves them (one strand per lane read 1.2x the algorithmic "
+                            "bytes; the sweep was 8 %% slower).  The kernel "
                             "is bound by VALU issue and LDS cycles together either way: see `derived`.")
         name = "filter" if w == "c2" else w
         with open(os.path.join(dst, f"{tag}_{name}_pmc.json"), "w") as fh:
