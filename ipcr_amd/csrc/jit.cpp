@@ -993,6 +993,11 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
     while ((1 << STEP_BITS) <= RT) ++STEP_BITS;
     const unsigned PAY = 6u + STEP_BITS; // `where` of a queue entry: lane | row << 6 | payload << PAY
     const bool chain_carry = geom.table_entries < (1u << (31u - PAY));
+    // A lane files one queue entry per TWO base steps when the shapes' bits of both fit the entry's 12 and the window of
+    // the earlier step is still in the 32-base k-mer one step later: half the ballots, slot computations and 16-byte
+    // LDS stores; the drain shifts k-mer, flags and row back by one step for a bit of the earlier step.
+    unsigned SPE = (2u * NS <= 12u && (unsigned)std::max(tail_rows, 0) + 2u <= 32u) ? 2u : 1u;
+    SPE = (unsigned)env_int("IPCR_INDEX_STEPS_PER_ENTRY", (int)SPE, 1, (int)SPE);
     const unsigned NQ = (unsigned)(RT + 3) / 4;        // row quads walked
     const unsigned NB = NQ * 4 / U;                    // full unrolled bodies
     const unsigned TAILSTEPS = NQ * 4 - NB * U;        // a shorter copy of the body finishes the walk
@@ -1018,6 +1023,7 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
     s << "#define CHAIN_CARRY " << (chain_carry ? "true" : "false") << " // further patterns of a key are handed back to the queue (entry index in " << 31u - PAY << " bits)\n";
     s << "#define SW " << SW << "u // strands a lane walks before the tail rows\n";
     s << "#define PAY " << PAY << "u // where = lane | row << 6 | payload << PAY\n";
+    s << "#define SPE " << SPE << "u // base steps per queue entry: payload bit j * NS + s = shape s, j steps before the entry's row\n";
     auto arr = [&](const char *type, const char *name, auto get) {
         s << "__device__ constexpr " << type << " " << name << "[NS] = {";
         for (size_t i = 0; i < NS; ++i) s << (i ? ", " : "") << get(shapes[i]);
@@ -1138,9 +1144,10 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "          }\n"
          "          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // every lane has read its slot: slots up to qb + 63 may be rewritten\n"
          "          const u32 rest = pend & (pend - 1u);\n"
-         "          hand_back(rest != 0u, hkm, hbad, (where & ((1u << PAY) - 1u)) | (rest << PAY));\n"
+         "          hand_back(rest != 0u, hkm, hbad, (where & ((1u << PAY) - 1u)) | (rest << PAY)); // (k-mer, flags and row as filed)\n"
          "          if (pend != 0u) {\n"
-         "            const u32 sidx = (u32)__builtin_ctz(pend);\n"
+         "            u32 sidx = (u32)__builtin_ctz(pend);\n"
+         "            if (SPE > 1u && sidx >= NS) { sidx -= NS; hkm >>= 2; hbad >>= 1; where -= 64u; } // a hit of the step before the entry's: its own k-mer, flags, row\n"
          "            const u32 c0 = lds[SHAPE_WORD0 + 2u * sidx], c1 = lds[SHAPE_WORD0 + 2u * sidx + 1u];\n"
          "            const u32 key = ((u32)(hkm >> (c0 & 63u)) & (c1 & 0xFFFFu)) | (((u32)(hkm >> ((c0 >> 8) & 63u)) & (c1 >> 16)) << ((c0 >> 16) & 31u));\n"
          "            const u32 wi = (c0 >> 21) * 16u + (key >> 6); // the shape's bitmap word with this key\n"
@@ -1182,7 +1189,8 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "    // two register sets for the row quads: the body holds two quads, each reads one set while the other is being loaded\n"
          "    v4 alo = *reinterpret_cast<const v4*>(pa), ahi = *reinterpret_cast<const v4*>(pa + 256u), aiv = *reinterpret_cast<const v4*>(pa + 512u);\n"
          "    v4 blo, bhi, biv;\n"
-         "    u32 b = bit;\n";
+         "    u32 b = bit;\n"
+         "    u32 hprev = 0u; // (SPE = 2) the shapes that held the key of the step before\n";
     // The walk is ONE copy of the U-step body inside a loop; the last pass stops after TAILSTEPS steps.  Every step is
     // guarded by the (wave-uniform) step counter, so that the queue drain exists once in the code, not once per
     // step: a step that fills the queue marks the counter, the remaining guards fall through (two scalar
@@ -1240,19 +1248,25 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
         }
         for (int x = 0; x < xv; ++x)
             s << "        { u32 dv; asm volatile(\"v_mov_b32 %0, %1\" : \"=v\"(dv) : \"v\"(bad)); asm volatile(\"\" :: \"v\"(dv)); }\n";
-        // qn <= QCAP - 64 on entry (a fuller queue is drained before the next step runs) and a step adds at most 64: no overflow
-        s << "        const u64 bal = __ballot(hm != 0u);\n"
-             "        if (bal != 0ull) { // one queue entry per lane whatever the number of shapes that hit: (k-mer, invalid flags, where | shapes)\n"
-             "          if (hm != 0u) {\n"
-             "            const u32 slot = qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));\n"
-             "            v4 e; e.x = (u32)km; e.y = (u32)(km >> 32); e.z = bad; e.w = lane | ((" << rq0 << " * 4u + " << k << "u) << 6) | (hm << PAY);\n"
-             "            *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
-             "          }\n"
-             "          qn += (u32)__popcll(bal);\n"
-             "        }\n";
+        const bool files = SPE == 1u || (k & 1u) == 1u; // this step files the queue entry (of itself, or of itself and the step before)
+        if (!files) s << "        hprev = hm;\n";
+        else {
+            if (SPE > 1u) s << "        hm |= hprev << NS;\n";
+            // qn <= QCAP - 64 on entry (a fuller queue is drained before the next step runs) and a step adds at most 64: no overflow
+            s << "        const u64 bal = __ballot(hm != 0u);\n"
+                 "        if (bal != 0ull) { // one queue entry per lane whatever the number of shapes that hit: (k-mer, invalid flags, where | shapes)\n"
+                 "          if (hm != 0u) {\n"
+                 "            const u32 slot = qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));\n"
+                 "            v4 e; e.x = (u32)km; e.y = (u32)(km >> 32); e.z = bad; e.w = lane | ((" << rq0 << " * 4u + " << k << "u) << 6) | (hm << PAY);\n"
+                 "            *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
+                 "          }\n"
+                 "          qn += (u32)__popcll(bal);\n"
+                 "        }\n";
+        }
         s << "        u = " << k + 1 << "u;\n";
         if (TAILSTEPS && k + 1 == TAILSTEPS) s << "        if (it == " << NB << "u) { done = true; u = 255u; } // the last pass ends here\n";
-        s << "        if (qn > QCAP - 64u) u |= 256u;\n      }\n";
+        if (files) s << "        if (qn > QCAP - 64u) u |= 256u;\n";
+        s << "      }\n";
     }
     s << "      const bool full = (u & 256u) != 0u;\n"
          "      u &= 255u;\n"
