@@ -660,6 +660,19 @@ def test_concurrent_workers_share_one_panel(hip):
     want_big = [w.sig() for w in O.simulate_batch(ocfg(cfg), big, opairs(pairs))]
     for sc in (s1, s2, s1):
         assert [p.sig() for p in eng.SimulateCompiledWithScratch("big", big, cp, sc)] == want_big and len(want_big) >= 4
+    # a chunk of up to 8 MiB goes in two halves (the split is rounded up to 4 KiB): lengths around the roundings, an
+    # amplicon across the split, and the degenerate ones
+    for n in (0, 1, 15, 16, 4095, 4096, 4097, 8191, 8193, 100_001, 8_388_608):
+        seq = bytearray(O.bench_dna(n, 99 + n)) if n else bytearray()
+        half = (((n + 1) // 2) + 4095) & ~4095
+        if n >= 8193:
+            a = min(half, n - 300) - 100
+            seq[a:a + 16] = pairs[0].Forward.encode()
+            seq[a + 200:a + 216] = O.revcomp(pairs[0].Reverse)
+        seq = bytes(seq)
+        want_n = [w.sig() for w in O.simulate_batch(ocfg(cfg), seq, opairs(pairs))]
+        assert [p.sig() for p in eng.SimulateCompiledWithScratch("n%d" % n, seq, cp, s2)] == want_n, n
+        assert n < 8193 or len(want_n) >= 1
     s1.close()
     s2.close()
 
