@@ -21,7 +21,7 @@ for r in range(nrec):
     torch.cuda.synchronize()
     g.add_record_device("chr%d" % (r + 1), buf.data_ptr(), reclen)
 del buf
-cfg = E.Config(MaxMM=2, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)
+cfg = E.Config(MaxMM=int(os.environ.get("C4_K", "2")), TerminalWindow=int(os.environ.get("C4_TW", "3")), MaxLen=2000, HitCap=10000, SeedLen=12)
 eng = E.New(cfg)
 t0 = time.time(); cp = eng.CompilePanel(pairs); print(f"CompilePanel {len(pairs)} pairs, {cp.num_patterns} patterns: {time.time()-t0:.2f} s", flush=True)
 sc = eng.NewSimulationScratch(cp)
