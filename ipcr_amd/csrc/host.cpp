@@ -314,7 +314,20 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         // (performance_benchmark_test.go:78-93), and a block that ends on them files 2048 primers under 891 keys.
         const int A = g.lmin - t;
         std::vector<int> bits((size_t)ns, 2 * b), pos((size_t)ns, 0);
-        for (int j = 1; j < ns; ++j) pos[(size_t)j] = pos[(size_t)j - 1] + (b > 0 ? b : 0);
+        if ((!tri || b < 5) && b > 0 && ns > 1) {
+            // fewer than three protected bases: a key is (the protected bases +) one block of up to 8 - tu bases, and
+            // short keys are dense (1024 rows, k = 2, no window: 2048 patterns per side under 12-bit keys).  The blocks
+            // tile ALL the A bases -- the first A mod (k+1) blocks one base longer -- and read as much of their span
+            // as a key can hold (20-mers, k = 2: 7 + 7 + 6 bases instead of 6 + 6 + 6: half the hits).  The same
+            // for three protected bases + blocks shorter than five (k = 3 on 20-mers: 5 + 4 + 4 + 4)
+            const int rem = A - bf * ns;
+            for (int j = 0; j < ns; ++j) {
+                const int span = bf + (j < rem ? 1 : 0);
+                bits[(size_t)j] = 2 * std::min(tri ? 5 : 8 - tu, span);
+                if (j) pos[(size_t)j] = pos[(size_t)j - 1] + bf + (j - 1 < rem ? 1 : 0);
+            }
+        } else
+            for (int j = 1; j < ns; ++j) pos[(size_t)j] = pos[(size_t)j - 1] + (b > 0 ? b : 0);
         for (int j = 0; j < ns; ++j) lds_used += shape_bytes((unsigned)(2 * tu + bits[(size_t)j]));
         // files the group's shapes and keys for one layout; returns its cost (see above)
         auto emit = [&](const std::vector<int> &pos, const std::vector<int> &bits) -> double {
