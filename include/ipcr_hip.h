@@ -118,6 +118,9 @@ typedef struct {
                                       not both arrived within 2 ms */
     uint64_t handover_checked;     /* IPCR_DEBUG_PUBLISH_CHECK=1: scans whose pinned records were compared with device memory */
     uint64_t handover_check_diffs; /* ... records that differed (must be 0) */
+    /* seed-index panels: patterns the index cannot key (primers > 32 nt, too many IUPAC expansions in a key) */
+    uint32_t leftover_patterns;    /* how many of the panel's patterns those are */
+    uint32_t leftover_kernels;     /* specialised spill-only filters that took them (0: the table-driven kernel did) */
 } ipcr_scan_stats;
 
 typedef struct ipcr_panel ipcr_panel;     /* engine.CompiledPanel + device tables */

@@ -67,7 +67,7 @@ class ScanStats(C.Structure):
                 ("kernel_kind", C.c_int32), ("n_patterns", C.c_int32), ("enqueue_ms", C.c_double),
                 ("wait_ms", C.c_double), ("sort_ms", C.c_double), ("join_ms", C.c_double),
                 ("handover_refetched", C.c_uint64), ("handover_checked", C.c_uint64),
-                ("handover_check_diffs", C.c_uint64)]
+                ("handover_check_diffs", C.c_uint64), ("leftover_patterns", C.c_uint32), ("leftover_kernels", C.c_uint32)]
 
 
 EMIT_FN = C.CFUNCTYPE(C.c_int, C.POINTER(Product), C.c_void_p)

@@ -199,6 +199,7 @@ struct IndexPlan {
     ipcr_index_entry *d_table = nullptr;
     uint32_t *d_leftover = nullptr;
     ipcr::JitFilter *jit = nullptr; // the kernel, with the key shapes baked in (hiprtc): lanes walk two strands each
+    std::vector<ipcr::JitFilter *> leftover_jit; // specialised spill-only filters for `leftover` (else the table-driven kernel takes them)
     ipcr::JitFilter *jit_sw[2] = {nullptr, nullptr}; // ... one strand / four strands, built when a genome of that size class is first scanned
 };
 
@@ -698,6 +699,7 @@ void ipcr_panel_destroy(ipcr_panel *p) {
         if (s.index.jit) ipcr::jit_destroy(s.index.jit);
         for (ipcr::JitFilter *f : s.index.jit_sw)
             if (f) ipcr::jit_destroy(f);
+        for (ipcr::JitFilter *f : s.index.leftover_jit) ipcr::jit_destroy(f);
         if (s.index.d_lds_image) (void)hipFree(s.index.d_lds_image);
         if (s.index.d_table) (void)hipFree(s.index.d_table);
         if (s.index.d_leftover) (void)hipFree(s.index.d_leftover);
@@ -1229,8 +1231,15 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode) {
             HIPCHK(hipMalloc((void **)&ix.d_table, ix.table.size() * sizeof(ipcr_index_entry)));
             HIPCHK(hipMemcpy(ix.d_table, ix.table.data(), ix.table.size() * sizeof(ipcr_index_entry), hipMemcpyHostToDevice));
             if (!ix.leftover.empty()) {
-                HIPCHK(hipMalloc((void **)&ix.d_leftover, ix.leftover.size() * 4));
-                HIPCHK(hipMemcpy(ix.d_leftover, ix.leftover.data(), ix.leftover.size() * 4, hipMemcpyHostToDevice));
+                // What the index cannot key (primers > 32 nt, too many IUPAC expansions in a key): a handful of patterns
+                // in practice.  The table-driven kernel costs ~4 ms per pattern and 3 Gb; specialised spill-only filters
+                // (their survivors join the index's in the candidate queue) cost one ~0.25 ms sweep per 12 patterns.
+                std::string lerr;
+                ix.leftover_jit = ipcr::jit_build(s.host, p->cfg.max_mm, lerr, &ix.leftover);
+                if (ix.leftover_jit.empty()) {
+                    HIPCHK(hipMalloc((void **)&ix.d_leftover, ix.leftover.size() * 4));
+                    HIPCHK(hipMemcpy(ix.d_leftover, ix.leftover.data(), ix.leftover.size() * 4, hipMemcpyHostToDevice));
+                }
             }
         }
     }
@@ -1427,11 +1436,29 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         const bool more = !ix.leftover.empty();
         HIPCHK(ipcr::jit_launch_index(index_kernel(p, pd.mode, nblocks), lane, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_lds_image, ix.d_table,
                                       (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, qc, s->ev[0], more ? nullptr : s->ev[1]));
-        if (more) // patterns the index cannot key
+        if (more && !ix.leftover_jit.empty()) { // patterns the index cannot key: specialised filters that only fill the queue
+            ipcr::JitVerify v;
+            v.rst = g->rst;
+            v.pats = set.dev;
+            v.rec_start = g->d_rec_start;
+            v.block_rec = g->d_block_rec;
+            v.rec_len = g->d_rec_len;
+            v.nrec = pd.nrec;
+            v.max_mm = (uint32_t)p->cfg.max_mm;
+            v.check_rst = pd.check_rst;
+            v.hits = s->d_hits;
+            v.hcap = s->hcap;
+            v.counts = cnt;
+            for (size_t gi = 0; gi < ix.leftover_jit.size(); ++gi)
+                HIPCHK(ipcr::jit_launch(ix.leftover_jit[gi], lane, g->planes, nblocks, s->d_queue, s->qcap, qc, v, nullptr,
+                                        gi + 1 == ix.leftover_jit.size() ? s->ev[1] : nullptr));
+        } else if (more)
             HIPCHK(ipcr::launch_filter_generic(lane, g->planes, nblocks, set.dev, (uint32_t)ix.leftover.size(),
                                                (uint32_t)p->cfg.max_mm, ix.d_leftover, s->d_queue, s->qcap, qc,
                                                nullptr, s->ev[1]));
         s->stats.kernel_kind = 3;
+        s->stats.leftover_patterns = (uint32_t)ix.leftover.size();
+        s->stats.leftover_kernels = (uint32_t)ix.leftover_jit.size();
     } else {
         HIPCHK(ipcr::launch_filter_generic(lane, g->planes, nblocks, set.dev, (uint32_t)set.ids.size(),
                                            (uint32_t)p->cfg.max_mm, nullptr, s->d_queue, s->qcap, qc, s->ev[0], s->ev[1]));

@@ -284,8 +284,10 @@ std::string count_code(int B, int k, int *cost) {
     return use_cs ? cs.str() : th.str();
 }
 
-std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, unsigned qbase) {
-    if (full_pats.empty() || full_pats.size() > 48) return "";
+std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, unsigned qbase,
+                       const std::vector<uint32_t> *ids, bool spill_only) {
+    if (full_pats.empty() || full_pats.size() > 48 || (ids && ids->size() != full_pats.size())) return "";
+    auto pid = [&](size_t q) { return ids ? (unsigned)(*ids)[q] : qbase + (unsigned)q; }; // index in the panel's device table
     // The register window is the kernel's budget (W rows x 4 planes), and the filter only has to be SOUND: a window
     // with <= k mismatches has <= k mismatches at any subset of its positions.  So a pattern longer than LF is
     // filtered by its LF positions next to the protected end (the others are left to the exact verifier, which reads
@@ -325,7 +327,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     const int QW = (LM1 + 3) / 4;            // head quads stashed for the wrap phase
     // survivor words a wave keeps for its own verify pass; 0 = every survivor spills to the global queue and the host
     // runs the stand-alone verifier (kernels with a primer longer than 32 nt)
-    const int LIST_CAP = long_pattern ? 0 : env_int("IPCR_JIT_LIST", 48, 1, 64);
+    const int LIST_CAP = (long_pattern || spill_only) ? 0 : env_int("IPCR_JIT_LIST", 48, 1, 64);
     const int CAND_CAP = env_int("IPCR_JIT_CANDS", 128, 2, 1024); // candidate windows verified two per load round
 
     // exact count in the rare branch (see row_code): emitted once per (row slot, pattern), so only for small kernels
@@ -430,10 +432,10 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
                 b << "              }\n";
             }
             if (offs[q] == 0)
-                b << "              if (f != 0xFFFFFFFFu) push(" << (qbase + q) << "ull, pos, ~f, lcnt, lkey, lbits, queue, qcap, qcount, counts);\n";
+                b << "              if (f != 0xFFFFFFFFu) push(" << pid(q) << "ull, pos, ~f, lcnt, lkey, lbits, queue, qcap, qcount, counts);\n";
             else // the window starts offs[q] rows before the filtered part: in the previous strand (= the previous bit) when that crosses row 0
                 b << "              if (f != 0xFFFFFFFFu) { u64 wp = pos; u32 wm = ~f; if (wp >= " << offs[q] << "ull) wp -= " << offs[q]
-                  << "ull; else { wp += " << 128 - offs[q] << "ull; wm >>= 1; } if (wm) push(" << (qbase + q)
+                  << "ull; else { wp += " << 128 - offs[q] << "ull; wm >>= 1; } if (wm) push(" << pid(q)
                   << "ull, wp, wm, lcnt, lkey, lbits, queue, qcap, qcount, counts); }\n";
             b << "            }\n";
         }
@@ -882,8 +884,13 @@ size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats, int max_mm) {
 
 // Large panels are cut into groups of patterns; every group becomes its own kernel (each
 // streams the tiles once and appends to the same candidate queue).  Groups compile in parallel.
-std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err) {
+std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &all_pats, int max_mm, std::string &err,
+                                   const std::vector<uint32_t> *subset) {
     std::vector<JitFilter *> out;
+    std::vector<ipcr_dev_pattern> chosen;
+    if (subset)
+        for (uint32_t q : *subset) chosen.push_back(all_pats[q]);
+    const std::vector<ipcr_dev_pattern> &pats = subset ? chosen : all_pats;
     const size_t G = jit_group_size(pats, max_mm);
     if (G == 0) { err = "panel not specialised (more pattern groups than IPCR_JIT_MAX_GROUPS)"; return out; }
     const size_t ngroups = (pats.size() + G - 1) / G;
@@ -901,7 +908,11 @@ std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, in
     std::vector<char> ok(ngroups, 0);
     for (size_t g = 0; g < ngroups; ++g) {
         const size_t q0 = g * G, q1 = std::min(pats.size(), q0 + G);
-        srcs[g] = jit_source(std::vector<ipcr_dev_pattern>(pats.begin() + (long)q0, pats.begin() + (long)q1), max_mm, (unsigned)q0);
+        if (subset) {
+            const std::vector<uint32_t> ids(subset->begin() + (long)q0, subset->begin() + (long)q1);
+            srcs[g] = jit_source(std::vector<ipcr_dev_pattern>(pats.begin() + (long)q0, pats.begin() + (long)q1), max_mm, 0, &ids, true);
+        } else
+            srcs[g] = jit_source(std::vector<ipcr_dev_pattern>(pats.begin() + (long)q0, pats.begin() + (long)q1), max_mm, (unsigned)q0);
     }
     unsigned nthreads = std::thread::hardware_concurrency();
     if (nthreads == 0) nthreads = 4;

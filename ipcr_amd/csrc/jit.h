@@ -15,12 +15,17 @@ struct JitFilter;
 
 // HIP source of the specialised filter for one group of patterns (also used by the build
 // check); queue entries carry pattern index qbase + position in `pats`
-std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int max_mm, unsigned qbase = 0);
+// ids: the patterns' indices in the panel's device table when they are not qbase, qbase + 1, ... (a subset of a panel);
+// spill_only: every survivor goes to the candidate queue (the stand-alone verifier follows), nothing is verified in the kernel
+std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int max_mm, unsigned qbase = 0,
+                       const std::vector<uint32_t> *ids = nullptr, bool spill_only = false);
 // patterns per kernel for this panel; 0 = not specialisable (table-driven filter)
 size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats, int max_mm);
 // one kernel per pattern group, compiled in parallel; empty (and `err` set) when the panel
 // cannot be specialised or hiprtc fails
-std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err);
+// subset: build for these patterns of `pats` only, as spill-only kernels (what a seed-index panel cannot key)
+std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &pats, int max_mm, std::string &err,
+                                   const std::vector<uint32_t> *subset = nullptr);
 // The specialised filter verifies its own survivors (each wave, when its block is done) and appends
 // the hit records itself: these are the exact verifier's operands.  counts = this scan's counter
 // set ([0] survivor words spilled to the queue because a wave's list was full -> the stand-alone

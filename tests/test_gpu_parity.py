@@ -782,6 +782,29 @@ def test_index_drain_under_chains_and_crowded_rounds(hip, force_index):
     assert [g.sig() for g in got] == [w.sig() for w in want]
 
 
+def test_index_panel_leftovers_take_specialised_filters(hip):
+    """a 120-row panel (seed index) in which four rows have primers of 36-40 nt and two have four N in what would be
+    their keys: the index cannot key those patterns, and they must not fall to the table-driven kernel (~4 ms per
+    pattern and 3 Gb) -- spill-only specialised filters take them, their survivors join the index's in the candidate
+    queue; vs the oracle"""
+    rng = random.Random(29)
+    P = hip.primer.Pair
+    def mk(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+    rows = [P("row%03d" % i, mk(rng.randint(18, 25)), mk(rng.randint(18, 25)), 0, 0) for i in range(114)]
+    rows += [P("long%d" % i, mk(36 + i), mk(40 - i), 0, 0) for i in range(4)]
+    for i in range(2):   # N at four of the five bases of the block next to the protected end: 256 expansions of that key
+        f = list(mk(20)); f[13:17] = "NNNN"
+        rows.append(P("deg%d" % i, "".join(f), mk(20), 0, 0))
+    plant_rows = rows[:6] + rows[114:]
+    g, seqs = build_planted_genome(hip, rng, 2, 300_000, plant_rows, 0x5eed1241)
+    cfg = hip.engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)
+    _, cp, sc, got = scan_and_compare(hip, cfg, rows, g, seqs)
+    st = sc.stats()
+    assert st.kernel_kind == 3 and st.leftover_patterns >= 18 and st.leftover_kernels >= 2 and len(got) >= 8
+    g.close()
+
+
 def test_need_sites(hip):  # core/engine/engine.go:175-183 (FwdSite / RevSite for pretty text)
     E, P = hip.engine, hip.primer.Pair
     seq = b"TTTTCGTACAAAAGGTACCTTT"

@@ -21,6 +21,9 @@ for r in range(nrec):
     torch.cuda.synchronize()
     g.add_record_device("chr%d" % (r + 1), buf.data_ptr(), reclen)
 del buf
+nlong = int(os.environ.get("C4_LONG", "0"))   # rows with 36-nt primers: patterns the seed index cannot key
+if nlong:
+    pairs = list(pairs) + [primer.Pair("long%d" % i, workloads.bench_primer(5000 + 2 * i, 36), workloads.bench_primer(5001 + 2 * i, 36), 128, 212) for i in range(nlong)]
 cfg = E.Config(MaxMM=int(os.environ.get("C4_K", "2")), TerminalWindow=int(os.environ.get("C4_TW", "3")), MaxLen=2000, HitCap=10000, SeedLen=12)
 eng = E.New(cfg)
 t0 = time.time(); cp = eng.CompilePanel(pairs); print(f"CompilePanel {len(pairs)} pairs, {cp.num_patterns} patterns: {time.time()-t0:.2f} s", flush=True)
@@ -29,4 +32,4 @@ t0 = time.time(); n = eng.ScanGenomeCount(g, cp, sc); print(f"first scan (incl. 
 for i in range(3):
     t0 = time.time(); n = eng.ScanGenomeCount(g, cp, sc); dt = time.time() - t0
     st = sc.stats()
-    print(f"scan: {dt*1e3:.1f} ms  filter {st.filter_ms:.1f} ms verify {st.verify_ms:.2f} ms sort {st.sort_ms:.2f} join {st.join_ms:.2f} wait {st.wait_ms:.2f}  products {n} hits {st.hits} cand {st.candidates} kind {st.kernel_kind} -> {g.total_bases/dt/1e9:.1f} Gbases/s", flush=True)
+    print(f"scan: {dt*1e3:.1f} ms  leftover {st.leftover_patterns} patterns in {st.leftover_kernels} kernels  filter {st.filter_ms:.1f} ms verify {st.verify_ms:.2f} ms sort {st.sort_ms:.2f} join {st.join_ms:.2f} wait {st.wait_ms:.2f}  products {n} hits {st.hits} cand {st.candidates} kind {st.kernel_kind} -> {g.total_bases/dt/1e9:.1f} Gbases/s", flush=True)
