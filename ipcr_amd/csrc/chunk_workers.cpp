@@ -119,7 +119,28 @@ int main(int argc, char **argv) {
                                 {"bench_000+A:self", fwd.c_str(), fwd.c_str(), 128, 212},
                                 {"bench_000+B:self", rev.c_str(), rev.c_str(), 128, 212}};
     ipcr_panel *panel = nullptr;
-    if (ipcr_panel_create(&cfg, pairs, 3, &panel) != IPCR_OK) { fprintf(stderr, "%s\n", ipcr_last_error()); return 4; }
+    // CHUNK_PANEL_ROWS=n: an n-row multiplex panel instead (rows 0..n-1 of the benchmark primers + their self pairs,
+    // internal/common/primers.go:41-74; k=2, window 3): what the seed-index kernel does under a worker pool
+    const int rows = getenv("CHUNK_PANEL_ROWS") ? atoi(getenv("CHUNK_PANEL_ROWS")) : 0;
+    std::vector<std::string> names, seqs;
+    std::vector<ipcr_pair> many;
+    if (rows > 0) {
+        cfg.terminal_window = 3;
+        for (int i = 0; i < rows; ++i) { seqs.push_back(bench_primer(2u * (unsigned)i)); seqs.push_back(bench_primer(2u * (unsigned)i + 1u)); }
+        for (int i = 0; i < rows; ++i) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "bench_%03d", i); names.push_back(nm);
+            snprintf(nm, sizeof nm, "bench_%03d+A:self", i); names.push_back(nm);
+            snprintf(nm, sizeof nm, "bench_%03d+B:self", i); names.push_back(nm);
+        }
+        for (int i = 0; i < rows; ++i) {
+            const char *a = seqs[2 * (size_t)i].c_str(), *b = seqs[2 * (size_t)i + 1].c_str();
+            many.push_back({names[3 * (size_t)i].c_str(), a, b, 128, 212});
+            many.push_back({names[3 * (size_t)i + 1].c_str(), a, a, 128, 212});
+            many.push_back({names[3 * (size_t)i + 2].c_str(), b, b, 128, 212});
+        }
+    }
+    if (ipcr_panel_create(&cfg, rows > 0 ? many.data() : pairs, rows > 0 ? (int32_t)many.size() : 3, &panel) != IPCR_OK) { fprintf(stderr, "%s\n", ipcr_last_error()); return 4; }
 
     std::vector<uint64_t> starts;
     if (n > chunk) for (uint64_t s = 0; s < n; s += chunk - overlap) { starts.push_back(s); if (s + chunk >= n) break; }
