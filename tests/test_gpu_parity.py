@@ -805,6 +805,44 @@ def test_index_panel_leftovers_take_specialised_filters(hip):
     g.close()
 
 
+def test_products_equal_the_definition(hip):
+    """the HIP path against the product list stated as a definition (tests/test_join_definition.py: plain-Python sets
+    and a sort key, no code shared with the oracle or with host.cpp's join) -- the third side of the triangle"""
+    from test_join_definition import products_by_definition, IUPAC, rc
+    rng = random.Random(9300)
+    E, P = hip.engine, hip.primer.Pair
+    total = 0
+    for case in range(30):
+        n = rng.choice([40, 200, 3000])
+        seq = [rng.choice("ACGT") for _ in range(n)]
+        k, tw = rng.choice([0, 1, 2]), rng.choice([0, 2, 3])
+        rows = []
+        for i in range(rng.randint(1, 3)):
+            f = "".join(rng.choice("ACGT") for _ in range(rng.randint(6, 12)))
+            r = "".join(rng.choice("ACGTRYN") if rng.random() < 0.1 else rng.choice("ACGT") for _ in range(rng.randint(6, 12)))
+            for _ in range(2):
+                a = rng.randrange(0, max(1, n - 40))
+                seq[a:a + len(f)] = list(f)
+                rr = [rng.choice(IUPAC[c]) for c in rc(r)]
+                seq[a + 20:a + 20 + len(rr)] = rr
+            rows.append(("p%d" % i, f, r, rng.choice([0, 0, 10]), rng.choice([0, 0, 60])))
+        cmin, cmax, circular = rng.choice([0, 8]), rng.choice([0, 100]), rng.random() < 0.4
+        s = "".join(seq[:n])
+        want = []
+        for pid, f, r, pmin, pmax in rows:
+            want += products_by_definition(s, pid, f, r, k, tw, pmin or cmin, pmax or cmax, circular)
+        cfg = E.Config(MaxMM=k, TerminalWindow=tw, MinLen=cmin, MaxLen=cmax, HitCap=0, SeedLen=rng.choice([0, 6, -1]), Circular=circular)
+        eng = E.New(cfg)
+        cp = eng.CompilePanel([P(*r) for r in rows])
+        sc = eng.NewSimulationScratch(cp)
+        got = [p.sig() for p in eng.SimulateCompiledWithScratch("s", s.encode(), cp, sc)]
+        assert got == want, (s, rows, k, tw, cmin, cmax, circular)
+        total += len(want)
+        sc.close()
+        cp.close()
+    assert total > 60
+
+
 def test_need_sites(hip):  # core/engine/engine.go:175-183 (FwdSite / RevSite for pretty text)
     E, P = hip.engine, hip.primer.Pair
     seq = b"TTTTCGTACAAAAGGTACCTTT"
