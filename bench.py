@@ -634,7 +634,8 @@ def main() -> None:
                 if nm == args.workload:
                     continue
                 r = run_workload(ctx, nm, st, wu)
-                rf = roofline_of(r)
+                opmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_pmc.json" % nm)))
+                rf = roofline_of(r, opmc[-1] if opmc else None)
                 others[nm] = {"workload": r["text"], "ms_per_step": round(r["ms_per_step"], 4), "gbases_per_s": round(r["value"], 1),
                               "sweep_ms": round(r["filter_ms"], 4), "kernel": r["kernel"], "roofline_frac": rf["frac"],
                               "steps": r["steps"], "warmup_actual": r["warmup_actual"], "products_per_step": r["nprod"],
