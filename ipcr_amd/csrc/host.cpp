@@ -200,7 +200,7 @@ struct IndexPlan {
     uint32_t *d_leftover = nullptr;
     ipcr::JitFilter *jit = nullptr; // the kernel, with the key shapes baked in (hiprtc): lanes walk two strands each
     std::vector<ipcr::JitFilter *> leftover_jit; // specialised spill-only filters for `leftover` (else the table-driven kernel takes them)
-    ipcr::JitFilter *jit_sw[2] = {nullptr, nullptr}; // ... one strand / four strands, built when a genome of that size class is first scanned
+    ipcr::JitFilter *jit_sw[2] = {nullptr, nullptr}; // ... one strand / four strands
 };
 
 struct PatternSet {
@@ -1220,8 +1220,15 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode) {
         if (!s.index.built) build_index(*p, s);
         IndexPlan &ix = s.index;
         if (ix.usable) {
-            std::string jerr;
+            // the three walks (host.cpp: index_kernel) compile side by side: no scan ever waits for a compile of its own
+            std::string jerr, jerr1, jerr4;
+            int dev = 0;
+            (void)hipGetDevice(&dev); // the current device is a per-thread setting: the helpers load their modules onto OURS
+            std::thread t1([&] { (void)hipSetDevice(dev); ix.jit_sw[0] = ipcr::jit_build_index(ix.shapes, ix.geom(1), jerr1); });
+            std::thread t4([&] { (void)hipSetDevice(dev); ix.jit_sw[1] = ipcr::jit_build_index(ix.shapes, ix.geom(4), jerr4); });
             ix.jit = ipcr::jit_build_index(ix.shapes, ix.geom(), jerr);
+            t1.join();
+            t4.join();
             if (!ix.jit) {
                 ix.usable = false; // no hiprtc: the table-driven kernel serves
                 return IPCR_OK;
@@ -1353,19 +1360,13 @@ ipcr_status wait_published(ipcr_scratch *s) {
 // The seed-index kernel for a genome of `nblocks` blocks.  A lane walks 1, 2 or 4 consecutive strands before the tail
 // rows of the next one: (128 s + 19) / 128 s rows per base scanned -- 1.15, 1.07, 1.04 -- but a wave's unit of work
 // grows with s (64 s strands), and the sweep needs several units per wave to end evenly (3 Gb: 8.35 / 7.9 / 7.8 ms for
-// s = 1 / 2 / 4; s = 8: 8.0).  The two-strand kernel is built with the panel, the others on first use.
+// s = 1 / 2 / 4; s = 8: 8.0).
 ipcr::JitFilter *index_kernel(const ipcr_panel *cp, int mode, uint64_t nblocks) {
     ipcr_panel *p = const_cast<ipcr_panel *>(cp);
     IndexPlan &ix = p->set[mode].index;
     const uint64_t waves = 256u * 16u, units1 = nblocks * 32u; // units of the one-strand kernel: column pairs
     const int strands = units1 / 4u >= 8u * waves ? 4 : (units1 / 2u >= 2u * waves ? 2 : 1);
-    if (strands == 2) return ix.jit;
-    std::lock_guard<std::mutex> lock(p->mu);
-    ipcr::JitFilter *&f = ix.jit_sw[strands == 1 ? 0 : 1];
-    if (!f) {
-        std::string jerr;
-        f = ipcr::jit_build_index(ix.shapes, ix.geom(strands), jerr);
-    }
+    ipcr::JitFilter *f = strands == 2 ? ix.jit : ix.jit_sw[strands == 1 ? 0 : 1]; // all built with the panel (panel_upload)
     return f ? f : ix.jit;
 }
 
