@@ -1436,7 +1436,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         const IndexPlan &ix = set.index;
         const bool more = !ix.leftover.empty();
         HIPCHK(ipcr::jit_launch_index(index_kernel(p, pd.mode, nblocks), lane, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_lds_image, ix.d_table,
-                                      (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, qc, s->ev[0], more ? nullptr : s->ev[1]));
+                                      (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, qc, s->d_tickets, s->ev[0], more ? nullptr : s->ev[1]));
         if (more && !ix.leftover_jit.empty()) { // patterns the index cannot key: specialised filters that only fill the queue
             ipcr::JitVerify v;
             v.rst = g->rst;

@@ -1105,7 +1105,7 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
 )SRC";
     s << "extern \"C\" __global__ void __launch_bounds__(" << IPCR_INDEX_WAVES * 64u << ", " << IPCR_INDEX_WAVES / 4u << ") ipcr_index_filter(const u32* __restrict__ planes, u64 ncolpairs,\n"
          "    const u32* __restrict__ lds_image, const v4* __restrict__ table, u32 max_mm,\n"
-         "    qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {\n"
+         "    qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount, u32* __restrict__ work, u64* __restrict__ stamps) {\n"
          "  __shared__ u32 lds[((LDS_WORDS + 3u) & ~3u) + " << IPCR_INDEX_WAVES << "u * QCAP * 4u]; // static: every LDS address is a compile-time offset\n"
          "  for (u32 i = threadIdx.x; i < LDS_WORDS; i += blockDim.x) lds[i] = lds_image[i];\n"
          "  __syncthreads();\n"
@@ -1117,7 +1117,19 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "  u32 qn = 0; // entries queued (wave-uniform)\n"
          "  const u64 wave0 = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);\n"
          "  const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);\n"
-         "  for (u64 cp = wave0; cp < ncolpairs / SW; cp += nwaves) { // one unit = 64 SW strands = 2 SW columns\n";
+         "  if (stamps && lane == 0u) stamps[wave0 * 2u] = __builtin_amdgcn_s_memrealtime();\n";
+    // Units are handed out by a counter (work[0]): the waves of a persistent grid do not all run at the same pace, and
+    // with a fixed share each the sweep ends when the slowest wave does.  The last wave to leave zeroes the counters
+    // again (work[32] counts the leavers), so the buffer needs no clearing between launches.
+    const bool dynamic = env_int("IPCR_INDEX_DYNAMIC", 1, 0, 1) != 0;
+    if (dynamic)
+        s << "  for (;;) { // one unit = 64 SW strands = 2 SW columns\n"
+             "    u32 take = 0u;\n"
+             "    if (lane == 0u) take = atomicAdd(work, 1u);\n"
+             "    const u64 cp = (u64)(u32)__builtin_amdgcn_readfirstlane((int)take);\n"
+             "    if (cp >= ncolpairs / SW) break;\n";
+    else
+        s << "  for (u64 cp = wave0; cp < ncolpairs / SW; cp += nwaves) { // one unit = 64 SW strands = 2 SW columns\n";
     // ---- drain of the hit queue: 64 entries per round, one per lane, ONE item of work per lane and round.
     // `where` of an entry: lane | row << 6 | payload << PAY; bit 31 clear: the payload (12 bits) is the set of shapes
     // that filed the hit's key: rank the first one's key among the shape's keys, load that entry, check the pattern --
@@ -1284,7 +1296,14 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "      if (u == " << U << "u) { u = 0u; ++it;" << (TAILSTEPS == 0 ? " if (it == " + std::to_string(NB) + "u) done = true;" : std::string()) << " }\n"
          "      if (full || done) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); flush(); }\n"
          "    }\n";
-    s << "  }\n}\n"; // (`where` is relative to the column pair: the queue is always empty when a pair ends)
+    s << "  }\n"; // (`where` is relative to the column pair: the queue is always empty when a pair ends)
+    if (dynamic)
+        s << "  if (lane == 0u) {\n"
+             "    const u32 left = atomicAdd(work + 32u, 1u);\n"
+             "    if ((u64)left + 1ull == nwaves) { __hip_atomic_store(work, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(work + 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n"
+             "  }\n";
+    s << "  if (stamps && lane == 0u) stamps[wave0 * 2u + 1u] = __builtin_amdgcn_s_memrealtime();\n";
+    s << "}\n";
     return s.str();
 }
 
@@ -1314,15 +1333,35 @@ JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, const In
 
 hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint32_t /*nshapes*/,
                             const uint32_t *lds_image, const void *table, uint32_t max_mm, void *queue,
-                            uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop) {
+                            uint64_t qcap, unsigned long long *qcount, uint32_t *work, hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0) return hipSuccess;
     uint64_t ncolpairs = nblocks * 32u;
     // one persistent 16-wave workgroup per CU: the bitmaps are staged into LDS once per CU
     uint64_t grid = 256ull;
     if (grid * IPCR_INDEX_WAVES > ncolpairs) grid = (ncolpairs + IPCR_INDEX_WAVES - 1u) / IPCR_INDEX_WAVES;
+    // dev tool: IPCR_INDEX_STAMPS=<file> appends every wave's start / end time (100 MHz counter) of every sweep
+    static const char *stamp_path = getenv("IPCR_INDEX_STAMPS");
+    unsigned long long *stamps = nullptr;
+    const size_t nstamp = (size_t)grid * IPCR_INDEX_WAVES * 2u;
+    if (stamp_path && *stamp_path) {
+        if (hipMalloc((void **)&stamps, nstamp * 8u) != hipSuccess) stamps = nullptr;
+        else (void)hipMemsetAsync(stamps, 0, nstamp * 8u, st);
+    }
     void *args[] = {(void *)&planes, (void *)&ncolpairs, (void *)&lds_image, (void *)&table,
-                    (void *)&max_mm, (void *)&queue, (void *)&qcap, (void *)&qcount};
-    return hipExtModuleLaunchKernel(f->fn, (unsigned)grid * IPCR_INDEX_WAVES * 64u, 1, 1, IPCR_INDEX_WAVES * 64u, 1, 1, 0, st, args, nullptr, start, stop, 0);
+                    (void *)&max_mm, (void *)&queue, (void *)&qcap, (void *)&qcount, (void *)&work, (void *)&stamps};
+    const hipError_t e = hipExtModuleLaunchKernel(f->fn, (unsigned)grid * IPCR_INDEX_WAVES * 64u, 1, 1, IPCR_INDEX_WAVES * 64u, 1, 1, 0, st, args, nullptr, start, stop, 0);
+    if (stamps) {
+        std::vector<unsigned long long> h(nstamp);
+        if (e == hipSuccess && hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), stamps, nstamp * 8u, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE *fh = fopen(stamp_path, "ab")) {
+                const unsigned long long n = nstamp;
+                fwrite(&n, 8, 1, fh);
+                fwrite(h.data(), 8, nstamp, fh);
+                fclose(fh);
+            }
+        (void)hipFree(stamps);
+    }
+    return e;
 }
 
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,

@@ -71,7 +71,8 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
 JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom, std::string &err);
 hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint32_t nshapes,
                             const uint32_t *lds_image, const void *table, uint32_t max_mm, void *queue,
-                            uint64_t qcap, unsigned long long *qcount, hipEvent_t start, hipEvent_t stop);
+                            uint64_t qcap, unsigned long long *qcount, uint32_t *work, hipEvent_t start, hipEvent_t stop);
+// work: two zeroed counters 128 B apart (unit counter, leavers); the kernel leaves them zeroed again
 void jit_destroy(JitFilter *f);
 
 } // namespace ipcr
