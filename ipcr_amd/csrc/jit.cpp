@@ -970,7 +970,7 @@ static unsigned index_words64(const std::vector<ipcr_index_shape> &shapes) {
     return t;
 }
 static unsigned index_image_bytes(const std::vector<ipcr_index_shape> &shapes) { // bitmaps + per-word rank prefixes + first entries + shape constants (build_index)
-    const unsigned image = index_words64(shapes) * 10u + (unsigned)shapes.size() * 12u;
+    const unsigned image = index_words64(shapes) * 10u + (unsigned)shapes.size() * 12u + 32u; // (+ the drain's bit table)
     return (image + 15u) & ~15u;
 }
 static unsigned index_queue_entries(const std::vector<ipcr_index_shape> &shapes) { // per-wave hit queue: what the image leaves of the 160 KiB, in rounds of 64
@@ -997,26 +997,89 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
     const unsigned U = 8;                              // base steps per copy of the loop body
     // A lane walks SW consecutive strands and then the tail rows of the one after: the rows walked per base scanned
     // are (128 SW + tail) / (128 SW) -- 1.15 for one strand and 19 tail rows, 1.07 for two.
-    unsigned SW = (unsigned)env_int("IPCR_INDEX_STRANDS", geom.strands, 1, 8); // (the env knob overrides the caller's choice: development)
+    unsigned SW = (unsigned)env_int("IPCR_INDEX_STRANDS", geom.strands, 1, 4); // (the env knob overrides the caller's choice: development)
     while (SW & (SW - 1u)) --SW; // a power of two: a lane's strands are bits of ONE column's words
-    const int RT = 128 * (int)SW + (tail_rows < 0 ? 0 : tail_rows);
-    unsigned STEP_BITS = 8;
-    while ((1 << STEP_BITS) <= RT) ++STEP_BITS;
-    const unsigned PAY = 6u + STEP_BITS; // `where` of a queue entry: lane | row << 6 | payload << PAY
-    const bool chain_carry = geom.table_entries < (1u << (31u - PAY));
-    // A lane files one queue entry per TWO base steps when the shapes' bits of both fit the entry's 12 and the window of
-    // the earlier step is still in the 32-base k-mer one step later: half the ballots, slot computations and 16-byte
-    // LDS stores; the drain shifts k-mer, flags and row back by one step for a bit of the earlier step.
-    unsigned SPE = (2u * NS <= 12u && (unsigned)std::max(tail_rows, 0) + 2u <= 32u) ? 2u : 1u;
-    SPE = (unsigned)env_int("IPCR_INDEX_STEPS_PER_ENTRY", (int)SPE, 1, (int)SPE);
+    const int TR = tail_rows < 0 ? 0 : tail_rows;
+    const int RT = 128 * (int)SW + TR;
+    // ---- how a base step reports its key hits.  Shapes are looked up in PACKS: the shapes of a FAST group share the
+    // six key bits of the protected bases, so their bitmap BYTES (ds_read_u8: byte = key >> 3) are put side by side in
+    // one register and tested with ONE shift by the shared low three key bits and one AND -- bits 0, 8, 16, 24 of the
+    // result say which shapes hold the key; a shape outside a fast group is a pack of its own (one bit).  Pack p's bits
+    // land on 8 i + p.  A lane files one queue entry per SPE base steps: the steps' masks are shifted together by SH =
+    // number of packs, so bit 8 i + p + SH j = shape i of pack p, j steps before the entry's row.
+    struct Pack { bool fast = false; int group = 0; std::vector<int> sh; };
+    std::vector<Pack> packs;
+    auto make_packs = [&](bool allow_fast) {
+        packs.clear();
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const Grp &g = groups[gi];
+            if (allow_fast && g.fast && g.sh.size() > 1) {
+                for (size_t a = 0; a < g.sh.size(); a += 4) {
+                    Pack p; p.fast = true; p.group = (int)gi;
+                    for (size_t b = a; b < std::min(g.sh.size(), a + 4); ++b) p.sh.push_back(g.sh[b]);
+                    packs.push_back(p);
+                }
+            } else
+                for (int sidx : g.sh) { Pack p; p.fast = false; p.group = (int)gi; p.sh.push_back(sidx); packs.push_back(p); }
+        }
+    };
+    make_packs(env_int("IPCR_INDEX_PACKED", 1, 0, 1) != 0);
+    if (packs.size() > 8) make_packs(false); // more packs than a byte has bits: every shape a bit of its own
+    bool byte_layout = false;
+    for (const Pack &p : packs) byte_layout |= p.sh.size() > 1;
+    const unsigned NP = (unsigned)packs.size();
+    const unsigned SH = NP;
+    // Queue entry (16 bytes): x, y = the k-mer (newest base in bits 1:0); only the 2 NBAS bits a check can reach are kept,
+    // z = the invalid-base flags of those bases, w = the steps' masks (bit 31 clear) or, for a further pattern chained
+    // under a key, bit 31 | entry index << 2 | steps back.  Lane (6 bits) and row (ROWB bits) go where bits are left:
+    //   mode A: both above the k-mer in y;  mode B: row above the k-mer in y, lane above the flags in z;
+    //   mode C (primers beyond 26 nt): both in w above a 15-bit payload, one step per entry, one bit per shape.
+    unsigned ROWB = 8;
+    while ((1 << ROWB) <= RT) ++ROWB;
+    unsigned SPE = 1, mode = 2;
+    {
+        unsigned want = byte_layout ? (SH <= 2 ? 4u : (SH <= 4 ? 2u : 1u)) : (SH * 4u <= 31u ? 4u : (SH * 2u <= 31u ? 2u : 1u));
+        want = (unsigned)env_int("IPCR_INDEX_STEPS_PER_ENTRY", (int)want, 1, (int)want);
+        while (want & (want - 1u)) --want;
+        for (unsigned spe = want; spe >= 1; spe >>= 1) {
+            const unsigned nb = (unsigned)TR + spe;
+            unsigned top = 0; // highest payload bit: bit 31 is the chain flag
+            for (unsigned p = 0; p < packs.size(); ++p) top = std::max(top, (byte_layout ? 8u * ((unsigned)packs[p].sh.size() - 1u) : 0u) + p + SH * (spe - 1u));
+            if (top > 30u) continue;
+            if (2u * nb + 6u + ROWB <= 64u) { SPE = spe; mode = 0; break; }
+            if (2u * nb + ROWB <= 64u && nb + 6u <= 32u) { SPE = spe; mode = 1; break; }
+        }
+        if (mode == 2) { // long primers: the whole k-mer and all its flags are needed
+            SPE = 1;
+            if (byte_layout) { make_packs(false); byte_layout = false; }
+        }
+    }
+    const unsigned NPK = (unsigned)packs.size(), SHF = NPK; // (mode C may have re-cut the packs)
+    (void)NP; (void)SH;
+    const unsigned NBAS = (unsigned)TR + SPE;                 // bases of the k-mer an entry must hold
+    const unsigned KMHI = 2u * NBAS > 32u ? 2u * NBAS - 32u : 0u; // k-mer bits kept in y
+    // position of (pack p, shape i of the pack, j steps back) in the payload, and the drain's table bit -> shape | j << 4
+    auto bitpos = [&](unsigned p, unsigned i, unsigned j) { return (byte_layout ? 8u * i : 0u) + p + SHF * j; };
+    std::vector<int> tab(32, 0);
+    unsigned paybits = 0;
+    for (unsigned p = 0; p < NPK; ++p)
+        for (unsigned i = 0; i < packs[p].sh.size(); ++i)
+            for (unsigned j = 0; j < SPE; ++j) {
+                const unsigned b = bitpos(p, i, j);
+                tab[b] = packs[p].sh[i] | (int)(j << 4);
+                paybits = std::max(paybits, b + 1u);
+            }
+    // chained patterns of a key go back into the queue when the entry index fits what w has for it
+    const unsigned idx_bits = mode == 2 ? 13u : 29u;
+    const bool chain_carry = geom.table_entries < (1u << idx_bits);
     const unsigned NQ = (unsigned)(RT + 3) / 4;        // row quads walked
     const unsigned NB = NQ * 4 / U;                    // full unrolled bodies
     const unsigned TAILSTEPS = NQ * 4 - NB * U;        // a shorter copy of the body finishes the walk
     const unsigned QCAP = index_queue_entries(shapes);
 
     std::ostringstream s;
-    s << "// generated by ipcr_amd/csrc/jit.cpp: seed-index filter, " << NS << " key shapes in " << groups.size() << " groups, "
-      << RT << " rows per strand, body of " << U << " steps\n";
+    s << "// generated by ipcr_amd/csrc/jit.cpp: seed-index filter, " << NS << " key shapes in " << groups.size() << " groups / " << NPK
+      << " packs, " << RT << " rows per strand, body of " << U << " steps, " << SPE << " steps per queue entry (entry layout " << "ABC"[mode] << ")\n";
     s << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
     s << "typedef unsigned int u32;\ntypedef unsigned long long u64;\n";
     s << "typedef u32 v4 __attribute__((ext_vector_type(4)));\n";
@@ -1031,10 +1094,16 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
         if (x.left && (int)x.dl != geom.uniform_len - 1) aligned = false;
     s << "#define WINDOW_AT_NEWEST " << (aligned ? "true" : "false") << "\n";
     s << "#define DL " << geom.dl << "u // left-anchored windows are tested DL bases after their start\n";
-    s << "#define CHAIN_CARRY " << (chain_carry ? "true" : "false") << " // further patterns of a key are handed back to the queue (entry index in " << 31u - PAY << " bits)\n";
+    s << "#define CHAIN_CARRY " << (chain_carry ? "true" : "false") << " // further patterns of a key are handed back to the queue (entry index in " << idx_bits << " bits)\n";
     s << "#define SW " << SW << "u // strands a lane walks before the tail rows\n";
-    s << "#define PAY " << PAY << "u // where = lane | row << 6 | payload << PAY\n";
-    s << "#define SPE " << SPE << "u // base steps per queue entry: payload bit j * NS + s = shape s, j steps before the entry's row\n";
+    s << "#define SPE " << SPE << "u // base steps per queue entry\n";
+    s << "#define ROWB " << ROWB << "u // bits of a row number\n";
+    s << "#define KMHI " << KMHI << "u // k-mer bits an entry keeps in y\n";
+    s << "#define NBAS " << NBAS << "u // bases (and invalid flags) an entry keeps\n";
+    s << "#define EMODE " << mode << " // entry layout: 0 = lane, row above the k-mer in y; 1 = row in y, lane above the flags in z; 2 = both in w\n";
+    s << "__device__ const unsigned char BITTAB[32] = {";
+    for (int b = 0; b < 32; ++b) s << (b ? ", " : "") << tab[(size_t)b];
+    s << "}; // payload bit -> shape | steps back << 4\n";
     auto arr = [&](const char *type, const char *name, auto get) {
         s << "__device__ constexpr " << type << " " << name << "[NS] = {";
         for (size_t i = 0; i < NS; ++i) s << (i ? ", " : "") << get(shapes[i]);
@@ -1052,11 +1121,12 @@ template <int S> struct key_of {
   }
 };
 // LDS image (host.cpp: build_index): the shapes' bitmaps, T64N 64-bit words | T64N uint16 rank prefixes | NS first-entry
-// indices | NS x 2 words of shape constants
+// indices | NS x 2 words of shape constants; behind it (kernel start) the 32 bytes of BITTAB
 #define PREFIX_WORD0 (T64N * 2u)
 #define BASE_WORD0 (T64N * 2u + T64N / 2u)
 #define SHAPE_WORD0 (BASE_WORD0 + NS)
-#define LDS_WORDS (SHAPE_WORD0 + 2u * NS)
+#define TAB_WORD0 (SHAPE_WORD0 + 2u * NS)
+#define LDS_WORDS (TAB_WORD0 + 8u)
 // invalid-base flags, one bit per base -> the even bits of a 2-bit-per-base word
 __device__ __forceinline__ u64 spread2(u32 v) {
   u64 x = v;
@@ -1107,9 +1177,11 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "    const u32* __restrict__ lds_image, const v4* __restrict__ table, u32 max_mm,\n"
          "    qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount, u32* __restrict__ work, u64* __restrict__ stamps) {\n"
          "  __shared__ u32 lds[((LDS_WORDS + 3u) & ~3u) + " << IPCR_INDEX_WAVES << "u * QCAP * 4u]; // static: every LDS address is a compile-time offset\n"
-         "  for (u32 i = threadIdx.x; i < LDS_WORDS; i += blockDim.x) lds[i] = lds_image[i];\n"
+         "  for (u32 i = threadIdx.x; i < TAB_WORD0; i += blockDim.x) lds[i] = lds_image[i];\n"
+         "  if (threadIdx.x < 8u) lds[TAB_WORD0 + threadIdx.x] = reinterpret_cast<const u32*>(BITTAB)[threadIdx.x];\n"
          "  __syncthreads();\n"
          "  const u64* T64 = reinterpret_cast<const u64*>(lds);\n"
+         "  const unsigned char* ldsb = reinterpret_cast<const unsigned char*>(lds);\n"
          "  const unsigned short* prefix = reinterpret_cast<const unsigned short*>(lds + PREFIX_WORD0);\n"
          "  const u32 lane = threadIdx.x & 63u;\n"
          "  const u32 bit = (lane * SW) & 31u; // my first strand's bit in its column's words\n"
@@ -1118,9 +1190,10 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "  const u64 wave0 = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);\n"
          "  const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);\n"
          "  if (stamps && lane == 0u) stamps[wave0 * 2u] = __builtin_amdgcn_s_memrealtime();\n";
-    // Units are handed out by a counter (work[0]): the waves of a persistent grid do not all run at the same pace, and
-    // with a fixed share each the sweep ends when the slowest wave does.  The last wave to leave zeroes the counters
-    // again (work[32] counts the leavers), so the buffer needs no clearing between launches.
+    // Units are handed out by a counter (work[0]): the waves of a persistent grid do not all run at the same pace (on
+    // MI355X the 16 waves of a CU end between 67 % and 100 % of the sweep when each has a fixed share: 7.29 ms per 3 Gb,
+    // 6.30 ms with the counter).  The last wave to leave zeroes the counters again (work[32] counts the leavers), so
+    // the buffer needs no clearing between launches.
     const bool dynamic = env_int("IPCR_INDEX_DYNAMIC", 1, 0, 1) != 0;
     if (dynamic)
         s << "  for (;;) { // one unit = 64 SW strands = 2 SW columns\n"
@@ -1131,26 +1204,26 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
     else
         s << "  for (u64 cp = wave0; cp < ncolpairs / SW; cp += nwaves) { // one unit = 64 SW strands = 2 SW columns\n";
     // ---- drain of the hit queue: 64 entries per round, one per lane, ONE item of work per lane and round.
-    // `where` of an entry: lane | row << 6 | payload << PAY; bit 31 clear: the payload (12 bits) is the set of shapes
-    // that filed the hit's key: rank the first one's key among the shape's keys, load that entry, check the pattern --
-    // the shape is a run-time value there (constants from LDS), so lanes whose hits belong to different shapes share one
-    // trip to the entry table.  A lane never holds the other 63 for a second trip: a key filed under a further shape as
-    // well (one hit in ten), or a further pattern filed under the same key (3 % of the keys of a 4096-pattern panel --
-    // but some lane of nearly every round), goes back into the queue as a new entry, written over slots this drain has
-    // consumed, and the next generation of rounds takes those at full occupancy again (bit 31 set: the payload, up to
-    // bit 30, is the index of the entry to check).
+    // w of an entry with bit 31 clear = the masks of its SPE steps: take the lowest bit -- BITTAB says which shape, how
+    // many steps back (k-mer, flags and row are shifted back by that) --, rank its key among the shape's keys, load that
+    // entry, check the pattern; the shape is a run-time value there (constants from LDS), so lanes whose hits belong to
+    // different shapes share one trip to the entry table.  A lane never holds the other 63 for a second trip: further
+    // bits of the mask (one entry in four), or a further pattern filed under the same key (3 % of the keys of a
+    // 4096-pattern panel -- but some lane of nearly every round), go back into the queue as a new entry, written over
+    // slots this drain has consumed, and the next generation of rounds takes those at full occupancy again (bit 31 set:
+    // index of the entry to check << 2 | steps back).
     s << "    auto flush = [&]() __attribute__((always_inline)) {\n"
          "      u32 n = qn;\n"
          "      const u64 pair_base = cp * (8192u * SW); // first position of this unit\n"
          "      const u32 shard = (u32)cp & 255u;\n"
          "      while (n != 0u) {\n"
          "        u32 nc = 0u; // entries handed back so far: slots [0, nc), always behind the round being read\n"
-         "        auto hand_back = [&](bool mine, u64 hkm, u32 hbad, u32 w) __attribute__((always_inline)) {\n"
+         "        auto hand_back = [&](bool mine, v4 e, u32 w) __attribute__((always_inline)) {\n"
          "          const u64 rb = __ballot(mine);\n"
          "          if (rb != 0ull) {\n"
          "            if (mine) {\n"
          "              const u32 slot = nc + __builtin_amdgcn_mbcnt_hi((u32)(rb >> 32), __builtin_amdgcn_mbcnt_lo((u32)rb, 0u));\n"
-         "              v4 e; e.x = (u32)hkm; e.y = (u32)(hkm >> 32); e.z = hbad; e.w = w;\n"
+         "              e.w = w;\n"
          "              *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
          "            }\n"
          "            nc += (u32)__popcll(rb);\n"
@@ -1158,21 +1231,27 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "        };\n"
          "        for (u32 qb = 0; qb < n; qb += 64u) {\n"
          "          const u32 i = qb + lane;\n"
-         "          u64 hkm = 0ull; u32 hbad = 0u, where = 0u, pend = 0u, idx = 0xFFFFFFFFu;\n"
-         "          if (i < n) {\n"
-         "            const v4 e = *reinterpret_cast<const v4*>(wq + i * 4u);\n"
-         "            hkm = ((u64)e.y << 32) | e.x; hbad = e.z; where = e.w;\n"
-         "            if (where & 0x80000000u) idx = (where & 0x7FFFFFFFu) >> PAY;\n"
-         "            else pend = (where >> PAY) & 0xFFFu;\n"
-         "          }\n"
+         "          v4 e; e.x = 0u; e.y = 0u; e.z = 0u; e.w = 0u;\n"
+         "          if (i < n) e = *reinterpret_cast<const v4*>(wq + i * 4u);\n"
          "          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // every lane has read its slot: slots up to qb + 63 may be rewritten\n"
+         "          u32 pend = 0u, idx = 0xFFFFFFFFu, back = 0u, keep = 0u; // keep: what of w a handed-back entry keeps (layout C: lane and row)\n"
+         "          u32 elane, erow0;\n"
+         "          u64 hkm; u32 hbad;\n"
+         "          if (EMODE == 0) { hkm = ((u64)(KMHI ? (e.y & ((1u << KMHI) - 1u)) : 0u) << 32) | e.x; hbad = e.z; elane = (e.y >> KMHI) & 63u; erow0 = (e.y >> (KMHI + 6u)) & ((1u << ROWB) - 1u); }\n"
+         "          else if (EMODE == 1) { hkm = ((u64)(KMHI ? (e.y & ((1u << KMHI) - 1u)) : 0u) << 32) | e.x; hbad = e.z & ((1u << NBAS) - 1u); elane = e.z >> NBAS; erow0 = (e.y >> KMHI) & ((1u << ROWB) - 1u); }\n"
+         "          else { hkm = ((u64)e.y << 32) | e.x; hbad = e.z; elane = (e.w >> 15) & 63u; erow0 = (e.w >> 21) & ((1u << ROWB) - 1u); keep = e.w & 0x7FFF8000u; }\n"
+         "          const u32 pay = EMODE == 2 ? (e.w & 0x7FFFu) : (e.w & 0x7FFFFFFFu);\n"
+         "          if (e.w & 0x80000000u) { idx = pay >> 2; back = pay & 3u; }\n"
+         "          else pend = pay;\n"
          "          const u32 rest = pend & (pend - 1u);\n"
-         "          hand_back(rest != 0u, hkm, hbad, (where & ((1u << PAY) - 1u)) | (rest << PAY)); // (k-mer, flags and row as filed)\n"
+         "          hand_back(rest != 0u, e, keep | rest); // (k-mer, flags and row as filed)\n"
          "          if (pend != 0u) {\n"
-         "            u32 sidx = (u32)__builtin_ctz(pend);\n"
-         "            if (SPE > 1u && sidx >= NS) { sidx -= NS; hkm >>= 2; hbad >>= 1; where -= 64u; } // a hit of the step before the entry's: its own k-mer, flags, row\n"
+         "            const u32 t = reinterpret_cast<const unsigned char*>(lds + TAB_WORD0)[__builtin_ctz(pend)];\n"
+         "            const u32 sidx = t & 15u;\n"
+         "            back = t >> 4;\n"
+         "            const u64 skm = hkm >> (2u * back); // a hit of an earlier step of the entry: its own k-mer\n"
          "            const u32 c0 = lds[SHAPE_WORD0 + 2u * sidx], c1 = lds[SHAPE_WORD0 + 2u * sidx + 1u];\n"
-         "            const u32 key = ((u32)(hkm >> (c0 & 63u)) & (c1 & 0xFFFFu)) | (((u32)(hkm >> ((c0 >> 8) & 63u)) & (c1 >> 16)) << ((c0 >> 16) & 31u));\n"
+         "            const u32 key = ((u32)(skm >> (c0 & 63u)) & (c1 & 0xFFFFu)) | (((u32)(skm >> ((c0 >> 8) & 63u)) & (c1 >> 16)) << ((c0 >> 16) & 31u));\n"
          "            const u32 wi = (c0 >> 21) * 16u + (key >> 6); // the shape's bitmap word with this key\n"
          "            const u64 w = T64[wi];\n"
          "            // the key is in the panel; its rank among the shape's keys is the index of its entry\n"
@@ -1180,15 +1259,17 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "          }\n"
          "          u32 next = 0xFFFFFFFFu;\n"
          "          if (idx != 0xFFFFFFFFu) {\n"
-         "            const u32 strand_off = ((where & 63u) * SW) << 7;\n"
-         "            const int erow = (int)((where >> 6) & ((1u << (PAY - 6u)) - 1u));\n"
-         "            next = check_entry(idx, hkm, hbad, erow, pair_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
+         "            const u64 skm = hkm >> (2u * back);\n"
+         "            const u32 sbad = hbad >> back;\n"
+         "            const u32 strand_off = (elane * SW) << 7;\n"
+         "            const int erow = (int)erow0 - (int)back;\n"
+         "            next = check_entry(idx, skm, sbad, erow, pair_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
          "            // a lane hands back at most ONE entry per round (so that slots [0, qb + 64) always hold them): one that\n"
-         "            // has done so for its shapes, or whose entry indices do not fit a queue entry, walks the chain here\n"
+         "            // has done so for its mask, or whose entry indices do not fit a queue entry, walks the chain here\n"
          "            if (!CHAIN_CARRY || rest != 0u)\n"
-         "              while (next != 0xFFFFFFFFu) next = check_entry(next, hkm, hbad, erow, pair_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
+         "              while (next != 0xFFFFFFFFu) next = check_entry(next, skm, sbad, erow, pair_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
          "          }\n"
-         "          if (CHAIN_CARRY) hand_back(next != 0xFFFFFFFFu, hkm, hbad, (where & ((1u << PAY) - 1u)) | (next << PAY) | 0x80000000u);\n"
+         "          if (CHAIN_CARRY) hand_back(next != 0xFFFFFFFFu, e, keep | 0x80000000u | (next << 2) | back);\n"
          "        }\n"
          "        n = nc;\n"
          "        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // the entries handed back are read by other lanes next\n"
@@ -1213,7 +1294,10 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "    v4 alo = *reinterpret_cast<const v4*>(pa), ahi = *reinterpret_cast<const v4*>(pa + 256u), aiv = *reinterpret_cast<const v4*>(pa + 512u);\n"
          "    v4 blo, bhi, biv;\n"
          "    u32 b = bit;\n"
-         "    u32 hprev = 0u; // (SPE = 2) the shapes that held the key of the step before\n";
+         "    u32 acc = 0u; // the masks of the steps since the last queue entry\n";
+    if (mode == 0) s << "    const u32 lane_y = lane << KMHI; // this lane's part of an entry's y\n";
+    if (mode == 1) s << "    const u32 lane_z = lane << NBAS;\n";
+    if (mode == 2) s << "    const u32 lane_w = lane << 15;\n";
     // The walk is ONE copy of the U-step body inside a loop; the last pass stops after TAILSTEPS steps.  Every step is
     // guarded by the (wave-uniform) step counter, so that the queue drain exists once in the code, not once per
     // step: a step that fills the queue marks the counter, the remaining guards fall through (two scalar
@@ -1234,36 +1318,49 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
         }
         s << "        km = (km << 2) | (u64)(__builtin_amdgcn_ubfe(" << cur << "lo[" << t << "], b, 1u) | (__builtin_amdgcn_ubfe(" << cur << "hi[" << t << "], b, 1u) << 1));\n"
           << "        bad = (bad << 1) | __builtin_amdgcn_ubfe(" << cur << "iv[" << t << "], b, 1u);\n"
-          << "        u32 hm; // shapes that hold this step's key\n";
+          << "        u32 hm; // shapes that hold this step's key (bit 8 i + p: shape i of pack p)\n";
         // dev knobs (tools/c4_knobs.sh): what one more LDS lookup / VALU instruction per base step costs -- which unit binds
         const int xl = env_int("IPCR_INDEX_XLDS", 0, 0, 8), xv = env_int("IPCR_INDEX_XVALU", 0, 0, 64);
         for (int x = 0; x < xl; ++x)
             s << "        u32 dummy" << x << "; { const u32 da = (((u32)(km >> " << 8 + 2 * x << "u) & 1023u) << 3) + " << (x % 4) * 8192 << "u; asm volatile(\"ds_read_b32 %0, %1\" : \"=v\"(dummy" << x << ") : \"v\"(da) : \"memory\"); }\n";
-        // the shapes' bits are shifted into the mask from the highest shape down (one v_lshl_or each): bit s = shape s
-        for (size_t gi = 0; gi < groups.size(); ++gi)
-            if (groups[gi].fast && !groups[gi].sh.empty()) // the group's six protected-base bits: c selects the bit, ch the half word
-                s << "        const u32 c" << gi << " = (u32)(km >> " << groups[gi].c_off << "u) & 63u, ch" << gi << " = (c" << gi << " >> 3) & 4u;\n";
-        for (int si = (int)NS - 1; si >= 0; --si) {
-            const ipcr_index_shape &sh = shapes[(size_t)si];
-            const size_t gi = sh.group;
-            std::string bitx;
-            if (groups[gi].fast) {
-                // byte address of the 32-bit half word = (bitmap word index) * 8 + (bit 5 of c) * 4; the bit test takes c's low five bits.
-                // A one-shape group keys on protected bases only: the word index is what follows the six bits of c
-                const bool single = sh.blk_mask == 0;
-                const unsigned off = single ? (unsigned)sh.tw_shift + 6u : (unsigned)sh.blk_shift;
-                const unsigned vmask = single ? ((1u << (sh.tw_bits - 6)) - 1u) : sh.blk_mask;
-                const std::string ch = "ch" + std::to_string(gi);
-                std::string a;
-                if (vmask == 0) a = ch;
-                else if (off >= 3) a = "(((u32)(km >> " + std::to_string(off - 3) + "u) & " + std::to_string(vmask << 3) + "u) | " + ch + ")";
-                else a = "((((u32)(km >> " + std::to_string(off) + "u) & " + std::to_string(vmask) + "u) << 3) | " + ch + ")";
-                bitx = "__builtin_amdgcn_ubfe(*reinterpret_cast<const u32*>(reinterpret_cast<const char*>(lds) + " + std::to_string(off64[(size_t)si] * 8u) + "u + " + a + "), c" + std::to_string(gi) + " & 31u, 1u)";
+        std::vector<char> group_c(groups.size(), 0);
+        bool first_pack = true;
+        for (unsigned p = 0; p < NPK; ++p) {
+            const Pack &pk = packs[p];
+            std::string q; // this pack's bits, at 8 i (byte layout) or bit 0
+            if (pk.fast) {
+                const size_t gi = (size_t)pk.group;
+                if (!group_c[gi]) { // the group's six protected-base bits: the low three select the bit of a byte, the high three the byte of a word
+                    s << "        const u32 cb" << gi << " = (u32)(km >> " << groups[gi].c_off << "u) & 7u, cw" << gi << " = (u32)(km >> " << groups[gi].c_off + 3 << "u) & 7u;\n";
+                    group_c[gi] = 1;
+                }
+                std::string packed;
+                for (size_t i = 0; i < pk.sh.size(); ++i) {
+                    const int si = pk.sh[i];
+                    const ipcr_index_shape &sh = shapes[(size_t)si];
+                    // byte address = (bitmap word index) * 8 + the high three bits of c.
+                    // A one-shape group keys on protected bases only: the word index is what follows the six bits of c
+                    const bool single = sh.blk_mask == 0;
+                    const unsigned off = single ? (unsigned)sh.tw_shift + 6u : (unsigned)sh.blk_shift;
+                    const unsigned vmask = single ? ((1u << (sh.tw_bits - 6)) - 1u) : sh.blk_mask;
+                    const std::string cw = "cw" + std::to_string(gi);
+                    std::string a;
+                    if (vmask == 0) a = cw;
+                    else if (off >= 3) a = "(((u32)(km >> " + std::to_string(off - 3) + "u) & " + std::to_string(vmask << 3) + "u) | " + cw + ")";
+                    else a = "((((u32)(km >> " + std::to_string(off) + "u) & " + std::to_string(vmask) + "u) << 3) | " + cw + ")";
+                    const std::string by = "(u32)ldsb[" + std::to_string(off64[(size_t)si] * 8u) + "u + " + a + "]";
+                    packed += (i ? " | (" : "(") + by + (i ? " << " + std::to_string(8 * i) + "u)" : ")");
+                }
+                unsigned m = 0;
+                for (size_t i = 0; i < pk.sh.size(); ++i) m |= 1u << (8 * i);
+                q = "(((" + packed + ") >> cb" + std::to_string(gi) + ") & " + std::to_string(m) + "u)";
             } else {
+                const int si = pk.sh[0];
                 s << "        const u32 key" << si << " = key_of<" << si << ">::get(km);\n";
-                bitx = "__builtin_amdgcn_ubfe(lds[" + std::to_string(off64[(size_t)si] * 2u) + "u + (key" + std::to_string(si) + " >> 5)], key" + std::to_string(si) + " & 31u, 1u)";
+                q = "__builtin_amdgcn_ubfe(lds[" + std::to_string(off64[(size_t)si] * 2u) + "u + (key" + std::to_string(si) + " >> 5)], key" + std::to_string(si) + " & 31u, 1u)";
             }
-            s << "        hm = " << (si == (int)NS - 1 ? std::string() : std::string("(hm << 1) | ")) << bitx << ";\n";
+            s << "        hm " << (first_pack ? "= " : "|= ") << q << (p ? " << " + std::to_string(p) + "u" : std::string()) << ";\n";
+            first_pack = false;
         }
         if (xl) {
             s << "        asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n";
@@ -1271,17 +1368,25 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
         }
         for (int x = 0; x < xv; ++x)
             s << "        { u32 dv; asm volatile(\"v_mov_b32 %0, %1\" : \"=v\"(dv) : \"v\"(bad)); asm volatile(\"\" :: \"v\"(dv)); }\n";
-        const bool files = SPE == 1u || (k & 1u) == 1u; // this step files the queue entry (of itself, or of itself and the step before)
-        if (!files) s << "        hprev = hm;\n";
-        else {
-            if (SPE > 1u) s << "        hm |= hprev << NS;\n";
+        const bool files = (k % SPE) == SPE - 1u; // this step files the queue entry (of itself and the SPE - 1 steps before)
+        if (SPE == 1u) s << "        acc = hm;\n";
+        else if (k % SPE == 0u) s << "        acc = hm;\n";
+        else s << "        acc = (acc << " << SHF << "u) | hm;\n";
+        if (files) {
             // qn <= QCAP - 64 on entry (a fuller queue is drained before the next step runs) and a step adds at most 64: no overflow
-            s << "        const u64 bal = __ballot(hm != 0u);\n"
-                 "        if (bal != 0ull) { // one queue entry per lane whatever the number of shapes that hit: (k-mer, invalid flags, where | shapes)\n"
-                 "          if (hm != 0u) {\n"
+            s << "        const u64 bal = __ballot(acc != 0u);\n"
+                 "        if (bal != 0ull) { // one queue entry per lane whatever the number of shapes and steps that hit\n"
+                 "          if (acc != 0u) {\n"
                  "            const u32 slot = qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));\n"
-                 "            v4 e; e.x = (u32)km; e.y = (u32)(km >> 32); e.z = bad; e.w = lane | ((" << rq0 << " * 4u + " << k << "u) << 6) | (hm << PAY);\n"
-                 "            *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
+                 "            const u32 row = " << rq0 << " * 4u + " << k << "u;\n"
+                 "            v4 e; e.x = (u32)km;\n";
+            if (mode == 0)
+                s << "            e.y = (KMHI ? ((u32)(km >> 32) & ((1u << KMHI) - 1u)) : 0u) | lane_y | (row << (KMHI + 6u)); e.z = bad; e.w = acc;\n";
+            else if (mode == 1)
+                s << "            e.y = (KMHI ? ((u32)(km >> 32) & ((1u << KMHI) - 1u)) : 0u) | (row << KMHI); e.z = (bad & ((1u << NBAS) - 1u)) | lane_z; e.w = acc;\n";
+            else
+                s << "            e.y = (u32)(km >> 32); e.z = bad; e.w = acc | lane_w | (row << 21);\n";
+            s << "            *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
                  "          }\n"
                  "          qn += (u32)__popcll(bal);\n"
                  "        }\n";
@@ -1296,7 +1401,7 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "      if (u == " << U << "u) { u = 0u; ++it;" << (TAILSTEPS == 0 ? " if (it == " + std::to_string(NB) + "u) done = true;" : std::string()) << " }\n"
          "      if (full || done) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); flush(); }\n"
          "    }\n";
-    s << "  }\n"; // (`where` is relative to the column pair: the queue is always empty when a pair ends)
+    s << "  }\n"; // (rows are relative to the unit: the queue is always empty when a unit ends)
     if (dynamic)
         s << "  if (lane == 0u) {\n"
              "    const u32 left = atomicAdd(work + 32u, 1u);\n"

@@ -466,8 +466,8 @@ def test_seed_index_source_compiles_for_gfx950(k, tw, lens, iupac, tmp_path):
     src = cp.filter_source(2)
     cp.close()
     assert "ipcr_index_filter" in src
-    if tw >= 3 and k >= 1:
-        assert re.search(r"const u32 c0 = \(u32\)\(km >> \d+u\) & 63u, ch0 = ", src), \
+    if tw >= 3 and k >= 1 and "(entry layout C)" not in src:   # (primers beyond 26 nt: one bit per shape, see jit.cpp)
+        assert re.search(r"const u32 cb0 = \(u32\)\(km >> \d+u\) & 7u, cw0 = ", src), \
             "a panel with >= 3 protected bases must take its shapes' common six key bits once per step"
     path = tmp_path / "index.hip"
     path.write_text(src)
