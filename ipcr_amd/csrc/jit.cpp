@@ -979,7 +979,7 @@ static unsigned index_queue_entries(const std::vector<ipcr_index_shape> &shapes)
     return q < 128u ? 128u : (q > 448u ? 448u : q);
 }
 
-std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom) {
+static std::string jit_index_source_rolled(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom) {
     const int tail_rows = geom.tail_rows;
     const bool all_acgt = geom.all_acgt;
     const size_t NS = shapes.size();
@@ -1101,7 +1101,7 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
     s << "#define KMHI " << KMHI << "u // k-mer bits an entry keeps in y\n";
     s << "#define NBAS " << NBAS << "u // bases (and invalid flags) an entry keeps\n";
     s << "#define EMODE " << mode << " // entry layout: 0 = lane, row above the k-mer in y; 1 = row in y, lane above the flags in z; 2 = both in w\n";
-    s << "__device__ const unsigned char BITTAB[32] = {";
+    s << "__device__ const unsigned char __attribute__((aligned(16))) BITTAB[32] = {";
     for (int b = 0; b < 32; ++b) s << (b ? ", " : "") << tab[(size_t)b];
     s << "}; // payload bit -> shape | steps back << 4\n";
     auto arr = [&](const char *type, const char *name, auto get) {
@@ -1412,6 +1412,421 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
     return s.str();
 }
 
+// ---- the same filter with the k-mers TRANSPOSED instead of rolled (default).
+// One unit of work = one column pair = 64 consecutive strands, lane = strand, 128 base steps, no tail rows: a lane starts
+// with the 32 bases in front of its strand (the end of the strand before) in its k-mer, so every window is looked up
+// exactly once, by the lane in whose strand it ENDS (right-anchored groups) / where its start + DL falls (left-anchored).
+// A strand's bases are bit columns of the tiles; a rolled k-mer takes them out one row at a time (two v_bfe, a 64-bit
+// shift, two shift-ors per step, and the same again for the invalid flags: 26 issue cycles of the ~130 a step costs).
+// Here the 32 lanes of a half wave load the 32 rows of a chunk, one word each -- lane j the plane j & 1 of row
+// 15 - (j >> 1) -- and a 32 x 32 bit transpose across the lanes (five butterfly stages: ds_swizzle xor d, a rotate and one
+// v_bitop3 select) hands every lane the 16 bases of ITS strand as one register, 2-bit codes interleaved, newest base in
+// bits 1:0; three transposes (two k-mer words, one word of invalid flags) per 32 steps.  Every key field of every step
+// then sits at a compile-time position of three registers: a shift (or v_alignbit) and a mask.
+static std::string jit_index_source_t(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom) {
+    const int tail_rows = geom.tail_rows;
+    const bool all_acgt = geom.all_acgt;
+    const size_t NS = shapes.size();
+    struct Grp { bool fast = false; std::vector<int> sh; int c_off = 0; };
+    std::vector<Grp> groups;
+    std::vector<unsigned> off64(NS + 1, 0); // first 64-bit word of every shape's bitmap
+    for (size_t i = 0; i < NS; ++i) {
+        if (shapes[i].group >= groups.size()) groups.resize((size_t)shapes[i].group + 1);
+        groups[shapes[i].group].sh.push_back((int)i);
+        groups[shapes[i].group].fast = shapes[i].fast != 0 && shapes[i].tw_bits >= 6;
+        groups[shapes[i].group].c_off = shapes[i].tw_shift;
+        off64[i + 1] = off64[i] + ipcr_index_words64(shapes[i]);
+    }
+    const unsigned T64N = off64[NS];
+    const unsigned U = 32; // base steps per copy of the loop body = one chunk of rows
+    const int TR = tail_rows < 0 ? 0 : tail_rows;
+    // packs, payload layout, entry layout: as in jit_index_source
+    struct Pack { bool fast = false; int group = 0; std::vector<int> sh; };
+    std::vector<Pack> packs;
+    auto make_packs = [&](bool allow_fast) {
+        packs.clear();
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const Grp &g = groups[gi];
+            if (allow_fast && g.fast && g.sh.size() > 1) {
+                for (size_t a = 0; a < g.sh.size(); a += 4) {
+                    Pack p; p.fast = true; p.group = (int)gi;
+                    for (size_t b = a; b < std::min(g.sh.size(), a + 4); ++b) p.sh.push_back(g.sh[b]);
+                    packs.push_back(p);
+                }
+            } else
+                for (int sidx : g.sh) { Pack p; p.fast = false; p.group = (int)gi; p.sh.push_back(sidx); packs.push_back(p); }
+        }
+    };
+    make_packs(env_int("IPCR_INDEX_PACKED", 1, 0, 1) != 0);
+    if (packs.size() > 8) make_packs(false);
+    bool byte_layout = false;
+    for (const Pack &p : packs) byte_layout |= p.sh.size() > 1;
+    const unsigned ROWB = 7; // rows 0..127 of the unit
+    unsigned SPE = 1, mode = 2;
+    {
+        const unsigned SH0 = (unsigned)packs.size();
+        unsigned want = byte_layout ? (SH0 <= 2 ? 4u : (SH0 <= 4 ? 2u : 1u)) : (SH0 * 4u <= 31u ? 4u : (SH0 * 2u <= 31u ? 2u : 1u));
+        want = (unsigned)env_int("IPCR_INDEX_STEPS_PER_ENTRY", (int)want, 1, (int)want);
+        while (want & (want - 1u)) --want;
+        for (unsigned spe = want; spe >= 1; spe >>= 1) {
+            const unsigned nb = (unsigned)TR + spe;
+            unsigned top = 0; // highest payload bit: bit 31 is the chain flag
+            for (unsigned p = 0; p < packs.size(); ++p) top = std::max(top, (byte_layout ? 8u * ((unsigned)packs[p].sh.size() - 1u) : 0u) + p + SH0 * (spe - 1u));
+            if (top > 30u) continue;
+            if (2u * nb + 6u + ROWB <= 64u) { SPE = spe; mode = 0; break; }
+            if (2u * nb + ROWB <= 64u && nb + 6u <= 32u) { SPE = spe; mode = 1; break; }
+        }
+        if (mode == 2) { // long primers: the whole k-mer and all its flags are needed
+            SPE = 1;
+            if (byte_layout) { make_packs(false); byte_layout = false; }
+        }
+    }
+    const unsigned NPK = (unsigned)packs.size(), SHF = NPK;
+    const unsigned NBAS = (unsigned)TR + SPE;
+    const unsigned KMHI = 2u * NBAS > 32u ? 2u * NBAS - 32u : 0u;
+    auto bitpos = [&](unsigned p, unsigned i, unsigned j) { return (byte_layout ? 8u * i : 0u) + p + SHF * j; };
+    std::vector<int> tab(32, 0);
+    for (unsigned p = 0; p < NPK; ++p)
+        for (unsigned i = 0; i < packs[p].sh.size(); ++i)
+            for (unsigned j = 0; j < SPE; ++j) tab[bitpos(p, i, j)] = packs[p].sh[i] | (int)(j << 4);
+    const unsigned idx_bits = mode == 2 ? 13u : 29u;
+    const bool chain_carry = geom.table_entries < (1u << idx_bits);
+    const unsigned QCAP = index_queue_entries(shapes);
+
+    std::ostringstream s;
+    s << "// generated by ipcr_amd/csrc/jit.cpp: seed-index filter (transposed k-mers), " << NS << " key shapes in " << groups.size() << " groups / " << NPK
+      << " packs, 128 rows per strand, " << SPE << " steps per queue entry (entry layout " << "ABC"[mode] << ")\n";
+    s << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
+    s << "typedef unsigned int u32;\ntypedef unsigned long long u64;\ntypedef long long i64;\n";
+    s << "typedef u32 v4 __attribute__((ext_vector_type(4)));\n";
+    s << "struct qent { u64 key; u32 bits; u32 pad; };\n";
+    s << "#define NS " << NS << "\n";
+    s << "#define T64N " << T64N << "u // 64-bit words of all bitmaps\n";
+    s << "#define QCAP " << QCAP << "u // per-wave queue of hits (16-byte entries), drained in rounds of 64 at full lane occupancy\n";
+    s << "#define ALL_ACGT " << (all_acgt ? "true" : "false") << " // no indexed pattern holds an IUPAC code\n";
+    s << "#define ULEN " << geom.uniform_len << "u // length of every indexed pattern (0: mixed)\n";
+    bool aligned = geom.uniform_len > 0; // ... and left-anchored windows are tested exactly when they end: no shift in the check
+    for (const ipcr_index_shape &x : shapes)
+        if (x.left && (int)x.dl != geom.uniform_len - 1) aligned = false;
+    s << "#define WINDOW_AT_NEWEST " << (aligned ? "true" : "false") << "\n";
+    s << "#define DL " << geom.dl << "u // left-anchored windows are tested DL bases after their start\n";
+    s << "#define CHAIN_CARRY " << (chain_carry ? "true" : "false") << " // further patterns of a key are handed back to the queue (entry index in " << idx_bits << " bits)\n";
+    s << "#define SPE " << SPE << "u // base steps per queue entry\n";
+    s << "#define ROWB " << ROWB << "u // bits of a row number\n";
+    s << "#define KMHI " << KMHI << "u // k-mer bits an entry keeps in y\n";
+    s << "#define NBAS " << NBAS << "u // bases (and invalid flags) an entry keeps\n";
+    s << "#define EMODE " << mode << " // entry layout: 0 = lane, row above the k-mer in y; 1 = row in y, lane above the flags in z; 2 = both in w\n";
+    s << "__device__ const unsigned char __attribute__((aligned(16))) BITTAB[32] = {";
+    for (int b = 0; b < 32; ++b) s << (b ? ", " : "") << tab[(size_t)b];
+    s << "}; // payload bit -> shape | steps back << 4\n";
+    s << R"SRC(
+// LDS image (host.cpp: build_index): the shapes' bitmaps, T64N 64-bit words | T64N uint16 rank prefixes | NS first-entry
+// indices | NS x 2 words of shape constants; behind it (kernel start) the 32 bytes of BITTAB
+#define PREFIX_WORD0 (T64N * 2u)
+#define BASE_WORD0 (T64N * 2u + T64N / 2u)
+#define SHAPE_WORD0 (BASE_WORD0 + NS)
+#define TAB_WORD0 (SHAPE_WORD0 + 2u * NS)
+#define LDS_WORDS (TAB_WORD0 + 8u)
+#define ANDOR(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA) /* (a & b) | c: v_bitop3_b32 issues in two cycles, v_and_or_b32 in four */
+// invalid-base flags, one bit per base -> the even bits of a 2-bit-per-base word
+__device__ __forceinline__ u64 spread2(u32 v) {
+  u64 x = v;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+// 32 x 32 bit transpose across the 32 lanes of each half wave: lane i gives row i, lane s receives column s (bit i = bit s
+// of row i).  Five butterfly stages: the partner's word (lane ^ d) comes through ds_swizzle, is rotated by d towards the
+// half that is exchanged, and one v_bitop3 keeps the own bits under the lane's mask and takes the rest from the partner.
+struct trc { u32 sh[5], mk[5]; };
+template <int D> __device__ __forceinline__ u32 tr_stage(u32 x, u32 sh, u32 mk) {
+  const u32 p = (u32)__builtin_amdgcn_ds_swizzle((int)x, (D << 10) | 0x1F);
+  const u32 r = __builtin_amdgcn_alignbit(p, p, sh);
+  return __builtin_amdgcn_bitop3_b32(x, r, mk, 0xE4); // (x & mk) | (r & ~mk)
+}
+__device__ __forceinline__ u32 tr32(u32 x, const trc& c) {
+  x = tr_stage<16>(x, c.sh[0], c.mk[0]);
+  x = tr_stage<8>(x, c.sh[1], c.mk[1]);
+  x = tr_stage<4>(x, c.sh[2], c.mk[2]);
+  x = tr_stage<2>(x, c.sh[3], c.mk[3]);
+  x = tr_stage<1>(x, c.sh[4], c.mk[4]);
+  return x;
+}
+// exact check of ONE pattern filed under a key (entry `idx`) against the k-mer of a hit; returns the entry of the
+// next pattern with the same key (0xFFFFFFFF: none).
+// Entry (device_types.h: ipcr_index_entry): {next, pattern, seq2 | prot2, len, flags | okA, okC | okG, okT}
+__device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u64 unit_base, u32 strand_off,
+    u32 shard, const v4* __restrict__ table, u32 max_mm, qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {
+  const v4 e0 = table[idx * 4u], e1 = table[idx * 4u + 1u];
+  const u64 seq2 = ((u64)e0.w << 32) | e0.z, prot2 = ((u64)e1.y << 32) | e1.x;
+  const u32 left = e1.w & 1u;
+  const u32 L = ULEN ? ULEN : e1.z;                 // one length for the whole panel: every shift and mask below is a constant
+  const u32 sft = WINDOW_AT_NEWEST ? 0u : (left ? 2u * (DL + 1u - L) : 0u); // the window's last base sits sft / 2 bases behind the newest
+  const u64 x = km >> sft;
+  const u64 E = 0x5555555555555555ull;
+  const u64 wmE = ((L >= 32u) ? ~0ull : ((1ull << (2u * L)) - 1ull)) & E;
+  u64 mm2;
+  if (ALL_ACGT || (e1.w & 2u)) {                     // one base per position: XOR against the primer's 2-bit codes
+    const u64 d = x ^ seq2;
+    mm2 = (d | (d >> 1)) & wmE;
+  } else {                                           // IUPAC codes: four sets of allowed positions
+    const v4 e2 = table[idx * 4u + 2u], e3 = table[idx * 4u + 3u];
+    const u64 okA = ((u64)e2.y << 32) | e2.x, okC = ((u64)e2.w << 32) | e2.z;
+    const u64 okG = ((u64)e3.y << 32) | e3.x, okT = ((u64)e3.w << 32) | e3.z;
+    const u64 lo = x & E, hi = (x >> 1) & E;
+    const u64 match = (~lo & ~hi & okA) | (lo & ~hi & okC) | (~lo & hi & okG) | (lo & hi & okT);
+    mm2 = ~match & wmE;
+  }
+  const u32 bw = (bad >> (sft >> 1)) & ((L >= 32u) ? 0xFFFFFFFFu : ((1u << L) - 1u));
+  if (bw) mm2 |= spread2(bw);                        // rare: the window holds an invalid base
+  const int srow = left ? erow - (int)DL : erow - (int)L + 1; // may lie in the strand before (the padded coordinate is continuous)
+  if ((mm2 & prot2) == 0ull && (u32)__popcll(mm2) <= max_mm) {
+    const u64 qi = atomicAdd(qcount + shard * 16u, 1ull);
+    // position = (the unit's first strand + the lane) * 128 + row
+    if (qi < qcap) { qent qe; qe.key = ((u64)e0.y << 48) | (u64)((i64)unit_base + (i64)((int)strand_off + srow)); qe.bits = 1u; qe.pad = 0u; queue[(u64)shard * qcap + qi] = qe; }
+  }
+  return e0.x;
+}
+)SRC";
+    s << "extern \"C\" __global__ void __launch_bounds__(" << IPCR_INDEX_WAVES * 64u << ", " << IPCR_INDEX_WAVES / 4u << ") ipcr_index_filter(const u32* __restrict__ planes, u64 ncolpairs,\n"
+         "    const u32* __restrict__ lds_image, const v4* __restrict__ table, u32 max_mm,\n"
+         "    qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount, u32* __restrict__ work, u64* __restrict__ stamps) {\n"
+         "  __shared__ u32 lds[((LDS_WORDS + 3u) & ~3u) + " << IPCR_INDEX_WAVES << "u * QCAP * 4u]; // static: every LDS address is a compile-time offset\n"
+         "  for (u32 i = threadIdx.x; i < TAB_WORD0; i += blockDim.x) lds[i] = lds_image[i];\n"
+         "  if (threadIdx.x < 8u) lds[TAB_WORD0 + threadIdx.x] = reinterpret_cast<const u32*>(BITTAB)[threadIdx.x];\n"
+         "  __syncthreads();\n"
+         "  const u64* T64 = reinterpret_cast<const u64*>(lds);\n"
+         "  const unsigned char* ldsb = reinterpret_cast<const unsigned char*>(lds);\n"
+         "  const unsigned short* prefix = reinterpret_cast<const unsigned short*>(lds + PREFIX_WORD0);\n"
+         "  const u32 lane = threadIdx.x & 63u;\n"
+         "  u32* wq = lds + ((LDS_WORDS + 3u) & ~3u) + (threadIdx.x >> 6) * (QCAP * 4u); // this wave's hit queue\n"
+         "  u32 qn = 0; // entries queued (wave-uniform)\n"
+         "  const u64 wave0 = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);\n"
+         "  const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);\n"
+         "  if (stamps && lane == 0u) stamps[wave0 * 2u] = __builtin_amdgcn_s_memrealtime();\n"
+         "  // the transpose's per-lane constants, and which word of a chunk this lane loads (tile_layout.h: word ((row quad * 3 + plane) * 64\n"
+         "  // + column) * 4 + row % 4 of a block; the column part is in the unit's base pointer, a chunk is 8 row quads = 6144 words)\n"
+         "  trc tc;\n"
+         "  { const u32 j = lane & 31u;\n"
+         "    const u32 m0[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};\n"
+         "    for (int st = 0; st < 5; ++st) { const u32 d = 16u >> st; tc.sh[st] = (j & d) ? d : 32u - d; tc.mk[st] = (j & d) ? ~m0[st] : m0[st]; } }\n"
+         "  const u32 jh = lane & 31u;\n"
+         "  const u32 rowA = 15u - (jh >> 1), rowB = 31u - (jh >> 1), rowI = 31u - jh;\n"
+         "  const u32 offA = ((rowA >> 2) * 3u + (jh & 1u)) * 256u + (rowA & 3u);\n"
+         "  const u32 offB = ((rowB >> 2) * 3u + (jh & 1u)) * 256u + (rowB & 3u);\n"
+         "  const u32 offI = ((rowI >> 2) * 3u + 2u) * 256u + (rowI & 3u);\n";
+    const bool dynamic = env_int("IPCR_INDEX_DYNAMIC", 1, 0, 1) != 0;
+    if (dynamic)
+        s << "  for (;;) { // one unit = one column pair = 64 strands (units are handed out by a counter: jit_index_source)\n"
+             "    u32 take = 0u;\n"
+             "    if (lane == 0u) take = atomicAdd(work, 1u);\n"
+             "    const u64 cp = (u64)(u32)__builtin_amdgcn_readfirstlane((int)take);\n"
+             "    if (cp >= ncolpairs) break;\n";
+    else
+        s << "  for (u64 cp = wave0; cp < ncolpairs; cp += nwaves) { // one unit = one column pair = 64 strands\n";
+    s << "    auto flush = [&]() __attribute__((always_inline)) {\n"
+         "      u32 n = qn;\n"
+         "      const u64 unit_base = cp * 8192u; // first position of this unit\n"
+         "      const u32 shard = (u32)cp & 255u;\n"
+         "      while (n != 0u) {\n"
+         "        u32 nc = 0u; // entries handed back so far: slots [0, nc), always behind the round being read\n"
+         "        auto hand_back = [&](bool mine, v4 e, u32 w) __attribute__((always_inline)) {\n"
+         "          const u64 rb = __ballot(mine);\n"
+         "          if (rb != 0ull) {\n"
+         "            if (mine) {\n"
+         "              const u32 slot = nc + __builtin_amdgcn_mbcnt_hi((u32)(rb >> 32), __builtin_amdgcn_mbcnt_lo((u32)rb, 0u));\n"
+         "              e.w = w;\n"
+         "              *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
+         "            }\n"
+         "            nc += (u32)__popcll(rb);\n"
+         "          }\n"
+         "        };\n"
+         "        for (u32 qb = 0; qb < n; qb += 64u) {\n"
+         "          const u32 i = qb + lane;\n"
+         "          v4 e; e.x = 0u; e.y = 0u; e.z = 0u; e.w = 0u;\n"
+         "          if (i < n) e = *reinterpret_cast<const v4*>(wq + i * 4u);\n"
+         "          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // every lane has read its slot: slots up to qb + 63 may be rewritten\n"
+         "          u32 pend = 0u, idx = 0xFFFFFFFFu, back = 0u, keep = 0u; // keep: what of w a handed-back entry keeps (layout C: lane and row)\n"
+         "          u32 elane, erow0;\n"
+         "          u64 hkm; u32 hbad;\n"
+         "          if (EMODE == 0) { hkm = ((u64)(KMHI ? (e.y & ((1u << KMHI) - 1u)) : 0u) << 32) | e.x; hbad = e.z; elane = (e.y >> KMHI) & 63u; erow0 = (e.y >> (KMHI + 6u)) & ((1u << ROWB) - 1u); }\n"
+         "          else if (EMODE == 1) { hkm = ((u64)(KMHI ? (e.y & ((1u << KMHI) - 1u)) : 0u) << 32) | e.x; hbad = e.z & ((1u << NBAS) - 1u); elane = e.z >> NBAS; erow0 = (e.y >> KMHI) & ((1u << ROWB) - 1u); }\n"
+         "          else { hkm = ((u64)e.y << 32) | e.x; hbad = e.z; elane = (e.w >> 15) & 63u; erow0 = (e.w >> 21) & ((1u << ROWB) - 1u); keep = e.w & 0x7FFF8000u; }\n"
+         "          const u32 pay = EMODE == 2 ? (e.w & 0x7FFFu) : (e.w & 0x7FFFFFFFu);\n"
+         "          if (e.w & 0x80000000u) { idx = pay >> 2; back = pay & 3u; }\n"
+         "          else pend = pay;\n"
+         "          const u32 rest = pend & (pend - 1u);\n"
+         "          hand_back(rest != 0u, e, keep | rest); // (k-mer, flags and row as filed)\n"
+         "          if (pend != 0u) {\n"
+         "            const u32 t = reinterpret_cast<const unsigned char*>(lds + TAB_WORD0)[__builtin_ctz(pend)];\n"
+         "            const u32 sidx = t & 15u;\n"
+         "            back = t >> 4;\n"
+         "            const u64 skm = hkm >> (2u * back); // a hit of an earlier step of the entry: its own k-mer\n"
+         "            const u32 c0 = lds[SHAPE_WORD0 + 2u * sidx], c1 = lds[SHAPE_WORD0 + 2u * sidx + 1u];\n"
+         "            const u32 key = ((u32)(skm >> (c0 & 63u)) & (c1 & 0xFFFFu)) | (((u32)(skm >> ((c0 >> 8) & 63u)) & (c1 >> 16)) << ((c0 >> 16) & 31u));\n"
+         "            const u32 wi = (c0 >> 21) * 16u + (key >> 6); // the shape's bitmap word with this key\n"
+         "            const u64 w = T64[wi];\n"
+         "            // the key is in the panel; its rank among the shape's keys is the index of its entry\n"
+         "            idx = lds[BASE_WORD0 + sidx] + (u32)prefix[wi] + (u32)__popcll((w << (63u - (key & 63u))) << 1);\n"
+         "          }\n"
+         "          u32 next = 0xFFFFFFFFu;\n"
+         "          if (idx != 0xFFFFFFFFu) {\n"
+         "            const u64 skm = hkm >> (2u * back);\n"
+         "            const u32 sbad = hbad >> back;\n"
+         "            const u32 strand_off = elane << 7;\n"
+         "            const int erow = (int)erow0 - (int)back;\n"
+         "            next = check_entry(idx, skm, sbad, erow, unit_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
+         "            if (!CHAIN_CARRY || rest != 0u)\n"
+         "              while (next != 0xFFFFFFFFu) next = check_entry(next, skm, sbad, erow, unit_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
+         "          }\n"
+         "          if (CHAIN_CARRY) hand_back(next != 0xFFFFFFFFu, e, keep | 0x80000000u | (next << 2) | back);\n"
+         "        }\n"
+         "        n = nc;\n"
+         "        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // the entries handed back are read by other lanes next\n"
+         "      }\n"
+         "      qn = 0;\n"
+         "      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // queue slots are rewritten by other lanes next\n"
+         "    };\n";
+    // the unit's tiles: column 2 cp + (lane >> 5)
+    s << "    const u64 col = cp * 2u + (lane >> 5);\n"
+         "    const u32* const base = planes + (((col >> 6) * 6144u + (col & 63u)) << 2);\n"
+         "    // history: the strand before mine ended with its chunk 3 -- lane - 1's, which is loaded and transposed first (and kept: the\n"
+         "    // walk comes back to it); lane 0's predecessor is strand 31 of the column before the unit's first: bit 31 of that column's\n"
+         "    // words, gathered by a ballot over the lanes that load them (half 0: the rows of word A, half 1: those of word B)\n"
+         "    const u32 SA = tr32(base[offA + 18432u], tc), SB = tr32(base[offB + 18432u], tc), SI = tr32(base[offI + 18432u], tc);\n"
+         "    u32 PA = (u32)__shfl_up((int)SA, 1), PB = (u32)__shfl_up((int)SB, 1), PI = (u32)__shfl_up((int)SI, 1);\n"
+         "    {\n"
+         "      u32 hA = 0u, hB = 0u, hI = 0xFFFFFFFFu; // the very first strand: nothing but invalid bases in front of it\n"
+         "      if (cp != 0ull) {\n"
+         "        const u64 pcol = cp * 2u - 1u;\n"
+         "        const u32* const pbase = planes + (((pcol >> 6) * 6144u + (pcol & 63u)) << 2);\n"
+         "        const u64 bk = __ballot((pbase[(lane < 32u ? offA : offB) + 18432u] >> 31) != 0u);\n"
+         "        const u64 bi = __ballot((pbase[offI + 18432u] >> 31) != 0u);\n"
+         "        hA = (u32)bk; hB = (u32)(bk >> 32); hI = (u32)bi;\n"
+         "      }\n"
+         "      if (lane == 0u) { PA = hA; PB = hB; PI = hI; }\n"
+         "    }\n"
+         "    u32 A = tr32(base[offA], tc), B = tr32(base[offB], tc), I = tr32(base[offI], tc);\n"
+         "    u32 rA = 0u, rB = 0u, rI = 0u; // the next chunk's words as loaded\n"
+         "    u32 acc = 0u; // the masks of the steps since the last queue entry\n";
+    if (mode == 0) s << "    const u32 lane_y = lane << KMHI; // this lane's part of an entry's y\n";
+    if (mode == 1) s << "    const u32 lane_z = lane << NBAS;\n";
+    if (mode == 2) s << "    const u32 lane_w = lane << 15;\n";
+    s << "    u32 it = 0u, u = 0u; // chunk, step of the chunk\n"
+         "    bool done = false;\n"
+         "    while (!done) {\n";
+    // field of the step's k-mer: (km >> f) & mask, where km = {W2, W1, W0} >> P0
+    for (unsigned k = 0; k < U; ++k) {
+        const unsigned half = k / 16u, tq = k % 16u, P0 = 2u * (15u - tq);
+        const char *W[3] = {half ? "B" : "A", half ? "A" : "PB", half ? "PB" : "PA"};
+        auto shifted = [&](unsigned f, unsigned width) { // (km >> f), valid in its low `width` bits at least
+            const unsigned P = P0 + f, q = P / 32u, r = P % 32u;
+            if (q > 2u) return std::string("0u");
+            if (r == 0u) return std::string(W[q]);
+            if (r + width <= 32u || q == 2u) return "(" + std::string(W[q]) + " >> " + std::to_string(r) + "u)";
+            return "__builtin_amdgcn_alignbit(" + std::string(W[q + 1]) + ", " + W[q] + ", " + std::to_string(r) + "u)";
+        };
+        auto width_of = [](unsigned mask) { unsigned w = 0; while (mask >> w) ++w; return w; };
+        auto field = [&](unsigned f, unsigned mask) { return "(" + shifted(f, width_of(mask)) + " & " + std::to_string(mask) + "u)"; };
+        s << "      if (u == " << k << "u) {\n";
+        if (k == 0)
+            s << "        if (it < 2u) { rA = base[offA + (it + 1u) * 6144u]; rB = base[offB + (it + 1u) * 6144u]; rI = base[offI + (it + 1u) * 6144u]; }\n";
+        s << "        u32 hm; // shapes that hold this step's key (bit 8 i + p: shape i of pack p)\n";
+        std::vector<char> group_c(groups.size(), 0);
+        bool first_pack = true;
+        for (unsigned p = 0; p < NPK; ++p) {
+            const Pack &pk = packs[p];
+            std::string q;
+            if (pk.fast) {
+                const size_t gi = (size_t)pk.group;
+                if (!group_c[gi]) {
+                    s << "        const u32 cb" << gi << " = " << field((unsigned)groups[gi].c_off, 7u) << ", cw" << gi << " = " << field((unsigned)groups[gi].c_off + 3u, 7u) << ";\n";
+                    group_c[gi] = 1;
+                }
+                std::string packed;
+                for (size_t i = 0; i < pk.sh.size(); ++i) {
+                    const int si = pk.sh[i];
+                    const ipcr_index_shape &sh = shapes[(size_t)si];
+                    const bool single = sh.blk_mask == 0;
+                    const unsigned off = single ? (unsigned)sh.tw_shift + 6u : (unsigned)sh.blk_shift;
+                    const unsigned vmask = single ? ((1u << (sh.tw_bits - 6)) - 1u) : sh.blk_mask;
+                    const std::string cw = "cw" + std::to_string(gi);
+                    std::string a;
+                    if (vmask == 0) a = cw;
+                    else if (off >= 3) a = "ANDOR(" + shifted(off - 3u, width_of(vmask) + 3u) + ", " + std::to_string(vmask << 3) + "u, " + cw + ")";
+                    else a = "((" + field(off, vmask) + " << 3) | " + cw + ")";
+                    const std::string by = "(u32)ldsb[" + std::to_string(off64[(size_t)si] * 8u) + "u + " + a + "]";
+                    packed += (i ? " | (" : "(") + by + (i ? " << " + std::to_string(8 * i) + "u)" : ")");
+                }
+                unsigned m = 0;
+                for (size_t i = 0; i < pk.sh.size(); ++i) m |= 1u << (8 * i);
+                q = "(((" + packed + ") >> cb" + std::to_string(gi) + ") & " + std::to_string(m) + "u)";
+            } else {
+                const int si = pk.sh[0];
+                const ipcr_index_shape &sh = shapes[(size_t)si];
+                std::string key = sh.tw_mask ? field(sh.tw_shift, sh.tw_mask) : std::string("0u");
+                if (sh.blk_mask) key = "(" + key + " | (" + field(sh.blk_shift, sh.blk_mask) + " << " + std::to_string(sh.tw_bits) + "u))";
+                s << "        const u32 key" << si << " = " << key << ";\n";
+                q = "((lds[" + std::to_string(off64[(size_t)si] * 2u) + "u + (key" + std::to_string(si) + " >> 5)] >> (key" + std::to_string(si) + " & 31u)) & 1u)";
+            }
+            s << "        hm " << (first_pack ? "= " : "|= ") << q << (p ? " << " + std::to_string(p) + "u" : std::string()) << ";\n";
+            first_pack = false;
+        }
+        const bool files = (k % SPE) == SPE - 1u;
+        if (SPE == 1u || k % SPE == 0u) s << "        acc = hm;\n";
+        else s << "        acc = (acc << " << SHF << "u) | hm;\n";
+        if (files) {
+            const std::string kmlo = P0 ? "__builtin_amdgcn_alignbit(" + std::string(W[1]) + ", " + W[0] + ", " + std::to_string(P0) + "u)" : std::string(W[0]);
+            const std::string kmhi = P0 ? "__builtin_amdgcn_alignbit(" + std::string(W[2]) + ", " + W[1] + ", " + std::to_string(P0) + "u)" : std::string(W[1]);
+            const std::string bad = k == 31u ? std::string("I") : "__builtin_amdgcn_alignbit(PI, I, " + std::to_string(31u - k) + "u)";
+            s << "        const u64 bal = __ballot(acc != 0u);\n"
+                 "        if (bal != 0ull) { // one queue entry per lane whatever the number of shapes and steps that hit\n"
+                 "          if (acc != 0u) {\n"
+                 "            const u32 slot = qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));\n"
+                 "            const u32 row = it * 32u + " << k << "u;\n"
+                 "            v4 e; e.x = " << kmlo << ";\n";
+            if (mode == 0)
+                s << "            e.y = (KMHI ? (" << kmhi << " & ((1u << KMHI) - 1u)) : 0u) | lane_y | (row << (KMHI + 6u)); e.z = " << bad << "; e.w = acc;\n";
+            else if (mode == 1)
+                s << "            e.y = (KMHI ? (" << kmhi << " & ((1u << KMHI) - 1u)) : 0u) | (row << KMHI); e.z = (" << bad << " & ((1u << NBAS) - 1u)) | lane_z; e.w = acc;\n";
+            else
+                s << "            e.y = " << kmhi << "; e.z = " << bad << "; e.w = acc | lane_w | (row << 21);\n";
+            s << "            *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
+                 "          }\n"
+                 "          qn += (u32)__popcll(bal);\n"
+                 "        }\n";
+        }
+        s << "        u = " << k + 1 << "u;\n";
+        if (files) s << "        if (qn > QCAP - 64u) u |= 256u;\n";
+        s << "      }\n";
+    }
+    s << "      const bool full = (u & 256u) != 0u;\n"
+         "      u &= 255u;\n"
+         "      if (u == " << U << "u) { // the chunk is walked: the next one's words take its place\n"
+         "        u = 0u; ++it;\n"
+         "        if (it == 4u) done = true;\n"
+         "        else { PA = A; PB = B; PI = I; if (it == 3u) { A = SA; B = SB; I = SI; } else { A = tr32(rA, tc); B = tr32(rB, tc); I = tr32(rI, tc); } }\n"
+         "      }\n"
+         "      if (full || done) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); flush(); }\n"
+         "    }\n";
+    s << "  }\n"; // (rows are relative to the unit: the queue is always empty when a unit ends)
+    if (dynamic)
+        s << "  if (lane == 0u) {\n"
+             "    const u32 left = atomicAdd(work + 32u, 1u);\n"
+             "    if ((u64)left + 1ull == nwaves) { __hip_atomic_store(work, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(work + 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n"
+             "  }\n";
+    s << "  if (stamps && lane == 0u) stamps[wave0 * 2u + 1u] = __builtin_amdgcn_s_memrealtime();\n";
+    s << "}\n";
+    return s.str();
+}
+
+std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom) {
+    return env_int("IPCR_INDEX_TRANSPOSED", 1, 0, 1) ? jit_index_source_t(shapes, geom) : jit_index_source_rolled(shapes, geom);
+}
+
 JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom, std::string &err) {
     if (shapes.empty() || shapes.size() > IPCR_INDEX_MAX_SHAPES) { err = "no index shapes"; return nullptr; }
     int dev = 0;
@@ -1440,7 +1855,7 @@ hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes
                             const uint32_t *lds_image, const void *table, uint32_t max_mm, void *queue,
                             uint64_t qcap, unsigned long long *qcount, uint32_t *work, hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0) return hipSuccess;
-    uint64_t ncolpairs = nblocks * 32u;
+    uint64_t ncolpairs = nblocks * 32u; // (the rolled kernel's unit is SW column pairs: a smaller genome only leaves some waves idle)
     // one persistent 16-wave workgroup per CU: the bitmaps are staged into LDS once per CU
     uint64_t grid = 256ull;
     if (grid * IPCR_INDEX_WAVES > ncolpairs) grid = (ncolpairs + IPCR_INDEX_WAVES - 1u) / IPCR_INDEX_WAVES;
