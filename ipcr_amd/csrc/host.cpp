@@ -179,9 +179,8 @@ struct IndexPlan {
     int dl = 0;        // left-anchored windows are tested dl bases after their start
     int max_right = 0; // longest right-anchored pattern served
     int uniform_len = 0; // length shared by every served pattern (0: mixed)
-    ipcr::IndexGeom geom(int strands = 2) const {
+    ipcr::IndexGeom geom() const {
         ipcr::IndexGeom g;
-        g.strands = strands;
         g.tail_rows = std::max(max_right - 1, dl);
         g.all_acgt = all_acgt;
         g.uniform_len = uniform_len;
@@ -198,9 +197,8 @@ struct IndexPlan {
     uint32_t *d_lds_image = nullptr;
     ipcr_index_entry *d_table = nullptr;
     uint32_t *d_leftover = nullptr;
-    ipcr::JitFilter *jit = nullptr; // the kernel, with the key shapes baked in (hiprtc): lanes walk two strands each
+    ipcr::JitFilter *jit = nullptr; // the kernel, with the key shapes baked in (hiprtc)
     std::vector<ipcr::JitFilter *> leftover_jit; // specialised spill-only filters for `leftover` (else the table-driven kernel takes them)
-    ipcr::JitFilter *jit_sw[2] = {nullptr, nullptr}; // ... one strand / four strands
 };
 
 struct PatternSet {
@@ -418,10 +416,10 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         };
         if (tri && b == 5 && ns > 1) {
             // Measured on the 4096-pattern panel (C4, 3 Gb): blocks of 11, 10, 11 bits are picked (cost 0.13 against 0.18
-            // for three 10-bit blocks) and a third fewer hits reach the drain -- but the bitmaps then leave the waves
-            // queues of 192 entries instead of 384, the drain's rounds run emptier, and the sweep takes 8.45 ms
-            // instead of 8.35.  Off unless asked for.
-            const bool half_bases = env_flag("IPCR_INDEX_HALF_BASES", false);
+            // for three 10-bit blocks) and a third fewer hits reach the drain.  The larger bitmaps leave the waves smaller
+            // hit queues (round 2, two steps per entry: 1 % slower); with one queue entry per four steps the queues fill
+            // half as fast and the layout wins: 5.13 -> 4.97 ms.  IPCR_INDEX_HALF_BASES=0 turns it off.
+            const bool half_bases = env_flag("IPCR_INDEX_HALF_BASES", true);
             const int spare = A - b * ns;
             double best = -1;
             unsigned best_mask = 0;
@@ -697,8 +695,6 @@ void ipcr_panel_destroy(ipcr_panel *p) {
     if (!p) return;
     for (auto &s : p->set) {
         if (s.index.jit) ipcr::jit_destroy(s.index.jit);
-        for (ipcr::JitFilter *f : s.index.jit_sw)
-            if (f) ipcr::jit_destroy(f);
         for (ipcr::JitFilter *f : s.index.leftover_jit) ipcr::jit_destroy(f);
         if (s.index.d_lds_image) (void)hipFree(s.index.d_lds_image);
         if (s.index.d_table) (void)hipFree(s.index.d_table);
@@ -1220,15 +1216,9 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode) {
         if (!s.index.built) build_index(*p, s);
         IndexPlan &ix = s.index;
         if (ix.usable) {
-            // the three walks (host.cpp: index_kernel) compile side by side: no scan ever waits for a compile of its own
-            std::string jerr, jerr1, jerr4;
-            int dev = 0;
-            (void)hipGetDevice(&dev); // the current device is a per-thread setting: the helpers load their modules onto OURS
-            std::thread t1([&] { (void)hipSetDevice(dev); ix.jit_sw[0] = ipcr::jit_build_index(ix.shapes, ix.geom(1), jerr1); });
-            std::thread t4([&] { (void)hipSetDevice(dev); ix.jit_sw[1] = ipcr::jit_build_index(ix.shapes, ix.geom(4), jerr4); });
+            std::string jerr;
             ix.jit = ipcr::jit_build_index(ix.shapes, ix.geom(), jerr);
-            t1.join();
-            t4.join();
+            if (!ix.jit && env_flag("IPCR_INDEX_DEBUG", false)) fprintf(stderr, "ipcr index kernel: %s\n", jerr.c_str());
             if (!ix.jit) {
                 ix.usable = false; // no hiprtc: the table-driven kernel serves
                 return IPCR_OK;
@@ -1357,19 +1347,6 @@ ipcr_status wait_published(ipcr_scratch *s) {
     }
 }
 
-// The seed-index kernel for a genome of `nblocks` blocks.  A lane walks 1, 2 or 4 consecutive strands before the tail
-// rows of the next one: (128 s + 19) / 128 s rows per base scanned -- 1.15, 1.07, 1.04 -- but a wave's unit of work
-// grows with s (64 s strands), and the sweep needs several units per wave to end evenly (3 Gb: 8.35 / 7.9 / 7.8 ms for
-// s = 1 / 2 / 4; s = 8: 8.0).
-ipcr::JitFilter *index_kernel(const ipcr_panel *cp, int mode, uint64_t nblocks) {
-    ipcr_panel *p = const_cast<ipcr_panel *>(cp);
-    IndexPlan &ix = p->set[mode].index;
-    const uint64_t waves = 256u * 16u, units1 = nblocks * 32u; // units of the one-strand kernel: column pairs
-    const int strands = units1 / 4u >= 8u * waves ? 4 : (units1 / 2u >= 2u * waves ? 2 : 1);
-    ipcr::JitFilter *f = strands == 2 ? ix.jit : ix.jit_sw[strands == 1 ? 0 : 1]; // all built with the panel (panel_upload)
-    return f ? f : ix.jit;
-}
-
 // enqueue one attempt: the specialised filter alone (it verifies and publishes itself), or the seed-index /
 // table-driven filter + verify kernel + read-back of counters and first hits behind a marker event
 ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
@@ -1435,7 +1412,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     } else if (set.index.usable) {
         const IndexPlan &ix = set.index;
         const bool more = !ix.leftover.empty();
-        HIPCHK(ipcr::jit_launch_index(index_kernel(p, pd.mode, nblocks), lane, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_lds_image, ix.d_table,
+        HIPCHK(ipcr::jit_launch_index(ix.jit, lane, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_lds_image, ix.d_table,
                                       (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, qc, s->d_tickets, s->ev[0], more ? nullptr : s->ev[1]));
         if (more && !ix.leftover_jit.empty()) { // patterns the index cannot key: specialised filters that only fill the queue
             ipcr::JitVerify v;

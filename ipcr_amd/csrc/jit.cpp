@@ -979,440 +979,7 @@ static unsigned index_queue_entries(const std::vector<ipcr_index_shape> &shapes)
     return q < 128u ? 128u : (q > 448u ? 448u : q);
 }
 
-static std::string jit_index_source_rolled(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom) {
-    const int tail_rows = geom.tail_rows;
-    const bool all_acgt = geom.all_acgt;
-    const size_t NS = shapes.size();
-    struct Grp { bool fast = false; std::vector<int> sh; int c_off = 0; };
-    std::vector<Grp> groups;
-    std::vector<unsigned> off64(NS + 1, 0); // first 64-bit word of every shape's bitmap
-    for (size_t i = 0; i < NS; ++i) {
-        if (shapes[i].group >= groups.size()) groups.resize((size_t)shapes[i].group + 1);
-        groups[shapes[i].group].sh.push_back((int)i);
-        groups[shapes[i].group].fast = shapes[i].fast != 0 && shapes[i].tw_bits >= 6;
-        groups[shapes[i].group].c_off = shapes[i].tw_shift;
-        off64[i + 1] = off64[i] + ipcr_index_words64(shapes[i]);
-    }
-    const unsigned T64N = off64[NS];
-    const unsigned U = 8;                              // base steps per copy of the loop body
-    // A lane walks SW consecutive strands and then the tail rows of the one after: the rows walked per base scanned
-    // are (128 SW + tail) / (128 SW) -- 1.15 for one strand and 19 tail rows, 1.07 for two.
-    unsigned SW = (unsigned)env_int("IPCR_INDEX_STRANDS", geom.strands, 1, 4); // (the env knob overrides the caller's choice: development)
-    while (SW & (SW - 1u)) --SW; // a power of two: a lane's strands are bits of ONE column's words
-    const int TR = tail_rows < 0 ? 0 : tail_rows;
-    const int RT = 128 * (int)SW + TR;
-    // ---- how a base step reports its key hits.  Shapes are looked up in PACKS: the shapes of a FAST group share the
-    // six key bits of the protected bases, so their bitmap BYTES (ds_read_u8: byte = key >> 3) are put side by side in
-    // one register and tested with ONE shift by the shared low three key bits and one AND -- bits 0, 8, 16, 24 of the
-    // result say which shapes hold the key; a shape outside a fast group is a pack of its own (one bit).  Pack p's bits
-    // land on 8 i + p.  A lane files one queue entry per SPE base steps: the steps' masks are shifted together by SH =
-    // number of packs, so bit 8 i + p + SH j = shape i of pack p, j steps before the entry's row.
-    struct Pack { bool fast = false; int group = 0; std::vector<int> sh; };
-    std::vector<Pack> packs;
-    auto make_packs = [&](bool allow_fast) {
-        packs.clear();
-        for (size_t gi = 0; gi < groups.size(); ++gi) {
-            const Grp &g = groups[gi];
-            if (allow_fast && g.fast && g.sh.size() > 1) {
-                for (size_t a = 0; a < g.sh.size(); a += 4) {
-                    Pack p; p.fast = true; p.group = (int)gi;
-                    for (size_t b = a; b < std::min(g.sh.size(), a + 4); ++b) p.sh.push_back(g.sh[b]);
-                    packs.push_back(p);
-                }
-            } else
-                for (int sidx : g.sh) { Pack p; p.fast = false; p.group = (int)gi; p.sh.push_back(sidx); packs.push_back(p); }
-        }
-    };
-    make_packs(env_int("IPCR_INDEX_PACKED", 1, 0, 1) != 0);
-    if (packs.size() > 8) make_packs(false); // more packs than a byte has bits: every shape a bit of its own
-    bool byte_layout = false;
-    for (const Pack &p : packs) byte_layout |= p.sh.size() > 1;
-    const unsigned NP = (unsigned)packs.size();
-    const unsigned SH = NP;
-    // Queue entry (16 bytes): x, y = the k-mer (newest base in bits 1:0); only the 2 NBAS bits a check can reach are kept,
-    // z = the invalid-base flags of those bases, w = the steps' masks (bit 31 clear) or, for a further pattern chained
-    // under a key, bit 31 | entry index << 2 | steps back.  Lane (6 bits) and row (ROWB bits) go where bits are left:
-    //   mode A: both above the k-mer in y;  mode B: row above the k-mer in y, lane above the flags in z;
-    //   mode C (primers beyond 26 nt): both in w above a 15-bit payload, one step per entry, one bit per shape.
-    unsigned ROWB = 8;
-    while ((1 << ROWB) <= RT) ++ROWB;
-    unsigned SPE = 1, mode = 2;
-    {
-        unsigned want = byte_layout ? (SH <= 2 ? 4u : (SH <= 4 ? 2u : 1u)) : (SH * 4u <= 31u ? 4u : (SH * 2u <= 31u ? 2u : 1u));
-        want = (unsigned)env_int("IPCR_INDEX_STEPS_PER_ENTRY", (int)want, 1, (int)want);
-        while (want & (want - 1u)) --want;
-        for (unsigned spe = want; spe >= 1; spe >>= 1) {
-            const unsigned nb = (unsigned)TR + spe;
-            unsigned top = 0; // highest payload bit: bit 31 is the chain flag
-            for (unsigned p = 0; p < packs.size(); ++p) top = std::max(top, (byte_layout ? 8u * ((unsigned)packs[p].sh.size() - 1u) : 0u) + p + SH * (spe - 1u));
-            if (top > 30u) continue;
-            if (2u * nb + 6u + ROWB <= 64u) { SPE = spe; mode = 0; break; }
-            if (2u * nb + ROWB <= 64u && nb + 6u <= 32u) { SPE = spe; mode = 1; break; }
-        }
-        if (mode == 2) { // long primers: the whole k-mer and all its flags are needed
-            SPE = 1;
-            if (byte_layout) { make_packs(false); byte_layout = false; }
-        }
-    }
-    const unsigned NPK = (unsigned)packs.size(), SHF = NPK; // (mode C may have re-cut the packs)
-    (void)NP; (void)SH;
-    const unsigned NBAS = (unsigned)TR + SPE;                 // bases of the k-mer an entry must hold
-    const unsigned KMHI = 2u * NBAS > 32u ? 2u * NBAS - 32u : 0u; // k-mer bits kept in y
-    // position of (pack p, shape i of the pack, j steps back) in the payload, and the drain's table bit -> shape | j << 4
-    auto bitpos = [&](unsigned p, unsigned i, unsigned j) { return (byte_layout ? 8u * i : 0u) + p + SHF * j; };
-    std::vector<int> tab(32, 0);
-    unsigned paybits = 0;
-    for (unsigned p = 0; p < NPK; ++p)
-        for (unsigned i = 0; i < packs[p].sh.size(); ++i)
-            for (unsigned j = 0; j < SPE; ++j) {
-                const unsigned b = bitpos(p, i, j);
-                tab[b] = packs[p].sh[i] | (int)(j << 4);
-                paybits = std::max(paybits, b + 1u);
-            }
-    // chained patterns of a key go back into the queue when the entry index fits what w has for it
-    const unsigned idx_bits = mode == 2 ? 13u : 29u;
-    const bool chain_carry = geom.table_entries < (1u << idx_bits);
-    const unsigned NQ = (unsigned)(RT + 3) / 4;        // row quads walked
-    const unsigned NB = NQ * 4 / U;                    // full unrolled bodies
-    const unsigned TAILSTEPS = NQ * 4 - NB * U;        // a shorter copy of the body finishes the walk
-    const unsigned QCAP = index_queue_entries(shapes);
-
-    std::ostringstream s;
-    s << "// generated by ipcr_amd/csrc/jit.cpp: seed-index filter, " << NS << " key shapes in " << groups.size() << " groups / " << NPK
-      << " packs, " << RT << " rows per strand, body of " << U << " steps, " << SPE << " steps per queue entry (entry layout " << "ABC"[mode] << ")\n";
-    s << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
-    s << "typedef unsigned int u32;\ntypedef unsigned long long u64;\n";
-    s << "typedef u32 v4 __attribute__((ext_vector_type(4)));\n";
-    s << "struct qent { u64 key; u32 bits; u32 pad; };\n";
-    s << "#define NS " << NS << "\n";
-    s << "#define T64N " << T64N << "u // 64-bit words of all bitmaps\n";
-    s << "#define QCAP " << QCAP << "u // per-wave queue of hits (16-byte entries), drained in rounds of 64 at full lane occupancy\n";
-    s << "#define ALL_ACGT " << (all_acgt ? "true" : "false") << " // no indexed pattern holds an IUPAC code\n";
-    s << "#define ULEN " << geom.uniform_len << "u // length of every indexed pattern (0: mixed)\n";
-    bool aligned = geom.uniform_len > 0; // ... and left-anchored windows are tested exactly when they end: no shift in the check
-    for (const ipcr_index_shape &x : shapes)
-        if (x.left && (int)x.dl != geom.uniform_len - 1) aligned = false;
-    s << "#define WINDOW_AT_NEWEST " << (aligned ? "true" : "false") << "\n";
-    s << "#define DL " << geom.dl << "u // left-anchored windows are tested DL bases after their start\n";
-    s << "#define CHAIN_CARRY " << (chain_carry ? "true" : "false") << " // further patterns of a key are handed back to the queue (entry index in " << idx_bits << " bits)\n";
-    s << "#define SW " << SW << "u // strands a lane walks before the tail rows\n";
-    s << "#define SPE " << SPE << "u // base steps per queue entry\n";
-    s << "#define ROWB " << ROWB << "u // bits of a row number\n";
-    s << "#define KMHI " << KMHI << "u // k-mer bits an entry keeps in y\n";
-    s << "#define NBAS " << NBAS << "u // bases (and invalid flags) an entry keeps\n";
-    s << "#define EMODE " << mode << " // entry layout: 0 = lane, row above the k-mer in y; 1 = row in y, lane above the flags in z; 2 = both in w\n";
-    s << "__device__ const unsigned char __attribute__((aligned(16))) BITTAB[32] = {";
-    for (int b = 0; b < 32; ++b) s << (b ? ", " : "") << tab[(size_t)b];
-    s << "}; // payload bit -> shape | steps back << 4\n";
-    auto arr = [&](const char *type, const char *name, auto get) {
-        s << "__device__ constexpr " << type << " " << name << "[NS] = {";
-        for (size_t i = 0; i < NS; ++i) s << (i ? ", " : "") << get(shapes[i]);
-        s << "};\n";
-    };
-    arr("u32", "TW_SHIFT", [](const ipcr_index_shape &x) { return std::to_string(x.tw_shift) + "u"; });
-    arr("u32", "BLK_SHIFT", [](const ipcr_index_shape &x) { return std::to_string(x.blk_shift) + "u"; });
-    arr("u32", "TW_BITS", [](const ipcr_index_shape &x) { return std::to_string(x.tw_bits) + "u"; });
-    arr("u32", "TW_MASK", [](const ipcr_index_shape &x) { return std::to_string(x.tw_mask) + "u"; });
-    arr("u32", "BLK_MASK", [](const ipcr_index_shape &x) { return std::to_string(x.blk_mask) + "u"; });
-    s << R"SRC(
-template <int S> struct key_of {
-  static __device__ __forceinline__ u32 get(u64 km) {
-    return ((u32)(km >> TW_SHIFT[S]) & TW_MASK[S]) | (((u32)(km >> BLK_SHIFT[S]) & BLK_MASK[S]) << TW_BITS[S]);
-  }
-};
-// LDS image (host.cpp: build_index): the shapes' bitmaps, T64N 64-bit words | T64N uint16 rank prefixes | NS first-entry
-// indices | NS x 2 words of shape constants; behind it (kernel start) the 32 bytes of BITTAB
-#define PREFIX_WORD0 (T64N * 2u)
-#define BASE_WORD0 (T64N * 2u + T64N / 2u)
-#define SHAPE_WORD0 (BASE_WORD0 + NS)
-#define TAB_WORD0 (SHAPE_WORD0 + 2u * NS)
-#define LDS_WORDS (TAB_WORD0 + 8u)
-// invalid-base flags, one bit per base -> the even bits of a 2-bit-per-base word
-__device__ __forceinline__ u64 spread2(u32 v) {
-  u64 x = v;
-  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-  x = (x | (x << 2)) & 0x3333333333333333ull;
-  x = (x | (x << 1)) & 0x5555555555555555ull;
-  return x;
-}
-// exact check of ONE pattern filed under a key (entry `idx`) against the k-mer of a hit; returns the entry of the
-// next pattern with the same key (0xFFFFFFFF: none).
-// Entry (device_types.h: ipcr_index_entry): {next, pattern, seq2 | prot2, len, flags | okA, okC | okG, okT}
-__device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u64 pair_base, u32 strand_off,
-    u32 shard, const v4* __restrict__ table, u32 max_mm, qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {
-  const v4 e0 = table[idx * 4u], e1 = table[idx * 4u + 1u];
-  const u64 seq2 = ((u64)e0.w << 32) | e0.z, prot2 = ((u64)e1.y << 32) | e1.x;
-  const u32 left = e1.w & 1u;
-  const u32 L = ULEN ? ULEN : e1.z;                 // one length for the whole panel: every shift and mask below is a constant
-  const u32 sft = WINDOW_AT_NEWEST ? 0u : (left ? 2u * (DL + 1u - L) : 0u); // the window's last base sits sft / 2 bases behind the newest
-  const u64 x = km >> sft;
-  const u64 E = 0x5555555555555555ull;
-  const u64 wmE = ((L >= 32u) ? ~0ull : ((1ull << (2u * L)) - 1ull)) & E;
-  u64 mm2;
-  if (ALL_ACGT || (e1.w & 2u)) {                     // one base per position: XOR against the primer's 2-bit codes
-    const u64 d = x ^ seq2;
-    mm2 = (d | (d >> 1)) & wmE;
-  } else {                                           // IUPAC codes: four sets of allowed positions
-    const v4 e2 = table[idx * 4u + 2u], e3 = table[idx * 4u + 3u];
-    const u64 okA = ((u64)e2.y << 32) | e2.x, okC = ((u64)e2.w << 32) | e2.z;
-    const u64 okG = ((u64)e3.y << 32) | e3.x, okT = ((u64)e3.w << 32) | e3.z;
-    const u64 lo = x & E, hi = (x >> 1) & E;
-    const u64 match = (~lo & ~hi & okA) | (lo & ~hi & okC) | (~lo & hi & okG) | (lo & hi & okT);
-    mm2 = ~match & wmE;
-  }
-  const u32 bw = (bad >> (sft >> 1)) & ((L >= 32u) ? 0xFFFFFFFFu : ((1u << L) - 1u));
-  if (bw) mm2 |= spread2(bw);                        // rare: the window holds an invalid base
-  const int srow = left ? erow - (int)DL : erow - (int)L + 1;
-  if ((mm2 & prot2) == 0ull && (u32)__popcll(mm2) <= max_mm && srow >= 0 && srow < (int)(128u * SW)) {
-    const u64 qi = atomicAdd(qcount + shard * 16u, 1ull);
-    // position = (the wave's first strand + the lane's) * 128 + row: a scalar 64-bit base plus one 32-bit lane offset
-    if (qi < qcap) { qent qe; qe.key = ((u64)e0.y << 48) | (pair_base + (u64)(strand_off + (u32)srow)); qe.bits = 1u; qe.pad = 0u; queue[(u64)shard * qcap + qi] = qe; }
-  }
-  return e0.x;
-}
-)SRC";
-    s << "extern \"C\" __global__ void __launch_bounds__(" << IPCR_INDEX_WAVES * 64u << ", " << IPCR_INDEX_WAVES / 4u << ") ipcr_index_filter(const u32* __restrict__ planes, u64 ncolpairs,\n"
-         "    const u32* __restrict__ lds_image, const v4* __restrict__ table, u32 max_mm,\n"
-         "    qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount, u32* __restrict__ work, u64* __restrict__ stamps) {\n"
-         "  __shared__ u32 lds[((LDS_WORDS + 3u) & ~3u) + " << IPCR_INDEX_WAVES << "u * QCAP * 4u]; // static: every LDS address is a compile-time offset\n"
-         "  for (u32 i = threadIdx.x; i < TAB_WORD0; i += blockDim.x) lds[i] = lds_image[i];\n"
-         "  if (threadIdx.x < 8u) lds[TAB_WORD0 + threadIdx.x] = reinterpret_cast<const u32*>(BITTAB)[threadIdx.x];\n"
-         "  __syncthreads();\n"
-         "  const u64* T64 = reinterpret_cast<const u64*>(lds);\n"
-         "  const unsigned char* ldsb = reinterpret_cast<const unsigned char*>(lds);\n"
-         "  const unsigned short* prefix = reinterpret_cast<const unsigned short*>(lds + PREFIX_WORD0);\n"
-         "  const u32 lane = threadIdx.x & 63u;\n"
-         "  const u32 bit = (lane * SW) & 31u; // my first strand's bit in its column's words\n"
-         "  u32* wq = lds + ((LDS_WORDS + 3u) & ~3u) + (threadIdx.x >> 6) * (QCAP * 4u); // this wave's hit queue\n"
-         "  u32 qn = 0; // entries queued (wave-uniform)\n"
-         "  const u64 wave0 = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);\n"
-         "  const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);\n"
-         "  if (stamps && lane == 0u) stamps[wave0 * 2u] = __builtin_amdgcn_s_memrealtime();\n";
-    // Units are handed out by a counter (work[0]): the waves of a persistent grid do not all run at the same pace (on
-    // MI355X the 16 waves of a CU end between 67 % and 100 % of the sweep when each has a fixed share: 7.29 ms per 3 Gb,
-    // 6.30 ms with the counter).  The last wave to leave zeroes the counters again (work[32] counts the leavers), so
-    // the buffer needs no clearing between launches.
-    const bool dynamic = env_int("IPCR_INDEX_DYNAMIC", 1, 0, 1) != 0;
-    if (dynamic)
-        s << "  for (;;) { // one unit = 64 SW strands = 2 SW columns\n"
-             "    u32 take = 0u;\n"
-             "    if (lane == 0u) take = atomicAdd(work, 1u);\n"
-             "    const u64 cp = (u64)(u32)__builtin_amdgcn_readfirstlane((int)take);\n"
-             "    if (cp >= ncolpairs / SW) break;\n";
-    else
-        s << "  for (u64 cp = wave0; cp < ncolpairs / SW; cp += nwaves) { // one unit = 64 SW strands = 2 SW columns\n";
-    // ---- drain of the hit queue: 64 entries per round, one per lane, ONE item of work per lane and round.
-    // w of an entry with bit 31 clear = the masks of its SPE steps: take the lowest bit -- BITTAB says which shape, how
-    // many steps back (k-mer, flags and row are shifted back by that) --, rank its key among the shape's keys, load that
-    // entry, check the pattern; the shape is a run-time value there (constants from LDS), so lanes whose hits belong to
-    // different shapes share one trip to the entry table.  A lane never holds the other 63 for a second trip: further
-    // bits of the mask (one entry in four), or a further pattern filed under the same key (3 % of the keys of a
-    // 4096-pattern panel -- but some lane of nearly every round), go back into the queue as a new entry, written over
-    // slots this drain has consumed, and the next generation of rounds takes those at full occupancy again (bit 31 set:
-    // index of the entry to check << 2 | steps back).
-    s << "    auto flush = [&]() __attribute__((always_inline)) {\n"
-         "      u32 n = qn;\n"
-         "      const u64 pair_base = cp * (8192u * SW); // first position of this unit\n"
-         "      const u32 shard = (u32)cp & 255u;\n"
-         "      while (n != 0u) {\n"
-         "        u32 nc = 0u; // entries handed back so far: slots [0, nc), always behind the round being read\n"
-         "        auto hand_back = [&](bool mine, v4 e, u32 w) __attribute__((always_inline)) {\n"
-         "          const u64 rb = __ballot(mine);\n"
-         "          if (rb != 0ull) {\n"
-         "            if (mine) {\n"
-         "              const u32 slot = nc + __builtin_amdgcn_mbcnt_hi((u32)(rb >> 32), __builtin_amdgcn_mbcnt_lo((u32)rb, 0u));\n"
-         "              e.w = w;\n"
-         "              *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
-         "            }\n"
-         "            nc += (u32)__popcll(rb);\n"
-         "          }\n"
-         "        };\n"
-         "        for (u32 qb = 0; qb < n; qb += 64u) {\n"
-         "          const u32 i = qb + lane;\n"
-         "          v4 e; e.x = 0u; e.y = 0u; e.z = 0u; e.w = 0u;\n"
-         "          if (i < n) e = *reinterpret_cast<const v4*>(wq + i * 4u);\n"
-         "          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // every lane has read its slot: slots up to qb + 63 may be rewritten\n"
-         "          u32 pend = 0u, idx = 0xFFFFFFFFu, back = 0u, keep = 0u; // keep: what of w a handed-back entry keeps (layout C: lane and row)\n"
-         "          u32 elane, erow0;\n"
-         "          u64 hkm; u32 hbad;\n"
-         "          if (EMODE == 0) { hkm = ((u64)(KMHI ? (e.y & ((1u << KMHI) - 1u)) : 0u) << 32) | e.x; hbad = e.z; elane = (e.y >> KMHI) & 63u; erow0 = (e.y >> (KMHI + 6u)) & ((1u << ROWB) - 1u); }\n"
-         "          else if (EMODE == 1) { hkm = ((u64)(KMHI ? (e.y & ((1u << KMHI) - 1u)) : 0u) << 32) | e.x; hbad = e.z & ((1u << NBAS) - 1u); elane = e.z >> NBAS; erow0 = (e.y >> KMHI) & ((1u << ROWB) - 1u); }\n"
-         "          else { hkm = ((u64)e.y << 32) | e.x; hbad = e.z; elane = (e.w >> 15) & 63u; erow0 = (e.w >> 21) & ((1u << ROWB) - 1u); keep = e.w & 0x7FFF8000u; }\n"
-         "          const u32 pay = EMODE == 2 ? (e.w & 0x7FFFu) : (e.w & 0x7FFFFFFFu);\n"
-         "          if (e.w & 0x80000000u) { idx = pay >> 2; back = pay & 3u; }\n"
-         "          else pend = pay;\n"
-         "          const u32 rest = pend & (pend - 1u);\n"
-         "          hand_back(rest != 0u, e, keep | rest); // (k-mer, flags and row as filed)\n"
-         "          if (pend != 0u) {\n"
-         "            const u32 t = reinterpret_cast<const unsigned char*>(lds + TAB_WORD0)[__builtin_ctz(pend)];\n"
-         "            const u32 sidx = t & 15u;\n"
-         "            back = t >> 4;\n"
-         "            const u64 skm = hkm >> (2u * back); // a hit of an earlier step of the entry: its own k-mer\n"
-         "            const u32 c0 = lds[SHAPE_WORD0 + 2u * sidx], c1 = lds[SHAPE_WORD0 + 2u * sidx + 1u];\n"
-         "            const u32 key = ((u32)(skm >> (c0 & 63u)) & (c1 & 0xFFFFu)) | (((u32)(skm >> ((c0 >> 8) & 63u)) & (c1 >> 16)) << ((c0 >> 16) & 31u));\n"
-         "            const u32 wi = (c0 >> 21) * 16u + (key >> 6); // the shape's bitmap word with this key\n"
-         "            const u64 w = T64[wi];\n"
-         "            // the key is in the panel; its rank among the shape's keys is the index of its entry\n"
-         "            idx = lds[BASE_WORD0 + sidx] + (u32)prefix[wi] + (u32)__popcll((w << (63u - (key & 63u))) << 1);\n"
-         "          }\n"
-         "          u32 next = 0xFFFFFFFFu;\n"
-         "          if (idx != 0xFFFFFFFFu) {\n"
-         "            const u64 skm = hkm >> (2u * back);\n"
-         "            const u32 sbad = hbad >> back;\n"
-         "            const u32 strand_off = (elane * SW) << 7;\n"
-         "            const int erow = (int)erow0 - (int)back;\n"
-         "            next = check_entry(idx, skm, sbad, erow, pair_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
-         "            // a lane hands back at most ONE entry per round (so that slots [0, qb + 64) always hold them): one that\n"
-         "            // has done so for its mask, or whose entry indices do not fit a queue entry, walks the chain here\n"
-         "            if (!CHAIN_CARRY || rest != 0u)\n"
-         "              while (next != 0xFFFFFFFFu) next = check_entry(next, skm, sbad, erow, pair_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
-         "          }\n"
-         "          if (CHAIN_CARRY) hand_back(next != 0xFFFFFFFFu, e, keep | 0x80000000u | (next << 2) | back);\n"
-         "        }\n"
-         "        n = nc;\n"
-         "        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // the entries handed back are read by other lanes next\n"
-         "      }\n"
-         "      qn = 0;\n"
-         "      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // queue slots are rewritten by other lanes next\n"
-         "    };\n";
-    s << "    const u64 col = cp * (2u * SW) + ((lane * SW) >> 5);\n"
-         "    const u64 ncol = (bit + SW == 32u) ? col + 1u : col; // the strand after mine: where the tail rows are\n"
-         "    const u32 nbit = (bit + SW) & 31u;\n"
-         "    u64 km = 0;\n"
-         "    u32 bad = 0xFFFFFFFFu; // invalid-base flags of the last 32 bases, one bit per base\n";
-    s << "    // tile_layout.h: ipcr_plane_word -- word ((block * 32 + row quad) * 3 planes * 64 + column in block) * 4: a per-lane base\n"
-         "    // per column and a wave-uniform offset per row quad (the full expression per quad was 29 VALU instructions of 64-bit math)\n"
-         "    const u32* const base_col = planes + (((col >> 6) * 6144u + (col & 63u)) << 2);\n"
-         "    const u32* const base_ncol = planes + (((ncol >> 6) * 6144u + (ncol & 63u)) << 2);\n"
-         "    auto quad_addr = [&](u32 rq) { // row quads: 32 per strand of mine, then those of the next one\n"
-         "      return (rq >= 32u * SW ? base_ncol : base_col) + (rq & 31u) * 768u;\n"
-         "    };\n"
-         "    const u32* pa = quad_addr(0u);\n"
-         "    // two register sets for the row quads: the body holds two quads, each reads one set while the other is being loaded\n"
-         "    v4 alo = *reinterpret_cast<const v4*>(pa), ahi = *reinterpret_cast<const v4*>(pa + 256u), aiv = *reinterpret_cast<const v4*>(pa + 512u);\n"
-         "    v4 blo, bhi, biv;\n"
-         "    u32 b = bit;\n"
-         "    u32 acc = 0u; // the masks of the steps since the last queue entry\n";
-    if (mode == 0) s << "    const u32 lane_y = lane << KMHI; // this lane's part of an entry's y\n";
-    if (mode == 1) s << "    const u32 lane_z = lane << NBAS;\n";
-    if (mode == 2) s << "    const u32 lane_w = lane << 15;\n";
-    // The walk is ONE copy of the U-step body inside a loop; the last pass stops after TAILSTEPS steps.  Every step is
-    // guarded by the (wave-uniform) step counter, so that the queue drain exists once in the code, not once per
-    // step: a step that fills the queue marks the counter, the remaining guards fall through (two scalar
-    // instructions each), the drain runs at the end of the pass and the next pass resumes behind that step.
-    s << "    u32 it = 0u, u = 0u;\n"
-         "    bool done = false;\n"
-         "    while (!done) {\n";
-    const std::string rq0 = "(it * " + std::to_string(U / 4) + "u)";
-    for (unsigned k = 0; k < U; ++k) {
-        const unsigned t = k & 3u;
-        s << "      if (u == " << k << "u) {\n";
-        const char cur = (k / 4) % 2 ? 'b' : 'a', nxt = (k / 4) % 2 ? 'a' : 'b'; // (U = 8: quad 0 of a body reads set a, quad 1 set b)
-        if (t == 0) {
-            s << "        { const u32 rq = " << rq0 << " + " << k / 4 << "u;\n"
-              << "          b = rq >= 32u * SW ? nbit : bit + (rq >> 5);\n"
-              << "          if (rq + 1u < " << NQ << "u) { pa = quad_addr(rq + 1u); " << nxt << "lo = *reinterpret_cast<const v4*>(pa); " << nxt << "hi = *reinterpret_cast<const v4*>(pa + 256u); " << nxt << "iv = *reinterpret_cast<const v4*>(pa + 512u); }\n"
-              << "        }\n";
-        }
-        s << "        km = (km << 2) | (u64)(__builtin_amdgcn_ubfe(" << cur << "lo[" << t << "], b, 1u) | (__builtin_amdgcn_ubfe(" << cur << "hi[" << t << "], b, 1u) << 1));\n"
-          << "        bad = (bad << 1) | __builtin_amdgcn_ubfe(" << cur << "iv[" << t << "], b, 1u);\n"
-          << "        u32 hm; // shapes that hold this step's key (bit 8 i + p: shape i of pack p)\n";
-        // dev knobs (tools/c4_knobs.sh): what one more LDS lookup / VALU instruction per base step costs -- which unit binds
-        const int xl = env_int("IPCR_INDEX_XLDS", 0, 0, 8), xv = env_int("IPCR_INDEX_XVALU", 0, 0, 64);
-        for (int x = 0; x < xl; ++x)
-            s << "        u32 dummy" << x << "; { const u32 da = (((u32)(km >> " << 8 + 2 * x << "u) & 1023u) << 3) + " << (x % 4) * 8192 << "u; asm volatile(\"ds_read_b32 %0, %1\" : \"=v\"(dummy" << x << ") : \"v\"(da) : \"memory\"); }\n";
-        std::vector<char> group_c(groups.size(), 0);
-        bool first_pack = true;
-        for (unsigned p = 0; p < NPK; ++p) {
-            const Pack &pk = packs[p];
-            std::string q; // this pack's bits, at 8 i (byte layout) or bit 0
-            if (pk.fast) {
-                const size_t gi = (size_t)pk.group;
-                if (!group_c[gi]) { // the group's six protected-base bits: the low three select the bit of a byte, the high three the byte of a word
-                    s << "        const u32 cb" << gi << " = (u32)(km >> " << groups[gi].c_off << "u) & 7u, cw" << gi << " = (u32)(km >> " << groups[gi].c_off + 3 << "u) & 7u;\n";
-                    group_c[gi] = 1;
-                }
-                std::string packed;
-                for (size_t i = 0; i < pk.sh.size(); ++i) {
-                    const int si = pk.sh[i];
-                    const ipcr_index_shape &sh = shapes[(size_t)si];
-                    // byte address = (bitmap word index) * 8 + the high three bits of c.
-                    // A one-shape group keys on protected bases only: the word index is what follows the six bits of c
-                    const bool single = sh.blk_mask == 0;
-                    const unsigned off = single ? (unsigned)sh.tw_shift + 6u : (unsigned)sh.blk_shift;
-                    const unsigned vmask = single ? ((1u << (sh.tw_bits - 6)) - 1u) : sh.blk_mask;
-                    const std::string cw = "cw" + std::to_string(gi);
-                    std::string a;
-                    if (vmask == 0) a = cw;
-                    else if (off >= 3) a = "(((u32)(km >> " + std::to_string(off - 3) + "u) & " + std::to_string(vmask << 3) + "u) | " + cw + ")";
-                    else a = "((((u32)(km >> " + std::to_string(off) + "u) & " + std::to_string(vmask) + "u) << 3) | " + cw + ")";
-                    const std::string by = "(u32)ldsb[" + std::to_string(off64[(size_t)si] * 8u) + "u + " + a + "]";
-                    packed += (i ? " | (" : "(") + by + (i ? " << " + std::to_string(8 * i) + "u)" : ")");
-                }
-                unsigned m = 0;
-                for (size_t i = 0; i < pk.sh.size(); ++i) m |= 1u << (8 * i);
-                q = "(((" + packed + ") >> cb" + std::to_string(gi) + ") & " + std::to_string(m) + "u)";
-            } else {
-                const int si = pk.sh[0];
-                s << "        const u32 key" << si << " = key_of<" << si << ">::get(km);\n";
-                q = "__builtin_amdgcn_ubfe(lds[" + std::to_string(off64[(size_t)si] * 2u) + "u + (key" + std::to_string(si) + " >> 5)], key" + std::to_string(si) + " & 31u, 1u)";
-            }
-            s << "        hm " << (first_pack ? "= " : "|= ") << q << (p ? " << " + std::to_string(p) + "u" : std::string()) << ";\n";
-            first_pack = false;
-        }
-        if (xl) {
-            s << "        asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n";
-            for (int x = 0; x < xl; ++x) s << "        asm volatile(\"\" :: \"v\"(dummy" << x << "));\n";
-        }
-        for (int x = 0; x < xv; ++x)
-            s << "        { u32 dv; asm volatile(\"v_mov_b32 %0, %1\" : \"=v\"(dv) : \"v\"(bad)); asm volatile(\"\" :: \"v\"(dv)); }\n";
-        const bool files = (k % SPE) == SPE - 1u; // this step files the queue entry (of itself and the SPE - 1 steps before)
-        if (SPE == 1u) s << "        acc = hm;\n";
-        else if (k % SPE == 0u) s << "        acc = hm;\n";
-        else s << "        acc = (acc << " << SHF << "u) | hm;\n";
-        if (files) {
-            // qn <= QCAP - 64 on entry (a fuller queue is drained before the next step runs) and a step adds at most 64: no overflow
-            s << "        const u64 bal = __ballot(acc != 0u);\n"
-                 "        if (bal != 0ull) { // one queue entry per lane whatever the number of shapes and steps that hit\n"
-                 "          if (acc != 0u) {\n"
-                 "            const u32 slot = qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));\n"
-                 "            const u32 row = " << rq0 << " * 4u + " << k << "u;\n"
-                 "            v4 e; e.x = (u32)km;\n";
-            if (mode == 0)
-                s << "            e.y = (KMHI ? ((u32)(km >> 32) & ((1u << KMHI) - 1u)) : 0u) | lane_y | (row << (KMHI + 6u)); e.z = bad; e.w = acc;\n";
-            else if (mode == 1)
-                s << "            e.y = (KMHI ? ((u32)(km >> 32) & ((1u << KMHI) - 1u)) : 0u) | (row << KMHI); e.z = (bad & ((1u << NBAS) - 1u)) | lane_z; e.w = acc;\n";
-            else
-                s << "            e.y = (u32)(km >> 32); e.z = bad; e.w = acc | lane_w | (row << 21);\n";
-            s << "            *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
-                 "          }\n"
-                 "          qn += (u32)__popcll(bal);\n"
-                 "        }\n";
-        }
-        s << "        u = " << k + 1 << "u;\n";
-        if (TAILSTEPS && k + 1 == TAILSTEPS) s << "        if (it == " << NB << "u) { done = true; u = 255u; } // the last pass ends here\n";
-        if (files) s << "        if (qn > QCAP - 64u) u |= 256u;\n";
-        s << "      }\n";
-    }
-    s << "      const bool full = (u & 256u) != 0u;\n"
-         "      u &= 255u;\n"
-         "      if (u == " << U << "u) { u = 0u; ++it;" << (TAILSTEPS == 0 ? " if (it == " + std::to_string(NB) + "u) done = true;" : std::string()) << " }\n"
-         "      if (full || done) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); flush(); }\n"
-         "    }\n";
-    s << "  }\n"; // (rows are relative to the unit: the queue is always empty when a unit ends)
-    if (dynamic)
-        s << "  if (lane == 0u) {\n"
-             "    const u32 left = atomicAdd(work + 32u, 1u);\n"
-             "    if ((u64)left + 1ull == nwaves) { __hip_atomic_store(work, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(work + 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n"
-             "  }\n";
-    s << "  if (stamps && lane == 0u) stamps[wave0 * 2u + 1u] = __builtin_amdgcn_s_memrealtime();\n";
-    s << "}\n";
-    return s.str();
-}
-
-// ---- the same filter with the k-mers TRANSPOSED instead of rolled (default).
+// ---- the k-mers are TRANSPOSED, not rolled.
 // One unit of work = one column pair = 64 consecutive strands, lane = strand, 128 base steps, no tail rows: a lane starts
 // with the 32 bases in front of its strand (the end of the strand before) in its k-mer, so every window is looked up
 // exactly once, by the lane in whose strand it ENDS (right-anchored groups) / where its start + DL falls (left-anchored).
@@ -1423,7 +990,7 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
 // v_bitop3 select) hands every lane the 16 bases of ITS strand as one register, 2-bit codes interleaved, newest base in
 // bits 1:0; three transposes (two k-mer words, one word of invalid flags) per 32 steps.  Every key field of every step
 // then sits at a compile-time position of three registers: a shift (or v_alignbit) and a mask.
-static std::string jit_index_source_t(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom) {
+std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom) {
     const int tail_rows = geom.tail_rows;
     const bool all_acgt = geom.all_acgt;
     const size_t NS = shapes.size();
@@ -1440,7 +1007,17 @@ static std::string jit_index_source_t(const std::vector<ipcr_index_shape> &shape
     const unsigned T64N = off64[NS];
     const unsigned U = 32; // base steps per copy of the loop body = one chunk of rows
     const int TR = tail_rows < 0 ? 0 : tail_rows;
-    // packs, payload layout, entry layout: as in jit_index_source
+    // ---- how a base step reports its key hits.  Shapes are looked up in PACKS: the shapes of a FAST group share the
+    // six key bits of the protected bases, so their bitmap BYTES (ds_read_u8: byte = key >> 3) are put side by side in
+    // one register and tested with ONE shift by the shared low three key bits and one AND -- bits 0, 8, 16, 24 of the
+    // result say which shapes hold the key; a shape outside a fast group is a pack of its own (one bit).  Pack p's bits
+    // land on 8 i + p.  A lane files one queue entry per SPE base steps: the steps' masks are shifted together by SH =
+    // number of packs, so bit 8 i + p + SH j = shape i of pack p, j steps before the entry's row.
+    // Queue entry (16 bytes): x, y = the k-mer (newest base in bits 1:0); only the 2 NBAS bits a check can reach are kept,
+    // z = the invalid-base flags of those bases, w = the steps' masks (bit 31 clear) or, for a further pattern chained
+    // under a key, bit 31 | entry index << 2 | steps back.  Lane (6 bits) and row (ROWB bits) go where bits are left:
+    //   layout A: both above the k-mer in y;  B: row above the k-mer in y, lane above the flags in z;
+    //   C (primers beyond 26 nt): both in w above a 15-bit payload, one step per entry, one bit per shape.
     struct Pack { bool fast = false; int group = 0; std::vector<int> sh; };
     std::vector<Pack> packs;
     auto make_packs = [&](bool allow_fast) {
@@ -1620,7 +1197,10 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "  const u32 offI = ((rowI >> 2) * 3u + 2u) * 256u + (rowI & 3u);\n";
     const bool dynamic = env_int("IPCR_INDEX_DYNAMIC", 1, 0, 1) != 0;
     if (dynamic)
-        s << "  for (;;) { // one unit = one column pair = 64 strands (units are handed out by a counter: jit_index_source)\n"
+        // Units are handed out by a counter (work[0]): the waves of a persistent grid do not all run at the same pace (with a
+        // fixed share each, the 16 waves of a CU ended between 67 % and 100 % of the sweep: 7.29 ms per 3 Gb, 6.30 ms with the
+        // counter).  The last wave to leave zeroes the counters again (work[32] counts the leavers): nothing to clear between launches.
+        s << "  for (;;) { // one unit = one column pair = 64 strands\n"
              "    u32 take = 0u;\n"
              "    if (lane == 0u) take = atomicAdd(work, 1u);\n"
              "    const u64 cp = (u64)(u32)__builtin_amdgcn_readfirstlane((int)take);\n"
@@ -1718,67 +1298,91 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
     s << "    u32 it = 0u, u = 0u; // chunk, step of the chunk\n"
          "    bool done = false;\n"
          "    while (!done) {\n";
-    // field of the step's k-mer: (km >> f) & mask, where km = {W2, W1, W0} >> P0
-    for (unsigned k = 0; k < U; ++k) {
+    // A queue entry's SPE steps are ONE block of code (a drain resumes behind an entry).  Their lookups are independent of
+    // one another -- every key field is a constant slice of the same three registers.  IPCR_INDEX_PHASED=1 issues all the
+    // block's LDS reads before any test (24 in flight for C4): measured 3 % SLOWER than letting every step wait for its
+    // own six (the LDS is the busy unit, 81 % of the sweep: bursts only queue up behind one another).
+    const bool phased = env_int("IPCR_INDEX_PHASED", 0, 0, 1) != 0;
+    for (unsigned k0 = 0; k0 < U; k0 += SPE) {
+        std::ostringstream pa, pb; // phase A (addresses, reads), phase B (tests)
+        for (unsigned k = k0; k < k0 + SPE; ++k) {
+            const unsigned half = k / 16u, tq = k % 16u, P0 = 2u * (15u - tq);
+            const char *W[3] = {half ? "B" : "A", half ? "A" : "PB", half ? "PB" : "PA"};
+            auto shifted = [&](unsigned f, unsigned width) { // (km >> f), valid in its low `width` bits at least; km = {W2, W1, W0} >> P0
+                const unsigned P = P0 + f, q = P / 32u, r = P % 32u;
+                if (q > 2u) return std::string("0u");
+                if (r == 0u) return std::string(W[q]);
+                if (r + width <= 32u || q == 2u) return "(" + std::string(W[q]) + " >> " + std::to_string(r) + "u)";
+                return "__builtin_amdgcn_alignbit(" + std::string(W[q + 1]) + ", " + W[q] + ", " + std::to_string(r) + "u)";
+            };
+            auto width_of = [](unsigned mask) { unsigned w = 0; while (mask >> w) ++w; return w; };
+            auto field = [&](unsigned f, unsigned mask) { return "(" + shifted(f, width_of(mask)) + " & " + std::to_string(mask) + "u)"; };
+            const std::string K = std::to_string(k);
+            pa << "        // step " << k << "\n";
+            std::vector<char> group_c(groups.size(), 0);
+            bool first_pack = true;
+            for (unsigned p = 0; p < NPK; ++p) {
+                const Pack &pk = packs[p];
+                std::string q;
+                if (pk.fast) {
+                    const size_t gi = (size_t)pk.group;
+                    const std::string G = std::to_string(gi) + "_" + K;
+                    if (!group_c[gi]) {
+                        pa << "        const u32 cb" << G << " = " << field((unsigned)groups[gi].c_off, 7u) << ", cw" << G << " = " << field((unsigned)groups[gi].c_off + 3u, 7u) << ";\n";
+                        group_c[gi] = 1;
+                    }
+                    std::vector<std::string> bytes;
+                    for (size_t i = 0; i < pk.sh.size(); ++i) {
+                        const int si = pk.sh[i];
+                        const ipcr_index_shape &sh = shapes[(size_t)si];
+                        // byte address = (bitmap word index) * 8 + the high three bits of c.
+                        // A one-shape group keys on protected bases only: the word index is what follows the six bits of c
+                        const bool single = sh.blk_mask == 0;
+                        const unsigned off = single ? (unsigned)sh.tw_shift + 6u : (unsigned)sh.blk_shift;
+                        const unsigned vmask = single ? ((1u << (sh.tw_bits - 6)) - 1u) : sh.blk_mask;
+                        const std::string cw = "cw" + G;
+                        std::string a;
+                        if (vmask == 0) a = cw;
+                        else if (off == (unsigned)groups[gi].c_off + 6u) a = field(off - 3u, (vmask << 3) | 7u); // the block lies right above the protected bases: one slice of the k-mer
+                        else if (off >= 3) a = "ANDOR(" + shifted(off - 3u, width_of(vmask) + 3u) + ", " + std::to_string(vmask << 3) + "u, " + cw + ")";
+                        else a = "((" + field(off, vmask) + " << 3) | " + cw + ")";
+                        const std::string nm = "y" + std::to_string(si) + "_" + K;
+                        pa << "        const u32 " << nm << " = ldsb[" << off64[(size_t)si] * 8u << "u + " << a << "];\n";
+                        bytes.push_back(nm);
+                    }
+                    std::string packed = bytes.back(); // ((b2 << 8 | b1) << 8) | b0
+                    for (size_t i = bytes.size() - 1; i-- > 0;) packed = "((" + packed + " << 8u) | " + bytes[i] + ")";
+                    unsigned m = 0;
+                    for (size_t i = 0; i < pk.sh.size(); ++i) m |= 1u << (8 * i);
+                    q = "((" + packed + " >> cb" + G + ") & " + std::to_string(m) + "u)";
+                } else {
+                    const int si = pk.sh[0];
+                    const ipcr_index_shape &sh = shapes[(size_t)si];
+                    std::string key = sh.tw_mask ? field(sh.tw_shift, sh.tw_mask) : std::string("0u");
+                    if (sh.blk_mask) key = "(" + key + " | (" + field(sh.blk_shift, sh.blk_mask) + " << " + std::to_string(sh.tw_bits) + "u))";
+                    const std::string kn = "key" + std::to_string(si) + "_" + K, wn = "w" + std::to_string(si) + "_" + K;
+                    pa << "        const u32 " << kn << " = " << key << ";\n";
+                    pa << "        const u32 " << wn << " = lds[" << off64[(size_t)si] * 2u << "u + (" << kn << " >> 5)];\n";
+                    q = "((" + wn + " >> (" + kn + " & 31u)) & 1u)";
+                }
+                if (first_pack) pb << "        u32 hm" << K << " = " << q << ";\n";
+                else // (kept apart: the compiler would otherwise pull the shift in front of the mask and spend a second mask on it)
+                    pb << "        { u32 qq = " << q << "; asm volatile(\"\" : \"+v\"(qq)); hm" << K << " = (qq << " << p << "u) | hm" << K << "; }\n";
+                first_pack = false;
+            }
+            if (SPE == 1u || k % SPE == 0u) pb << "        acc = hm" << K << ";\n";
+            else pb << "        acc = (acc << " << SHF << "u) | hm" << K << ";\n";
+        }
+        const unsigned k = k0 + SPE - 1u; // the step that files the entry
         const unsigned half = k / 16u, tq = k % 16u, P0 = 2u * (15u - tq);
         const char *W[3] = {half ? "B" : "A", half ? "A" : "PB", half ? "PB" : "PA"};
-        auto shifted = [&](unsigned f, unsigned width) { // (km >> f), valid in its low `width` bits at least
-            const unsigned P = P0 + f, q = P / 32u, r = P % 32u;
-            if (q > 2u) return std::string("0u");
-            if (r == 0u) return std::string(W[q]);
-            if (r + width <= 32u || q == 2u) return "(" + std::string(W[q]) + " >> " + std::to_string(r) + "u)";
-            return "__builtin_amdgcn_alignbit(" + std::string(W[q + 1]) + ", " + W[q] + ", " + std::to_string(r) + "u)";
-        };
-        auto width_of = [](unsigned mask) { unsigned w = 0; while (mask >> w) ++w; return w; };
-        auto field = [&](unsigned f, unsigned mask) { return "(" + shifted(f, width_of(mask)) + " & " + std::to_string(mask) + "u)"; };
-        s << "      if (u == " << k << "u) {\n";
-        if (k == 0)
+        s << "      if (u == " << k0 << "u) {\n";
+        if (k0 == 0)
             s << "        if (it < 2u) { rA = base[offA + (it + 1u) * 6144u]; rB = base[offB + (it + 1u) * 6144u]; rI = base[offI + (it + 1u) * 6144u]; }\n";
-        s << "        u32 hm; // shapes that hold this step's key (bit 8 i + p: shape i of pack p)\n";
-        std::vector<char> group_c(groups.size(), 0);
-        bool first_pack = true;
-        for (unsigned p = 0; p < NPK; ++p) {
-            const Pack &pk = packs[p];
-            std::string q;
-            if (pk.fast) {
-                const size_t gi = (size_t)pk.group;
-                if (!group_c[gi]) {
-                    s << "        const u32 cb" << gi << " = " << field((unsigned)groups[gi].c_off, 7u) << ", cw" << gi << " = " << field((unsigned)groups[gi].c_off + 3u, 7u) << ";\n";
-                    group_c[gi] = 1;
-                }
-                std::string packed;
-                for (size_t i = 0; i < pk.sh.size(); ++i) {
-                    const int si = pk.sh[i];
-                    const ipcr_index_shape &sh = shapes[(size_t)si];
-                    const bool single = sh.blk_mask == 0;
-                    const unsigned off = single ? (unsigned)sh.tw_shift + 6u : (unsigned)sh.blk_shift;
-                    const unsigned vmask = single ? ((1u << (sh.tw_bits - 6)) - 1u) : sh.blk_mask;
-                    const std::string cw = "cw" + std::to_string(gi);
-                    std::string a;
-                    if (vmask == 0) a = cw;
-                    else if (off >= 3) a = "ANDOR(" + shifted(off - 3u, width_of(vmask) + 3u) + ", " + std::to_string(vmask << 3) + "u, " + cw + ")";
-                    else a = "((" + field(off, vmask) + " << 3) | " + cw + ")";
-                    const std::string by = "(u32)ldsb[" + std::to_string(off64[(size_t)si] * 8u) + "u + " + a + "]";
-                    packed += (i ? " | (" : "(") + by + (i ? " << " + std::to_string(8 * i) + "u)" : ")");
-                }
-                unsigned m = 0;
-                for (size_t i = 0; i < pk.sh.size(); ++i) m |= 1u << (8 * i);
-                q = "(((" + packed + ") >> cb" + std::to_string(gi) + ") & " + std::to_string(m) + "u)";
-            } else {
-                const int si = pk.sh[0];
-                const ipcr_index_shape &sh = shapes[(size_t)si];
-                std::string key = sh.tw_mask ? field(sh.tw_shift, sh.tw_mask) : std::string("0u");
-                if (sh.blk_mask) key = "(" + key + " | (" + field(sh.blk_shift, sh.blk_mask) + " << " + std::to_string(sh.tw_bits) + "u))";
-                s << "        const u32 key" << si << " = " << key << ";\n";
-                q = "((lds[" + std::to_string(off64[(size_t)si] * 2u) + "u + (key" + std::to_string(si) + " >> 5)] >> (key" + std::to_string(si) + " & 31u)) & 1u)";
-            }
-            s << "        hm " << (first_pack ? "= " : "|= ") << q << (p ? " << " + std::to_string(p) + "u" : std::string()) << ";\n";
-            first_pack = false;
-        }
-        const bool files = (k % SPE) == SPE - 1u;
-        if (SPE == 1u || k % SPE == 0u) s << "        acc = hm;\n";
-        else s << "        acc = (acc << " << SHF << "u) | hm;\n";
-        if (files) {
+        s << pa.str();
+        if (phased) s << "        __builtin_amdgcn_sched_barrier(0);\n";
+        s << pb.str();
+        {
             const std::string kmlo = P0 ? "__builtin_amdgcn_alignbit(" + std::string(W[1]) + ", " + W[0] + ", " + std::to_string(P0) + "u)" : std::string(W[0]);
             const std::string kmhi = P0 ? "__builtin_amdgcn_alignbit(" + std::string(W[2]) + ", " + W[1] + ", " + std::to_string(P0) + "u)" : std::string(W[1]);
             const std::string bad = k == 31u ? std::string("I") : "__builtin_amdgcn_alignbit(PI, I, " + std::to_string(31u - k) + "u)";
@@ -1800,7 +1404,7 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
                  "        }\n";
         }
         s << "        u = " << k + 1 << "u;\n";
-        if (files) s << "        if (qn > QCAP - 64u) u |= 256u;\n";
+        s << "        if (qn > QCAP - 64u) u |= 256u;\n";
         s << "      }\n";
     }
     s << "      const bool full = (u & 256u) != 0u;\n"
@@ -1821,10 +1425,6 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
     s << "  if (stamps && lane == 0u) stamps[wave0 * 2u + 1u] = __builtin_amdgcn_s_memrealtime();\n";
     s << "}\n";
     return s.str();
-}
-
-std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom) {
-    return env_int("IPCR_INDEX_TRANSPOSED", 1, 0, 1) ? jit_index_source_t(shapes, geom) : jit_index_source_rolled(shapes, geom);
 }
 
 JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom, std::string &err) {

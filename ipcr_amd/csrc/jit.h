@@ -60,11 +60,10 @@ hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint
                       uint64_t qcap, unsigned long long *qcount, const JitVerify &v, hipEvent_t start, hipEvent_t stop);
 // seed-index filter for large panels, with the panel's key shapes baked in (host.cpp: build_index)
 struct IndexGeom {
-    int tail_rows = 0;     // rows of the following strand a window that starts in this one can reach
+    int tail_rows = 0;     // bases of history a window can reach behind the newest base (longest pattern - 1)
     bool all_acgt = false; // no indexed pattern holds an IUPAC code (the exact check then needs half an entry)
     int uniform_len = 0;   // every indexed pattern has this length (0: mixed); shifts and masks of the check become constants
     int dl = 0;            // left-anchored windows are tested dl bases after their start (one value for the panel)
-    int strands = 2;       // consecutive strands a lane walks before the tail rows (1, 2 or 4): fewer tail rows per base, coarser work units
     uint32_t table_entries = 0; // entries of the panel's table: chained patterns of a key go back into the queue when an entry index fits the bits a queue entry has for it
 };
 std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom);

@@ -530,10 +530,10 @@ def force_index(monkeypatch):
 @pytest.mark.parametrize("seed", range(4))
 def test_index_filter_random(hip, force_index, monkeypatch, seed):
     """same differential test as above, every panel pushed through the seed-index filter
-    (IUPAC primers take its table-driven side path); seeds 1 and 2 with the kernels whose lanes walk two and four
-    strands (what genomes above 134 Mb / 1 Gb get: host.cpp index_kernel)"""
+    (IUPAC primers take its table-driven side path); seeds 1 and 2 with one and two base steps per queue entry
+    instead of as many as the entry layout allows (jit.cpp: jit_index_source)"""
     if seed in (1, 2):
-        monkeypatch.setenv("IPCR_INDEX_STRANDS", str(2 * seed))
+        monkeypatch.setenv("IPCR_INDEX_STEPS_PER_ENTRY", str(seed))
     rng = random.Random(4321 + seed)
     E, P = hip.engine, hip.primer.Pair
     kinds = set()

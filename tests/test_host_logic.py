@@ -467,7 +467,7 @@ def test_seed_index_source_compiles_for_gfx950(k, tw, lens, iupac, tmp_path):
     cp.close()
     assert "ipcr_index_filter" in src
     if tw >= 3 and k >= 1 and "(entry layout C)" not in src:   # (primers beyond 26 nt: one bit per shape, see jit.cpp)
-        assert re.search(r"const u32 cb0 = \(.*& 7u\), cw0 = ", src), \
+        assert re.search(r"const u32 cb0_0 = \(.*& 7u\), cw0_0 = ", src), \
             "a panel with >= 3 protected bases must take its shapes' common six key bits once per step"
     path = tmp_path / "index.hip"
     path.write_text(src)
