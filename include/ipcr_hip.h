@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IPCR_ABI_VERSION 2
+#define IPCR_ABI_VERSION 3
 #define IPCR_MAX_PRIMER_LEN 128 /* longest primer/probe the device path accepts */
 #define IPCR_MAX_MM 16          /* largest --mismatches the device path accepts */
 
@@ -130,7 +130,18 @@ typedef struct ipcr_genome ipcr_genome;   /* packed reference tiles resident in 
 /* ---- process / device ---- */
 const char *ipcr_version(void);             /* internal/version/version.go:12-15 analogue */
 const char *ipcr_last_error(void);          /* thread-local message of the last failing call */
-ipcr_status ipcr_set_device(int device);    /* one process per GPU: call once before anything else */
+/* Devices.  One host process may drive every GPU of a node: a scratch and a genome belong to the device they were
+ * created on, a panel keeps one set of device tables and kernels per device it is scanned on (built at the first scan
+ * there, under the panel's lock), and EVERY entry point selects its object's device for the calling thread itself and
+ * puts the thread's previous device back -- HIP's current device is a per-thread setting, and a Go worker
+ * (internal/pipeline/pipeline.go:60-125) may run on any thread.  Worker i of a pool uses device i mod N
+ * (ipcr_scratch_create_on); chunks are independent, so there is no collective.
+ * ipcr_set_device(d): the default device of ipcr_scratch_create / ipcr_genome_create from now on, for every thread of
+ * the process (one process per GPU calls it once); it also selects d for the calling thread.  Without it the default
+ * is the calling thread's current HIP device.
+ * IPCR_DEVICE_SLOTS=N in the environment (tests, rehearsals on a one-GPU box): ipcr_device_count() = max(N, GPUs);
+ * device d then runs on GPU d mod GPUs, with tables and kernels of its own. */
+ipcr_status ipcr_set_device(int device);
 int ipcr_device_count(void);                /* 0 when no HIP device is visible */
 
 /* ---- core/primer helpers used by callers of the path ---- */
@@ -149,6 +160,8 @@ int32_t ipcr_panel_max_primer_len(const ipcr_panel *p);
 int32_t ipcr_panel_have(const ipcr_panel *p, int32_t pair, char which);
 /* 0 = table-driven filter only, 1 = allow the panel-specialised filter (default) */
 ipcr_status ipcr_panel_set_specialize(ipcr_panel *p, int32_t enable);
+/* devices this panel holds tables and kernels on (one per device it has been scanned on) */
+int32_t ipcr_panel_device_slots(const ipcr_panel *p);
 /* Pattern-axis sharding (one genome x a huge panel over several GPUs): this panel object scans only
  * every count-th distinct pattern of its scanned-pattern list, starting at `index` (the orientations of a pair are
  * independent until the per-pair join, core/engine/compiled.go:192-207,260-265).  Call before the first scan.  The
@@ -179,7 +192,9 @@ ipcr_status ipcr_panel_pattern_info(const ipcr_panel *p, int32_t pattern, char *
 int32_t ipcr_panel_slot_pattern(const ipcr_panel *p, int32_t pair, char which, int32_t mode);
 
 /* ---- Engine.NewSimulationScratch -- core/engine/hit_collect.go:21-34 ---- */
-ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out);
+ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out);          /* on the default device */
+ipcr_status ipcr_scratch_create_on(const ipcr_panel *p, int32_t device, ipcr_scratch **out);
+int32_t ipcr_scratch_device(const ipcr_scratch *s);                                  /* -1 for a host-only scratch */
 /* host-only scratch: holds results of ipcr_join_hits, owns no device resources; every
  * ipcr_scan_* call on it fails with IPCR_ERR_DEVICE */
 ipcr_status ipcr_scratch_create_host(const ipcr_panel *p, ipcr_scratch **out);
@@ -206,7 +221,9 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
                             ipcr_emit_fn emit, void *user);
 
 /* ---- resident genome: many records packed once, scanned by any panel ---- */
-ipcr_status ipcr_genome_create(uint64_t capacity_bases, uint32_t max_records, ipcr_genome **out);
+ipcr_status ipcr_genome_create(uint64_t capacity_bases, uint32_t max_records, ipcr_genome **out); /* on the default device */
+ipcr_status ipcr_genome_create_on(uint64_t capacity_bases, uint32_t max_records, int32_t device, ipcr_genome **out);
+int32_t ipcr_genome_device(const ipcr_genome *g);
 void ipcr_genome_destroy(ipcr_genome *g);
 /* append one record: ASCII in host memory, or in device memory (16-byte aligned) */
 ipcr_status ipcr_genome_add_record(ipcr_genome *g, const uint8_t *seq, uint64_t len);
@@ -241,7 +258,8 @@ ipcr_status ipcr_fasta_next(ipcr_fasta *f, const char **id, const uint8_t **seq,
 ipcr_status ipcr_genome_add_fasta(ipcr_genome *g, const char *path, uint32_t *n_added, char *ids_out, size_t cap,
                                   size_t *ids_needed);
 
-/* scan every record of a resident genome with one launch; products carry `record` */
+/* scan every record of a resident genome with one launch; products carry `record`.  Scratch and genome must live on
+ * the same device (IPCR_ERR_INVALID otherwise) */
 ipcr_status ipcr_scan_genome(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g,
                              ipcr_emit_fn emit, void *user);
 /* split form of ipcr_scan_genome, for pipelining as the reference's worker pool + collector do
@@ -266,6 +284,36 @@ ipcr_status ipcr_join_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_hit 
                            const uint64_t *record_len, const uint8_t *record_flags, uint32_t n_records,
                            ipcr_emit_fn emit, void *user);
 uint8_t ipcr_genome_record_flags(const ipcr_genome *g, uint32_t record);
+
+/* ---- several GPUs, one process each: the all-gatherv of hit records (RCCL over xGMI) ----
+ * The reference has no distributed mode; its unit of parallelism is the independent record / chunk
+ * (internal/pipeline/pipeline.go:60-125).  Every rank scans its own records with the whole panel (or, ipcr_panel_set_shard,
+ * its share of the patterns over the same records) -- no data-path collective -- and only the hit records are
+ * exchanged: ncclAllGather straight out of every scratch's DEVICE hit buffer.  The gathered list goes to ipcr_join_hits.
+ * (One process driving several devices needs none of this: the hits of all its scratches are in host memory already.)
+ *   rank 0: ipcr_exchange_unique_id -> send the 128 bytes to every rank over the host's own channel
+ *   every rank: ipcr_exchange_create (collective), ipcr_exchange_set_records (collective) once the genome is loaded
+ *   per pass: scan on scratch s (ipcr_scan_genome_hits / _end) -> ipcr_exchange_begin(x, s, &t) -> ... -> ipcr_exchange_end
+ * Up to two exchanges may be in flight; end them in the order they began.  The scratch's next scan must not begin
+ * before its exchange has ended (the all-gather reads the scratch's hit buffer).  Lock step: a rank with more hits
+ * than the capacity still enters the collective; every rank then sees the same counts, and all regrow and repeat that
+ * exchange together inside ipcr_exchange_end (ipcr_exchange_redone counts those). */
+#define IPCR_EXCHANGE_ID_BYTES 128
+typedef struct ipcr_exchange ipcr_exchange;
+ipcr_status ipcr_exchange_unique_id(uint8_t *id_out /* IPCR_EXCHANGE_ID_BYTES */);
+/* same_records: every rank scanned the SAME records (pattern shards): record indices are not rebased */
+ipcr_status ipcr_exchange_create(const uint8_t *id, int32_t world, int32_t rank, int32_t device, uint64_t cap_hits,
+                                 int32_t same_records, ipcr_exchange **out);
+void ipcr_exchange_destroy(ipcr_exchange *x);
+ipcr_status ipcr_exchange_set_records(ipcr_exchange *x, uint32_t n_local_records);            /* collective */
+ipcr_status ipcr_exchange_set_record_counts(ipcr_exchange *x, const uint32_t *counts /* world */); /* local: the host knows them */
+ipcr_status ipcr_exchange_begin(ipcr_exchange *x, const ipcr_scratch *s, int32_t *ticket);
+/* every rank's hits in rank order, `record` rebased to the job-global record index; rank r's hits are
+ * [rank_hit_start[r], rank_hit_start[r + 1]), its records start at rank_record_offset[r].  Valid until the next end. */
+ipcr_status ipcr_exchange_end(ipcr_exchange *x, int32_t ticket, const ipcr_hit **hits, int64_t *n_hits,
+                              const uint64_t **rank_hit_start, const uint32_t **rank_record_offset);
+uint64_t ipcr_exchange_capacity(const ipcr_exchange *x);
+uint64_t ipcr_exchange_redone(const ipcr_exchange *x);
 
 /* ---- oligo.BestHit / probe.AnnotateAmplicon -- core/oligo/oligo.go:19-77 ----
  * amplicon in host memory; runs the probe rescan on the device. */

@@ -95,6 +95,11 @@ SYMBOLS = {
     "ipcr_panel_pattern_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ipcr_panel_slot_pattern": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char, C.c_int32]),
     "ipcr_scratch_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ipcr_scratch_create_on": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "ipcr_scratch_device": (C.c_int32, [C.c_void_p]),
+    "ipcr_panel_device_slots": (C.c_int32, [C.c_void_p]),
+    "ipcr_genome_create_on": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "ipcr_genome_device": (C.c_int32, [C.c_void_p]),
     "ipcr_scratch_create_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ipcr_scratch_destroy": (None, [C.c_void_p]),
     "ipcr_scratch_stats": (C.c_int, [C.c_void_p, C.POINTER(ScanStats)]),
@@ -126,6 +131,16 @@ SYMBOLS = {
     "ipcr_scan_genome_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipcr_join_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_uint64),
                                  C.POINTER(C.c_uint8), C.c_uint32, C.c_void_p, C.c_void_p]),
+    "ipcr_exchange_unique_id": (C.c_int, [C.c_char_p]),
+    "ipcr_exchange_create": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "ipcr_exchange_destroy": (None, [C.c_void_p]),
+    "ipcr_exchange_set_records": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "ipcr_exchange_set_record_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "ipcr_exchange_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    "ipcr_exchange_end": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(Hit)), C.POINTER(C.c_int64),
+                                    C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint32))]),
+    "ipcr_exchange_capacity": (C.c_uint64, [C.c_void_p]),
+    "ipcr_exchange_redone": (C.c_uint64, [C.c_void_p]),
     "ipcr_probe_best_hit": (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_int32, C.POINTER(ProbeHit)]),
     "ipcr_probe_products": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(ProbeHit), C.c_int64]),
     "ipcr_nested_windows": (C.c_int, [C.c_void_p, C.POINTER(Window), C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(NestedHit)]),

@@ -1,6 +1,11 @@
 // chunk_workers -- the drop-in entry point under the reference's worker model, driven from native threads.
 //
-//   chunk_workers [record_bases] [chunk_bases] [workers ...]        (defaults: 125000000 4000000 1 8 16)
+//   chunk_workers [--devices d0,d1,...] [record_bases] [chunk_bases] [workers ...]   (defaults: device 0, 125000000 4000000 1 8 16)
+//
+// --devices: worker i creates its scratch on device d[i mod n] (ipcr_scratch_create_on) -- one host process, every GPU of
+// the node, no collective: chunks are independent.  The worker threads never select a device themselves; every entry
+// point of the library does.  A device may be listed twice, and with IPCR_DEVICE_SLOTS=N in the environment devices
+// beyond the physical ones exist as slots with tables of their own (a one-GPU box rehearses the N-device flow).
 //
 // internal/pipeline/pipeline.go:60-125: CompilePanel once, one scratch per worker, every worker pulls rolling chunks
 // (core/fasta/path_ctx.go:83-179: chunk size, overlap = max product length) of a record from one queue and calls
@@ -38,18 +43,45 @@ static std::string bench_primer(unsigned idx, int n = 20) { // core/engine/perfo
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+static int usage(const char *why) {
+    fprintf(stderr, "chunk_workers: %s\nusage: chunk_workers [--devices d0,d1,...] [record_bases] [chunk_bases > 2000] [workers >= 1 ...]\n", why);
+    return 2;
+}
+
 int main(int argc, char **argv) {
-    const uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 10) : 125000000ull;
-    const uint64_t chunk = argc > 2 ? strtoull(argv[2], nullptr, 10) : 4000000ull;
+    std::vector<int> devices;
+    std::vector<const char *> pos;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--devices")) {
+            if (i + 1 >= argc) return usage("--devices needs a list");
+            for (const char *q = argv[++i]; *q;) {
+                char *end = nullptr;
+                const long d = strtol(q, &end, 10);
+                if (end == q || d < 0) return usage("--devices: comma-separated device numbers");
+                devices.push_back((int)d);
+                q = *end == ',' ? end + 1 : end;
+                if (*end && *end != ',') return usage("--devices: comma-separated device numbers");
+            }
+        } else pos.push_back(argv[i]);
+    }
+    const uint64_t n = pos.size() > 0 ? strtoull(pos[0], nullptr, 10) : 125000000ull;
+    const uint64_t chunk = pos.size() > 1 ? strtoull(pos[1], nullptr, 10) : 4000000ull;
     std::vector<int> workers;
-    for (int i = 3; i < argc; ++i) workers.push_back(atoi(argv[i]));
+    for (size_t i = 2; i < pos.size(); ++i) workers.push_back(atoi(pos[i]));
     if (workers.empty()) workers = {1, 8, 16};
     const uint64_t overlap = 2000;
+    if (n == 0) return usage("record_bases must be positive");
+    if (chunk <= overlap) return usage("chunk_bases must exceed the overlap of 2000 (the rolling window would not advance)");
+    for (int W : workers)
+        if (W < 1 || W > 1024) return usage("a worker count must be in 1..1024");
     // HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order.  Measured with 8 / 16 / 24
     // workers, three runs each: 4 queues 44 / 27 / - Gbases/s; 8 queues 44 / 49 / 51, every run; 16 or 32 queues the
     // same or 28 / 20 from run to run (more queues than the firmware keeps resident).  8 it is.
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (ipcr_device_count() < 1) { fprintf(stderr, "chunk_workers: no HIP device (the scan path has no CPU fallback)\n"); return 2; }
+    if (devices.empty()) devices.push_back(0);
+    for (int d : devices)
+        if (d >= ipcr_device_count()) { fprintf(stderr, "chunk_workers: device %d of %d\n", d, ipcr_device_count()); return 2; }
 
     // the record: benchDNA (performance_benchmark_test.go:67-76) + an amplicon of pair 0 every 1 Mb
     std::vector<uint8_t> seq(n);
@@ -149,13 +181,15 @@ int main(int argc, char **argv) {
     std::vector<std::vector<uint8_t>> jobs;
     for (uint64_t s : starts) jobs.emplace_back(seq.begin() + (long)s, seq.begin() + (long)std::min(n, s + chunk));
 
-    printf("{\"pinned_h2d_GBps\": %.1f, \"record_bases\": %llu, \"chunk_bases\": %llu, \"chunks\": %zu, \"planted\": %llu",
+    printf("{\"pinned_h2d_GBps\": %.1f, \"record_bases\": %llu, \"chunk_bases\": %llu, \"chunks\": %zu, \"planted\": %llu, \"devices\": [",
            h2d, (unsigned long long)n, (unsigned long long)chunk, jobs.size(), (unsigned long long)planted);
+    for (size_t i = 0; i < devices.size(); ++i) printf("%s%d", i ? ", " : "", devices[i]);
+    printf("]");
     int rc = 0;
     for (int W : workers) {
         std::vector<ipcr_scratch *> scs((size_t)W, nullptr);
-        for (auto &sc : scs)
-            if (ipcr_scratch_create(panel, &sc) != IPCR_OK) { fprintf(stderr, "%s\n", ipcr_last_error()); return 5; }
+        for (size_t w = 0; w < scs.size(); ++w) // worker w -> device w mod N
+            if (ipcr_scratch_create_on(panel, devices[w % devices.size()], &scs[w]) != IPCR_OK) { fprintf(stderr, "%s\n", ipcr_last_error()); return 5; }
         for (auto &sc : scs) (void)ipcr_scan_chunk(panel, sc, jobs[0].data(), jobs[0].size(), nullptr, nullptr); // kernel build, buffers
         const size_t reps = std::max<size_t>(1, ((size_t)32 * (size_t)W + jobs.size() - 1) / jobs.size()); // >= 32 chunks per worker
         const size_t total = reps * jobs.size();
@@ -220,12 +254,12 @@ int main(int argc, char **argv) {
         // per call: the rest of `call` is the copy into device memory (through pinned slices under a pool) and the pack enqueue
         printf(", \"call_ms_%d_worker%s\": {\"call\": %.3f, \"enqueue\": %.3f, \"wait\": %.3f, \"sort_join\": %.3f}", W, W == 1 ? "" : "s",
                call_ms[0], call_ms[1], call_ms[2], call_ms[3]);
-        if (W == workers.back()) printf(", \"products_per_pass\": %lld", products);
+        if (W == workers.back()) printf(", \"products_per_pass\": %lld, \"panel_device_slots\": %d", products, ipcr_panel_device_slots(panel));
         for (auto &sc : scs) ipcr_scratch_destroy(sc);
     }
     {   // one worker, the whole record in one call
         ipcr_scratch *sc = nullptr;
-        if (ipcr_scratch_create(panel, &sc) != IPCR_OK) return 5;
+        if (ipcr_scratch_create_on(panel, devices[0], &sc) != IPCR_OK) return 5;
         double best = 0;
         for (int r = 0; r < 4; ++r) {
             const double t0 = now();

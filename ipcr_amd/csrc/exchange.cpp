@@ -1,0 +1,311 @@
+// exchange.cpp -- the all-gatherv of hit records between the GPUs of a job, inside the library (RCCL over xGMI).
+//
+// The reference has no distributed mode: its unit of parallelism is the independent record / chunk
+// (internal/pipeline/pipeline.go:60-125).  One process per GPU scans its own records with the whole panel -- no
+// data-path collective -- and only the verified hit records (32 bytes each, tens of KB per genome) are exchanged, after
+// which the amplicon join (core/engine/engine.go:108-404) runs on the gathered list (ipcr_join_hits).  This file is that
+// exchange for a Go or C++ host: ncclAllGather straight out of the scratch's DEVICE hit buffer (64-byte counter header +
+// hit slots), so the records never visit the host on the sending side.  ipcr_amd/dist.py is a thin caller of it.
+//
+// Lock step: no rank ever decides alone.  A rank whose hits exceed the exchange capacity still enters the collective
+// (its header carries the true count); after the gather EVERY rank reads the same headers, sees the same overflow, and
+// all of them double the capacity and repeat that exchange together (ipcr_exchange_end).  A rank whose scratch buffer is
+// smaller than the agreed shape sends through a device staging buffer of that shape: the collective's shape never
+// depends on a local condition.
+//
+// librccl is opened at the first use (dlopen by SONAME: a process that already holds a copy -- PyTorch bundles one --
+// keeps using that one), so single-GPU users of libipcr_hip.so never load it.
+#include "ipcr_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+ipcr_status ipcr_internal_fail(ipcr_status st, const char *fmt, ...);
+int ipcr_internal_slot_phys(int slot);
+int ipcr_internal_slot_count();
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) { r.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char *n) { void *p = dlsym(r.handle, n); if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + n; return p; };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return r.error.empty() ? &r : nullptr;
+}
+
+#define XHIP(expr)                                                                                         \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return ipcr_internal_fail(IPCR_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define XNCCL(x, expr)                                                                                     \
+    do {                                                                                                   \
+        ncclResult_t r_ = (expr);                                                                          \
+        if (r_ != ncclSuccess) return ipcr_internal_fail(IPCR_ERR_DEVICE, "%s: %s", #expr, (x)->GetErrorString ? (x)->GetErrorString(r_) : "rccl error"); \
+    } while (0)
+
+struct OnDevice { // the exchange's device for the calling thread, the previous one put back
+    int prev = -1, want;
+    explicit OnDevice(int phys) : want(phys) { if (hipGetDevice(&prev) == hipSuccess && prev != want) (void)hipSetDevice(want); else prev = want; }
+    ~OnDevice() { if (prev != want) (void)hipSetDevice(prev); }
+};
+
+constexpr int SLOTS = 2; // exchanges in flight
+
+} // namespace
+
+struct ipcr_exchange {
+    Rccl *lib = nullptr;
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0, device = 0, phys = 0;
+    bool same_records = false;
+    hipStream_t stream = nullptr;
+    uint64_t cap = 0; // hit slots every rank sends
+    void *d_stage = nullptr;           // 64 + cap * 32 bytes: for a scratch buffer smaller than the agreed shape
+    void *d_recv[SLOTS] = {nullptr, nullptr}; // world x (64 + cap * 32)
+    void *h_recv = nullptr;            // pinned, same size: where ipcr_exchange_end unpacks from
+    void *d_meta = nullptr, *h_meta = nullptr; // record counts (world x 8 bytes)
+    hipEvent_t done[SLOTS] = {nullptr, nullptr};
+    struct Pending { bool active = false; const ipcr_scratch *scratch = nullptr; uint64_t cap = 0; } pend[SLOTS];
+    int next_slot = 0;
+    std::vector<uint64_t> rec_counts;  // records per rank (ipcr_exchange_set_records)
+    std::vector<ipcr_hit> hits;        // result of the last ipcr_exchange_end
+    std::vector<uint64_t> hit_start;   // world + 1: rank r's hits are [hit_start[r], hit_start[r + 1])
+    std::vector<uint32_t> rec_offset;  // world + 1
+    uint64_t redone = 0;
+};
+
+namespace {
+
+size_t block_bytes(uint64_t cap) { return 64u + (size_t)cap * sizeof(ipcr_hit); }
+
+ipcr_status alloc_buffers(ipcr_exchange *x, uint64_t cap) {
+    for (int i = 0; i < SLOTS; ++i)
+        if (x->d_recv[i]) { (void)hipFree(x->d_recv[i]); x->d_recv[i] = nullptr; }
+    if (x->d_stage) { (void)hipFree(x->d_stage); x->d_stage = nullptr; }
+    if (x->h_recv) { (void)hipHostFree(x->h_recv); x->h_recv = nullptr; }
+    x->cap = cap;
+    const size_t nb = block_bytes(cap);
+    XHIP(hipMalloc(&x->d_stage, nb));
+    XHIP(hipMemset(x->d_stage, 0, nb));
+    for (int i = 0; i < SLOTS; ++i) XHIP(hipMalloc(&x->d_recv[i], nb * (size_t)x->world));
+    XHIP(hipHostMalloc(&x->h_recv, nb * (size_t)x->world, hipHostMallocDefault));
+    return IPCR_OK;
+}
+
+// enqueue one all-gather of the scratch's device hit block into receive slot `slot`
+ipcr_status enqueue(ipcr_exchange *x, const ipcr_scratch *s, int slot) {
+    const void *dev_block = nullptr;
+    uint64_t n_hits = 0, hcap = 0;
+    const ipcr_status st = ipcr_scratch_device_hits(s, &dev_block, &n_hits, &hcap);
+    if (st != IPCR_OK) return st;
+    const size_t nb = block_bytes(x->cap);
+    const void *send = dev_block;
+    if (hcap < x->cap) { // this rank's buffer is smaller than the agreed shape: the same bytes through the staging buffer
+        XHIP(hipMemcpyAsync(x->d_stage, dev_block, block_bytes(hcap), hipMemcpyDeviceToDevice, x->stream));
+        send = x->d_stage;
+    }
+    XNCCL(x->lib, x->lib->AllGather(send, x->d_recv[slot], nb, ncclUint8, x->comm, x->stream));
+    XHIP(hipEventRecord(x->done[slot], x->stream));
+    x->pend[slot].active = true;
+    x->pend[slot].scratch = s;
+    x->pend[slot].cap = x->cap;
+    return IPCR_OK;
+}
+
+// the counter set of the last scan is the non-zero one of the header's two
+uint64_t header_hits(const uint8_t *block) {
+    uint64_t h[8];
+    memcpy(h, block, sizeof h);
+    return std::max(h[1], h[5]);
+}
+
+} // namespace
+
+extern "C" {
+
+ipcr_status ipcr_exchange_unique_id(uint8_t *id_out) {
+    if (!id_out) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_unique_id: null argument");
+    Rccl *r = rccl();
+    if (!r) return ipcr_internal_fail(IPCR_ERR_DEVICE, "RCCL is not available");
+    ncclUniqueId id;
+    XNCCL(r, r->GetUniqueId(&id));
+    static_assert(sizeof id == IPCR_EXCHANGE_ID_BYTES, "id size");
+    memcpy(id_out, &id, sizeof id);
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_exchange_create(const uint8_t *id, int32_t world, int32_t rank, int32_t device, uint64_t cap_hits,
+                                 int32_t same_records, ipcr_exchange **out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_create: bad argument");
+    *out = nullptr;
+    if (device < 0 || device >= ipcr_internal_slot_count()) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_create: device %d of %d", device, ipcr_internal_slot_count());
+    Rccl *r = rccl();
+    if (!r) return ipcr_internal_fail(IPCR_ERR_DEVICE, "RCCL is not available");
+    ipcr_exchange *x = new ipcr_exchange;
+    x->lib = r;
+    x->world = world;
+    x->rank = rank;
+    x->device = device;
+    x->phys = ipcr_internal_slot_phys(device);
+    x->same_records = same_records != 0;
+    x->rec_counts.assign((size_t)world, 0);
+    OnDevice on(x->phys);
+    auto build = [&]() -> ipcr_status {
+        ncclUniqueId uid;
+        memcpy(&uid, id, sizeof uid);
+        XNCCL(r, r->CommInitRank(&x->comm, world, uid, rank)); // synchronises with the other ranks
+        XHIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
+        for (int i = 0; i < SLOTS; ++i) XHIP(hipEventCreateWithFlags(&x->done[i], hipEventDisableTiming));
+        XHIP(hipMalloc(&x->d_meta, 8u * (size_t)(world + 1)));
+        XHIP(hipHostMalloc(&x->h_meta, 8u * (size_t)(world + 1), hipHostMallocDefault));
+        return alloc_buffers(x, std::max<uint64_t>(cap_hits, 1));
+    };
+    const ipcr_status st = build();
+    if (st != IPCR_OK) { ipcr_exchange_destroy(x); return st; }
+    *out = x;
+    return IPCR_OK;
+}
+
+void ipcr_exchange_destroy(ipcr_exchange *x) {
+    if (!x) return;
+    OnDevice on(x->phys);
+    if (x->stream) (void)hipStreamSynchronize(x->stream);
+    if (x->comm && x->lib) (void)x->lib->CommDestroy(x->comm);
+    for (int i = 0; i < SLOTS; ++i) {
+        if (x->d_recv[i]) (void)hipFree(x->d_recv[i]);
+        if (x->done[i]) (void)hipEventDestroy(x->done[i]);
+    }
+    if (x->d_stage) (void)hipFree(x->d_stage);
+    if (x->h_recv) (void)hipHostFree(x->h_recv);
+    if (x->d_meta) (void)hipFree(x->d_meta);
+    if (x->h_meta) (void)hipHostFree(x->h_meta);
+    if (x->stream) (void)hipStreamDestroy(x->stream);
+    delete x;
+}
+
+// records per rank (static for a job): one small synchronous all-gather, called by every rank together
+ipcr_status ipcr_exchange_set_records(ipcr_exchange *x, uint32_t n_local_records) {
+    if (!x) return ipcr_internal_fail(IPCR_ERR_INVALID, "null exchange");
+    OnDevice on(x->phys);
+    uint64_t *hm = static_cast<uint64_t *>(x->h_meta);
+    hm[x->world] = n_local_records;
+    uint64_t *dm = static_cast<uint64_t *>(x->d_meta);
+    XHIP(hipMemcpyAsync(dm + x->world, hm + x->world, 8, hipMemcpyHostToDevice, x->stream));
+    XNCCL(x->lib, x->lib->AllGather(dm + x->world, dm, 8, ncclUint8, x->comm, x->stream));
+    XHIP(hipMemcpyAsync(hm, dm, 8u * (size_t)x->world, hipMemcpyDeviceToHost, x->stream));
+    XHIP(hipStreamSynchronize(x->stream));
+    for (int r = 0; r < x->world; ++r) x->rec_counts[(size_t)r] = hm[r];
+    return IPCR_OK;
+}
+
+// the same, when the host already knows every rank's count (no collective)
+ipcr_status ipcr_exchange_set_record_counts(ipcr_exchange *x, const uint32_t *counts) {
+    if (!x || !counts) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_set_record_counts: null argument");
+    for (int r = 0; r < x->world; ++r) x->rec_counts[(size_t)r] = counts[r];
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_exchange_begin(ipcr_exchange *x, const ipcr_scratch *s, int32_t *ticket) {
+    if (!x || !s || !ticket) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_begin: null argument");
+    if (ipcr_scratch_device(s) != x->device) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_begin: the scratch lives on device %d, the exchange on %d", ipcr_scratch_device(s), x->device);
+    const int slot = x->next_slot;
+    if (x->pend[slot].active) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_begin: %d exchanges are in flight already (ipcr_exchange_end first)", SLOTS);
+    OnDevice on(x->phys);
+    const ipcr_status st = enqueue(x, s, slot);
+    if (st != IPCR_OK) return st;
+    x->next_slot = (slot + 1) % SLOTS;
+    *ticket = slot;
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_exchange_end(ipcr_exchange *x, int32_t ticket, const ipcr_hit **hits, int64_t *n_hits,
+                              const uint64_t **rank_hit_start, const uint32_t **rank_record_offset) {
+    if (!x || ticket < 0 || ticket >= SLOTS || !x->pend[ticket].active) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_end: no such exchange in flight");
+    OnDevice on(x->phys);
+    ipcr_exchange::Pending pd = x->pend[ticket];
+    x->pend[ticket].active = false;
+    for (int attempt = 0; attempt < 24; ++attempt) {
+        XHIP(hipEventSynchronize(x->done[ticket]));
+        const size_t nb = block_bytes(pd.cap);
+        // every rank's header first: all ranks read the same counts and take the same decision
+        XHIP(hipMemcpy2DAsync(x->h_recv, 64, x->d_recv[ticket], nb, 64, (size_t)x->world, hipMemcpyDeviceToHost, x->stream));
+        XHIP(hipStreamSynchronize(x->stream));
+        uint64_t need = 0;
+        std::vector<uint64_t> counts((size_t)x->world);
+        for (int r = 0; r < x->world; ++r) {
+            counts[(size_t)r] = header_hits(static_cast<const uint8_t *>(x->h_recv) + 64u * (size_t)r);
+            need = std::max(need, counts[(size_t)r]);
+        }
+        if (need > pd.cap) { // some rank overflowed: every rank regrows and repeats the exchange (the scratch still holds the scan)
+            ++x->redone;
+            for (int i = 0; i < SLOTS; ++i)
+                if (x->pend[i].active) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_end: capacity overflow while another exchange is in flight; end exchanges in the order they began");
+            uint64_t cap = pd.cap;
+            while (cap < need) cap *= 2;
+            ipcr_status st = alloc_buffers(x, cap);
+            if (st != IPCR_OK) return st;
+            st = enqueue(x, pd.scratch, ticket);
+            if (st != IPCR_OK) return st;
+            pd = x->pend[ticket];
+            x->pend[ticket].active = false;
+            continue;
+        }
+        // the records: only the valid prefix of every rank's block
+        x->hit_start.assign((size_t)x->world + 1, 0);
+        x->rec_offset.assign((size_t)x->world + 1, 0);
+        for (int r = 0; r < x->world; ++r) {
+            x->hit_start[(size_t)r + 1] = x->hit_start[(size_t)r] + counts[(size_t)r];
+            x->rec_offset[(size_t)r + 1] = x->rec_offset[(size_t)r] + (x->same_records ? 0u : (uint32_t)x->rec_counts[(size_t)r]);
+        }
+        x->hits.resize((size_t)x->hit_start[(size_t)x->world]);
+        for (int r = 0; r < x->world; ++r)
+            if (counts[(size_t)r])
+                XHIP(hipMemcpyAsync(x->hits.data() + x->hit_start[(size_t)r], static_cast<const uint8_t *>(x->d_recv[ticket]) + nb * (size_t)r + 64,
+                                    (size_t)counts[(size_t)r] * sizeof(ipcr_hit), hipMemcpyDeviceToHost, x->stream));
+        XHIP(hipStreamSynchronize(x->stream));
+        for (int r = 0; r < x->world; ++r) // job-global record index
+            for (uint64_t i = x->hit_start[(size_t)r]; i < x->hit_start[(size_t)r + 1]; ++i) x->hits[(size_t)i].record += x->rec_offset[(size_t)r];
+        if (hits) *hits = x->hits.data();
+        if (n_hits) *n_hits = (int64_t)x->hits.size();
+        if (rank_hit_start) *rank_hit_start = x->hit_start.data();
+        if (rank_record_offset) *rank_record_offset = x->rec_offset.data();
+        return IPCR_OK;
+    }
+    return ipcr_internal_fail(IPCR_ERR_CAPACITY, "ipcr_exchange_end: the exchange kept overflowing");
+}
+
+uint64_t ipcr_exchange_capacity(const ipcr_exchange *x) { return x ? x->cap : 0; }
+uint64_t ipcr_exchange_redone(const ipcr_exchange *x) { return x ? x->redone : 0; }
+
+} // extern "C"

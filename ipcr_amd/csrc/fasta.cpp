@@ -56,6 +56,7 @@ extern ipcr_status ipcr_internal_fail(ipcr_status st, const char *fmt, ...);
 // host.cpp: pack a record that already lies in device memory (16-byte aligned) and remember its ID
 extern ipcr_status ipcr_internal_genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len, const char *id);
 extern hipStream_t ipcr_internal_genome_stream(ipcr_genome *g);
+extern int ipcr_internal_genome_phys_device(const ipcr_genome *g);
 // host.cpp: records lying anywhere in one device buffer, packed by one launch (d_tmp: room for the record table)
 extern ipcr_status ipcr_internal_genome_add_batch(ipcr_genome *g, const uint8_t *dbase, const uint64_t *offs, const uint64_t *lens,
                                                   const std::string *ids, size_t n, void *d_tmp, size_t tmp_bytes);
@@ -555,6 +556,12 @@ ipcr_status ipcr_fasta_next(ipcr_fasta *f, const char **id, const uint8_t **seq,
 ipcr_status ipcr_genome_add_fasta(ipcr_genome *g, const char *path, uint32_t *n_added, char *ids_out, size_t cap,
                                   size_t *ids_needed) {
     if (!g || !path) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_genome_add_fasta: null argument");
+    // the genome's device, whatever the calling thread had selected (put back on return)
+    struct OnDevice {
+        int prev = -1, want;
+        explicit OnDevice(int d) : want(d) { if (hipGetDevice(&prev) == hipSuccess && prev != want) (void)hipSetDevice(want); else prev = want; }
+        ~OnDevice() { if (prev != want) (void)hipSetDevice(prev); }
+    } on_device(ipcr_internal_genome_phys_device(g));
     if (n_added) *n_added = 0;
     FastaLoader L;
     ipcr_status st = L.open(g, path);

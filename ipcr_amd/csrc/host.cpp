@@ -63,6 +63,49 @@ ipcr_status ipcr_internal_fail(ipcr_status st, const char *fmt, ...) { // for th
 }
 namespace {
 
+// ------------------------------------------------------------ devices
+// One host process may drive every GPU of a node: each scratch / genome belongs to a DEVICE SLOT, the panel keeps one set of
+// device tables and code objects per slot, and every entry point selects its object's device itself -- HIP's current
+// device is a per-thread setting, and a Go runtime moves goroutines between threads (internal/pipeline/pipeline.go:60-125:
+// worker i -> slot i mod N, no collective).  Slot d is physical device d; IPCR_DEVICE_SLOTS=N (tests, rehearsals on a
+// one-GPU box) adds slots beyond the physical devices, mapped onto them round-robin, each with tables of its own.
+std::atomic<int> g_default_slot{-1}; // ipcr_set_device; -1: the calling thread's current HIP device
+
+int phys_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int slot_count() {
+    const int n = phys_count();
+    if (n <= 0) return 0;
+    const char *v = getenv("IPCR_DEVICE_SLOTS");
+    const int extra = (v && *v) ? atoi(v) : 0;
+    return std::max(n, std::min(extra, 64));
+}
+int slot_phys(int slot) {
+    const int n = phys_count();
+    return n > 0 ? slot % n : 0;
+}
+int default_slot() {
+    const int d = g_default_slot.load(std::memory_order_relaxed);
+    if (d >= 0) return d;
+    int cur = 0;
+    return hipGetDevice(&cur) == hipSuccess ? cur : 0;
+}
+// selects a slot's device for the calling thread, and puts back what was there
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int slot) {
+        const int phys = slot_phys(slot);
+        if (hipGetDevice(&prev) == hipSuccess && prev != phys) changed = hipSetDevice(phys) == hipSuccess;
+    }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
@@ -194,20 +237,30 @@ struct IndexPlan {
     std::vector<uint32_t> lds_image;
     std::vector<ipcr_index_entry> table; // entry r = first pattern of the r-th distinct (shape, key); more patterns of a key are chained
     std::vector<uint32_t> leftover;      // set-local patterns the index cannot serve (> 32 nt, too degenerate, ...)
+};
+
+// what a pattern set holds on ONE device slot: tables and the code objects loaded there (hiprtc output is cached per
+// process by source, so a second slot pays the module load only)
+struct SetDev {
+    ipcr_dev_pattern *dev = nullptr;
+    std::vector<ipcr::JitFilter *> jit; // one kernel per pattern group
+    bool jit_tried = false;
+    bool index_tried = false;
     uint32_t *d_lds_image = nullptr;
     ipcr_index_entry *d_table = nullptr;
     uint32_t *d_leftover = nullptr;
-    ipcr::JitFilter *jit = nullptr; // the kernel, with the key shapes baked in (hiprtc)
-    std::vector<ipcr::JitFilter *> leftover_jit; // specialised spill-only filters for `leftover` (else the table-driven kernel takes them)
+    ipcr::JitFilter *index_jit = nullptr; // the seed-index kernel, with the key shapes baked in (hiprtc)
+    std::vector<ipcr::JitFilter *> leftover_jit; // specialised spill-only filters for the index's leftovers (else the table-driven kernel takes them)
+};
+struct PanelDev {
+    int slot = 0;
+    SetDev set[2];
 };
 
 struct PatternSet {
     std::vector<uint32_t> ids; // global pattern ids scanned in this mode
     IndexPlan index;
     std::vector<ipcr_dev_pattern> host;
-    ipcr_dev_pattern *dev = nullptr;
-    std::vector<ipcr::JitFilter *> jit; // one kernel per pattern group
-    bool jit_tried = false;
     std::string jit_error;
 };
 
@@ -226,8 +279,8 @@ struct ipcr_panel {
     int max_len = 0;
     bool specialize = true;
     int32_t shard_index = 0, shard_count = 1; // ipcr_panel_set_shard: this panel object scans every count-th pattern
-    int device = -1;
     mutable std::mutex mu;
+    mutable std::map<int, std::unique_ptr<PanelDev>> devs; // device slot -> tables and kernels there (created at the first scan on the slot)
     // device scratches alive = workers scanning with this panel (shared: a scratch may outlive its panel object)
     std::shared_ptr<std::atomic<int>> live_scratches = std::make_shared<std::atomic<int>>(0);
 };
@@ -575,14 +628,12 @@ extern "C" {
 const char *ipcr_version(void) { return "ipcr-hip 0.1.0 (bitsliced-pigeonhole-gfx950)"; }
 const char *ipcr_last_error(void) { return g_err.c_str(); }
 
-int ipcr_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
+int ipcr_device_count(void) { return slot_count(); }
 
 ipcr_status ipcr_set_device(int device) {
-    HIPCHK(hipSetDevice(device));
+    if (device < 0 || device >= slot_count()) return fail(IPCR_ERR_INVALID, "ipcr_set_device: device %d of %d", device, slot_count());
+    g_default_slot.store(device, std::memory_order_relaxed); // what ipcr_scratch_create / ipcr_genome_create use from now on, on any thread
+    HIPCHK(hipSetDevice(slot_phys(device)));                 // and the calling thread's own HIP device (a Python host shares it with torch)
     return IPCR_OK;
 }
 
@@ -693,16 +744,25 @@ ipcr_status ipcr_panel_create(const ipcr_config *cfg, const ipcr_pair *pairs, in
 
 void ipcr_panel_destroy(ipcr_panel *p) {
     if (!p) return;
-    for (auto &s : p->set) {
-        if (s.index.jit) ipcr::jit_destroy(s.index.jit);
-        for (ipcr::JitFilter *f : s.index.leftover_jit) ipcr::jit_destroy(f);
-        if (s.index.d_lds_image) (void)hipFree(s.index.d_lds_image);
-        if (s.index.d_table) (void)hipFree(s.index.d_table);
-        if (s.index.d_leftover) (void)hipFree(s.index.d_leftover);
-        if (s.dev) (void)hipFree(s.dev);
-        for (ipcr::JitFilter *f : s.jit) ipcr::jit_destroy(f);
+    for (auto &kv : p->devs) {
+        DeviceGuard dg(kv.first);
+        for (SetDev &s : kv.second->set) {
+            if (s.index_jit) ipcr::jit_destroy(s.index_jit);
+            for (ipcr::JitFilter *f : s.leftover_jit) ipcr::jit_destroy(f);
+            if (s.d_lds_image) (void)hipFree(s.d_lds_image);
+            if (s.d_table) (void)hipFree(s.d_table);
+            if (s.d_leftover) (void)hipFree(s.d_leftover);
+            if (s.dev) (void)hipFree(s.dev);
+            for (ipcr::JitFilter *f : s.jit) ipcr::jit_destroy(f);
+        }
     }
     delete p;
+}
+
+int32_t ipcr_panel_device_slots(const ipcr_panel *p) {
+    if (!p) return 0;
+    std::lock_guard<std::mutex> lock(p->mu);
+    return (int32_t)p->devs.size();
 }
 
 int32_t ipcr_panel_num_pairs(const ipcr_panel *p) { return p ? (int32_t)p->id.size() : 0; }
@@ -775,7 +835,7 @@ ipcr_status ipcr_panel_set_shard(ipcr_panel *p, int32_t index, int32_t count) {
     std::lock_guard<std::mutex> lock(p->mu);
     for (int mode = 0; mode < 2; ++mode) {
         PatternSet &s = p->set[mode];
-        if (s.dev || s.jit_tried || s.index.built) return fail(IPCR_ERR_INVALID, "ipcr_panel_set_shard: the panel has already been scanned with");
+        if (!p->devs.empty() || s.index.built) return fail(IPCR_ERR_INVALID, "ipcr_panel_set_shard: the panel has already been scanned with");
         if (p->shard_count != 1) return fail(IPCR_ERR_INVALID, "ipcr_panel_set_shard: the panel is already a shard");
     }
     for (int mode = 0; mode < 2; ++mode) { // every count-th distinct pattern of the scanned list, starting at index
@@ -810,7 +870,7 @@ ipcr_status ipcr_panel_set_specialize(ipcr_panel *p, int32_t enable) {
 // ---------------------------------------------------------------------------- genome
 
 struct ipcr_genome {
-    int device = 0;
+    int device = 0; // device slot
     uint64_t cap_cols = 0; // columns available for records (buffer holds one extra pad block beyond)
     uint32_t max_records = 0;
     uint32_t *planes = nullptr;
@@ -1021,11 +1081,20 @@ bool genome_any_reset(const ipcr_genome *g) {
 extern "C" {
 
 ipcr_status ipcr_genome_create(uint64_t capacity_bases, uint32_t max_records, ipcr_genome **out) {
+    return ipcr_genome_create_on(capacity_bases, max_records, default_slot(), out);
+}
+
+int32_t ipcr_genome_device(const ipcr_genome *g) { return g ? g->device : -1; }
+
+ipcr_status ipcr_genome_create_on(uint64_t capacity_bases, uint32_t max_records, int32_t device, ipcr_genome **out) {
     if (!out) return fail(IPCR_ERR_INVALID, "null out");
     *out = nullptr;
+    if (slot_count() == 0) return fail(IPCR_ERR_DEVICE, "no HIP device visible: the ipcr scan path has no CPU fallback");
+    if (device < 0 || device >= slot_count()) return fail(IPCR_ERR_INVALID, "ipcr_genome_create_on: device %d of %d", device, slot_count());
     if (max_records == 0) max_records = 1;
+    DeviceGuard dg(device);
     std::unique_ptr<ipcr_genome> g(new ipcr_genome);
-    HIPCHK(hipGetDevice(&g->device));
+    g->device = device;
     HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&g->e0));
     HIPCHK(hipEventCreate(&g->e1));
@@ -1038,6 +1107,7 @@ ipcr_status ipcr_genome_create(uint64_t capacity_bases, uint32_t max_records, ip
 
 void ipcr_genome_destroy(ipcr_genome *g) {
     if (!g) return;
+    DeviceGuard dg(g->device);
     genome_free_buffers(g);
     if (g->staging) (void)hipFree(g->staging);
     if (g->e0) (void)hipEventDestroy(g->e0);
@@ -1048,6 +1118,7 @@ void ipcr_genome_destroy(ipcr_genome *g) {
 
 ipcr_status ipcr_genome_add_record(ipcr_genome *g, const uint8_t *seq, uint64_t len) {
     if (!g || (!seq && len)) return fail(IPCR_ERR_INVALID, "ipcr_genome_add_record: null argument");
+    DeviceGuard dg(g->device);
     if (len + 16 > g->staging_cap) {
         if (g->staging) (void)hipFree(g->staging);
         g->staging = nullptr;
@@ -1060,6 +1131,7 @@ ipcr_status ipcr_genome_add_record(ipcr_genome *g, const uint8_t *seq, uint64_t 
 
 ipcr_status ipcr_genome_add_record_device(ipcr_genome *g, const void *dev_seq, uint64_t len) {
     if (!g || (!dev_seq && len)) return fail(IPCR_ERR_INVALID, "ipcr_genome_add_record_device: null argument");
+    DeviceGuard dg(g->device);
     HIPCHK(hipDeviceSynchronize()); // the caller's producer may live on another stream
     return genome_add_device(g, static_cast<const uint8_t *>(dev_seq), len);
 }
@@ -1075,6 +1147,9 @@ ipcr_status ipcr_internal_genome_add_device(ipcr_genome *g, const uint8_t *dseq,
     return st;
 }
 hipStream_t ipcr_internal_genome_stream(ipcr_genome *g) { return g->stream; }
+int ipcr_internal_genome_phys_device(const ipcr_genome *g) { return slot_phys(g->device); }
+int ipcr_internal_slot_phys(int slot) { return slot_phys(slot); }
+int ipcr_internal_slot_count() { return slot_count(); }
 ipcr_status ipcr_internal_genome_add_batch(ipcr_genome *g, const uint8_t *dbase, const uint64_t *offs, const uint64_t *lens,
                                            const std::string *ids, size_t n, void *d_tmp, size_t tmp_bytes) {
     return genome_add_device_batch(g, dbase, offs, lens, n, d_tmp, tmp_bytes, ids);
@@ -1085,6 +1160,13 @@ extern "C" {
 
 ipcr_status ipcr_lcg_fill_device(void *dev_out, uint64_t len, uint32_t seed, uint64_t stream_offset) {
     if (!dev_out && len) return fail(IPCR_ERR_INVALID, "ipcr_lcg_fill_device: null argument");
+    if (len == 0) return IPCR_OK;
+    hipPointerAttribute_t attr; // the buffer says which device it lives on
+    HIPCHK(hipPointerGetAttributes(&attr, dev_out));
+    int prev = -1;
+    HIPCHK(hipGetDevice(&prev));
+    if (prev != attr.device) HIPCHK(hipSetDevice(attr.device));
+    struct Back { int d, cur; ~Back() { if (d != cur) (void)hipSetDevice(d); } } back{prev, attr.device};
     HIPCHK(ipcr::launch_lcg(nullptr, static_cast<uint8_t *>(dev_out), len, seed, stream_offset));
     HIPCHK(hipDeviceSynchronize());
     return IPCR_OK;
@@ -1094,6 +1176,7 @@ ipcr_status ipcr_genome_read(const ipcr_genome *g, uint32_t record, uint64_t pos
     if (!g || !out) return fail(IPCR_ERR_INVALID, "ipcr_genome_read: null argument");
     if (record >= g->rec_start.size() || pos + len > g->rec_len[record]) return fail(IPCR_ERR_INVALID, "ipcr_genome_read: range outside record");
     if (len == 0) return IPCR_OK;
+    DeviceGuard dg(g->device);
     uint8_t *d = nullptr;
     HIPCHK(hipMalloc((void **)&d, len));
     hipError_t e = ipcr::launch_unpack(g->stream, g->planes, g->rst, g->rec_start[record] + pos, len, d);
@@ -1116,6 +1199,7 @@ double ipcr_genome_pack_ms(const ipcr_genome *g) { return g ? g->pack_ms : 0; }
 uint8_t ipcr_genome_record_flags(const ipcr_genome *g, uint32_t record) {
     if (!g || record >= g->rec_start.size()) return 0;
     if (!g->flags_valid) {
+        DeviceGuard dg(g->device);
         if (genome_finalize(const_cast<ipcr_genome *>(g)) != IPCR_OK) return 0;
     }
     return (uint8_t)((g->flags[record] & 1u) | (genome_any_reset(g) ? 2u : 0u));
@@ -1127,7 +1211,8 @@ uint8_t ipcr_genome_record_flags(const ipcr_genome *g, uint32_t record) {
 
 struct ipcr_scratch {
     const ipcr_panel *panel = nullptr;
-    int device = 0;
+    int device = 0; // device slot
+    SetDev *sdev[2] = {nullptr, nullptr}; // the panel's tables and kernels on this slot, per scan mode (panel_upload)
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // filter start/stop, verify start/stop
     ipcr_queue_entry *d_queue = nullptr; // IPCR_QUEUE_SHARDS segments of qcap entries
@@ -1198,44 +1283,48 @@ constexpr uint64_t HCAP_INIT = 1ull << 20;  // 1 Mi hits (32 MiB)
 constexpr uint64_t QCAP_MAX = 1ull << 23;   // per segment (2 Gi words in all)
 constexpr uint64_t HCAP_MAX = 1ull << 28;
 
-ipcr_status panel_upload(const ipcr_panel *cp, int mode) {
+ipcr_status panel_upload(const ipcr_panel *cp, int mode, int slot, SetDev **out) {
     ipcr_panel *p = const_cast<ipcr_panel *>(cp);
     std::lock_guard<std::mutex> lock(p->mu);
+    std::unique_ptr<PanelDev> &pd = p->devs[slot];
+    if (!pd) { pd.reset(new PanelDev); pd->slot = slot; }
     PatternSet &s = p->set[mode];
-    if (!s.dev && !s.host.empty()) {
-        HIPCHK(hipMalloc((void **)&s.dev, s.host.size() * sizeof(ipcr_dev_pattern)));
-        HIPCHK(hipMemcpy(s.dev, s.host.data(), s.host.size() * sizeof(ipcr_dev_pattern), hipMemcpyHostToDevice));
+    SetDev &d = pd->set[mode];
+    *out = &d;
+    if (!d.dev && !s.host.empty()) {
+        HIPCHK(hipMalloc((void **)&d.dev, s.host.size() * sizeof(ipcr_dev_pattern)));
+        HIPCHK(hipMemcpy(d.dev, s.host.data(), s.host.size() * sizeof(ipcr_dev_pattern), hipMemcpyHostToDevice));
     }
     const bool force_index = getenv("IPCR_FORCE_INDEX") && atoi(getenv("IPCR_FORCE_INDEX")) != 0;
-    if (p->specialize && !s.jit_tried && !s.host.empty()) {
-        s.jit_tried = true;
-        if (!force_index) s.jit = ipcr::jit_build(s.host, p->cfg.max_mm, s.jit_error);
+    if (p->specialize && !d.jit_tried && !s.host.empty()) {
+        d.jit_tried = true;
+        if (!force_index) d.jit = ipcr::jit_build(s.host, p->cfg.max_mm, s.jit_error);
     }
     // panels too large to specialise: seed-index filter (+ table-driven kernel for what it cannot key)
-    if (p->specialize && s.jit.empty() && !s.index.d_table && !s.host.empty() && p->cfg.max_mm <= 3) {
+    if (p->specialize && d.jit.empty() && !d.index_tried && !s.host.empty() && p->cfg.max_mm <= 3) {
+        d.index_tried = true;
         if (!s.index.built) build_index(*p, s);
         IndexPlan &ix = s.index;
         if (ix.usable) {
             std::string jerr;
-            ix.jit = ipcr::jit_build_index(ix.shapes, ix.geom(), jerr);
-            if (!ix.jit && env_flag("IPCR_INDEX_DEBUG", false)) fprintf(stderr, "ipcr index kernel: %s\n", jerr.c_str());
-            if (!ix.jit) {
-                ix.usable = false; // no hiprtc: the table-driven kernel serves
+            d.index_jit = ipcr::jit_build_index(ix.shapes, ix.geom(), jerr);
+            if (!d.index_jit) { // no hiprtc: the table-driven kernel serves
+                if (env_flag("IPCR_INDEX_DEBUG", false)) fprintf(stderr, "ipcr index kernel: %s\n", jerr.c_str());
                 return IPCR_OK;
             }
-            HIPCHK(hipMalloc((void **)&ix.d_lds_image, ix.lds_image.size() * 4));
-            HIPCHK(hipMemcpy(ix.d_lds_image, ix.lds_image.data(), ix.lds_image.size() * 4, hipMemcpyHostToDevice));
-            HIPCHK(hipMalloc((void **)&ix.d_table, ix.table.size() * sizeof(ipcr_index_entry)));
-            HIPCHK(hipMemcpy(ix.d_table, ix.table.data(), ix.table.size() * sizeof(ipcr_index_entry), hipMemcpyHostToDevice));
+            HIPCHK(hipMalloc((void **)&d.d_lds_image, ix.lds_image.size() * 4));
+            HIPCHK(hipMemcpy(d.d_lds_image, ix.lds_image.data(), ix.lds_image.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMalloc((void **)&d.d_table, ix.table.size() * sizeof(ipcr_index_entry)));
+            HIPCHK(hipMemcpy(d.d_table, ix.table.data(), ix.table.size() * sizeof(ipcr_index_entry), hipMemcpyHostToDevice));
             if (!ix.leftover.empty()) {
                 // What the index cannot key (primers > 32 nt, too many IUPAC expansions in a key): a handful of patterns
                 // in practice.  The table-driven kernel costs ~4 ms per pattern and 3 Gb; specialised spill-only filters
                 // (their survivors join the index's in the candidate queue) cost one ~0.25 ms sweep per 12 patterns.
                 std::string lerr;
-                ix.leftover_jit = ipcr::jit_build(s.host, p->cfg.max_mm, lerr, &ix.leftover);
-                if (ix.leftover_jit.empty()) {
-                    HIPCHK(hipMalloc((void **)&ix.d_leftover, ix.leftover.size() * 4));
-                    HIPCHK(hipMemcpy(ix.d_leftover, ix.leftover.data(), ix.leftover.size() * 4, hipMemcpyHostToDevice));
+                d.leftover_jit = ipcr::jit_build(s.host, p->cfg.max_mm, lerr, &ix.leftover);
+                if (d.leftover_jit.empty()) {
+                    HIPCHK(hipMalloc((void **)&d.d_leftover, ix.leftover.size() * 4));
+                    HIPCHK(hipMemcpy(d.d_leftover, ix.leftover.data(), ix.leftover.size() * 4, hipMemcpyHostToDevice));
                 }
             }
         }
@@ -1352,6 +1441,7 @@ ipcr_status wait_published(ipcr_scratch *s) {
 ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     ipcr_scratch::Pending &pd = s->pend;
     const PatternSet &set = p->set[pd.mode];
+    const SetDev &sd = *s->sdev[pd.mode]; // this slot's tables and kernels
     const auto te = std::chrono::steady_clock::now();
     unsigned long long *cnt = s->d_counts + 4u * s->cset, *cnt_next = s->d_counts + 4u * (s->cset ^ 1u);
     const uint64_t qset = (uint64_t)IPCR_QUEUE_SHARDS * IPCR_QUEUE_COUNTER_STRIDE;
@@ -1367,10 +1457,10 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     pd.fused = false;
     pd.verified = false;
     pd.published = false;
-    if (!set.jit.empty()) {
+    if (!sd.jit.empty()) {
         ipcr::JitVerify v;
         v.rst = g->rst;
-        v.pats = set.dev;
+        v.pats = sd.dev;
         v.rec_start = g->d_rec_start;
         v.block_rec = g->d_block_rec;
         v.rec_len = g->d_rec_len;
@@ -1382,7 +1472,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         v.counts = cnt;
         pd.pre = std::min<uint64_t>(PREFIX_HITS, s->hcap);
         ++s->seq;
-        for (size_t gi = 0; gi < set.jit.size(); ++gi) { // every group streams the tiles once
+        for (size_t gi = 0; gi < sd.jit.size(); ++gi) { // every group streams the tiles once
             v.next_counts = gi == 0 ? cnt_next : nullptr;
             v.next_qcount = gi == 0 ? qc_next : nullptr;
             if (publish_enabled()) { // every kernel of the scan writes its first hits to the pinned buffer too
@@ -1391,7 +1481,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
                 v.pub_hits = reinterpret_cast<ipcr_hit_rec *>(static_cast<unsigned long long *>(s->pinned) + 8);
                 v.pre = (uint32_t)pd.pre;
             }
-            if (gi + 1 == set.jit.size() && publish_enabled()) { // the scan's last kernel hands the results over itself
+            if (gi + 1 == sd.jit.size() && publish_enabled()) { // the scan's last kernel hands the results over itself
                 v.tickets = s->d_tickets;
                 v.pub = static_cast<unsigned long long *>(s->pinned) + 4u * pd.cset_used;
                 v.pub_seq = pinned_seq(s);
@@ -1404,20 +1494,20 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
                 static const int withhold = getenv("IPCR_TEST_WITHHOLD_TAG") ? atoi(getenv("IPCR_TEST_WITHHOLD_TAG")) : 0;
                 v.withhold = withhold > 0 ? (uint32_t)withhold : 0u;
             }
-            HIPCHK(ipcr::jit_launch(set.jit[gi], lane, g->planes, nblocks, s->d_queue, s->qcap, qc, v,
-                                    gi == 0 ? s->ev[0] : nullptr, gi + 1 == set.jit.size() ? s->ev[1] : nullptr));
+            HIPCHK(ipcr::jit_launch(sd.jit[gi], lane, g->planes, nblocks, s->d_queue, s->qcap, qc, v,
+                                    gi == 0 ? s->ev[0] : nullptr, gi + 1 == sd.jit.size() ? s->ev[1] : nullptr));
         }
         s->stats.kernel_kind = 1;
         pd.fused = true;
-    } else if (set.index.usable) {
+    } else if (sd.index_jit) {
         const IndexPlan &ix = set.index;
         const bool more = !ix.leftover.empty();
-        HIPCHK(ipcr::jit_launch_index(ix.jit, lane, g->planes, nblocks, (uint32_t)ix.shapes.size(), ix.d_lds_image, ix.d_table,
+        HIPCHK(ipcr::jit_launch_index(sd.index_jit, lane, g->planes, nblocks, (uint32_t)ix.shapes.size(), sd.d_lds_image, sd.d_table,
                                       (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, qc, s->d_tickets, s->ev[0], more ? nullptr : s->ev[1]));
-        if (more && !ix.leftover_jit.empty()) { // patterns the index cannot key: specialised filters that only fill the queue
+        if (more && !sd.leftover_jit.empty()) { // patterns the index cannot key: specialised filters that only fill the queue
             ipcr::JitVerify v;
             v.rst = g->rst;
-            v.pats = set.dev;
+            v.pats = sd.dev;
             v.rec_start = g->d_rec_start;
             v.block_rec = g->d_block_rec;
             v.rec_len = g->d_rec_len;
@@ -1427,23 +1517,23 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             v.hits = s->d_hits;
             v.hcap = s->hcap;
             v.counts = cnt;
-            for (size_t gi = 0; gi < ix.leftover_jit.size(); ++gi)
-                HIPCHK(ipcr::jit_launch(ix.leftover_jit[gi], lane, g->planes, nblocks, s->d_queue, s->qcap, qc, v, nullptr,
-                                        gi + 1 == ix.leftover_jit.size() ? s->ev[1] : nullptr));
+            for (size_t gi = 0; gi < sd.leftover_jit.size(); ++gi)
+                HIPCHK(ipcr::jit_launch(sd.leftover_jit[gi], lane, g->planes, nblocks, s->d_queue, s->qcap, qc, v, nullptr,
+                                        gi + 1 == sd.leftover_jit.size() ? s->ev[1] : nullptr));
         } else if (more)
-            HIPCHK(ipcr::launch_filter_generic(lane, g->planes, nblocks, set.dev, (uint32_t)ix.leftover.size(),
-                                               (uint32_t)p->cfg.max_mm, ix.d_leftover, s->d_queue, s->qcap, qc,
+            HIPCHK(ipcr::launch_filter_generic(lane, g->planes, nblocks, sd.dev, (uint32_t)ix.leftover.size(),
+                                               (uint32_t)p->cfg.max_mm, sd.d_leftover, s->d_queue, s->qcap, qc,
                                                nullptr, s->ev[1]));
         s->stats.kernel_kind = 3;
         s->stats.leftover_patterns = (uint32_t)ix.leftover.size();
-        s->stats.leftover_kernels = (uint32_t)ix.leftover_jit.size();
+        s->stats.leftover_kernels = (uint32_t)sd.leftover_jit.size();
     } else {
-        HIPCHK(ipcr::launch_filter_generic(lane, g->planes, nblocks, set.dev, (uint32_t)set.ids.size(),
+        HIPCHK(ipcr::launch_filter_generic(lane, g->planes, nblocks, sd.dev, (uint32_t)set.ids.size(),
                                            (uint32_t)p->cfg.max_mm, nullptr, s->d_queue, s->qcap, qc, s->ev[0], s->ev[1]));
         s->stats.kernel_kind = 2;
     }
     if (!pd.fused) {
-        HIPCHK(ipcr::launch_verify(lane, g->planes, g->rst, set.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
+        HIPCHK(ipcr::launch_verify(lane, g->planes, g->rst, sd.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
                                    g->d_rec_len, pd.nrec, pd.check_rst, s->d_queue, s->qcap, qc, s->d_hits,
                                    s->hcap, cnt + 1, cnt + 2, cnt_next, qc_next, s->ev[2], s->ev[3]));
         pd.verified = true;
@@ -1482,7 +1572,7 @@ ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g, b
     s->last_rec_len = g->rec_len;
     s->last_rec_start = g->rec_start;
     pd.mode = chunk ? (p->modes_equal ? 0 : 1) : ((!p->modes_equal && genome_any_reset(g)) ? 1 : 0);
-    st = panel_upload(p, pd.mode);
+    st = panel_upload(p, pd.mode, s->device, &s->sdev[pd.mode]);
     if (st != IPCR_OK) return st;
     const PatternSet &set = p->set[pd.mode];
     pd.nrec = (uint32_t)g->rec_start.size();
@@ -1530,14 +1620,14 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         if (!pd.verified && pc[0] > 0) {
             // some wave's survivor list was full and spilled to the queue (dense matches): run the
             // stand-alone verifier over the spilled words; it appends to the same hit buffer
-            const PatternSet &set = p->set[pd.mode];
+            const SetDev &sd = *s->sdev[pd.mode];
             // the sweep may have run on another scratch's stream (chained scans) and has only published, not retired:
             // its queue entries become visible to a later kernel on OUR stream when it has ended
             if (pd.published) HIPCHK(hipEventSynchronize(s->ev[1]));
             const uint64_t qset = (uint64_t)IPCR_QUEUE_SHARDS * IPCR_QUEUE_COUNTER_STRIDE;
             unsigned long long *cnt = s->d_counts + 4u * pd.cset_used, *cnt_next = s->d_counts + 4u * (pd.cset_used ^ 1u);
             unsigned long long *qc = s->d_qcounts + qset * pd.cset_used, *qc_next = s->d_qcounts + qset * (pd.cset_used ^ 1u);
-            HIPCHK(ipcr::launch_verify(s->stream, g->planes, g->rst, set.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
+            HIPCHK(ipcr::launch_verify(s->stream, g->planes, g->rst, sd.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
                                        g->d_rec_len, pd.nrec, pd.check_rst, s->d_queue, s->qcap, qc, s->d_hits,
                                        s->hcap, cnt + 1, cnt + 2, cnt_next, qc_next, s->ev[2], s->ev[3]));
             HIPCHK(hipMemcpyAsync(s->pinned, s->d_hitbuf, 64 + pd.pre * sizeof(ipcr_hit), hipMemcpyDeviceToHost, s->stream));
@@ -1882,21 +1972,34 @@ ipcr_status scratch_ready(const ipcr_panel *p, ipcr_scratch *s, bool need_device
     return IPCR_OK;
 }
 
+ipcr_status same_device(const ipcr_scratch *s, const ipcr_genome *g) {
+    if (!g) return fail(IPCR_ERR_INVALID, "null genome");
+    if (s->stream && s->device != g->device)
+        return fail(IPCR_ERR_INVALID, "scratch lives on device %d, the genome on device %d: scan a genome with a scratch of its own device (ipcr_scratch_create_on)", s->device, g->device);
+    return IPCR_OK;
+}
+
 } // namespace
 
 extern "C" {
 
 ipcr_status ipcr_scratch_create(const ipcr_panel *p, ipcr_scratch **out) {
+    return ipcr_scratch_create_on(p, default_slot(), out);
+}
+
+int32_t ipcr_scratch_device(const ipcr_scratch *s) { return (s && s->stream) ? s->device : -1; }
+
+ipcr_status ipcr_scratch_create_on(const ipcr_panel *p, int32_t device, ipcr_scratch **out) {
     if (!p || !out) return fail(IPCR_ERR_INVALID, "ipcr_scratch_create: null argument");
     *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(IPCR_ERR_DEVICE, "no HIP device visible: the ipcr scan path has no CPU fallback");
+    if (slot_count() == 0) return fail(IPCR_ERR_DEVICE, "no HIP device visible: the ipcr scan path has no CPU fallback");
+    if (device < 0 || device >= slot_count()) return fail(IPCR_ERR_INVALID, "ipcr_scratch_create_on: device %d of %d", device, slot_count());
+    DeviceGuard dg(device);
     std::unique_ptr<ipcr_scratch> s(new ipcr_scratch);
     s->panel = p;
     ipcr_scratch *raw = s.get();
     auto build = [&]() -> ipcr_status {
-        HIPCHK(hipGetDevice(&raw->device));
+        raw->device = device;
         raw->own_lane = std::make_shared<ipcr_scratch::Lane>();
         {
             // Streams share a few hardware queues (creation order decides which); a sweep lane that lands on the queue
@@ -1946,6 +2049,7 @@ ipcr_status ipcr_scratch_create_host(const ipcr_panel *p, ipcr_scratch **out) {
 
 void ipcr_scratch_destroy(ipcr_scratch *s) {
     if (!s) return;
+    DeviceGuard dg(s->device);
     if (s->stream) { // a scan left in flight still reads and writes the buffers freed below
         if (s->pend.active && s->lane_used) (void)hipStreamSynchronize(s->lane_used->s);
         (void)hipStreamSynchronize(s->stream);
@@ -2003,8 +2107,9 @@ ipcr_status ipcr_scratch_device_hits(const ipcr_scratch *s, const void **dev_blo
 
 ipcr_status ipcr_scan_genome_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g) {
     ipcr_status st = scratch_ready(p, s);
+    if (st == IPCR_OK) st = same_device(s, g);
     if (st != IPCR_OK) return st;
-    if (!g) return fail(IPCR_ERR_INVALID, "null genome");
+    DeviceGuard dg(s->device);
     s->stats.pack_ms = 0;
     return scan_hits(p, s, const_cast<ipcr_genome *>(g));
 }
@@ -2035,16 +2140,18 @@ ipcr_status ipcr_scratch_chain_after(ipcr_scratch *s, const ipcr_scratch *prev) 
 
 ipcr_status ipcr_scan_genome_begin(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g) {
     ipcr_status st = scratch_ready(p, s);
+    if (st == IPCR_OK) st = same_device(s, g);
     if (st != IPCR_OK) return st;
-    if (!g) return fail(IPCR_ERR_INVALID, "null genome");
+    DeviceGuard dg(s->device);
     s->stats.pack_ms = 0;
     return scan_enqueue(p, s, const_cast<ipcr_genome *>(g));
 }
 
 ipcr_status ipcr_scan_genome_end(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g, ipcr_emit_fn emit, void *user) {
     ipcr_status st = scratch_ready(p, s);
+    if (st == IPCR_OK) st = same_device(s, g);
     if (st != IPCR_OK) return st;
-    if (!g) return fail(IPCR_ERR_INVALID, "null genome");
+    DeviceGuard dg(s->device);
     st = scan_collect(p, s, const_cast<ipcr_genome *>(g));
     if (st != IPCR_OK) return st;
     std::vector<uint8_t> fl(g->rec_start.size());
@@ -2102,11 +2209,12 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
     s->products.clear();
     memset(&s->stats, 0, sizeof s->stats);
     if (p->id.empty()) return IPCR_OK; // compiled.go:163-165
+    DeviceGuard dg(s->device); // the worker's thread may never have selected a device (a goroutine on any thread)
     const uint64_t need_cols = record_cols(len) + 64;
     if (!s->chunk || s->chunk->cap_cols < need_cols) {
         if (s->chunk) ipcr_genome_destroy(s->chunk);
         s->chunk = nullptr;
-        st = ipcr_genome_create((need_cols + (need_cols >> 2)) * IPCR_COLUMN_BASES, 1, &s->chunk);
+        st = ipcr_genome_create_on((need_cols + (need_cols >> 2)) * IPCR_COLUMN_BASES, 1, s->device, &s->chunk);
         if (st != IPCR_OK) return st;
         // the private chunk genome lives on the scratch's stream: copy, pack, sweep and hand-over are one
         // in-order sequence and the host waits once, at the end
@@ -2228,9 +2336,8 @@ ipcr_status ipcr_probe_best_hit(const uint8_t *amplicon, uint64_t len, const cha
     ipcr_status st = normalize_probe(probe, prb);
     if (st != IPCR_OK) return st;
     if (prb.empty()) return IPCR_OK; // oligo.go:21-23
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(IPCR_ERR_DEVICE, "no HIP device visible: the probe rescan has no CPU fallback");
+    if (slot_count() == 0) return fail(IPCR_ERR_DEVICE, "no HIP device visible: the probe rescan has no CPU fallback");
+    DeviceGuard dg(default_slot());
     uint8_t *d = nullptr;
     const uint64_t bytes = len + 16 + 16 + 256 + sizeof(ipcr_probe_rec);
     HIPCHK(hipMalloc((void **)&d, bytes + 64));
@@ -2249,6 +2356,9 @@ ipcr_status ipcr_probe_best_hit(const uint8_t *amplicon, uint64_t len, const cha
 ipcr_status ipcr_probe_products(ipcr_scratch *s, const ipcr_genome *g, const char *probe, int32_t max_mm,
                                 ipcr_probe_hit *out, int64_t n_out) {
     if (!s || !g || !probe || (!out && n_out)) return fail(IPCR_ERR_INVALID, "ipcr_probe_products: null argument");
+    if (!s->stream) return fail(IPCR_ERR_DEVICE, "host-only scratch: the probe rescan has no CPU fallback");
+    { const ipcr_status ds = same_device(s, g); if (ds != IPCR_OK) return ds; }
+    DeviceGuard dg(s->device);
     const size_t n = s->products.size();
     if ((int64_t)n != n_out) return fail(IPCR_ERR_INVALID, "n_out (%lld) != products of the last scan (%zu)", (long long)n_out, n);
     if (n == 0) return IPCR_OK;
@@ -2304,8 +2414,10 @@ ipcr_status ipcr_probe_products(ipcr_scratch *s, const ipcr_genome *g, const cha
 ipcr_status ipcr_nested_windows(const ipcr_genome *g, const ipcr_window *windows, int64_t n64, const ipcr_panel *inner,
                                 ipcr_scratch *s, ipcr_nested_hit *out) {
     ipcr_status st = scratch_ready(inner, s);
+    if (st == IPCR_OK) st = same_device(s, g);
     if (st != IPCR_OK) return st;
-    if (!g || n64 < 0 || (n64 && (!windows || !out))) return fail(IPCR_ERR_INVALID, "ipcr_nested_windows: null argument");
+    if (n64 < 0 || (n64 && (!windows || !out))) return fail(IPCR_ERR_INVALID, "ipcr_nested_windows: null argument");
+    DeviceGuard dg(s->device);
     const size_t n = (size_t)n64;
     if (n == 0) return IPCR_OK;
     memset(out, 0, n * sizeof *out);
@@ -2351,7 +2463,7 @@ ipcr_status ipcr_nested_windows(const ipcr_genome *g, const ipcr_window *windows
     if (!s->nest || s->nest->cap_cols < cols + 64 || s->nest->max_records < n) {
         if (s->nest) ipcr_genome_destroy(s->nest);
         s->nest = nullptr;
-        st = ipcr_genome_create((cols + (cols >> 2) + 64) * IPCR_COLUMN_BASES, (uint32_t)std::max<size_t>(n + (n >> 2), 16), &s->nest);
+        st = ipcr_genome_create_on((cols + (cols >> 2) + 64) * IPCR_COLUMN_BASES, (uint32_t)std::max<size_t>(n + (n >> 2), 16), s->device, &s->nest);
         if (st != IPCR_OK) return st;
         (void)hipStreamDestroy(s->nest->stream);
         s->nest->stream = s->stream;

@@ -164,6 +164,63 @@ class HitExchanger:
         self.device_path = self.device.type == "cuda"
         self._rec_counts = [0] * self.world
         self._alloc(cap_hits)
+        self._native = None                  # ipcr_exchange handle (csrc/exchange.cpp): RCCL inside the library
+        self._native_redone0 = 0
+        if self.active and self.device.type == "cuda" and not os.environ.get("IPCR_EXCHANGE_TORCH"):
+            self._native_create(cap_hits)
+
+    def _native_create(self, cap_hits: int) -> None:
+        """The library's own all-gather (ncclAllGather straight out of the scratch's device hit buffer, the same one a
+        Go or C++ host calls).  Collective: every rank constructs its exchanger at the same point.  Rank 0 makes the
+        RCCL id and broadcasts it (with an ok flag: nobody enters ncclCommInitRank alone); the ranks then take the minimum
+        of their verdicts, so all of them use the native form or none does."""
+        import ctypes as C
+        from . import _lib
+        torch, dist = self.torch, self.dist
+        L = _lib.lib()
+        buf = torch.zeros(1 + 128, dtype=torch.uint8, device=self.device)
+        if self.rank == 0:
+            raw = C.create_string_buffer(128)
+            if L.ipcr_exchange_unique_id(raw) == _lib.OK:
+                buf[0] = 1
+                buf[1:] = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).to(self.device)
+        if self.world > 1:
+            dist.broadcast(buf, src=0, group=self.group)
+        got = bytes(buf.cpu().numpy().tobytes())
+        ok, handle = 0, C.c_void_p()
+        if got[0] == 1:
+            dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            st = L.ipcr_exchange_create(got[1:], self.world, self.rank, int(dev_index), int(cap_hits), int(self.same_records), C.byref(handle))
+            ok = int(st == _lib.OK)
+        t = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        if int(t.item()) == 1:
+            self._native = handle
+        elif ok:
+            L.ipcr_exchange_destroy(handle)
+
+    def close(self) -> None:
+        if self._native is not None:
+            from . import _lib
+            _lib.lib().ipcr_exchange_destroy(self._native)
+            self._native = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def native(self) -> bool:
+        return self._native is not None
+
+    def _native_counts(self) -> None:
+        import ctypes as C
+        from . import _lib
+        arr = (C.c_uint32 * self.world)(*[int(c) for c in self._rec_counts])
+        _lib.check(_lib.lib().ipcr_exchange_set_record_counts(self._native, arr))
 
     def _alloc(self, cap: int) -> None:
         torch = self.torch
@@ -247,6 +304,12 @@ class HitExchanger:
         buffer must stay untouched until finish(): do not begin the scratch's next scan before."""
         if not self.active:
             return None
+        if self._native is not None:
+            import ctypes as C
+            from . import _lib
+            ticket = C.c_int32(-1)
+            _lib.check(_lib.lib().ipcr_exchange_begin(self._native, scratch._h, C.byref(ticket)))
+            return ("native", ticket.value, scratch, n_local_records)
         if self.device.type != "cuda" or not self.device_path:
             return self.start(hits_from_scratch(scratch), n_local_records)
         ptr, n, cap = scratch.device_hits()
@@ -278,13 +341,32 @@ class HitExchanger:
         complete result."""
         if work is None:
             return
+        if work[0] == "native":
+            import ctypes as C
+            from . import _lib
+            L = _lib.lib()
+            hits, n = C.POINTER(_lib.Hit)(), C.c_int64(0)
+            starts, offs = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)()
+            _lib.check(L.ipcr_exchange_end(self._native, work[1], C.byref(hits), C.byref(n), C.byref(starts), C.byref(offs)))
+            if n.value:
+                raw = (C.c_uint8 * (n.value * 32)).from_address(C.addressof(hits.contents))
+                arr = np.frombuffer(raw, dtype=HIT_DTYPE, count=n.value).copy()
+            else:
+                arr = np.zeros(0, dtype=HIT_DTYPE)
+            ranges = [(int(starts[r]), int(starts[r + 1])) for r in range(self.world)]
+            self._last = ("full", arr, ranges, [int(offs[r]) for r in range(self.world)])
+            self.redone = self._native_redone0 + int(L.ipcr_exchange_redone(self._native))
+            self.cap = max(self.cap, int(L.ipcr_exchange_capacity(self._native)))
+            return
         if work[0] == "dev":
             _, _, ev, recv, hdr, cap, scratch, nrec = work
             ev.synchronize()
             counts = self._device_counts(hdr.numpy(), self.world)
             if int(counts.max()) > cap:
                 self.redone += 1
-                self._last = ("full",) + tuple(self.allgather(hits_from_scratch(scratch), nrec))
+                # size_hint: the RAW device count (duplicates included) every rank has just read -- the de-duplicated host
+                # list may fit a capacity the device buffer does not, and the next device-form exchange would overflow again
+                self._last = ("full",) + tuple(self.allgather(hits_from_scratch(scratch), nrec, size_hint=int(counts.max())))
             else:
                 self._last = ("dev", recv, cap, counts)
             return
@@ -320,6 +402,8 @@ class HitExchanger:
     def set_record_counts(self, counts) -> None:
         """records per rank (static for a job; the device form does not resend them every step)"""
         self._rec_counts = [int(c) for c in counts]
+        if self._native is not None:
+            self._native_counts()
 
     def _unpack_device(self, hr: np.ndarray, cap: int, counts: np.ndarray):
         parts, ranges, offsets, off, pos = [], [], [], 0, 0
@@ -379,6 +463,8 @@ class HitExchanger:
             meta = np.ascontiguousarray(meta3[:, :2])
             need = int(max(meta3[:, 0].max(), meta3[:, 2].max()))
             self._rec_counts = [int(c) for c in meta[:, 1]]
+            if self._native is not None:
+                self._native_counts()
             if need <= self.cap:
                 break
             cap = self.cap
@@ -387,6 +473,7 @@ class HitExchanger:
             rc = self._rec_counts
             self._alloc(cap)  # identical on every rank: all saw the same header
             self._rec_counts = rc
+            self.redone_sync = getattr(self, "redone_sync", 0) + 1
         out = self._unpack(hr, meta)
         self._last = ("full",) + tuple(out)
         return out

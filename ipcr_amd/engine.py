@@ -151,6 +151,11 @@ class CompiledPanel:
         _lib.lib().ipcr_panel_scanned_patterns(self._h, mode, out, n)
         return [out[i] for i in range(n)]
 
+    @property
+    def device_slots(self) -> int:
+        """devices this panel holds tables and kernels on"""
+        return int(_lib.lib().ipcr_panel_device_slots(self._h))
+
     def set_specialize(self, enable: bool) -> None:
         _lib.check(_lib.lib().ipcr_panel_set_specialize(self._h, 1 if enable else 0))
 
@@ -159,14 +164,22 @@ class SimulationScratch:
     """engine.SimulationScratch -- core/engine/hit_collect.go:12-34: one HIP stream + device
     staging buffers per worker; never shared between workers."""
 
-    def __init__(self, cp: CompiledPanel, host_only: bool = False):
+    def __init__(self, cp: CompiledPanel, host_only: bool = False, device: Optional[int] = None):
+        """device: the GPU this worker's stream and buffers live on (ipcr_scratch_create_on); None = the process default
+        (ipcr_set_device, else the calling thread's current HIP device)"""
         self._cp = cp
         h = C.c_void_p()
         if host_only:  # results of JoinHits only; cannot scan
             _lib.check(_lib.lib().ipcr_scratch_create_host(cp._h, C.byref(h)))
-        else:
+        elif device is None:
             _lib.check(_lib.lib().ipcr_scratch_create(cp._h, C.byref(h)))
+        else:
+            _lib.check(_lib.lib().ipcr_scratch_create_on(cp._h, int(device), C.byref(h)))
         self._h = h
+
+    @property
+    def device(self) -> int:
+        return int(_lib.lib().ipcr_scratch_device(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -260,11 +273,18 @@ def _product(cp: CompiledPanel, p: _lib.Product, seq_ids: Sequence[str]) -> Prod
 class Genome:
     """Reference records packed once into 2-bit + invalid-bit tiles resident in HBM."""
 
-    def __init__(self, capacity_bases: int, max_records: int = 1):
+    def __init__(self, capacity_bases: int, max_records: int = 1, device: Optional[int] = None):
         h = C.c_void_p()
-        _lib.check(_lib.lib().ipcr_genome_create(capacity_bases, max_records, C.byref(h)))
+        if device is None:
+            _lib.check(_lib.lib().ipcr_genome_create(capacity_bases, max_records, C.byref(h)))
+        else:
+            _lib.check(_lib.lib().ipcr_genome_create_on(capacity_bases, max_records, int(device), C.byref(h)))
         self._h = h
         self.ids: List[str] = []
+
+    @property
+    def device(self) -> int:
+        return int(_lib.lib().ipcr_genome_device(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -344,8 +364,8 @@ class Engine:
         return CompiledPanel(self.cfg, pairs)
 
     # -- hit_collect.go:31-34
-    def NewSimulationScratch(self, cp: CompiledPanel) -> SimulationScratch:
-        return SimulationScratch(cp)
+    def NewSimulationScratch(self, cp: CompiledPanel, device: Optional[int] = None) -> SimulationScratch:
+        return SimulationScratch(cp, device=device)
 
     # -- compiled.go:162-267
     def ForEachCompiledProduct(self, seqID: str, seq, cp: Optional[CompiledPanel],

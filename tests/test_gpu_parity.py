@@ -952,6 +952,26 @@ def test_device_hit_exchange_one_rank_rccl(hip, monkeypatch):
         assert np.array_equal(key(np.unique(h2)), key(local))
         x2.finish(x2.start_scratch(scs[0], g.num_records))            # now it fits: device form, nothing redone
         assert x2.redone == 1 and np.array_equal(key(np.unique(x2.gathered()[0])), key(local))
+        assert x.native and x2.native                                 # RCCL inside the library (csrc/exchange.cpp) did all of the above
+        # the same through torch.distributed (IPCR_EXCHANGE_TORCH=1: what a host without the native exchange runs), and
+        # the overflow redo when the host's list is much shorter than the device's (the seed index files a window under
+        # several keys; here: simulated by a list cut to ten records): the capacity must grow to the DEVICE count every rank
+        # read in the headers, or every later exchange would overflow and be redone again
+        monkeypatch.setenv("IPCR_EXCHANGE_TORCH", "1")
+        x3 = dist.HitExchanger(device=dev, cap_hits=max(1, len(local) // 2))
+        assert not x3.native
+        x3.set_record_counts([g.num_records])
+        x3.agree_on_device_path(scs[0])
+        eng.ScanGenomeHits(g, cp, scs[0])
+        monkeypatch.setattr(dist, "hits_from_scratch", lambda sc, _f=dist.hits_from_scratch: _f(sc)[:10])
+        x3.finish(x3.start_scratch(scs[0], g.num_records))
+        assert x3.redone == 1 and x3.cap >= len(local)
+        monkeypatch.undo()
+        monkeypatch.setenv("IPCR_EXCHANGE_SELFTEST", "1")
+        x3.finish(x3.start_scratch(scs[0], g.num_records))
+        assert x3.redone == 1 and np.array_equal(key(np.unique(x3.gathered()[0])), key(local))
+        for xx in (x, x2, x3):
+            xx.close()
     finally:
         if started_here and tdist.is_initialized():
             tdist.destroy_process_group()
@@ -1117,3 +1137,103 @@ def test_handover_matches_device_memory():
     what the kernel left in device memory -- zero differences, nothing refetched, plain and chained sweeps."""
     (refetched, checked, diffs, hits), err = _run_handover_child({"IPCR_DEBUG_PUBLISH_CHECK": "1"})
     assert checked == 15 and diffs == 0 and refetched == 0 and hits >= 40, err[-2000:]
+
+
+# ---- one host process, several devices through the C ABI ------------------------------------------
+
+def test_one_process_drives_several_device_slots(hip, monkeypatch):
+    """The reference's unit of parallelism is a pool of workers calling ForEachCompiledProduct on independent chunks
+    (internal/pipeline/pipeline.go:60-125); over several GPUs that is worker i -> device i mod N with no collective.
+    On the one-GPU test box IPCR_DEVICE_SLOTS adds device slots (each with panel tables and kernels of its own, all on
+    the physical GPU): one compiled panel, scratches on three slots, worker threads that never select a device -- every
+    entry point selects its object's device itself -- and results equal to the oracle on every slot."""
+    import threading
+    monkeypatch.setenv("IPCR_DEVICE_SLOTS", "3")
+    E, P, L = hip.engine, hip.primer.Pair, hip.lib
+    assert L.lib().ipcr_device_count() >= 3
+    cfg = E.Config(MaxMM=2, TerminalWindow=3, MaxLen=400, HitCap=10000, SeedLen=12)
+    pairs = hip.primer.AddSelfPairs([P("p", "ACGTTGCATGCAAGCT", "GGCCTTAAGGCCATAT")])
+    eng = E.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    rng = random.Random(5)
+    jobs = []
+    for j in range(12):
+        n = rng.choice([4000, 60000, 300000])
+        s = rand_case(rng, n, with_junk=(j % 3 == 0))
+        for _ in range(3):
+            a = rng.randrange(0, n - 400)
+            plant(rng, s, pairs[0].Forward, a, rng.choice([0, 1, 2]))
+            plant(rng, s, O.revcomp(pairs[0].Reverse).decode(), a + rng.randint(40, 300), 0)
+        jobs.append("".join(s).encode())
+    want = [[w.sig() for w in O.simulate_batch(ocfg(cfg), s, opairs(pairs))] for s in jobs]
+    slots = [0, 1, 2, 1]
+    scs = [eng.NewSimulationScratch(cp, device=d) for d in slots]
+    assert [sc.device for sc in scs] == slots
+    got, errors = [None] * len(jobs), []
+
+    def worker(w):     # a fresh thread: no ipcr_set_device, no hipSetDevice
+        try:
+            for j in range(w, len(jobs), len(scs)):
+                got[j] = [p.sig() for p in eng.SimulateCompiledWithScratch("job%d" % j, jobs[j], cp, scs[w])]
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(len(scs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and got == want and sum(map(len, want)) >= 12
+    assert cp.device_slots == 3                       # three sets of tables, built at the first scan on each slot
+    # resident genomes belong to a device too: a scratch of another device is refused, not silently misused
+    g2 = E.Genome(1 << 20, 4, device=2)
+    assert g2.device == 2
+    g2.add_record("r0", jobs[1])
+    assert [p.sig() for p in eng.ScanGenome(g2, cp, scs[2])] == want[1]
+    with pytest.raises(L.IpcrError) as ei:
+        eng.ScanGenome(g2, cp, scs[0])
+    assert ei.value.status == L.ERR_INVALID
+    with pytest.raises(L.IpcrError):
+        eng.NewSimulationScratch(cp, device=7)
+    g2.close()
+    for sc in scs:
+        sc.close()
+    cp.close()
+
+
+def test_device_slots_large_panel_and_native_pool(hip, monkeypatch, tmp_path):
+    """the seed-index kernel's image and entry table are per-slot state as well; and the native worker pool
+    (csrc/chunk_workers.cpp --devices) spreads its workers over the listed devices"""
+    import json
+    import os
+    import subprocess
+    from ipcr_amd import workloads
+    monkeypatch.setenv("IPCR_DEVICE_SLOTS", "2")
+    rng = random.Random(31)
+    pairs = workloads.c4_pairs(160)
+    cfg = hip.engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)
+    eng = hip.engine.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    seq = rand_case(rng, 400_000, with_junk=True)
+    for t in range(20):
+        p = pairs[t * 7 % 160]
+        a = 2000 + t * 19000
+        plant(rng, seq, p.Forward, a, t % 3)
+        plant(rng, seq, O.revcomp(p.Reverse).decode(), a + 150, 0)
+    seq = "".join(seq).encode()
+    want = [w.sig() for w in O.simulate_batch(ocfg(cfg), seq, opairs(pairs))]
+    for d in (1, 0):
+        sc = eng.NewSimulationScratch(cp, device=d)
+        assert [p.sig() for p in eng.SimulateCompiledWithScratch("s", seq, cp, sc)] == want and len(want) >= 15
+        assert sc.stats().kernel_kind == 3
+        sc.close()
+    assert cp.device_slots == 2
+    cp.close()
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ipcr_amd", "chunk_workers")
+    r = subprocess.run([exe, "--devices", "0,1", "6000000", "1000000", "4"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, IPCR_DEVICE_SLOTS="2"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["devices"] == [0, 1] and out["panel_device_slots"] == 2 and out["products_per_pass"] >= out["planted"] >= 5
+    assert subprocess.run([exe, "1000000", "1500"], capture_output=True).returncode == 2      # chunk <= overlap: usage error
+    assert subprocess.run([exe, "1000000", "500000", "0"], capture_output=True).returncode == 2  # no workers
