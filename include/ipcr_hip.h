@@ -121,6 +121,7 @@ typedef struct {
     /* seed-index panels: patterns the index cannot key (primers > 32 nt, too many IUPAC expansions in a key) */
     uint32_t leftover_patterns;    /* how many of the panel's patterns those are */
     uint32_t leftover_kernels;     /* specialised spill-only filters that took them (0: the table-driven kernel did) */
+    double hostpack_ms;            /* ipcr_scan_chunk: host time packing the caller's ASCII into bit planes (0: the bases went over the link as ASCII) */
 } ipcr_scan_stats;
 
 typedef struct ipcr_panel ipcr_panel;     /* engine.CompiledPanel + device tables */
@@ -219,6 +220,13 @@ ipcr_status ipcr_scratch_device_hits(const ipcr_scratch *s, const void **dev_blo
 typedef int (*ipcr_emit_fn)(const ipcr_product *product, void *user);
 ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t *seq, uint64_t len,
                             ipcr_emit_fn emit, void *user);
+
+/* ASCII bases -> the linear bit planes ipcr_scan_chunk sends over the link (bit i of word w = base 32 w + i; lo, hi = 2-bit
+ * code A 0 C 1 G 2 T 3, zero for other bytes; inv = not an upper-case ACGT, core/primer/iupac.go:62-67; rst = outside
+ * ACGTacgt, core/engine/ac.go:16-30).  padded_bases: a multiple of 32 >= len; bases past len are inv 1, rst 0.  Every
+ * array takes padded_bases / 32 words.  *flags: bit 0 = some byte lies outside ACGTacgt, bit 1 = some lower-case acgt. */
+ipcr_status ipcr_pack_ascii(const uint8_t *seq, uint64_t len, uint64_t padded_bases, uint32_t *lo, uint32_t *hi,
+                            uint32_t *inv, uint32_t *rst, uint32_t *flags);
 
 /* ---- resident genome: many records packed once, scanned by any panel ---- */
 ipcr_status ipcr_genome_create(uint64_t capacity_bases, uint32_t max_records, ipcr_genome **out); /* on the default device */

@@ -67,7 +67,8 @@ class ScanStats(C.Structure):
                 ("kernel_kind", C.c_int32), ("n_patterns", C.c_int32), ("enqueue_ms", C.c_double),
                 ("wait_ms", C.c_double), ("sort_ms", C.c_double), ("join_ms", C.c_double),
                 ("handover_refetched", C.c_uint64), ("handover_checked", C.c_uint64),
-                ("handover_check_diffs", C.c_uint64), ("leftover_patterns", C.c_uint32), ("leftover_kernels", C.c_uint32)]
+                ("handover_check_diffs", C.c_uint64), ("leftover_patterns", C.c_uint32), ("leftover_kernels", C.c_uint32),
+                ("hostpack_ms", C.c_double)]
 
 
 EMIT_FN = C.CFUNCTYPE(C.c_int, C.POINTER(Product), C.c_void_p)
@@ -107,6 +108,8 @@ SYMBOLS = {
     "ipcr_scratch_hits": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(Hit)), C.POINTER(C.c_int64)]),
     "ipcr_scratch_device_hits": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ipcr_scan_chunk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "ipcr_pack_ascii": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ipcr_genome_create": (C.c_int, [C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p)]),
     "ipcr_genome_destroy": (None, [C.c_void_p]),
     "ipcr_genome_add_record": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64]),

@@ -18,6 +18,8 @@
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -942,6 +944,17 @@ void genome_clear(ipcr_genome *g, bool flags_elsewhere = false) { // forget the 
     g->total_bases = 0;
 }
 
+void genome_account_record(ipcr_genome *g, uint64_t len, uint64_t cols) { // a record's tiles are (being) written at next_col
+    g->rec_start.push_back(g->next_col * IPCR_COLUMN_BASES);
+    g->rec_len.push_back(len);
+    g->ids.emplace_back();
+    g->next_col += cols;
+    if (g->padded_until < g->next_col) g->padded_until = g->next_col;
+    g->total_bases += len;
+    g->tables_dirty = true;
+    g->flags_valid = false;
+}
+
 // ext_flag: where the record's reset-byte flag goes instead of d_flags (the chunk path keeps it in pinned host memory);
 // with it the pack kernel also writes the record's start / length into the device tables (no copy operations)
 ipcr_status genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len, bool wait = true, uint32_t *ext_flag = nullptr) {
@@ -960,14 +973,7 @@ ipcr_status genome_add_device(ipcr_genome *g, const uint8_t *dseq, uint64_t len,
         HIPCHK(hipEventElapsedTime(&ms, g->e0, g->e1));
         g->pack_ms += ms;
     }
-    g->rec_start.push_back(g->next_col * IPCR_COLUMN_BASES);
-    g->rec_len.push_back(len);
-    g->ids.emplace_back();
-    g->next_col += cols;
-    if (g->padded_until < g->next_col) g->padded_until = g->next_col;
-    g->total_bases += len;
-    g->tables_dirty = true;
-    g->flags_valid = false;
+    genome_account_record(g, len, cols);
     return IPCR_OK;
 }
 
@@ -1268,6 +1274,8 @@ struct ipcr_scratch {
     // own pageable-copy path
     uint8_t *h_stage[2] = {nullptr, nullptr};
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    uint8_t *h_planes = nullptr; // a whole record's host-packed planes (one worker, large record: packed by the process's pool)
+    uint64_t h_planes_cap = 0;
     std::shared_ptr<std::atomic<int>> counted_in; // the panel's worker count this scratch is part of
     // probe buffers
     uint8_t *d_amps = nullptr; uint64_t amps_cap = 0;
@@ -1331,6 +1339,63 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode, int slot, SetDev **out)
     }
     return IPCR_OK;
 }
+
+// A few threads that pack slices of ONE large record (a single worker scanning whole chromosomes: a lone core packs
+// ~10 GB/s of ASCII, the link carries 57): created at the first use, they live as long as the process.  A pool of
+// workers never comes here -- every worker packs its own chunk.
+class PackPool {
+public:
+    static PackPool &get() { static PackPool *p = new PackPool; return *p; } // never destroyed: its threads sleep on the condition variable until the process ends
+    unsigned size() const { return (unsigned)threads_.size() + 1u; }
+    // fn(i) for i in [0, n), on the pool's threads and the caller's; returns when all are done
+    template <class F> void run(size_t n, F fn) {
+        std::unique_lock<std::mutex> big(run_mu_); // one record at a time
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = [&](size_t i) { fn(i); };
+            n_ = n; next_.store(0); done_.store(0); ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return done_.load() >= n_; });
+        fn_ = nullptr;
+    }
+private:
+    PackPool() {
+        unsigned t = std::thread::hardware_concurrency();
+        if (const char *v = getenv("IPCR_PACK_THREADS")) t = (unsigned)std::max(1, atoi(v));
+        t = std::min(std::max(t, 1u), 16u);
+        for (unsigned i = 1; i < t; ++i) threads_.emplace_back([this] { loop(); });
+        for (auto &th : threads_) th.detach(); // they sleep on the condition variable for the rest of the process's life
+    }
+    void work() {
+        for (;;) {
+            const size_t i = next_.fetch_add(1);
+            if (i >= n_) break;
+            fn_(i);
+            if (done_.fetch_add(1) + 1 >= n_) { std::lock_guard<std::mutex> lk(mu_); cv_done_.notify_all(); }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, cv_done_;
+    std::function<void(size_t)> fn_;
+    size_t n_ = 0;
+    std::atomic<size_t> next_{0}, done_{0};
+    uint64_t gen_ = 0;
+    std::vector<std::thread> threads_;
+};
 
 struct HitLess {
     bool operator()(const ipcr_hit &a, const ipcr_hit &b) const {
@@ -2058,6 +2123,7 @@ void ipcr_scratch_destroy(ipcr_scratch *s) {
     for (int h = 0; h < 2; ++h) {
         if (s->h_stage[h]) (void)hipHostFree(s->h_stage[h]);
         if (s->ev_stage[h]) (void)hipEventDestroy(s->ev_stage[h]);
+        if (h == 0 && s->h_planes) (void)hipHostFree(s->h_planes);
     }
     if (s->chunk) ipcr_genome_destroy(s->chunk);
     if (s->nest) ipcr_genome_destroy(s->nest);
@@ -2225,14 +2291,97 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
     }
     ipcr_genome *g = s->chunk;
     genome_clear(g, true);
-    uint32_t *pinned_flag = pinned_seq(s) + 4; // the pack kernel sets it when the record holds a byte outside ACGTacgt
+    uint32_t *pinned_flag = pinned_seq(s) + 4; // set when the record holds a byte outside ACGTacgt (by the pack kernel, or by the host's packer)
     *pinned_flag = 0u;
+    const int live = p->live_scratches->load(std::memory_order_relaxed);
+    // How the bases reach the device.  (a) Packed on the host into 2-bit + invalid-bit planes while they are staged in
+    // pinned memory -- 0.375 bytes per base on the link instead of 1 (hostpack.cpp), tiles made from them on the device:
+    // what a pool of workers does (every worker packs its own chunk), and a single worker with a record of 16 Mb or more
+    // (the process's pack pool shares the slices).  (b) As ASCII: a single worker with a small chunk -- the runtime's
+    // pageable copy pins the caller's pages in place and runs at the link rate, faster than one core packs.
+    // IPCR_CHUNK_HOSTPACK=0/1 forces.
+    static const int hp_env = getenv("IPCR_CHUNK_HOSTPACK") ? atoi(getenv("IPCR_CHUNK_HOSTPACK")) : -1;
+    const bool hostpack = hp_env >= 0 ? hp_env != 0 : (ipcr::pack_linear_is_simd() && (live > 1 || len >= (16ull << 20)));
+    if (hostpack) {
+        const auto th0 = std::chrono::steady_clock::now();
+        const uint64_t cols = record_cols(len), col0 = g->next_col;
+        if (g->rec_start.size() >= g->max_records || col0 + cols > g->cap_cols) return fail(IPCR_ERR_CAPACITY, "chunk genome capacity exceeded");
+        const uint64_t dev_bytes = cols * 2048ull; // four planes x 128 words per column
+        if (dev_bytes > g->staging_cap) {
+            if (g->staging) (void)hipFree(g->staging);
+            g->staging = nullptr;
+            g->staging_cap = dev_bytes + (dev_bytes >> 3);
+            HIPCHK(hipMalloc((void **)&g->staging, g->staging_cap));
+        }
+        const bool pooled = live <= 1 && PackPool::get().size() > 1 && cols >= 64;
+        // columns per slice: up to 1024 = 4 Mbases, i.e. a worker's 4 Mb chunk is ONE copy + ONE conversion launch.  Cutting it
+        // in two or four (IPCR_CHUNK_SPLIT: the first part crosses the link while the next is packed) was slower under a
+        // pool -- 16 workers: 94 / 72 / 49 Gbases/s for 1 / 2 / 4 parts -- every operation on a stream costs its dispatch latency
+        static const uint64_t split_env = getenv("IPCR_CHUNK_SPLIT") ? strtoull(getenv("IPCR_CHUNK_SPLIT"), nullptr, 10) : 1;
+        const uint64_t SLC = pooled ? std::min<uint64_t>(1024, std::max<uint64_t>(128, cols / (2ull * PackPool::get().size())))
+                                    : std::min<uint64_t>(1024, std::max<uint64_t>(128, (cols + split_env - 1) / std::max<uint64_t>(split_env, 1)));
+        const uint64_t nsl = (cols + SLC - 1) / SLC;
+        std::vector<uint32_t> sflags((size_t)nsl, 0);
+        auto pack_slice = [&](uint64_t i, uint8_t *slab) { // planes of slice i: [lo | hi | inv | rst], nc x 128 words each
+            const uint64_t c0 = i * SLC, nc = std::min<uint64_t>(SLC, cols - c0), b0 = c0 * IPCR_COLUMN_BASES, W = nc * 128u;
+            const uint64_t nb = b0 < len ? std::min<uint64_t>(len - b0, nc * IPCR_COLUMN_BASES) : 0;
+            uint32_t *w = reinterpret_cast<uint32_t *>(slab);
+            sflags[(size_t)i] = ipcr::pack_linear(seq + (nb ? b0 : 0), nb, nc * IPCR_COLUMN_BASES, w, w + W, w + 2 * W, w + 3 * W);
+        };
+        auto send_slice = [&](uint64_t i, const uint8_t *slab) -> ipcr_status { // the rst plane crosses the link only if the slice holds lower case
+            const uint64_t c0 = i * SLC, nc = std::min<uint64_t>(SLC, cols - c0), W = nc * 128u;
+            const bool lower = (sflags[(size_t)i] & 2u) != 0;
+            uint8_t *d = g->staging + c0 * 2048ull;
+            HIPCHK(hipMemcpyAsync(d, slab, W * 4u * (lower ? 4u : 3u), hipMemcpyHostToDevice, g->stream));
+            const uint32_t *dl = reinterpret_cast<const uint32_t *>(d);
+            HIPCHK(ipcr::launch_tiles_from_linear(g->stream, dl, dl + W, dl + 2 * W, lower ? dl + 3 * W : nullptr, col0, col0 + c0, nc, len,
+                                                  g->planes, g->rst, i == 0 ? g->d_rec_start : nullptr, i == 0 ? g->d_rec_len : nullptr,
+                                                  i == 0 ? g->e0 : nullptr, i + 1 == nsl ? g->e1 : nullptr));
+            return IPCR_OK;
+        };
+        if (!pooled) { // this worker's own two pinned slices: slice i + 1 is packed while slice i crosses the link
+            constexpr uint64_t SLAB = 8ull << 20;
+            for (int h = 0; h < 2; ++h) {
+                if (!s->h_stage[h]) HIPCHK(hipHostMalloc((void **)&s->h_stage[h], SLAB, hipHostMallocDefault));
+                if (!s->ev_stage[h]) HIPCHK(hipEventCreateWithFlags(&s->ev_stage[h], hipEventDisableTiming));
+            }
+            for (uint64_t i = 0; i < nsl; ++i) {
+                const int h = (int)(i & 1u);
+                if (i >= 2) HIPCHK(hipEventSynchronize(s->ev_stage[h])); // the DMA that read this slab has finished
+                pack_slice(i, s->h_stage[h]);
+                st = send_slice(i, s->h_stage[h]);
+                if (st != IPCR_OK) { (void)hipStreamSynchronize(g->stream); return st; } // no DMA may still read a slab the next call rewrites
+                if (i + 2 < nsl) HIPCHK(hipEventRecord(s->ev_stage[h], g->stream));
+            }
+        } else { // one worker, a large record: the pool packs a group of slices while the group before crosses the link
+            if (dev_bytes > s->h_planes_cap) {
+                if (s->h_planes) (void)hipHostFree(s->h_planes);
+                s->h_planes = nullptr;
+                s->h_planes_cap = dev_bytes + (dev_bytes >> 3);
+                HIPCHK(hipHostMalloc((void **)&s->h_planes, s->h_planes_cap, hipHostMallocDefault));
+            }
+            const uint64_t group = std::max<uint64_t>(PackPool::get().size(), (nsl + 3) / 4);
+            for (uint64_t g0 = 0; g0 < nsl; g0 += group) {
+                const uint64_t g1 = std::min(nsl, g0 + group);
+                PackPool::get().run((size_t)(g1 - g0), [&](size_t k) { pack_slice(g0 + k, s->h_planes + (g0 + k) * SLC * 2048ull); });
+                for (uint64_t i = g0; i < g1; ++i) {
+                    st = send_slice(i, s->h_planes + i * SLC * 2048ull);
+                    if (st != IPCR_OK) { (void)hipStreamSynchronize(g->stream); return st; }
+                }
+            }
+        }
+        uint32_t fl = 0;
+        for (uint32_t f : sflags) fl |= f;
+        *pinned_flag = fl & 1u;
+        genome_account_record(g, len, cols);
+        s->stats.hostpack_ms = ms_since(th0);
+    } else {
     constexpr uint64_t SLICE_MAX = 8ull << 20;
     // One worker: the runtime's pageable copy (it pins the caller's pages in place) runs at the link rate.  Several
     // workers calling it at once serialise inside the runtime (8 workers x 4 Mb chunks: 12 Gbases/s in all, a single
     // worker 22): then every worker stages through its own pinned slices instead.  IPCR_CHUNK_STAGING=0/1 forces.
     static const int force = getenv("IPCR_CHUNK_STAGING") ? atoi(getenv("IPCR_CHUNK_STAGING")) : -1;
-    const bool staged = force >= 0 ? force != 0 : p->live_scratches->load(std::memory_order_relaxed) > 1;
+    const bool staged = force >= 0 ? force != 0 : live > 1;
     const uint8_t *pack_src = nullptr;
     if (len + 16 > g->staging_cap) {
         if (g->staging) (void)hipFree(g->staging);
@@ -2269,10 +2418,13 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         }
     }
     st = genome_add_device(g, pack_src, len, false, pinned_flag);
-    if (st != IPCR_OK) return st;
+    if (st != IPCR_OK) { (void)hipStreamSynchronize(g->stream); return st; } // (staged copies may still be reading the pinned slices)
+    }
+    const double hostpack_keep = s->stats.hostpack_ms; // (scan_enqueue starts the statistics afresh)
     st = scan_enqueue(p, s, g, true);
     if (st == IPCR_OK) st = scan_collect(p, s, g);
-    if (st != IPCR_OK) return st;
+    if (st != IPCR_OK) { (void)hipStreamSynchronize(g->stream); return st; } // nothing of this call may still read the pinned slices
+    s->stats.hostpack_ms = hostpack_keep;
     {
         float ms = 0; // the pack kernel's events lie in front of the sweep on the same stream
         HIPCHK(hipEventElapsedTime(&ms, g->e0, g->e1));

@@ -139,6 +139,61 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const uint8_t *__restri
 }
 
 // fill columns [col_begin, col_end) with padding (inv=1, everything else 0)
+// ------------------------------------------------------------------------------- tiles from host-packed planes
+// Linear bit planes (hostpack.cpp: bit i of word w = base 32 w + i) -> strand-major tiles.  A column is 32 strands of
+// 128 bases = 4 linear words each; rows 32 j .. 32 j + 31 of its tile words are the 32 x 32 bit transpose of the strands'
+// j-th words.  One half wave per (column, plane): lane s loads the four words of strand s (one 16-byte load, 512
+// contiguous bytes per half wave), four cross-lane transposes (butterflies over ds_swizzle, as the seed-index kernel's
+// k-mer transposes), lane i stores rows i, 32 + i, 64 + i, 96 + i.  Plane 3 = rst; without a fourth linear plane
+// (no lower-case acgt in the chunk) rst is inv.
+template <int D> __device__ __forceinline__ uint32_t tl_stage(uint32_t x, uint32_t lane) {
+    constexpr uint32_t m0 = D == 16 ? 0x0000FFFFu : D == 8 ? 0x00FF00FFu : D == 4 ? 0x0F0F0F0Fu : D == 2 ? 0x33333333u : 0x55555555u;
+    const uint32_t p = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, (D << 10) | 0x1F);
+    const bool up = (lane & D) != 0;
+    const uint32_t r = __builtin_amdgcn_alignbit(p, p, up ? D : 32 - D);
+    return __builtin_amdgcn_bitop3_b32(x, r, up ? ~m0 : m0, 0xE4); // (x & m) | (r & ~m)
+}
+__device__ __forceinline__ uint32_t tl_transpose(uint32_t x, uint32_t lane) {
+    x = tl_stage<16>(x, lane);
+    x = tl_stage<8>(x, lane);
+    x = tl_stage<4>(x, lane);
+    x = tl_stage<2>(x, lane);
+    x = tl_stage<1>(x, lane);
+    return x;
+}
+__global__ __launch_bounds__(256) void tiles_from_linear_kernel(const uint4 *__restrict__ lin_lo, const uint4 *__restrict__ lin_hi,
+                                                               const uint4 *__restrict__ lin_iv, const uint4 *__restrict__ lin_rs,
+                                                               uint64_t rec_col0, uint64_t col0, uint64_t ncol, uint64_t len,
+                                                               uint32_t *__restrict__ planes, uint32_t *__restrict__ rst,
+                                                               uint64_t *__restrict__ rec_start_out, uint64_t *__restrict__ rec_len_out) {
+    if (rec_start_out && blockIdx.x == 0 && threadIdx.x == 0) { // chunk path: the one record's table entries, no copy operation
+        rec_start_out[0] = rec_col0 * IPCR_COLUMN_BASES;
+        rec_len_out[0] = len;
+    }
+    const uint32_t lane = threadIdx.x & 31u;
+    const uint64_t item = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 5; // (column, plane)
+    const bool live = item < ncol * 4u;
+    const uint64_t c = live ? item >> 2 : 0u; // column of this launch's range
+    const uint32_t plane = (uint32_t)item & 3u;
+    const uint4 *src = plane == 0u ? lin_lo : plane == 1u ? lin_hi : (plane == 2u || !lin_rs) ? lin_iv : lin_rs;
+    const uint4 v = src[c * 32u + lane];
+    const uint32_t t0 = tl_transpose(v.x, lane), t1 = tl_transpose(v.y, lane), t2 = tl_transpose(v.z, lane), t3 = tl_transpose(v.w, lane);
+    if (!live) return;
+    const uint64_t col = col0 + c, block = col >> 6;
+    const uint32_t ln = (uint32_t)(col & 63u);
+    if (plane < 3u) {
+        planes[ipcr_plane_word(block, lane, plane, ln)] = t0;
+        planes[ipcr_plane_word(block, 32u + lane, plane, ln)] = t1;
+        planes[ipcr_plane_word(block, 64u + lane, plane, ln)] = t2;
+        planes[ipcr_plane_word(block, 96u + lane, plane, ln)] = t3;
+    } else {
+        rst[ipcr_rst_word(block, lane, ln)] = t0;
+        rst[ipcr_rst_word(block, 32u + lane, ln)] = t1;
+        rst[ipcr_rst_word(block, 64u + lane, ln)] = t2;
+        rst[ipcr_rst_word(block, 96u + lane, ln)] = t3;
+    }
+}
+
 __global__ void fill_pad_kernel(uint32_t *__restrict__ planes, uint32_t *__restrict__ rst,
                                 uint64_t col_begin, uint64_t col_end) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // (column, row)
@@ -504,6 +559,21 @@ hipError_t launch_pack(hipStream_t st, const uint8_t *seq, uint64_t len, uint64_
     // start / stop ride on the dispatch itself (its begin and end timestamps): no marker packets around the kernel
     hipExtLaunchKernelGGL(pack_kernel, dim3((uint32_t)grid), dim3(256), 0, st, start, stop, 0,
                           seq, len, col0, ncol, planes, rst, rec_flags, rec_start_out, rec_len_out);
+    return hipGetLastError();
+}
+
+// columns [col0, col0 + ncol) of the tiles from the linear planes of those columns (rec_col0 = the record's first column, len
+// its length: the table entries the kernel writes for the chunk path are the record's, whatever slice a launch converts)
+hipError_t launch_tiles_from_linear(hipStream_t st, const uint32_t *lin_lo, const uint32_t *lin_hi, const uint32_t *lin_iv,
+                                    const uint32_t *lin_rs, uint64_t rec_col0, uint64_t col0, uint64_t ncol, uint64_t len,
+                                    uint32_t *planes, uint32_t *rst, uint64_t *rec_start_out, uint64_t *rec_len_out,
+                                    hipEvent_t start, hipEvent_t stop) {
+    const uint64_t grid = (ncol * 4u + 7u) / 8u; // 8 half waves per workgroup
+    if (grid == 0) return hipSuccess;
+    hipExtLaunchKernelGGL(tiles_from_linear_kernel, dim3((uint32_t)grid), dim3(256), 0, st, start, stop, 0,
+                          reinterpret_cast<const uint4 *>(lin_lo), reinterpret_cast<const uint4 *>(lin_hi),
+                          reinterpret_cast<const uint4 *>(lin_iv), reinterpret_cast<const uint4 *>(lin_rs), rec_col0, col0, ncol, len,
+                          planes, rst, rec_start_out, rec_len_out);
     return hipGetLastError();
 }
 

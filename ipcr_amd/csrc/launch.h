@@ -10,6 +10,14 @@ hipError_t launch_pack(hipStream_t st, const uint8_t *seq, uint64_t len, uint64_
                        uint32_t *planes, uint32_t *rst, uint32_t *rec_flags, uint64_t *rec_start_out = nullptr,
                        uint64_t *rec_len_out = nullptr, // rec_*_out: the kernel also writes the record's table entries (chunk path)
                        hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// host-packed linear bit planes (hostpack.cpp) -> tiles; lin_* point at the words of column col0 (the slice's first)
+hipError_t launch_tiles_from_linear(hipStream_t st, const uint32_t *lin_lo, const uint32_t *lin_hi, const uint32_t *lin_iv,
+                                    const uint32_t *lin_rs, uint64_t rec_col0, uint64_t col0, uint64_t ncol, uint64_t len,
+                                    uint32_t *planes, uint32_t *rst, uint64_t *rec_start_out, uint64_t *rec_len_out,
+                                    hipEvent_t start, hipEvent_t stop);
+// ASCII -> linear planes on the host (returns bit 0: a byte outside ACGTacgt, bit 1: a lower-case acgt)
+uint32_t pack_linear(const uint8_t *seq, uint64_t len, uint64_t padded, uint32_t *lo, uint32_t *hi, uint32_t *iv, uint32_t *rs);
+bool pack_linear_is_simd();
 hipError_t launch_pack_batch(hipStream_t st, const uint8_t *base, const ipcr_pack_rec *recs, const uint32_t *pair_prefix,
                              uint32_t nrec, uint64_t total_pairs, uint32_t *planes, uint32_t *rst, uint32_t *rec_flags);
 hipError_t launch_fill_pad(hipStream_t st, uint32_t *planes, uint32_t *rst, uint64_t col_begin, uint64_t col_end);

@@ -477,3 +477,61 @@ def test_seed_index_source_compiles_for_gfx950(k, tw, lens, iupac, tmp_path):
     vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", asm).group(1))
     spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", asm).group(1))
     assert lds <= 160 * 1024 and vgpr <= 128 and spill <= 16, (lds, vgpr, spill)
+
+
+PACK_CHECK = r'''
+import ctypes as C, random, sys
+from ipcr_amd import _lib
+L = _lib.lib()
+rng = random.Random(3)
+CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
+def ref(seq, padded):   # the semantics of kernels.hip: pack_pair, one base at a time
+    W = padded // 32
+    lo, hi, iv, rs, fl = [0] * W, [0] * W, [0] * W, [0] * W, 0
+    for i in range(padded):
+        w, b = divmod(i, 32)
+        if i < len(seq):
+            c = chr(seq[i])
+            if c in "ACGTacgt":
+                lo[w] |= (CODE[c.upper()] & 1) << b
+                hi[w] |= (CODE[c.upper()] >> 1) << b
+                if c.islower():
+                    iv[w] |= 1 << b
+                    fl |= 2
+            else:
+                iv[w] |= 1 << b
+                rs[w] |= 1 << b
+                fl |= 1
+        else:
+            iv[w] |= 1 << b          # padding: invalid, not a reset byte
+    return [lo, hi, iv, rs], fl
+for trial in range(400):
+    n = rng.choice([0, 1, 31, 32, 33, 63, 64, 65, 100, 1000, 4097])
+    kind = rng.random()
+    seq = bytes((ord(rng.choice("ACGT")) if kind < 0.3 else ord(rng.choice("ACGTacgtN")) if kind < 0.6 else rng.randrange(256))
+                for _ in range(n))
+    padded = ((n + 31) // 32) * 32 + 32 * rng.choice([0, 1, 4])
+    W = padded // 32
+    arrs = [(C.c_uint32 * max(W, 1))() for _ in range(4)]
+    f = C.c_uint32(99)
+    _lib.check(L.ipcr_pack_ascii(seq, n, padded, *arrs, C.byref(f)))
+    want, fl = ref(seq, padded)
+    assert [list(a)[:W] for a in arrs] == want and f.value == fl, (trial, n, padded)
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("scalar,avx512", [("0", "1"), ("0", "0"), ("1", "0")])
+def test_host_packer_matches_the_pack_kernel_semantics(scalar, avx512):
+    """ipcr_pack_ascii (csrc/hostpack.cpp: what ipcr_scan_chunk sends over PCIe instead of ASCII) against a
+    base-at-a-time statement of the device pack kernel's semantics: upper-case ACGT valid (core/primer/iupac.go:62-67),
+    lower-case acgt invalid but not a reset byte (core/engine/ac.go:16-30), everything else both, padding invalid only;
+    AVX-512BW (where the CPU has it), AVX2 and scalar paths, every byte value, lengths around the 32-base word."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", PACK_CHECK], capture_output=True, text=True, cwd=root,
+                       env=dict(os.environ, IPCR_PACK_SCALAR=scalar, IPCR_PACK_AVX512=avx512, PYTHONPATH=root))
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
+    with pytest.raises(_lib.IpcrError):
+        _lib.check(_lib.lib().ipcr_pack_ascii(b"ACGT", 4, 33, None, None, None, None, None))
