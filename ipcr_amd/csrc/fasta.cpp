@@ -17,6 +17,9 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
@@ -149,6 +152,26 @@ void start_record(ipcr_fasta *f, const std::string &header) { // path_ctx.go:100
         if (e_ != hipSuccess) return ipcr_internal_fail(IPCR_ERR_DEVICE, "HIP: %s (%s)", hipGetErrorString(e_), #call); \
     } while (0)
 
+// The loader's big buffers (two pinned slabs, two raw device slabs, the compacted slab) are kept for the next load
+// of the process instead of being freed: allocating and pinning them costs ~9 ms, a fifth of loading a 1 GB file.
+struct FastaBuffers {
+    int device = -1;
+    size_t slab = 0;
+    uint8_t *pin = nullptr, *pin2 = nullptr, *d_raw = nullptr, *d_raw2 = nullptr, *d_out = nullptr;
+    uint32_t *d_counts = nullptr;
+    void release() {
+        if (pin) (void)hipHostFree(pin);
+        if (pin2) (void)hipHostFree(pin2);
+        if (d_raw) (void)hipFree(d_raw);
+        if (d_raw2) (void)hipFree(d_raw2);
+        if (d_out) (void)hipFree(d_out);
+        if (d_counts) (void)hipFree(d_counts);
+        *this = FastaBuffers();
+    }
+};
+std::mutex g_fasta_cache_mu;
+FastaBuffers g_fasta_cache; // at most one set (IPCR_FASTA_CACHE=0: none)
+
 struct FastaLoader {
     ipcr_genome *g = nullptr;
     int fd = -1;
@@ -158,7 +181,11 @@ struct FastaLoader {
     uint64_t foff = 0;
     size_t slab = 0;
     hipStream_t st = nullptr;
-    uint8_t *pin = nullptr, *pin2 = nullptr, *d_raw = nullptr, *d_out = nullptr, *d_rec = nullptr;
+    uint8_t *pin = nullptr, *pin2 = nullptr, *d_raw = nullptr, *d_raw2 = nullptr, *d_out = nullptr, *d_rec = nullptr;
+    int phys_device = 0;
+    hipStream_t cs = nullptr;                  // the slabs' host-to-device copies: slab j + 1 crosses the link while slab j is decoded
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}; // d_raw[k] holds its slab
+    hipEvent_t ev_free[2] = {nullptr, nullptr}; // the kernels that read d_raw[k] have run
     uint32_t *d_counts = nullptr, *d_hdr_off = nullptr, *h_small = nullptr; // h_small: pinned, hdr_off[nh] + total
     ipcr_fasta_range *d_hdr = nullptr;
     size_t hdr_cap = 0;
@@ -173,18 +200,30 @@ struct FastaLoader {
     void *d_tab = nullptr;
     size_t tab_cap = 0;
     uint32_t n_added = 0;
-    double t_read = 0, t_host = 0, t_decode = 0, t_pack = 0;
+    double t_read = 0, t_host = 0, t_decode = 0, t_pack = 0, t_alloc = 0;
 
     ~FastaLoader() {
         if (gz) gzclose(gz);
         else if (fd >= 0) close(fd);
-        if (pin) (void)hipHostFree(pin);
-        if (pin2) (void)hipHostFree(pin2);
+        if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+        for (int k = 0; k < 2; ++k) {
+            if (ev_h2d[k]) (void)hipEventDestroy(ev_h2d[k]);
+            if (ev_free[k]) (void)hipEventDestroy(ev_free[k]);
+        }
+        {   // the big buffers go to the cache (a set already there is dropped), or are freed
+            FastaBuffers mine;
+            mine.device = phys_device; mine.slab = slab;
+            mine.pin = pin; mine.pin2 = pin2; mine.d_raw = d_raw; mine.d_raw2 = d_raw2; mine.d_out = d_out; mine.d_counts = d_counts;
+            static const bool cache_on = !(getenv("IPCR_FASTA_CACHE") && atoi(getenv("IPCR_FASTA_CACHE")) == 0);
+            const bool complete = pin && pin2 && d_raw && d_raw2 && d_out && d_counts;
+            if (cache_on && complete) {
+                std::lock_guard<std::mutex> lk(g_fasta_cache_mu);
+                std::swap(mine, g_fasta_cache);
+            }
+            mine.release();
+        }
         if (h_small) (void)hipHostFree(h_small);
-        if (d_raw) (void)hipFree(d_raw);
-        if (d_out) (void)hipFree(d_out);
         if (d_rec) (void)hipFree(d_rec);
-        if (d_counts) (void)hipFree(d_counts);
         if (d_hdr_off) (void)hipFree(d_hdr_off);
         if (d_hdr) (void)hipFree(d_hdr);
         if (d_tab) (void)hipFree(d_tab);
@@ -214,11 +253,30 @@ struct FastaLoader {
             }
         }
         if (fd < 0 && !gz) return ipcr_internal_fail(IPCR_ERR_INVALID, "cannot open %s", path);
-        FHIP(hipHostMalloc((void **)&pin, slab, hipHostMallocDefault));
-        FHIP(hipHostMalloc((void **)&pin2, slab, hipHostMallocDefault));
-        FHIP(hipMalloc((void **)&d_raw, slab));
-        FHIP(hipMalloc((void **)&d_out, slab));
-        FHIP(hipMalloc((void **)&d_counts, (slab / 4096 + 2) * 4));
+        const auto ta = std::chrono::steady_clock::now();
+        FHIP(hipGetDevice(&phys_device));
+        {
+            std::lock_guard<std::mutex> lk(g_fasta_cache_mu);
+            if (g_fasta_cache.pin && g_fasta_cache.device == phys_device && g_fasta_cache.slab == slab) {
+                pin = g_fasta_cache.pin; pin2 = g_fasta_cache.pin2; d_raw = g_fasta_cache.d_raw; d_raw2 = g_fasta_cache.d_raw2;
+                d_out = g_fasta_cache.d_out; d_counts = g_fasta_cache.d_counts;
+                g_fasta_cache = FastaBuffers();
+            }
+        }
+        if (!pin) {
+            FHIP(hipHostMalloc((void **)&pin, slab, hipHostMallocDefault));
+            FHIP(hipHostMalloc((void **)&pin2, slab, hipHostMallocDefault));
+            FHIP(hipMalloc((void **)&d_raw, slab));
+            FHIP(hipMalloc((void **)&d_raw2, slab));
+            FHIP(hipMalloc((void **)&d_out, slab));
+            FHIP(hipMalloc((void **)&d_counts, (slab / 4096 + 4) * 4));
+        }
+        FHIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            FHIP(hipEventCreateWithFlags(&ev_h2d[k], hipEventDisableTiming));
+            FHIP(hipEventCreateWithFlags(&ev_free[k], hipEventDisableTiming));
+        }
+        t_alloc = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
         return IPCR_OK;
     }
 
@@ -227,8 +285,10 @@ struct FastaLoader {
     ipcr_status fill(uint8_t *buf, size_t have, size_t *n) {
         if (!gz && fsize >= 0) {
             const size_t want = (size_t)std::min<uint64_t>(slab - have, (uint64_t)fsize - foff);
-            const size_t piece = (size_t)4 << 20;
-            const unsigned nt = (unsigned)std::min<size_t>(8, (want + piece - 1) / piece);
+            const size_t piece = (size_t)2 << 20;
+            // (one pread stream copies from the page cache at ~8 GB/s; the link takes 57: IPCR_FASTA_READERS, default 16)
+            static const unsigned max_readers = [] { const char *v = getenv("IPCR_FASTA_READERS"); const int n = v && *v ? atoi(v) : 16; return (unsigned)std::min(std::max(n, 1), 64); }();
+            const unsigned nt = (unsigned)std::min<size_t>(max_readers, (want + piece - 1) / piece);
             std::atomic<bool> bad{false};
             auto reader = [&](size_t a, size_t b) {
                 while (a < b) {
@@ -316,101 +376,146 @@ struct FastaLoader {
         return IPCR_OK;
     }
 
-    // header lines of buf[0, cut): '>' at a line start (scan.go:27).  A few threads search their piece
-    // of the slab (memchr runs at ~35 GB/s, the slab arrives faster than that)
-    ipcr_status find_headers(const uint8_t *buf, size_t cut) {
+    // header lines of the slab's bytes [0, cut), already on their way to d_raw: found on the device ('>' at a line start,
+    // scan.go:27) -- the host reads none of the sequence bytes; it sorts the handful of ranges and parses the IDs out of
+    // the pinned slab.  (Round 2 searched the slab on the host with 8 threads: 0.9-1.5 ms per 64 MiB on the critical path.)
+    ipcr_status find_headers(const uint8_t *d_raw, size_t cut) {
         ranges.clear();
-        const size_t piece = (size_t)8 << 20;
-        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(8, cut / piece));
-        std::vector<std::vector<size_t>> found(nt);
-        auto search = [&](unsigned t) {
-            const size_t a = cut * t / nt, b = cut * (t + 1) / nt;
-            for (size_t pos = a; pos < b;) {
-                const void *p = memchr(buf + pos, '>', b - pos);
-                if (!p) break;
-                const size_t i = (size_t)((const uint8_t *)p - buf);
-                if (i == 0 ? at_line_start : buf[i - 1] == '\n') found[t].push_back(i);
-                pos = i + 1;
+        for (;;) {
+            if (hdr_cap == 0) {
+                hdr_cap = 4096;
+                FHIP(hipMalloc((void **)&d_hdr, hdr_cap * sizeof(ipcr_fasta_range)));
+                FHIP(hipMalloc((void **)&d_hdr_off, hdr_cap * 4));
+                FHIP(hipHostMalloc((void **)&h_small, (hdr_cap + 4) * 4 + hdr_cap * sizeof(ipcr_fasta_range), hipHostMallocDefault));
             }
-        };
-        if (nt == 1) search(0);
-        else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; ++t) th.emplace_back(search, t);
-            for (auto &t : th) t.join();
+            uint32_t *d_count = d_counts + (slab / 4096 + 1); // one spare word behind the block counts
+            FHIP(ipcr::launch_fasta_find_headers(st, d_raw, cut, at_line_start ? 1u : 0u, d_hdr, (uint32_t)hdr_cap, d_count));
+            FHIP(hipMemcpyAsync(h_small, d_count, 4, hipMemcpyDeviceToHost, st));
+            FHIP(hipStreamSynchronize(st));
+            const uint32_t nh = h_small[0];
+            if (nh > hdr_cap) { // a slab of very short records: a larger list, again
+                (void)hipFree(d_hdr); (void)hipFree(d_hdr_off); (void)hipHostFree(h_small);
+                d_hdr = nullptr; d_hdr_off = nullptr; h_small = nullptr;
+                hdr_cap = (size_t)nh + (nh >> 2) + 64;
+                FHIP(hipMalloc((void **)&d_hdr, hdr_cap * sizeof(ipcr_fasta_range)));
+                FHIP(hipMalloc((void **)&d_hdr_off, hdr_cap * 4));
+                FHIP(hipHostMalloc((void **)&h_small, (hdr_cap + 4) * 4 + hdr_cap * sizeof(ipcr_fasta_range), hipHostMallocDefault));
+                continue;
+            }
+            if (nh) {
+                ipcr_fasta_range *hr = reinterpret_cast<ipcr_fasta_range *>(h_small + hdr_cap + 1 + ((hdr_cap + 1) & 1u)); // 8-byte aligned, behind the offsets
+                FHIP(hipMemcpyAsync(hr, d_hdr, (size_t)nh * sizeof(ipcr_fasta_range), hipMemcpyDeviceToHost, st));
+                FHIP(hipStreamSynchronize(st));
+                ranges.assign(hr, hr + nh);
+                std::sort(ranges.begin(), ranges.end(), [](const ipcr_fasta_range &x, const ipcr_fasta_range &y) { return x.start < y.start; });
+            }
+            return IPCR_OK;
         }
-        for (unsigned t = 0; t < nt; ++t)
-            for (const size_t i : found[t]) {
-                const void *e = memchr(buf + i, '\n', cut - i);
-                if (!e && !eof) return ipcr_internal_fail(IPCR_ERR_UNSUPPORTED, "FASTA: a header line longer than the %zu-byte slab", slab);
-                ranges.push_back({(uint64_t)i, (uint64_t)(e ? (size_t)((const uint8_t *)e - buf) + 1 : cut)});
-            }
-        return IPCR_OK;
     }
+
+    // What the read-ahead thread hands over: slab j sits in pinned buffer j & 1, its bytes [0, cut) are on their way to
+    // d_raw[j & 1] (ev_h2d[j & 1]); what follows the cut is carried into the next slab.
+    struct SlabInfo { size_t n = 0, cut = 0; bool last = false; ipcr_status st = IPCR_OK; };
 
     ipcr_status run() {
         uint8_t *buf[2] = {pin, pin2};
-        int cur = 0;
-        size_t n = 0;
-        auto tr0 = std::chrono::steady_clock::now();
-        ipcr_status s = fill(buf[0], 0, &n);
-        t_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
-        if (s != IPCR_OK) return s;
-        while (n > 0) {
-            const uint8_t *raw = buf[cur];
-            const auto th0 = std::chrono::steady_clock::now();
-            // where to cut: behind the last line end; a slab without one is cut in front of its trailing
-            // white space (whether that is kept depends on what follows)
-            size_t cut = n;
-            const bool last = eof;
-            if (!last) {
-                const void *nl = memrchr(raw, '\n', n);
-                if (nl) cut = (size_t)((const uint8_t *)nl - raw) + 1;
-                else {
-                    while (cut > 0 && is_space(raw[cut - 1])) --cut;
-                    if (cut == 0 && n == slab) return ipcr_internal_fail(IPCR_ERR_UNSUPPORTED, "FASTA: a run of white space longer than the %zu-byte slab", slab);
+        uint8_t *draw[2] = {d_raw, d_raw2};
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<SlabInfo> ready;
+        uint64_t consumed = 0; // slabs the main thread has finished with (their pinned buffer may be overwritten)
+        bool stop = false;
+        // ---- read-ahead: file -> pinned slab (a few pread threads), cut behind the last line end, copy to the device on
+        // the copy stream.  It runs one slab ahead of the decode: the read of slab j + 2 waits for slab j to be consumed.
+        std::thread reader([&]() {
+            (void)hipSetDevice(phys_device);
+            size_t carry = 0, cut_prev = 0;
+            for (uint64_t j = 0;; ++j) {
+                SlabInfo si;
+                uint8_t *b = buf[j & 1];
+                if (j >= 2) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || consumed + 1 >= j; }); // slab j - 2 is done with on the host ...
+                    if (stop) return;
+                    lk.unlock();
+                    (void)hipEventSynchronize(ev_h2d[j & 1]);                // ... and has left the pinned buffer
                 }
+                if (carry) memcpy(b, buf[(j - 1) & 1] + cut_prev, carry);
+                size_t n = 0;
+                const auto t0 = std::chrono::steady_clock::now();
+                si.st = fill(b, carry, &n);
+                t_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                si.n = n;
+                si.last = eof;
+                size_t cut = n;
+                if (si.st == IPCR_OK && !si.last && n) {
+                    // where to cut: behind the last line end; a slab without one is cut in front of its trailing
+                    // white space (whether that is kept depends on what follows)
+                    const void *nl = memrchr(b, '\n', n);
+                    if (nl) cut = (size_t)((const uint8_t *)nl - b) + 1;
+                    else {
+                        while (cut > 0 && is_space(b[cut - 1])) --cut;
+                        if (cut == 0 && n == slab) si.st = ipcr_internal_fail(IPCR_ERR_UNSUPPORTED, "FASTA: a run of white space longer than the %zu-byte slab", slab);
+                    }
+                }
+                si.cut = cut;
+                if (si.st == IPCR_OK) {
+                    hipError_t e = hipSuccess;
+                    if (j >= 2) e = hipStreamWaitEvent(cs, ev_free[j & 1], 0); // the kernels over slab j - 2 have read d_raw[j & 1]
+                    if (e == hipSuccess && cut) e = hipMemcpyAsync(draw[j & 1], b, cut, hipMemcpyHostToDevice, cs);
+                    if (e == hipSuccess) e = hipEventRecord(ev_h2d[j & 1], cs);
+                    if (e != hipSuccess) si.st = ipcr_internal_fail(IPCR_ERR_DEVICE, "HIP: %s (FASTA slab copy)", hipGetErrorString(e));
+                }
+                const bool end = si.st != IPCR_OK || si.last || n == 0;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ready.push_back(si);
+                }
+                cv.notify_all();
+                if (end) return;
+                carry = n - cut;
+                cut_prev = cut;
             }
-            if (cut) FHIP(hipMemcpyAsync(d_raw, raw, cut, hipMemcpyHostToDevice, st)); // in flight during the header search
-            s = find_headers(raw, cut);
+        });
+        struct Stopper { // whatever way run() is left: the reader ends and is joined
+            std::mutex &mu; std::condition_variable &cv; bool &stop; std::thread &t;
+            ~Stopper() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); }
+        } stopper{mu, cv, stop, reader};
+        ipcr_status s = IPCR_OK;
+        for (uint64_t j = 0;; ++j) {
+            SlabInfo si;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !ready.empty(); });
+                si = ready.front();
+                ready.pop_front();
+            }
+            if (si.st != IPCR_OK) return si.st;
+            const size_t n = si.n, cut = si.cut;
+            if (n == 0) break;
+            const bool last = si.last;
+            const uint8_t *raw = buf[j & 1];
+            uint8_t *d_cur = draw[j & 1];
+            const auto th0 = std::chrono::steady_clock::now();
+            FHIP(hipStreamWaitEvent(st, ev_h2d[j & 1], 0));
+            s = find_headers(d_cur, cut);
             if (s != IPCR_OK) return s;
             const uint32_t nh = (uint32_t)ranges.size();
-            if (nh + 1 > hdr_cap) {
-                if (d_hdr) (void)hipFree(d_hdr);
-                if (d_hdr_off) (void)hipFree(d_hdr_off);
-                if (h_small) (void)hipHostFree(h_small);
-                d_hdr = nullptr; d_hdr_off = nullptr; h_small = nullptr;
-                hdr_cap = (size_t)nh * 2 + 64;
-                FHIP(hipMalloc((void **)&d_hdr, hdr_cap * sizeof(ipcr_fasta_range)));
-                FHIP(hipMalloc((void **)&d_hdr_off, hdr_cap * 4));
-                FHIP(hipHostMalloc((void **)&h_small, (hdr_cap + 1) * 4, hipHostMallocDefault));
-            }
-            // the next slab is read (behind the bytes carried over) while the device works on this one
-            size_t n_next = 0;
-            ipcr_status s_next = IPCR_OK;
-            std::thread reader;
-            const size_t ncarry = n - cut;
-            if (!last) {
-                memcpy(buf[cur ^ 1], raw + cut, ncarry);
-                reader = std::thread([&, ncarry]() {
-                    const auto t0 = std::chrono::steady_clock::now();
-                    s_next = fill(buf[cur ^ 1], ncarry, &n_next);
-                    t_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                });
-            }
-            struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{reader};
+            if (nh && !last && ranges.back().end > cut) return ipcr_internal_fail(IPCR_ERR_UNSUPPORTED, "FASTA: a header line longer than the %zu-byte slab", slab);
             uint32_t total = 0;
             const auto td0 = std::chrono::steady_clock::now();
             t_host += std::chrono::duration<double>(td0 - th0).count();
             if (cut) {
                 const uint32_t nb = (uint32_t)((cut + 4095) / 4096);
                 if (nh) FHIP(hipMemcpyAsync(d_hdr, ranges.data(), (size_t)nh * sizeof(ipcr_fasta_range), hipMemcpyHostToDevice, st));
-                FHIP(ipcr::launch_fasta_decode(st, d_raw, cut, d_hdr, nh, (at_line_start || lead_open) ? 1u : 0u, d_counts, d_out, d_hdr_off));
+                FHIP(ipcr::launch_fasta_decode(st, d_cur, cut, d_hdr, nh, (at_line_start || lead_open) ? 1u : 0u, d_counts, d_out, d_hdr_off));
+                FHIP(hipEventRecord(ev_free[j & 1], st));
                 if (nh) FHIP(hipMemcpyAsync(h_small, d_hdr_off, (size_t)nh * 4, hipMemcpyDeviceToHost, st));
                 FHIP(hipMemcpyAsync(h_small + nh, d_counts + nb, 4, hipMemcpyDeviceToHost, st));
                 FHIP(hipStreamSynchronize(st));
                 total = h_small[nh];
-            }
+            } else
+                FHIP(hipEventRecord(ev_free[j & 1], st));
             const auto tp0 = std::chrono::steady_clock::now();
             t_decode += std::chrono::duration<double>(tp0 - td0).count();
             // hand the compacted bytes to the records.  A record that begins and ends in this slab is packed straight
@@ -452,16 +557,17 @@ struct FastaLoader {
                 at_line_start = raw[cut - 1] == '\n';
                 lead_open = at_line_start; // a cut inside a line is behind one of its non-blank bytes
             }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                consumed = j + 1;
+            }
+            cv.notify_all();
             if (last) break; // cut == n: everything has been consumed
-            reader.join();
-            if (s_next != IPCR_OK) return s_next;
-            n = n_next;
-            cur ^= 1;
         }
         const ipcr_status fs = finish_record();
         if (getenv("IPCR_DEBUG_TIMES"))
-            fprintf(stderr, "fasta loader: read %.3f s (overlapped), cut + header search %.3f s, h2d + decode %.3f s, copy + pack %.3f s\n",
-                    t_read, t_host, t_decode, t_pack);
+            fprintf(stderr, "fasta loader: buffers %.3f s, read %.3f s (overlapped), cut + header search %.3f s, h2d + decode %.3f s, copy + pack %.3f s\n",
+                    t_alloc, t_read, t_host, t_decode, t_pack);
         return fs;
     }
 };

@@ -2,9 +2,9 @@
 //
 // The reference normalises every sequence line on one CPU thread (core/fasta/scan.go:10-69 splits
 // lines, core/fasta/normalize.go:5-14 trims white space at both ends and folds a-z to A-Z).  Here a
-// slab of raw file bytes is copied to HBM as it is; the host only locates the header lines (a
-// memchr for '>' at line starts) and hands their byte ranges over.  Three small kernels then do
-// what the per-line loop does, for all lines at once:
+// slab of raw file bytes is copied to HBM as it is; the header lines are located there too
+// (fasta_find_headers: '>' at a line start), the host sorts the handful of ranges and parses the
+// IDs.  Three small kernels then do what the per-line loop does, for all lines at once:
 //   fasta_count    keep-mask of every 16-byte group -> kept bytes per 4 KiB block
 //   fasta_scan     exclusive prefix sum of the block counts (one workgroup)
 //   fasta_scatter  kept bytes, upper-cased, to their compacted position; for every header the
@@ -79,6 +79,30 @@ __device__ __forceinline__ uint4 fasta_load16(const uint8_t *__restrict__ raw, u
     uint32_t w[4] = {0, 0, 0, 0};
     for (uint32_t t = 0; t < 16 && g0 + t < n; ++t) w[t >> 2] |= (uint32_t)raw[g0 + t] << ((t & 3u) * 8u);
     return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// header lines of the slab: '>' at a line start (core/fasta/scan.go:27) up to and including its '\n' (or the slab's end).
+// One thread per 16 bytes; the few threads that find one walk to the line end themselves and append the range --
+// in no particular order, the host sorts the handful.  list[cap] ranges; *count may exceed cap (the host then retries).
+__global__ __launch_bounds__(256) void fasta_find_headers_kernel(const uint8_t *__restrict__ raw, uint64_t n, uint32_t at_line_start,
+                                                                 ipcr_fasta_range *__restrict__ list, uint32_t cap, uint32_t *__restrict__ count) {
+    const uint64_t g0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 16u;
+    if (g0 >= n) return;
+    const uint4 v = fasta_load16(raw, n, g0);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t prev = g0 == 0 ? (at_line_start ? (uint32_t)'\n' : 0u) : (uint32_t)raw[g0 - 1];
+#pragma unroll
+    for (uint32_t t = 0; t < 16; ++t) {
+        if (g0 + t >= n) break;
+        const uint32_t c = (w[t >> 2] >> ((t & 3u) * 8u)) & 0xFFu;
+        if (c == '>' && prev == '\n') {
+            uint64_t e = g0 + t + 1;
+            while (e < n && raw[e] != '\n') ++e;
+            const uint32_t slot = atomicAdd(count, 1u);
+            if (slot < cap) { list[slot].start = g0 + t; list[slot].end = e < n ? e + 1 : n; }
+        }
+        prev = c;
+    }
 }
 
 __global__ __launch_bounds__(256) void fasta_count_kernel(const uint8_t *__restrict__ raw, uint64_t n,
@@ -165,6 +189,16 @@ __global__ __launch_bounds__(256) void fasta_scatter_kernel(const uint8_t *__res
 } // namespace
 
 namespace ipcr {
+
+// list: cap ranges, count: one word (cleared here)
+hipError_t launch_fasta_find_headers(hipStream_t st, const uint8_t *raw, uint64_t n, uint32_t at_line_start, ipcr_fasta_range *list,
+                                     uint32_t cap, uint32_t *count) {
+    hipError_t e = hipMemsetAsync(count, 0, 4, st);
+    if (e != hipSuccess || n == 0) return e;
+    const uint32_t nb = (uint32_t)((n + 4095u) / 4096u);
+    hipLaunchKernelGGL(fasta_find_headers_kernel, dim3(nb), dim3(256), 0, st, raw, n, at_line_start, list, cap, count);
+    return hipGetLastError();
+}
 
 // counts: (nblocks + 1) words of scratch; afterwards counts[nblocks] = kept bytes of the slab
 hipError_t launch_fasta_decode(hipStream_t st, const uint8_t *raw, uint64_t n, const ipcr_fasta_range *hdr, uint32_t nh,

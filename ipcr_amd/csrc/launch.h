@@ -39,6 +39,9 @@ hipError_t launch_gather(hipStream_t st, const uint32_t *planes, const uint32_t 
 hipError_t launch_probe(hipStream_t st, const uint8_t *amps, const uint64_t *amp_off, uint32_t namp,
                         const uint8_t *pmask, const uint8_t *rmask, uint32_t plen, uint32_t max_mm,
                         uint32_t fastpath, ipcr_probe_rec *out);
+// header lines ('>' at a line start .. its line end) of a raw FASTA slab, unordered; *count may exceed cap
+hipError_t launch_fasta_find_headers(hipStream_t st, const uint8_t *raw, uint64_t n, uint32_t at_line_start, ipcr_fasta_range *list,
+                                     uint32_t cap, uint32_t *count);
 // raw FASTA slab -> compacted upper-case sequence bytes (fasta_kernels.hip); counts = nblocks(4 KiB) + 1 words
 hipError_t launch_fasta_decode(hipStream_t st, const uint8_t *raw, uint64_t n, const ipcr_fasta_range *hdr, uint32_t nh,
                                uint32_t lead_open0, uint32_t *counts, uint8_t *out, uint32_t *hdr_off);
