@@ -34,6 +34,7 @@
 #include <mutex>
 #include <sstream>
 #include <thread>
+#include <sys/stat.h>
 #include <unistd.h>
 
 namespace ipcr {
@@ -777,11 +778,29 @@ CodeCache &code_cache() {
 
 bool compile_group_uncached(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &err);
 
+// Where code objects persist between processes: a cold `ipcr` run of a panel that has been scanned before skips hiprtc
+// (C2: 1.9 s) and pays the module load only.  IPCR_JIT_CACHE_DIR=<dir>, or "" to turn the disk cache off; default
+// $XDG_CACHE_HOME/ipcr_hip, else $HOME/.cache/ipcr_hip (created on first use; a directory that cannot be written
+// simply caches nothing).
+std::string jit_cache_dir() {
+    if (const char *dir = getenv("IPCR_JIT_CACHE_DIR")) return dir;
+    std::string base;
+    if (const char *x = getenv("XDG_CACHE_HOME")) base = x;
+    if (base.empty())
+        if (const char *h = getenv("HOME")) if (*h) base = std::string(h) + "/.cache";
+    if (base.empty()) return "";
+    const std::string dir = base + "/ipcr_hip";
+    static std::once_flag once;
+    std::call_once(once, [&] { (void)mkdir(base.c_str(), 0700); (void)mkdir(dir.c_str(), 0700); });
+    return dir;
+}
+
 // hiprtc -> code object for one group (no device needed except for the arch name)
 bool compile_group(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &err) {
     const std::string key = arch + "\n" + src;
     CodeCache &cc = code_cache();
-    {
+    const bool memcache = !(getenv("IPCR_JIT_NO_MEMCACHE") && atoi(getenv("IPCR_JIT_NO_MEMCACHE"))); // (off: bench.py measures what a fresh process pays)
+    if (memcache) {
         std::lock_guard<std::mutex> lk(cc.mu);
         const auto it = cc.map.find(key);
         if (it != cc.map.end()) { code = it->second; return true; }
@@ -791,7 +810,9 @@ bool compile_group(const std::string &src, const std::string &arch, std::vector<
     // of the code object and is used only when that key is byte-identical: a hash collision or a code object built
     // by another ROCm release is compiled afresh, never loaded silently.
     std::string disk, fullkey;
-    if (const char *dir = getenv("IPCR_JIT_CACHE_DIR")) {
+    {
+        const std::string cache_dir = jit_cache_dir();
+        const char *dir = cache_dir.c_str();
         if (*dir) {
             int vmaj = 0, vmin = 0;
             (void)hiprtcVersion(&vmaj, &vmin);

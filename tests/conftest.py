@@ -11,3 +11,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _private_jit_cache(tmp_path_factory):
+    """compiled kernels persist on disk by default ($XDG_CACHE_HOME/ipcr_hip): the tests use a directory of their own,
+    empty at the start of every session, so that every run compiles what it tests"""
+    if "IPCR_JIT_CACHE_DIR" not in os.environ:
+        os.environ["IPCR_JIT_CACHE_DIR"] = str(tmp_path_factory.mktemp("jit_cache"))
+    yield
