@@ -1237,3 +1237,59 @@ def test_device_slots_large_panel_and_native_pool(hip, monkeypatch, tmp_path):
     assert out["devices"] == [0, 1] and out["panel_device_slots"] == 2 and out["products_per_pass"] >= out["planted"] >= 5
     assert subprocess.run([exe, "1000000", "1500"], capture_output=True).returncode == 2      # chunk <= overlap: usage error
     assert subprocess.run([exe, "1000000", "500000", "0"], capture_output=True).returncode == 2  # no workers
+
+
+# ---- the whole range of --mismatches the ABI accepts (IPCR_MAX_MM = 16) -----------------------------
+
+@pytest.mark.parametrize("k", [5, 8, 16])
+@pytest.mark.parametrize("kind", ["specialised", "specialised_long", "table_driven"])
+def test_large_k_on_every_kernel(hip, k, kind):
+    """k = 5, 8, 16 (the seed index stops at k = 3; beyond it panels go to the specialised filter in groups, or to
+    filter_generic_kernel<17>): primers of up to 32 nt (the specialised filter verifies its own survivors), primers of
+    40-60 nt (filtered by their 20 positions next to the protected end, every survivor through the stand-alone verifier)
+    and the table-driven kernel, on random sequence with junk bytes and sites planted with up to k substitutions outside
+    the 3' window; HitCap 10000 and 0; vs the oracle (core/primer/match.go:67-84, core/engine/ac.go:186-213)"""
+    rng = random.Random(1000 * k + len(kind))
+    E, P = hip.engine, hip.primer.Pair
+    lo, hi = (40, 60) if kind == "specialised_long" else ((26, 32) if kind == "specialised" else (28, 50))
+    def mk():
+        L = rng.randint(lo, hi)
+        s = [rng.choice("ACGT") for _ in range(L)]
+        if rng.random() < 0.3:
+            s[rng.randrange(3, L - 4)] = rng.choice("RYSWKMN")
+        return "".join(s)
+    pairs = [P("p%d" % i, mk(), mk(), 0, 0) for i in range(2)]
+    n = 40_000
+    seq = rand_case(rng, n, with_junk=True)
+    for t in range(12):
+        p = pairs[t % 2]
+        a = 500 + t * 3000
+        def put(site, pos, nmut, protect_right):
+            site = list(site)
+            L = len(site)
+            free = list(range(0, L - 4)) if protect_right else list(range(4, L))
+            for j in rng.sample(free, min(nmut, len(free))):
+                site[j] = rng.choice([c for c in "ACGT" if c != site[j]])
+            seq[pos:pos + L] = site
+        fwd = [c if c in "ACGT" else "A" for c in p.Forward]
+        put(fwd, a, rng.choice([0, 1, k // 2, k]), True)
+        rc = [c if c in "ACGT" else "A" for c in O.revcomp(p.Reverse).decode()]
+        put(rc, a + 200, rng.choice([0, k // 2, k]), False)
+    text = "".join(seq).encode()
+    for hit_cap in (10000, 0):
+        cfg = E.Config(MaxMM=k, TerminalWindow=3, MaxLen=400, HitCap=hit_cap, SeedLen=12)
+        eng = E.New(cfg)
+        cp = eng.CompilePanel(pairs)
+        if kind == "table_driven":
+            cp.set_specialize(False)
+        sc = eng.NewSimulationScratch(cp)
+        got = eng.SimulateCompiledWithScratch("seq", text, cp, sc)
+        st = sc.stats()
+        assert st.kernel_kind == (2 if kind == "table_driven" else 1)
+        if kind == "specialised_long":
+            assert st.verify_ms > 0          # primers beyond 32 nt: every survivor goes through the stand-alone verifier
+        want = O.simulate_batch(ocfg(cfg), text, opairs(pairs))
+        assert [g.sig() for g in got] == [w.sig() for w in want]
+        assert len(want) >= 6, len(want)
+        sc.close()
+        cp.close()

@@ -368,6 +368,11 @@ def _counter_blocks(src):
     (3, 0, ("ACGTTGCATGCAAGCTAGCTAGGATC", "GGCCTTAAGGCCATATGGCATTACGGA")),
     (4, 2, ("ACGTTGCATGCAAGCTAGCTAGGATCAA", "GGCCTTAAGGCCATATGGCATTACGGAT")),
     (5, 0, ("ACGTTGCATGCAAGCTAGCTAGGATCAATT", "GGCCTTAAGGCCATATGGCATTACGGATCC")),
+    # the range the ABI accepts beyond what the index serves (IPCR_MAX_MM = 16): wide counters, long primers
+    (6, 3, ("ACGTTGCATGCAAGCTAGCTAGGATCAATT", "GGCCTTAAGGCCATATGGCATTACGGATCC")),
+    (8, 2, ("ACGTTGCATGCAAGCTAGCTAGGATCAATTGGCATGCAAT", "GGCCTTAAGGCCATATGGCATTACGGATCCAAGTCCGTAA")),
+    (12, 0, ("ACGTTGCATGCAAGCTAGCTAGGATCAATTGGCATGCAATTTGACCA", "GGCCTTAAGGCCATATGGCATTACGGATCCAAGTCCGTAACCGATTG")),
+    (16, 3, ("ACGTTGCATGCAAGCTAGCTAGGATCAATTGGCATGCAATTTGACCAGGT", "GGCCTTAAGGCCATATGGCATTACGGATCCAAGTCCGTAACCGATTGACC")),
 ])
 def test_generated_block_counters_are_exact(k, tw, primers, monkeypatch):
     """the "more than k of the B block flags are set" circuits the generator emits (thermometer or carry-save adder
@@ -379,24 +384,31 @@ def test_generated_block_counters_are_exact(k, tw, primers, monkeypatch):
         src = cp.filter_source(0)
         cp.close()
         blocks = _counter_blocks(src)
-        assert blocks, "no counter found in the generated source"
+        # (with k >= the unprotected positions of the 20-position filter window nothing is counted there: any number of
+        # mismatches passes the filter and the exact verifier decides)
+        assert blocks or k >= 16, "no counter found in the generated source"
         seen = set()
         for flags, stmts in blocks:
             key = (flags, tuple(stmts))
-            if key in seen or flags > 16:
+            if key in seen or flags > 20:   # (a filter window has 20 positions: 2^20 assignments at most)
                 continue
             seen.add(key)
             n = 1 << flags
             full = (1 << n) - 1
             env = {"f": 0, "FULL": full, "XOR3": lambda a, b, c: a ^ b ^ c, "MAJ3": lambda a, b, c: (a & b) | (c & (a | b))}
+            assign = np.arange(n, dtype=np.uint32)      # every assignment of the flags, as a number
+            as_int = lambda bits: int.from_bytes(np.packbits(bits, bitorder="little").tobytes(), "little")
             for i in range(flags):     # flag i as a truth-table column over all 2^flags assignments
-                env["e%d" % i] = sum(1 << a for a in range(n) if (a >> i) & 1)
+                env["e%d" % i] = as_int(((assign >> i) & 1).astype(np.uint8))
             for st in stmts:
                 st = st.rstrip(";").replace("const u32 ", "").replace("u32 ", "").replace("0u", "0")
                 for part in re.split(r",\s*(?=x\d+ = )", st):
                     part = re.sub(r"~(\w+)", r"(FULL ^ \1)", part)
                     exec(part, {}, env)
-            want = sum(1 << a for a in range(n) if bin(a).count("1") > k)
+            ones = np.zeros(n, dtype=np.uint8)
+            for i in range(flags):
+                ones += ((assign >> i) & 1).astype(np.uint8)
+            want = as_int((ones > k).astype(np.uint8))
             assert env["f"] & full == want, (k, flags, force, stmts)
 
 
