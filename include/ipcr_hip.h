@@ -122,6 +122,9 @@ typedef struct {
     uint32_t leftover_patterns;    /* how many of the panel's patterns those are */
     uint32_t leftover_kernels;     /* specialised spill-only filters that took them (0: the table-driven kernel did) */
     double hostpack_ms;            /* ipcr_scan_chunk: host time packing the caller's ASCII into bit planes (0: the bases went over the link as ASCII) */
+    uint32_t segmented;            /* 1: a capped scan with more raw matches than the hit buffer may take was repeated in position
+                                      order, range of blocks by range of blocks, keeping what HitCap can use (host.cpp: scan_segmented) */
+    uint32_t reserved0;
 } ipcr_scan_stats;
 
 typedef struct ipcr_panel ipcr_panel;     /* engine.CompiledPanel + device tables */

@@ -1256,11 +1256,14 @@ struct ipcr_scratch {
         bool times_pending = false;
         uint32_t nrec = 0, check_rst = 0, cset_used = 0;
         uint64_t nblocks = 0, pre = 0;
+        uint64_t block0 = 0;   // the launch sweeps blocks [block0, block0 + nblocks): the whole genome unless ...
+        bool segment = false;  // ... the scan runs in segments (scan_segmented)
         std::chrono::steady_clock::time_point t0;
     } pend;
     void *pinned = nullptr;                 // two counter sets (64 B) + first PREFIX hits + the sequence word
     uint32_t *d_tickets = nullptr;          // 65 counters, 128 B apart (specialised filter: last wave publishes)
     uint32_t seq = 0;                       // id of the last scan launched on this scratch
+    uint64_t seg_overflow = 0;       // scan_segmented: raw hits of a segment that did not fit
     std::vector<ipcr_hit> hits;      // sorted by (record, pattern, pos)
     std::vector<ipcr_hit> hits_raw;  // in device append order
     std::vector<uint32_t> bucket;    // scratch of sort_hits
@@ -1290,6 +1293,13 @@ constexpr uint64_t QCAP_INIT = 1ull << 13;  // per segment: 256 x 8 Ki surviving
 constexpr uint64_t HCAP_INIT = 1ull << 20;  // 1 Mi hits (32 MiB)
 constexpr uint64_t QCAP_MAX = 1ull << 23;   // per segment (2 Gi words in all)
 constexpr uint64_t HCAP_MAX = 1ull << 28;
+// With a hit cap, only the first HitCap matches per orientation and record can matter (core/primer/match.go:86-88,
+// core/engine/hit_collect.go:80-82): a scan whose raw matches exceed this many records is not regrown any further but
+// repeated in position order, segment by segment (scan_segmented).  IPCR_TEST_HCAP_SOFT: tests.
+uint64_t hcap_soft() {
+    const char *e = getenv("IPCR_TEST_HCAP_SOFT"); // (read at every overflow: a rare path)
+    return e && *e ? std::max<uint64_t>(64, strtoull(e, nullptr, 10)) : (1ull << 24);
+}
 
 ipcr_status panel_upload(const ipcr_panel *cp, int mode, int slot, SetDev **out) {
     ipcr_panel *p = const_cast<ipcr_panel *>(cp);
@@ -1501,6 +1511,9 @@ ipcr_status wait_published(ipcr_scratch *s) {
     }
 }
 
+ipcr_status scan_segmented(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g, uint64_t seen_hits);
+inline bool hit_has_idx_below(const ipcr_hit *h, int tw);
+
 // enqueue one attempt: the specialised filter alone (it verifies and publishes itself), or the seed-index /
 // table-driven filter + verify kernel + read-back of counters and first hits behind a marker event
 ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
@@ -1513,7 +1526,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     unsigned long long *qc = s->d_qcounts + qset * s->cset, *qc_next = s->d_qcounts + qset * (s->cset ^ 1u);
     pd.cset_used = s->cset;
     s->cset ^= 1u;
-    const uint64_t nblocks = pd.nblocks;
+    const uint64_t nblocks = pd.nblocks, block0 = pd.block0;
     trace("launch>", s);
     const hipStream_t own = s->stream;
     const hipStream_t lane = s->lane_next ? s->lane_next->s : own;
@@ -1559,7 +1572,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
                 static const int withhold = getenv("IPCR_TEST_WITHHOLD_TAG") ? atoi(getenv("IPCR_TEST_WITHHOLD_TAG")) : 0;
                 v.withhold = withhold > 0 ? (uint32_t)withhold : 0u;
             }
-            HIPCHK(ipcr::jit_launch(sd.jit[gi], lane, g->planes, nblocks, s->d_queue, s->qcap, qc, v,
+            HIPCHK(ipcr::jit_launch(sd.jit[gi], lane, g->planes, block0, nblocks, s->d_queue, s->qcap, qc, v,
                                     gi == 0 ? s->ev[0] : nullptr, gi + 1 == sd.jit.size() ? s->ev[1] : nullptr));
         }
         s->stats.kernel_kind = 1;
@@ -1567,7 +1580,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     } else if (sd.index_jit) {
         const IndexPlan &ix = set.index;
         const bool more = !ix.leftover.empty();
-        HIPCHK(ipcr::jit_launch_index(sd.index_jit, lane, g->planes, nblocks, (uint32_t)ix.shapes.size(), sd.d_lds_image, sd.d_table,
+        HIPCHK(ipcr::jit_launch_index(sd.index_jit, lane, g->planes, block0, nblocks, (uint32_t)ix.shapes.size(), sd.d_lds_image, sd.d_table,
                                       (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, qc, s->d_tickets, s->ev[0], more ? nullptr : s->ev[1]));
         if (more && !sd.leftover_jit.empty()) { // patterns the index cannot key: specialised filters that only fill the queue
             ipcr::JitVerify v;
@@ -1583,17 +1596,17 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             v.hcap = s->hcap;
             v.counts = cnt;
             for (size_t gi = 0; gi < sd.leftover_jit.size(); ++gi)
-                HIPCHK(ipcr::jit_launch(sd.leftover_jit[gi], lane, g->planes, nblocks, s->d_queue, s->qcap, qc, v, nullptr,
+                HIPCHK(ipcr::jit_launch(sd.leftover_jit[gi], lane, g->planes, block0, nblocks, s->d_queue, s->qcap, qc, v, nullptr,
                                         gi + 1 == sd.leftover_jit.size() ? s->ev[1] : nullptr));
         } else if (more)
-            HIPCHK(ipcr::launch_filter_generic(lane, g->planes, nblocks, sd.dev, (uint32_t)ix.leftover.size(),
+            HIPCHK(ipcr::launch_filter_generic(lane, g->planes, block0, nblocks, sd.dev, (uint32_t)ix.leftover.size(),
                                                (uint32_t)p->cfg.max_mm, sd.d_leftover, s->d_queue, s->qcap, qc,
                                                nullptr, s->ev[1]));
         s->stats.kernel_kind = 3;
         s->stats.leftover_patterns = (uint32_t)ix.leftover.size();
         s->stats.leftover_kernels = (uint32_t)sd.leftover_jit.size();
     } else {
-        HIPCHK(ipcr::launch_filter_generic(lane, g->planes, nblocks, sd.dev, (uint32_t)set.ids.size(),
+        HIPCHK(ipcr::launch_filter_generic(lane, g->planes, block0, nblocks, sd.dev, (uint32_t)set.ids.size(),
                                            (uint32_t)p->cfg.max_mm, nullptr, s->d_queue, s->qcap, qc, s->ev[0], s->ev[1]));
         s->stats.kernel_kind = 2;
     }
@@ -1642,6 +1655,8 @@ ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g, b
     const PatternSet &set = p->set[pd.mode];
     pd.nrec = (uint32_t)g->rec_start.size();
     pd.nblocks = (g->next_col + 63) / 64;
+    pd.block0 = 0;
+    pd.segment = false;
     pd.check_rst = (chunk || genome_any_reset(g)) ? 1u : 0u;
     s->stats.bases = g->total_bases;
     s->stats.tile_bytes = pd.nblocks * IPCR_BLOCK_PLANE_WORDS * 4ull;
@@ -1705,7 +1720,13 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         if (fullest > s->qcap) { // a queue segment overflowed: regrow all segments and rescan
             uint64_t want = s->qcap;
             while (want < fullest) want *= 2;
-            if (want > QCAP_MAX) return fail(IPCR_ERR_CAPACITY, "%llu filter survivors in one queue segment exceed the device queue limit", (unsigned long long)fullest);
+            if (want > QCAP_MAX) {
+                if (p->cfg.hit_cap > 0) { // as below: a capped scan goes on in segments
+                    if (pd.segment) { s->seg_overflow = ~0ull; return IPCR_ERR_CAPACITY; }
+                    return scan_segmented(p, s, g, hcap_soft() * 16u);
+                }
+                return fail(IPCR_ERR_CAPACITY, "%llu filter survivors in one queue segment exceed the device queue limit", (unsigned long long)fullest);
+            }
             HIPCHK(hipFree(s->d_queue));
             s->d_queue = nullptr;
             HIPCHK(hipMalloc((void **)&s->d_queue, want * IPCR_QUEUE_SHARDS * sizeof(ipcr_queue_entry)));
@@ -1717,6 +1738,12 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         if (nhit > s->hcap) {
             uint64_t want = s->hcap;
             while (want < nhit) want *= 2;
+            if (p->cfg.hit_cap > 0 && nhit > hcap_soft()) {
+                // far more raw matches than a capped scan can use (a low-complexity primer on low-complexity sequence): the
+                // reference stops every orientation at HitCap; here the scan is repeated in position order, in segments
+                if (pd.segment) { s->seg_overflow = nhit; return IPCR_ERR_CAPACITY; } // (a segment of scan_segmented: it halves and retries)
+                return scan_segmented(p, s, g, nhit);
+            }
             if (want > HCAP_MAX) return fail(IPCR_ERR_CAPACITY, "%llu hits exceed the device hit-buffer limit", (unsigned long long)nhit);
             HIPCHK(hipFree(s->d_hitbuf));
             s->d_hitbuf = nullptr;
@@ -1802,6 +1829,67 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         return IPCR_OK;
     }
     return fail(IPCR_ERR_CAPACITY, "scan buffers kept overflowing");
+}
+
+// A capped scan with far more raw matches than anybody can use.  The reference's collectors stop at HitCap matches
+// per orientation and record, in ascending position (core/engine/hit_collect.go:80-82; FindMatches: core/primer/match.go:86-88),
+// so it never holds more; the device appends matches in no particular order, so it cannot stop early in one sweep.  Here the
+// sweep is repeated over consecutive RANGES OF BLOCKS (positions ascend from range to range; every window belongs to the
+// block it starts in, so the ranges partition the windows exactly), the host keeps a (record, pattern)'s matches until
+// HitCap of them have passed the 5' window filter the host applies for patterns the device scans unprotected (that is
+// at least HitCap raw ones: enough for the reference's cap-before-filter quirk too, orientation_matches), and ignores the
+// rest.  Memory stays bounded by the soft limit per range; a range that still overflows is halved.
+ipcr_status scan_segmented(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g, uint64_t seen_hits) {
+    ipcr_scratch::Pending &pd = s->pend;
+    const uint64_t total = (g->next_col + 63) / 64;
+    const uint64_t cap = (uint64_t)p->cfg.hit_cap;
+    const size_t ndefs = p->defs.size();
+    std::vector<ipcr_hit> kept;
+    std::map<uint64_t, uint64_t> passed; // (record << 32 | pattern) -> matches that passed the host's window filter so far
+    uint64_t seg = std::max<uint64_t>(1, total * (hcap_soft() / 2) / std::max<uint64_t>(seen_hits, 1)); // expect ~half the limit per range
+    double filter_ms = 0, verify_ms = 0;
+    uint64_t cand = 0;
+    for (uint64_t b0 = 0; b0 < total;) {
+        const uint64_t nb = std::min(seg, total - b0);
+        pd.active = true;
+        pd.segment = true;
+        pd.block0 = b0;
+        pd.nblocks = nb;
+        ipcr_status st = scan_launch(p, s, g);
+        if (st == IPCR_OK) st = scan_collect(p, s, g);
+        if (st == IPCR_ERR_CAPACITY && s->seg_overflow) { // this range alone exceeds the limit: smaller ranges
+            s->seg_overflow = 0;
+            if (seg == 1) return fail(IPCR_ERR_CAPACITY, "one block of the genome holds more raw matches than the device hit buffer may take");
+            seg = std::max<uint64_t>(1, nb / 2);
+            continue;
+        }
+        if (st != IPCR_OK) return st;
+        filter_ms += s->stats.filter_ms;
+        verify_ms += s->stats.verify_ms;
+        cand += s->stats.candidates;
+        // s->hits: this range's matches, sorted by (record, pattern, position) and free of duplicates
+        for (const ipcr_hit &h : s->hits) {
+            const uint32_t pat = h.pattern & 0x7FFFFFFFu;
+            uint64_t &n = passed[((uint64_t)h.record << 32) | pat];
+            if (n >= cap) continue; // this orientation of this record has all it can use
+            kept.push_back(h);
+            const bool dropped_by_host = pat < ndefs && p->defs[pat].left && hit_has_idx_below(&h, p->tw);
+            if (!dropped_by_host) ++n;
+        }
+        b0 += nb;
+    }
+    pd.segment = false;
+    pd.block0 = 0;
+    pd.nblocks = total;
+    s->hits_raw = kept;
+    sort_hits(s->hits_raw, s->hits, pd.nrec, (uint32_t)ndefs);
+    s->stats.filter_ms = filter_ms;
+    s->stats.verify_ms = verify_ms;
+    s->stats.candidates = cand;
+    s->stats.hits = s->hits.size();
+    s->stats.segmented = 1;
+    s->stats.total_ms = ms_since(pd.t0);
+    return IPCR_OK;
 }
 
 ipcr_status scan_hits(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {

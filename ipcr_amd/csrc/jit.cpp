@@ -573,7 +573,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     s << "};\n";
     s << "#define CAND_CAP " << CAND_CAP << "u\n";
     s << "// IPCR_WAVES_PER_GROUP " << WPG << "\n";
-    s << "extern \"C\" __global__ void __launch_bounds__(" << WPG * 64 << ", " << WPS << ") ipcr_filter(const v4* __restrict__ planes, u64 nblocks,\n"
+    s << "extern \"C\" __global__ void __launch_bounds__(" << WPG * 64 << ", " << WPS << ") ipcr_filter(const v4* __restrict__ planes, u64 block0, u64 nblocks,\n"
          "    qent* __restrict__ queue_all, u64 qcap, u64* __restrict__ qcount_all,\n"
          "    const u32* __restrict__ rst, const dpat* __restrict__ pats, const u64* __restrict__ rec_start,\n"
          "    const u64* __restrict__ rec_len, const u32* __restrict__ block_rec, u32 nrec, u32 max_mm, u32 check_rst,\n"
@@ -583,13 +583,14 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
          "    u32 withhold) {\n";
     s << "  const u32 lane = threadIdx.x & 63u;\n";
     s << "  const u32 wv = threadIdx.x >> 6;\n";
-    s << "  const u64 block = (u64)blockIdx.x * " << WPG << "u + wv;\n";
+    s << "  const u64 bidx = (u64)blockIdx.x * " << WPG << "u + wv; // this launch sweeps blocks [block0, block0 + nblocks)\n";
+    s << "  const u64 block = block0 + bidx;\n";
     // the counters alternate between two sets; workgroup 0 clears the set the NEXT scan will use
     s << "  if (blockIdx.x == 0u && next_counts) {\n"
          "    if (threadIdx.x < 4u) next_counts[threadIdx.x] = 0ull;\n"
          "    for (u32 t = threadIdx.x; t < 256u; t += " << WPG * 64 << "u) next_qcount[t * 16u] = 0ull;\n"
          "  }\n";
-    s << "  if (block >= nblocks) return;\n";
+    s << "  if (bidx >= nblocks) return;\n";
     s << "  __shared__ u64 lkey_all[" << WPG << "][LIST_CAP + 1u];\n";
     s << "  __shared__ u32 lbits_all[" << WPG << "][LIST_CAP + 1u];\n";
     s << "  __shared__ u32 lcnt_all[" << WPG << "];\n";
@@ -730,7 +731,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
          "    // my ticket; nothing of mine sits dirty in this XCD's L2 that the last wave reads, so no L2 write-back\n"
          "    // (thousands of waves issuing one cost half the kernel time again)\n"
          "    if (wrote || ncand) asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
-         "    const u32 sh = (u32)block & 63u;\n"
+         "    const u32 sh = (u32)bidx & 63u;\n"
          "    const u32 expect = (u32)((nblocks - sh + 63ull) >> 6); // waves of this ticket shard\n"
          "    u32 t = 0u;\n"
          "    if (lane == 0u) t = atomicAdd(tickets + sh * 32u, 1u);\n"
@@ -1189,7 +1190,7 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
   return e0.x;
 }
 )SRC";
-    s << "extern \"C\" __global__ void __launch_bounds__(" << IPCR_INDEX_WAVES * 64u << ", " << IPCR_INDEX_WAVES / 4u << ") ipcr_index_filter(const u32* __restrict__ planes, u64 ncolpairs,\n"
+    s << "extern \"C\" __global__ void __launch_bounds__(" << IPCR_INDEX_WAVES * 64u << ", " << IPCR_INDEX_WAVES / 4u << ") ipcr_index_filter(const u32* __restrict__ planes, u64 cp0, u64 ncolpairs, // units [cp0, cp0 + ncolpairs)\n"
          "    const u32* __restrict__ lds_image, const v4* __restrict__ table, u32 max_mm,\n"
          "    qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount, u32* __restrict__ work, u64* __restrict__ stamps) {\n"
          "  __shared__ u32 lds[((LDS_WORDS + 3u) & ~3u) + " << IPCR_INDEX_WAVES << "u * QCAP * 4u]; // static: every LDS address is a compile-time offset\n"
@@ -1224,10 +1225,10 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
         s << "  for (;;) { // one unit = one column pair = 64 strands\n"
              "    u32 take = 0u;\n"
              "    if (lane == 0u) take = atomicAdd(work, 1u);\n"
-             "    const u64 cp = (u64)(u32)__builtin_amdgcn_readfirstlane((int)take);\n"
-             "    if (cp >= ncolpairs) break;\n";
+             "    if ((u64)(u32)__builtin_amdgcn_readfirstlane((int)take) >= ncolpairs) break;\n"
+             "    const u64 cp = cp0 + (u64)(u32)__builtin_amdgcn_readfirstlane((int)take);\n";
     else
-        s << "  for (u64 cp = wave0; cp < ncolpairs; cp += nwaves) { // one unit = one column pair = 64 strands\n";
+        s << "  for (u64 cp = cp0 + wave0; cp < cp0 + ncolpairs; cp += nwaves) { // one unit = one column pair = 64 strands\n";
     s << "    auto flush = [&]() __attribute__((always_inline)) {\n"
          "      u32 n = qn;\n"
          "      const u64 unit_base = cp * 8192u; // first position of this unit\n"
@@ -1472,11 +1473,11 @@ JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, const In
     return f; // the kernel's LDS (image + hit queues, up to 160 KiB) is static: nothing to request at launch
 }
 
-hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint32_t /*nshapes*/,
+hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t block0, uint64_t nblocks, uint32_t /*nshapes*/,
                             const uint32_t *lds_image, const void *table, uint32_t max_mm, void *queue,
                             uint64_t qcap, unsigned long long *qcount, uint32_t *work, hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0) return hipSuccess;
-    uint64_t ncolpairs = nblocks * 32u; // (the rolled kernel's unit is SW column pairs: a smaller genome only leaves some waves idle)
+    uint64_t cp0 = block0 * 32u, ncolpairs = nblocks * 32u; // one unit = one column pair
     // one persistent 16-wave workgroup per CU: the bitmaps are staged into LDS once per CU
     uint64_t grid = 256ull;
     if (grid * IPCR_INDEX_WAVES > ncolpairs) grid = (ncolpairs + IPCR_INDEX_WAVES - 1u) / IPCR_INDEX_WAVES;
@@ -1488,7 +1489,7 @@ hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes
         if (hipMalloc((void **)&stamps, nstamp * 8u) != hipSuccess) stamps = nullptr;
         else (void)hipMemsetAsync(stamps, 0, nstamp * 8u, st);
     }
-    void *args[] = {(void *)&planes, (void *)&ncolpairs, (void *)&lds_image, (void *)&table,
+    void *args[] = {(void *)&planes, (void *)&cp0, (void *)&ncolpairs, (void *)&lds_image, (void *)&table,
                     (void *)&max_mm, (void *)&queue, (void *)&qcap, (void *)&qcount, (void *)&work, (void *)&stamps};
     const hipError_t e = hipExtModuleLaunchKernel(f->fn, (unsigned)grid * IPCR_INDEX_WAVES * 64u, 1, 1, IPCR_INDEX_WAVES * 64u, 1, 1, 0, st, args, nullptr, start, stop, 0);
     if (stamps) {
@@ -1505,11 +1506,11 @@ hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes
     return e;
 }
 
-hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,
+hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t block0, uint64_t nblocks, void *queue,
                       uint64_t qcap, unsigned long long *qcount, const JitVerify &v, hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0) return hipSuccess;
     JitVerify a = v;
-    void *args[] = {(void *)&planes, (void *)&nblocks, (void *)&queue, (void *)&qcap, (void *)&qcount,
+    void *args[] = {(void *)&planes, (void *)&block0, (void *)&nblocks, (void *)&queue, (void *)&qcap, (void *)&qcount,
                     (void *)&a.rst, (void *)&a.pats, (void *)&a.rec_start, (void *)&a.rec_len, (void *)&a.block_rec, (void *)&a.nrec,
                     (void *)&a.max_mm, (void *)&a.check_rst, (void *)&a.hits, (void *)&a.hcap, (void *)&a.counts,
                     (void *)&a.next_counts, (void *)&a.next_qcount, (void *)&a.tickets, (void *)&a.pub,

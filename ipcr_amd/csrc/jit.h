@@ -56,7 +56,8 @@ struct JitVerify {
     uint32_t seq = 0;
     uint32_t withhold = 0; // tests: slot + 1 of a record published with a stale tag in its first half (a torn record)
 };
-hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, void *queue,
+// blocks [block0, block0 + nblocks) of the tiles
+hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t block0, uint64_t nblocks, void *queue,
                       uint64_t qcap, unsigned long long *qcount, const JitVerify &v, hipEvent_t start, hipEvent_t stop);
 // seed-index filter for large panels, with the panel's key shapes baked in (host.cpp: build_index)
 struct IndexGeom {
@@ -68,7 +69,7 @@ struct IndexGeom {
 };
 std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom);
 JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom, std::string &err);
-hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t nblocks, uint32_t nshapes,
+hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t block0, uint64_t nblocks, uint32_t nshapes,
                             const uint32_t *lds_image, const void *table, uint32_t max_mm, void *queue,
                             uint64_t qcap, unsigned long long *qcount, uint32_t *work, hipEvent_t start, hipEvent_t stop);
 // work: two zeroed counters 128 B apart (unit counter, leavers); the kernel leaves them zeroed again

@@ -253,7 +253,7 @@ __device__ __forceinline__ uint32_t fetch_row(const uint32_t *__restrict__ plane
 // count > k, kills the position.  Survivors go to the candidate queue.
 template <int KMAX>
 __global__ __launch_bounds__(256) void filter_generic_kernel(const uint32_t *__restrict__ planes,
-                                                             uint64_t nblocks,
+                                                             uint64_t block0, uint64_t nblocks, // blocks [block0, block0 + nblocks)
                                                              const ipcr_dev_pattern *__restrict__ pats,
                                                              uint32_t npat, uint32_t max_mm,
                                                              const uint32_t *__restrict__ sel, // pattern subset or null
@@ -261,9 +261,9 @@ __global__ __launch_bounds__(256) void filter_generic_kernel(const uint32_t *__r
                                                              unsigned long long *__restrict__ qcount) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t tile = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); // (block, row)
-    const uint64_t block = tile >> 7;
+    if ((tile >> 7) >= nblocks) return;
+    const uint64_t block = block0 + (tile >> 7);
     const uint32_t row = (uint32_t)(tile & 127u);
-    if (block >= nblocks) return;
 
     for (uint32_t qi = 0; qi < npat; ++qi) {
         const uint32_t q = sel ? sel[qi] : qi;
@@ -314,10 +314,10 @@ __global__ __launch_bounds__(256) void filter_generic_kernel(const uint32_t *__r
     }
 }
 
-template __global__ void filter_generic_kernel<4>(const uint32_t *, uint64_t, const ipcr_dev_pattern *, uint32_t,
+template __global__ void filter_generic_kernel<4>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t,
                                                   uint32_t, const uint32_t *, ipcr_queue_entry *, uint64_t,
                                                   unsigned long long *);
-template __global__ void filter_generic_kernel<17>(const uint32_t *, uint64_t, const ipcr_dev_pattern *, uint32_t,
+template __global__ void filter_generic_kernel<17>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t,
                                                    uint32_t, const uint32_t *, ipcr_queue_entry *, uint64_t,
                                                    unsigned long long *);
 
@@ -599,7 +599,7 @@ hipError_t launch_lcg(hipStream_t st, uint8_t *out, uint64_t n, uint32_t seed, u
     return hipGetLastError();
 }
 
-hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_t nblocks,
+hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_t block0, uint64_t nblocks,
                                  const ipcr_dev_pattern *pats, uint32_t npat, uint32_t max_mm, const uint32_t *sel,
                                  ipcr_queue_entry *queue, uint64_t qcap, unsigned long long *qcount,
                                  hipEvent_t start, hipEvent_t stop) {
@@ -607,10 +607,10 @@ hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_
     const uint64_t tiles = nblocks * 128u; // one wave per (block, row)
     const dim3 grid((uint32_t)((tiles + 3u) / 4u));
     if (max_mm <= 3u)
-        hipExtLaunchKernelGGL(filter_generic_kernel<4>, grid, dim3(256), 0, st, start, stop, 0, planes, nblocks, pats,
+        hipExtLaunchKernelGGL(filter_generic_kernel<4>, grid, dim3(256), 0, st, start, stop, 0, planes, block0, nblocks, pats,
                               npat, max_mm, sel, queue, qcap, qcount);
     else
-        hipExtLaunchKernelGGL(filter_generic_kernel<17>, grid, dim3(256), 0, st, start, stop, 0, planes, nblocks, pats,
+        hipExtLaunchKernelGGL(filter_generic_kernel<17>, grid, dim3(256), 0, st, start, stop, 0, planes, block0, nblocks, pats,
                               npat, max_mm, sel, queue, qcap, qcount);
     return hipGetLastError();
 }

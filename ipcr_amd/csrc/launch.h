@@ -22,7 +22,7 @@ hipError_t launch_pack_batch(hipStream_t st, const uint8_t *base, const ipcr_pac
                              uint32_t nrec, uint64_t total_pairs, uint32_t *planes, uint32_t *rst, uint32_t *rec_flags);
 hipError_t launch_fill_pad(hipStream_t st, uint32_t *planes, uint32_t *rst, uint64_t col_begin, uint64_t col_end);
 hipError_t launch_lcg(hipStream_t st, uint8_t *out, uint64_t n, uint32_t seed, uint64_t offset);
-hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_t nblocks,
+hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_t block0, uint64_t nblocks,
                                  const ipcr_dev_pattern *pats, uint32_t npat, uint32_t max_mm, const uint32_t *sel,
                                  ipcr_queue_entry *queue, uint64_t qcap, unsigned long long *qcount,
                                  hipEvent_t start, hipEvent_t stop);

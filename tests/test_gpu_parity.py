@@ -1293,3 +1293,46 @@ def test_large_k_on_every_kernel(hip, k, kind):
         assert len(want) >= 6, len(want)
         sc.close()
         cp.close()
+
+
+@pytest.mark.parametrize("k,tw,cap", [(0, 3, 50), (1, 3, 7), (2, 0, 1000)])
+def test_hit_cap_bounds_device_memory(hip, monkeypatch, k, tw, cap):
+    """A low-complexity primer on low-complexity sequence: millions of raw matches of which HitCap per orientation and
+    record can matter (core/primer/match.go:86-88, core/engine/hit_collect.go:80-82).  Beyond a soft limit of raw hit
+    records (lowered here: IPCR_TEST_HCAP_SOFT) the scan is not regrown but repeated in position order over ranges of
+    blocks, the host keeping what the cap can use (host.cpp: scan_segmented): the products equal the oracle's, the
+    5'-window / cap-before-filter quirks of the rc orientations included, and the device hit buffer stays small."""
+    monkeypatch.setenv("IPCR_TEST_HCAP_SOFT", "30000")
+    E, P = hip.engine, hip.primer.Pair
+    rng = random.Random(9 + k)
+    recs = []
+    for r in range(3):
+        s = bytearray(b"A" * 400_000)
+        for _ in range(40):                     # a few other bases and junk bytes: mismatches, reset bytes, record-specific caps
+            i = rng.randrange(len(s))
+            s[i] = rng.choice(b"CGTNn")
+        if r == 1:
+            s[1000:1012] = b"TTTTTTTTTTTT"
+        recs.append(bytes(s))
+    pairs = [P("polyA", "AAAAAAAAAAAA", "TTTTTTTTTTTT"), P("mixed", "AAAAAACAAAAA", "TTTTTTTTTTGT")]
+    cfg = E.Config(MaxMM=k, TerminalWindow=tw, MaxLen=60, HitCap=cap, SeedLen=12)
+    eng = E.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    sc = eng.NewSimulationScratch(cp)
+    g = E.Genome(sum(map(len, recs)) + (1 << 16), 4)
+    for r, s in enumerate(recs):
+        g.add_record("r%d" % r, s)
+    got = eng.ScanGenome(g, cp, sc)
+    st = sc.stats()
+    assert st.segmented == 1
+    _, _, hcap = sc.device_hits()
+    assert hcap <= (1 << 20)                    # the initial buffer: never regrown towards the raw match count
+    want = []
+    for r, s in enumerate(recs):
+        for w in O.simulate_batch(ocfg(cfg), s, opairs(pairs)):
+            want.append((r,) + w.sig())
+    assert [(p.Record,) + p.sig() for p in got] == want and len(want) >= 10
+    # the chunk path goes the same way (one record may fit the buffer as it is)
+    got1 = eng.SimulateCompiledWithScratch("r1", recs[1], cp, sc)
+    assert [p.sig() for p in got1] == [w.sig() for w in O.simulate_batch(ocfg(cfg), recs[1], opairs(pairs))]
+    g.close(); sc.close(); cp.close()
