@@ -164,6 +164,11 @@ int32_t ipcr_panel_max_primer_len(const ipcr_panel *p);
 int32_t ipcr_panel_have(const ipcr_panel *p, int32_t pair, char which);
 /* 0 = table-driven filter only, 1 = allow the panel-specialised filter (default) */
 ipcr_status ipcr_panel_set_specialize(ipcr_panel *p, int32_t enable);
+/* A small panel (<= 16 distinct patterns) does not make its first scans wait for the kernel build (hiprtc, ~0.8 s): the
+ * build runs on a thread of its own and the scans before it is done take the table-driven kernel -- same results,
+ * ipcr_scan_stats.kernel_kind says which ran.  ipcr_panel_wait_ready blocks until the kernels of every device the panel
+ * has been scanned on are built (measurements; IPCR_JIT_ASYNC=0 in the environment makes every build synchronous). */
+ipcr_status ipcr_panel_wait_ready(const ipcr_panel *p);
 /* devices this panel holds tables and kernels on (one per device it has been scanned on) */
 int32_t ipcr_panel_device_slots(const ipcr_panel *p);
 /* Pattern-axis sharding (one genome x a huge panel over several GPUs): this panel object scans only

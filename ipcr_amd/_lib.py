@@ -99,6 +99,7 @@ SYMBOLS = {
     "ipcr_scratch_create_on": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "ipcr_scratch_device": (C.c_int32, [C.c_void_p]),
     "ipcr_panel_device_slots": (C.c_int32, [C.c_void_p]),
+    "ipcr_panel_wait_ready": (C.c_int, [C.c_void_p]),
     "ipcr_genome_create_on": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int32, C.POINTER(C.c_void_p)]),
     "ipcr_genome_device": (C.c_int32, [C.c_void_p]),
     "ipcr_scratch_create_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

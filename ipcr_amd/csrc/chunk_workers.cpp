@@ -191,6 +191,7 @@ int main(int argc, char **argv) {
         for (size_t w = 0; w < scs.size(); ++w) // worker w -> device w mod N
             if (ipcr_scratch_create_on(panel, devices[w % devices.size()], &scs[w]) != IPCR_OK) { fprintf(stderr, "%s\n", ipcr_last_error()); return 5; }
         for (auto &sc : scs) (void)ipcr_scan_chunk(panel, sc, jobs[0].data(), jobs[0].size(), nullptr, nullptr); // kernel build, buffers
+        (void)ipcr_panel_wait_ready(panel); // (a small panel's kernels are built in the background: the timed passes run on them)
         const size_t reps = std::max<size_t>(1, ((size_t)32 * (size_t)W + jobs.size() - 1) / jobs.size()); // >= 32 chunks per worker
         const size_t total = reps * jobs.size();
         uint64_t bases = 0;

@@ -245,7 +245,11 @@ struct IndexPlan {
 // process by source, so a second slot pays the module load only)
 struct SetDev {
     ipcr_dev_pattern *dev = nullptr;
-    std::vector<ipcr::JitFilter *> jit; // one kernel per pattern group
+    std::vector<ipcr::JitFilter *> jit; // one kernel per pattern group; written once, then published through jit_pub
+    // what a scan uses: null until the kernels exist (a scan of a small panel does not wait for hiprtc: panel_upload)
+    std::atomic<const std::vector<ipcr::JitFilter *> *> jit_pub{nullptr};
+    std::thread jit_thread;     // builds `jit` in the background
+    std::atomic<int> jit_state{0}; // 0 nothing in flight, 1 building, 2 built (to be published by the next panel_upload)
     bool jit_tried = false;
     bool index_tried = false;
     uint32_t *d_lds_image = nullptr;
@@ -749,6 +753,7 @@ void ipcr_panel_destroy(ipcr_panel *p) {
     for (auto &kv : p->devs) {
         DeviceGuard dg(kv.first);
         for (SetDev &s : kv.second->set) {
+            if (s.jit_thread.joinable()) s.jit_thread.join();
             if (s.index_jit) ipcr::jit_destroy(s.index_jit);
             for (ipcr::JitFilter *f : s.leftover_jit) ipcr::jit_destroy(f);
             if (s.d_lds_image) (void)hipFree(s.d_lds_image);
@@ -759,6 +764,21 @@ void ipcr_panel_destroy(ipcr_panel *p) {
         }
     }
     delete p;
+}
+
+ipcr_status ipcr_panel_wait_ready(const ipcr_panel *cp) {
+    if (!cp) return fail(IPCR_ERR_INVALID, "null panel");
+    ipcr_panel *p = const_cast<ipcr_panel *>(cp);
+    std::lock_guard<std::mutex> lock(p->mu);
+    for (auto &kv : p->devs)
+        for (SetDev &d : kv.second->set) {
+            if (d.jit_thread.joinable()) d.jit_thread.join();
+            if (d.jit_state.load(std::memory_order_acquire) == 2) {
+                d.jit_pub.store(&d.jit, std::memory_order_release);
+                d.jit_state.store(0);
+            }
+        }
+    return IPCR_OK;
 }
 
 int32_t ipcr_panel_device_slots(const ipcr_panel *p) {
@@ -1316,10 +1336,39 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode, int slot, SetDev **out)
     const bool force_index = getenv("IPCR_FORCE_INDEX") && atoi(getenv("IPCR_FORCE_INDEX")) != 0;
     if (p->specialize && !d.jit_tried && !s.host.empty()) {
         d.jit_tried = true;
-        if (!force_index) d.jit = ipcr::jit_build(s.host, p->cfg.max_mm, s.jit_error);
+        // hiprtc takes ~0.8 s for a C2-sized panel; the table-driven kernel scans such a panel at ~4 ms per pattern and 3 Gb.
+        // So a SMALL panel's first scans do not wait: the kernels are built on a thread of their own, the scans that come
+        // before they are ready take the table-driven kernel (same results: both are parity-tested against the oracle), and
+        // the first panel_upload after the build publishes them.  A cold `ipcr` run on a 3 Gb genome has its products after
+        // ~20 ms instead of ~0.8 s.  Larger panels wait (their table-driven scan would cost more than the build).
+        // IPCR_JIT_ASYNC=0: always wait (tests, measurements); ipcr_panel_wait_ready: wait now.
+        static const bool async_on = env_flag("IPCR_JIT_ASYNC", true);
+        const bool async = async_on && !force_index && s.host.size() <= 16;
+        if (!force_index && !async) {
+            d.jit = ipcr::jit_build(s.host, p->cfg.max_mm, s.jit_error);
+            d.jit_pub.store(&d.jit, std::memory_order_release);
+        } else if (async) {
+            d.jit_state.store(1);
+            const int max_mm = p->cfg.max_mm;
+            SetDev *dp = &d;
+            PatternSet *sp = &s;
+            d.jit_thread = std::thread([dp, sp, max_mm, slot] {
+                DeviceGuard dgt(slot); // the code objects are loaded onto the slot's device
+                std::string err;
+                dp->jit = ipcr::jit_build(sp->host, max_mm, err);
+                if (dp->jit.empty()) sp->jit_error = err; // (read only after the join / state 2)
+                dp->jit_state.store(2, std::memory_order_release);
+            });
+        }
     }
+    if (d.jit_state.load(std::memory_order_acquire) == 2) { // the background build has finished: scans from now on use its kernels
+        if (d.jit_thread.joinable()) d.jit_thread.join();
+        d.jit_pub.store(&d.jit, std::memory_order_release);
+        d.jit_state.store(0);
+    }
+    const bool building = d.jit_state.load() == 1;
     // panels too large to specialise: seed-index filter (+ table-driven kernel for what it cannot key)
-    if (p->specialize && d.jit.empty() && !d.index_tried && !s.host.empty() && p->cfg.max_mm <= 3) {
+    if (p->specialize && !building && d.jit.empty() && !d.index_tried && !s.host.empty() && p->cfg.max_mm <= 3) {
         d.index_tried = true;
         if (!s.index.built) build_index(*p, s);
         IndexPlan &ix = s.index;
@@ -1520,6 +1569,9 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     ipcr_scratch::Pending &pd = s->pend;
     const PatternSet &set = p->set[pd.mode];
     const SetDev &sd = *s->sdev[pd.mode]; // this slot's tables and kernels
+    static const std::vector<ipcr::JitFilter *> none;
+    const std::vector<ipcr::JitFilter *> *pub = sd.jit_pub.load(std::memory_order_acquire);
+    const std::vector<ipcr::JitFilter *> &jit = pub ? *pub : none; // (empty while a small panel's kernels are still being built)
     const auto te = std::chrono::steady_clock::now();
     unsigned long long *cnt = s->d_counts + 4u * s->cset, *cnt_next = s->d_counts + 4u * (s->cset ^ 1u);
     const uint64_t qset = (uint64_t)IPCR_QUEUE_SHARDS * IPCR_QUEUE_COUNTER_STRIDE;
@@ -1535,7 +1587,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     pd.fused = false;
     pd.verified = false;
     pd.published = false;
-    if (!sd.jit.empty()) {
+    if (!jit.empty()) {
         ipcr::JitVerify v;
         v.rst = g->rst;
         v.pats = sd.dev;
@@ -1550,7 +1602,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         v.counts = cnt;
         pd.pre = std::min<uint64_t>(PREFIX_HITS, s->hcap);
         ++s->seq;
-        for (size_t gi = 0; gi < sd.jit.size(); ++gi) { // every group streams the tiles once
+        for (size_t gi = 0; gi < jit.size(); ++gi) { // every group streams the tiles once
             v.next_counts = gi == 0 ? cnt_next : nullptr;
             v.next_qcount = gi == 0 ? qc_next : nullptr;
             if (publish_enabled()) { // every kernel of the scan writes its first hits to the pinned buffer too
@@ -1559,7 +1611,7 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
                 v.pub_hits = reinterpret_cast<ipcr_hit_rec *>(static_cast<unsigned long long *>(s->pinned) + 8);
                 v.pre = (uint32_t)pd.pre;
             }
-            if (gi + 1 == sd.jit.size() && publish_enabled()) { // the scan's last kernel hands the results over itself
+            if (gi + 1 == jit.size() && publish_enabled()) { // the scan's last kernel hands the results over itself
                 v.tickets = s->d_tickets;
                 v.pub = static_cast<unsigned long long *>(s->pinned) + 4u * pd.cset_used;
                 v.pub_seq = pinned_seq(s);
@@ -1569,11 +1621,16 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
                 pd.published = true;
             }
             {   // tests: IPCR_TEST_WITHHOLD_TAG=<slot+1>: that record's first half carries a stale tag (a torn record)
-                static const int withhold = getenv("IPCR_TEST_WITHHOLD_TAG") ? atoi(getenv("IPCR_TEST_WITHHOLD_TAG")) : 0;
+                static const int withhold = [] {
+                    const int w = getenv("IPCR_TEST_WITHHOLD_TAG") ? atoi(getenv("IPCR_TEST_WITHHOLD_TAG")) : 0;
+                    if (w > 0) fprintf(stderr, "ipcr_hip: IPCR_TEST_WITHHOLD_TAG=%d is set: hit record %d of every scan is published torn on purpose "
+                                               "(a test hook; every scan then waits out the hand-over deadline and refetches)\n", w, w - 1);
+                    return w;
+                }();
                 v.withhold = withhold > 0 ? (uint32_t)withhold : 0u;
             }
-            HIPCHK(ipcr::jit_launch(sd.jit[gi], lane, g->planes, block0, nblocks, s->d_queue, s->qcap, qc, v,
-                                    gi == 0 ? s->ev[0] : nullptr, gi + 1 == sd.jit.size() ? s->ev[1] : nullptr));
+            HIPCHK(ipcr::jit_launch(jit[gi], lane, g->planes, block0, nblocks, s->d_queue, s->qcap, qc, v,
+                                    gi == 0 ? s->ev[0] : nullptr, gi + 1 == jit.size() ? s->ev[1] : nullptr));
         }
         s->stats.kernel_kind = 1;
         pd.fused = true;

@@ -151,6 +151,10 @@ class CompiledPanel:
         _lib.lib().ipcr_panel_scanned_patterns(self._h, mode, out, n)
         return [out[i] for i in range(n)]
 
+    def wait_ready(self) -> None:
+        """block until the kernels of a small panel, built in the background, are in use (ipcr_panel_wait_ready)"""
+        _lib.check(_lib.lib().ipcr_panel_wait_ready(self._h))
+
     @property
     def device_slots(self) -> int:
         """devices this panel holds tables and kernels on"""

@@ -19,4 +19,7 @@ def _private_jit_cache(tmp_path_factory):
     empty at the start of every session, so that every run compiles what it tests"""
     if "IPCR_JIT_CACHE_DIR" not in os.environ:
         os.environ["IPCR_JIT_CACHE_DIR"] = str(tmp_path_factory.mktemp("jit_cache"))
+    # a small panel's kernels are built in the background and its first scans take the table-driven kernel: the tests
+    # say which kernel they mean to exercise (ipcr_scan_stats.kernel_kind), so every build is synchronous here
+    os.environ.setdefault("IPCR_JIT_ASYNC", "0")
     yield

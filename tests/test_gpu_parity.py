@@ -1336,3 +1336,41 @@ def test_hit_cap_bounds_device_memory(hip, monkeypatch, k, tw, cap):
     got1 = eng.SimulateCompiledWithScratch("r1", recs[1], cp, sc)
     assert [p.sig() for p in got1] == [w.sig() for w in O.simulate_batch(ocfg(cfg), recs[1], opairs(pairs))]
     g.close(); sc.close(); cp.close()
+
+
+def test_small_panel_scans_before_its_kernels_are_built(tmp_path):
+    """IPCR_JIT_ASYNC (the default outside the tests): hiprtc builds a small panel's kernels on a thread of its own; a scan
+    that comes before they are ready takes the table-driven kernel, later ones the specialised one; same products."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, time
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import ipcr_oracle as O
+        from ipcr_amd import engine, primer, workloads
+        pairs = workloads.c2_pairs()
+        seq = bytearray(O.bench_dna(300000, 77))
+        for a in (1000, 90000, 250000):
+            seq[a:a + 20] = pairs[0].Forward.encode()
+            seq[a + 160:a + 180] = O.revcomp(pairs[0].Reverse)
+        seq = bytes(seq)
+        cfg = engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12)
+        want = [w.sig() for w in O.simulate_batch(O.Config(max_mm=2, terminal_window=5, max_len=2000, hit_cap=10000, seed_len=12), seq,
+                                                  [O.Pair(p.ID, p.Forward, p.Reverse, p.MinProduct, p.MaxProduct) for p in pairs])]
+        eng = engine.New(cfg); cp = eng.CompilePanel(pairs); sc = eng.NewSimulationScratch(cp)
+        t0 = time.perf_counter()
+        got = [p.sig() for p in eng.SimulateCompiledWithScratch("s", seq, cp, sc)]
+        t1 = time.perf_counter()
+        k1 = sc.stats().kernel_kind
+        assert got == want and len(got) >= 3, (got, want)
+        cp.wait_ready()
+        t2 = time.perf_counter()
+        got = [p.sig() for p in eng.SimulateCompiledWithScratch("s", seq, cp, sc)]
+        assert got == want and sc.stats().kernel_kind == 1
+        print("OK", k1, round(t1 - t0, 3), round(t2 - t0, 3))
+    """ % (root, os.path.join(root, "oracle")))
+    env = dict(os.environ, IPCR_JIT_ASYNC="1", IPCR_JIT_CACHE_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout, r.stderr[-3000:])
+    _, k1, first_s, built_s = r.stdout.split()
+    assert k1 == "2" and float(first_s) < float(built_s)   # cold cache: the first scan did not wait for hiprtc

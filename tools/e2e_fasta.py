@@ -65,6 +65,7 @@ def main():
     warm = engine.Genome(1 << 20, max_records=2)       # kernel specialisation (hiprtc) outside the timed stages
     warm.add_record("w", b"ACGT" * 1000)
     eng.ScanGenomeCount(warm, cp, sc)
+    cp.wait_ready()
     warm.close()
 
     res = {"file_bytes": fsize, "gz": args.gz, "records": args.records, "bases": args.records * args.record_len,
