@@ -1127,6 +1127,7 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
 #define TAB_WORD0 (SHAPE_WORD0 + 2u * NS)
 #define LDS_WORDS (TAB_WORD0 + 8u)
 #define ANDOR(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA) /* (a & b) | c: v_bitop3_b32 issues in two cycles, v_and_or_b32 in four */
+__device__ __forceinline__ u32 LSHL_OR(u32 a, u32 sh, u32 b) { u32 r; asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(8), "v"(b)); (void)sh; return r; }
 // invalid-base flags, one bit per base -> the even bits of a 2-bit-per-base word
 __device__ __forceinline__ u64 spread2(u32 v) {
   u64 x = v;
@@ -1372,8 +1373,8 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
                         pa << "        const u32 " << nm << " = ldsb[" << off64[(size_t)si] * 8u << "u + " << a << "];\n";
                         bytes.push_back(nm);
                     }
-                    std::string packed = bytes.back(); // ((b2 << 8 | b1) << 8) | b0
-                    for (size_t i = bytes.size() - 1; i-- > 0;) packed = "((" + packed + " << 8u) | " + bytes[i] + ")";
+                    std::string packed = bytes.back(); // ((b2 << 8 | b1) << 8) | b0: one v_lshl_or_b32 per byte (left alone the compiler shifts each byte and ORs three)
+                    for (size_t i = bytes.size() - 1; i-- > 0;) packed = "LSHL_OR(" + packed + ", 8u, " + bytes[i] + ")";
                     unsigned m = 0;
                     for (size_t i = 0; i < pk.sh.size(); ++i) m |= 1u << (8 * i);
                     q = "((" + packed + " >> cb" + G + ") & " + std::to_string(m) + "u)";
