@@ -499,15 +499,18 @@ def roofline_of(res, traffic_file=None):
         except Exception:
             pass
     if res["kernel"] == "ipcr_index_filter":
-        lim = ("not HBM: VALU issue and LDS cycles together (one random 4-byte LDS bitmap lookup per key shape and base step, "
-               "the queue entry and the drain of ~0.19 key hits per lane and step); see DESIGN.md section 4.3")
+        lim = ("not HBM: the LDS (one random 1-byte bitmap lookup per key shape and base step -- most of their cycles bank "
+               "conflicts -- plus the hit queue and the drain of ~0.12 key hits per lane and step), with VALU issue behind it; "
+               "see DESIGN.md section 4.3")
         try:
-            dv = json.load(open(traffic_file)).get("derived")
-            if dv:
-                lim += ("; %s when profiles/ was collected: %.1f VALU instructions per base step = %.0f %% of the issue slots, "
-                        "LDS busy %.0f %% (%.0f %% of it bank conflicts)"
-                        % (os.path.relpath(traffic_file, ROOT), dv["valu_instructions_per_base_step"], 100 * dv["valu_issue_busy_frac"],
-                           100 * dv["lds_busy_frac"], 100 * dv["lds_bank_conflict_frac_of_busy"]))
+            d = json.load(open(traffic_file))
+            dv = d.get("derived")
+            # the counters describe the run they were collected on: quoted only for the same genome size
+            if dv and d.get("algorithmic_bytes_per_launch") == int(alg_bytes):
+                lim += ("; %s when profiles/ was collected: LDS busy %.0f %% of the sweep (%.0f %% of it bank conflicts, %.1f LDS "
+                        "instructions and %.1f VALU instructions per 64-base step)"
+                        % (os.path.relpath(traffic_file, ROOT), 100 * dv["lds_busy_frac"], 100 * dv["lds_bank_conflict_frac_of_busy"],
+                           dv["lds_instructions_per_base_step"], dv["valu_instructions_per_base_step"]))
         except Exception:
             pass
         out["limiter"] = lim

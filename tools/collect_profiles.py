@@ -34,7 +34,7 @@ def counters(dirname, kernel):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     line = open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]
@@ -45,6 +45,11 @@ def main():
     if os.path.exists(serial):
         with open(os.path.join(dst, f"{tag}_bench_serial.json"), "w") as fh:
             fh.write(open(serial).read().strip().splitlines()[-1] + "\n")
+    for w in ("c3", "c4"):   # the other workloads as the main line (their own cpu_baseline)
+        f = os.path.join(src, f"bench_{w}.json")
+        if os.path.exists(f):
+            with open(os.path.join(dst, f"{tag}_bench_{w}.json"), "w") as fh:
+                fh.write(open(f).read().strip().splitlines()[-1] + "\n")
     alg = int(bench["roofline"].get("algorithmic_bytes_per_launch", 0)) or None
     for w, kernel in KERNEL.items():
         stats = newest(os.path.join(src, f"stats_{w}", "**", "*kernel_stats.csv"))
@@ -68,25 +73,30 @@ def main():
             out.update(hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
                        algorithmic_bytes_per_launch=alg)
         if w == "c4" and all(k in out for k in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")):
-            # the index kernel is not HBM-bound: say what binds it, from the counters themselves
-            steps = 3.0e9 / 64.0 * 531.0 / 512.0   # wave-level base steps: a lane walks four strands (3 Gb: host.cpp index_kernel) + 19 rows of the next
+            # the index kernel is not HBM-bound: say what binds it, from the counters themselves.  One wave-level base step =
+            # 64 bases (lane = strand, no tail rows): the genome of the profiled run / 64 (its size is in the bench line's
+            # algorithmic bytes: 0.375 bytes per base)
+            genome_bases = (alg or 0) / 0.375
+            steps = genome_bases / 64.0
             cu_cycles = 256.0 * out["GRBM_GUI_ACTIVE"]["avg"] / 8.0          # GRBM_GUI_ACTIVE is summed over the 8 XCDs
             out["derived"] = {
+                "genome_bases": int(genome_bases),
                 "wave_base_steps_per_launch": round(steps),
                 "valu_instructions_per_base_step": round(out["SQ_INSTS_VALU"]["avg"] / steps, 1),
                 "lds_instructions_per_base_step": round(out["SQ_INSTS_LDS"]["avg"] / steps, 2) if "SQ_INSTS_LDS" in out else None,
-                "valu_issue_busy_frac": round(out["SQ_INSTS_VALU"]["avg"] * 4.0 / (4.0 * cu_cycles), 3),   # 4 cycles per wave instruction, 4 SIMDs per CU
+                # an upper bound: 4 cycles per wave instruction on 4 SIMDs per CU -- v_and / v_or / v_xor / v_lshrrev / v_add /
+                # v_bitop3 issue in 2 (tools/ubench/valu_rates.hip), so the SIMDs are less busy than this says
+                "valu_issue_busy_frac_upper_bound": round(out["SQ_INSTS_VALU"]["avg"] * 4.0 / (4.0 * cu_cycles), 3),
                 "lds_busy_frac": round(out["SQ_LDS_IDX_ACTIVE"]["avg"] / cu_cycles, 3),
                 "lds_bank_conflict_frac_of_busy": round(out["SQ_LDS_BANK_CONFLICT"]["avg"] / out["SQ_LDS_IDX_ACTIVE"]["avg"], 3),
+                "lds_cycles_per_lds_instruction": round(out["SQ_LDS_IDX_ACTIVE"]["avg"] / out["SQ_INSTS_LDS"]["avg"], 2) if "SQ_INSTS_LDS" in out else None,
             }
-            out["note"] += (" CAUTION for this kernel: the x2 rule is calibrated for 16 B/lane coalesced streams; the index filter's tile "
-                            "loads are two distinct 16-byte pieces per wave instruction (the 32 lanes of a half-wave share one "
-                            "word), an access width the guide calls uncalibrated, so hbm_read is an upper bound and the raw counter "
-                            "a lower one.  A lane walks four strands of one column (3 Gb), i.e. the column's words four times, 128 base steps "
-                            "apart: 192 KB of rows per CU are live, more than a CU's share of the L2, so most re-reads miss it and are "
-                            "counted here although the 256 MB Infinity Cache serves them (one strand per lane read 1.2x the algorithmic "
-                            "bytes; the sweep was 8 %% slower).  The kernel "
-                            "is bound by VALU issue and LDS cycles together either way: see `derived`.")
+            out["note"] += (" CAUTION for this kernel: the x2 rule is calibrated for 16 B/lane coalesced streams; the index filter loads "
+                            "its tiles one dword per lane (the 32 lanes of a half wave take the 32 rows of a chunk of one column: "
+                            "eight 16-byte pieces per wave instruction), an access width the guide calls uncalibrated, so hbm_read "
+                            "is an upper bound and the raw counter a lower one.  Every tile word is loaded once per sweep, plus the "
+                            "last chunk of a strand a second time as the next strand's history.  The kernel is bound by the LDS "
+                            "(random byte lookups, most of their cycles bank conflicts), see `derived`.")
         name = "filter" if w == "c2" else w
         with open(os.path.join(dst, f"{tag}_{name}_pmc.json"), "w") as fh:
             json.dump(out, fh, indent=1)

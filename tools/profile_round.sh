@@ -1,17 +1,25 @@
 #!/bin/bash
 # Collects the evidence profiles/ holds for one round, on the GPU box:
-#   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02'
-# then, back in the container:  python tools/collect_profiles.py r02
+#   gpurun --timeout 1150 -- 'bash tools/profile_round.sh r03 bench'; gpurun --timeout 1150 -- 'bash tools/profile_round.sh r03 prof'
+# then, back in the container:  python tools/collect_profiles.py r03
 # Separate passes: bench line (all workloads + cpu_baseline), then per workload a rocprofv3 kernel trace + stats and
 # one --pmc pass per counter set (never mixed with other trace domains).
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
+stage=${2:-all}   # bench | prof | all (a gpurun call is limited to 20 minutes: two calls for one round)
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
+export IPCR_JIT_ASYNC=0   # every pass on the panel's own kernels, from the first one
+if [ $stage != prof ]; then
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || { tail -5 "$out/bench.err"; exit 1; }
 tail -c 600 "$out/bench.json"; echo
 python3 bench.py --no-pipeline --no-cpu-baseline --no-others > "$out/bench_serial.json" 2> "$out/bench_serial.err" || exit 1
+for w in c3 c4; do
+  python3 bench.py --workload $w --no-others > "$out/bench_$w.json" 2> "$out/bench_$w.err" || { tail -5 "$out/bench_$w.err"; exit 1; }
+done
+fi
+[ $stage = bench ] && { echo done; exit 0; }
 for w in c2 c3 c4; do
   steps=400; warm=50; psteps=4
   if [ $w = c4 ]; then steps=20; warm=3; psteps=3; fi
