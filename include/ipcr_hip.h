@@ -310,7 +310,7 @@ uint8_t ipcr_genome_record_flags(const ipcr_genome *g, uint32_t record);
  *   rank 0: ipcr_exchange_unique_id -> send the 128 bytes to every rank over the host's own channel
  *   every rank: ipcr_exchange_create (collective), ipcr_exchange_set_records (collective) once the genome is loaded
  *   per pass: scan on scratch s (ipcr_scan_genome_hits / _end) -> ipcr_exchange_begin(x, s, &t) -> ... -> ipcr_exchange_end
- * Up to two exchanges may be in flight; end them in the order they began.  The scratch's next scan must not begin
+ * Up to two exchanges may be in flight; end them in the order they began (an overflow redo of one does not disturb the other).  The scratch's next scan must not begin
  * before its exchange has ended (the all-gather reads the scratch's hit buffer).  Lock step: a rank with more hits
  * than the capacity still enters the collective; every rank then sees the same counts, and all regrow and repeat that
  * exchange together inside ipcr_exchange_end (ipcr_exchange_redone counts those). */
@@ -328,6 +328,8 @@ ipcr_status ipcr_exchange_begin(ipcr_exchange *x, const ipcr_scratch *s, int32_t
  * [rank_hit_start[r], rank_hit_start[r + 1]), its records start at rank_record_offset[r].  Valid until the next end. */
 ipcr_status ipcr_exchange_end(ipcr_exchange *x, int32_t ticket, const ipcr_hit **hits, int64_t *n_hits,
                               const uint64_t **rank_hit_start, const uint32_t **rank_record_offset);
+/* hit slots every rank sends: grows by itself on overflow; a host that knows what it needs says so (the SAME value on every rank) */
+ipcr_status ipcr_exchange_reserve(ipcr_exchange *x, uint64_t cap_hits);
 uint64_t ipcr_exchange_capacity(const ipcr_exchange *x);
 uint64_t ipcr_exchange_redone(const ipcr_exchange *x);
 

@@ -143,6 +143,7 @@ SYMBOLS = {
     "ipcr_exchange_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "ipcr_exchange_end": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(Hit)), C.POINTER(C.c_int64),
                                     C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint32))]),
+    "ipcr_exchange_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
     "ipcr_exchange_capacity": (C.c_uint64, [C.c_void_p]),
     "ipcr_exchange_redone": (C.c_uint64, [C.c_void_p]),
     "ipcr_probe_best_hit": (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_int32, C.POINTER(ProbeHit)]),

@@ -93,6 +93,8 @@ struct ipcr_exchange {
     uint64_t cap = 0; // hit slots every rank sends
     void *d_stage = nullptr;           // 64 + cap * 32 bytes: for a scratch buffer smaller than the agreed shape
     void *d_recv[SLOTS] = {nullptr, nullptr}; // world x (64 + cap * 32)
+    uint64_t recv_cap[SLOTS] = {0, 0};        // capacity each receive slot is allocated for (grown when the slot is next used)
+    uint64_t stage_cap = 0, host_cap = 0;
     void *h_recv = nullptr;            // pinned, same size: where ipcr_exchange_end unpacks from
     void *d_meta = nullptr, *h_meta = nullptr; // record counts (world x 8 bytes)
     hipEvent_t done[SLOTS] = {nullptr, nullptr};
@@ -109,17 +111,38 @@ namespace {
 
 size_t block_bytes(uint64_t cap) { return 64u + (size_t)cap * sizeof(ipcr_hit); }
 
-ipcr_status alloc_buffers(ipcr_exchange *x, uint64_t cap) {
-    for (int i = 0; i < SLOTS; ++i)
-        if (x->d_recv[i]) { (void)hipFree(x->d_recv[i]); x->d_recv[i] = nullptr; }
-    if (x->d_stage) { (void)hipFree(x->d_stage); x->d_stage = nullptr; }
-    if (x->h_recv) { (void)hipHostFree(x->h_recv); x->h_recv = nullptr; }
+// The capacity every rank sends from now on.  Buffers follow lazily: a receive slot (and the staging / host buffers) is
+// regrown when it is next used, so an exchange still in flight in the other slot keeps the buffers it was enqueued with.
+ipcr_status set_capacity(ipcr_exchange *x, uint64_t cap) {
     x->cap = cap;
-    const size_t nb = block_bytes(cap);
-    XHIP(hipMalloc(&x->d_stage, nb));
-    XHIP(hipMemset(x->d_stage, 0, nb));
-    for (int i = 0; i < SLOTS; ++i) XHIP(hipMalloc(&x->d_recv[i], nb * (size_t)x->world));
-    XHIP(hipHostMalloc(&x->h_recv, nb * (size_t)x->world, hipHostMallocDefault));
+    return IPCR_OK;
+}
+
+ipcr_status ensure_slot(ipcr_exchange *x, int slot) {
+    const size_t nb = block_bytes(x->cap);
+    if (x->recv_cap[slot] < x->cap) {
+        if (x->d_recv[slot]) (void)hipFree(x->d_recv[slot]); // (hipFree waits for the device: nothing still reads it)
+        x->d_recv[slot] = nullptr;
+        XHIP(hipMalloc(&x->d_recv[slot], nb * (size_t)x->world));
+        x->recv_cap[slot] = x->cap;
+    }
+    if (x->stage_cap < x->cap) {
+        if (x->d_stage) (void)hipFree(x->d_stage);
+        x->d_stage = nullptr;
+        XHIP(hipMalloc(&x->d_stage, nb));
+        XHIP(hipMemset(x->d_stage, 0, nb));
+        x->stage_cap = x->cap;
+    }
+    return IPCR_OK;
+}
+
+ipcr_status ensure_host(ipcr_exchange *x, uint64_t cap) {
+    if (x->host_cap < cap) {
+        if (x->h_recv) (void)hipHostFree(x->h_recv);
+        x->h_recv = nullptr;
+        XHIP(hipHostMalloc(&x->h_recv, block_bytes(cap) * (size_t)x->world, hipHostMallocDefault));
+        x->host_cap = cap;
+    }
     return IPCR_OK;
 }
 
@@ -127,7 +150,8 @@ ipcr_status alloc_buffers(ipcr_exchange *x, uint64_t cap) {
 ipcr_status enqueue(ipcr_exchange *x, const ipcr_scratch *s, int slot) {
     const void *dev_block = nullptr;
     uint64_t n_hits = 0, hcap = 0;
-    const ipcr_status st = ipcr_scratch_device_hits(s, &dev_block, &n_hits, &hcap);
+    ipcr_status st = ipcr_scratch_device_hits(s, &dev_block, &n_hits, &hcap);
+    if (st == IPCR_OK) st = ensure_slot(x, slot);
     if (st != IPCR_OK) return st;
     const size_t nb = block_bytes(x->cap);
     const void *send = dev_block;
@@ -189,7 +213,7 @@ ipcr_status ipcr_exchange_create(const uint8_t *id, int32_t world, int32_t rank,
         for (int i = 0; i < SLOTS; ++i) XHIP(hipEventCreateWithFlags(&x->done[i], hipEventDisableTiming));
         XHIP(hipMalloc(&x->d_meta, 8u * (size_t)(world + 1)));
         XHIP(hipHostMalloc(&x->h_meta, 8u * (size_t)(world + 1), hipHostMallocDefault));
-        return alloc_buffers(x, std::max<uint64_t>(cap_hits, 1));
+        return set_capacity(x, std::max<uint64_t>(cap_hits, 1));
     };
     const ipcr_status st = build();
     if (st != IPCR_OK) { ipcr_exchange_destroy(x); return st; }
@@ -258,6 +282,7 @@ ipcr_status ipcr_exchange_end(ipcr_exchange *x, int32_t ticket, const ipcr_hit *
     for (int attempt = 0; attempt < 24; ++attempt) {
         XHIP(hipEventSynchronize(x->done[ticket]));
         const size_t nb = block_bytes(pd.cap);
+        { const ipcr_status hs = ensure_host(x, pd.cap); if (hs != IPCR_OK) return hs; }
         // every rank's header first: all ranks read the same counts and take the same decision
         XHIP(hipMemcpy2DAsync(x->h_recv, 64, x->d_recv[ticket], nb, 64, (size_t)x->world, hipMemcpyDeviceToHost, x->stream));
         XHIP(hipStreamSynchronize(x->stream));
@@ -269,11 +294,9 @@ ipcr_status ipcr_exchange_end(ipcr_exchange *x, int32_t ticket, const ipcr_hit *
         }
         if (need > pd.cap) { // some rank overflowed: every rank regrows and repeats the exchange (the scratch still holds the scan)
             ++x->redone;
-            for (int i = 0; i < SLOTS; ++i)
-                if (x->pend[i].active) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_end: capacity overflow while another exchange is in flight; end exchanges in the order they began");
-            uint64_t cap = pd.cap;
+            uint64_t cap = std::max(pd.cap, x->cap);
             while (cap < need) cap *= 2;
-            ipcr_status st = alloc_buffers(x, cap);
+            ipcr_status st = set_capacity(x, cap); // (an exchange in flight in the other slot keeps its own buffers and shape)
             if (st != IPCR_OK) return st;
             st = enqueue(x, pd.scratch, ticket);
             if (st != IPCR_OK) return st;
@@ -303,6 +326,13 @@ ipcr_status ipcr_exchange_end(ipcr_exchange *x, int32_t ticket, const ipcr_hit *
         return IPCR_OK;
     }
     return ipcr_internal_fail(IPCR_ERR_CAPACITY, "ipcr_exchange_end: the exchange kept overflowing");
+}
+
+// a capacity every rank already knows it needs (e.g. from a first, synchronous exchange): the same value on every rank
+ipcr_status ipcr_exchange_reserve(ipcr_exchange *x, uint64_t cap_hits) {
+    if (!x) return ipcr_internal_fail(IPCR_ERR_INVALID, "null exchange");
+    if (cap_hits > x->cap) x->cap = cap_hits;
+    return IPCR_OK;
 }
 
 uint64_t ipcr_exchange_capacity(const ipcr_exchange *x) { return x ? x->cap : 0; }

@@ -463,8 +463,10 @@ class HitExchanger:
             meta = np.ascontiguousarray(meta3[:, :2])
             need = int(max(meta3[:, 0].max(), meta3[:, 2].max()))
             self._rec_counts = [int(c) for c in meta[:, 1]]
-            if self._native is not None:
+            if self._native is not None:   # every rank has read the same `need`: the native exchange is sized for it too
+                from . import _lib
                 self._native_counts()
+                _lib.check(_lib.lib().ipcr_exchange_reserve(self._native, max(int(need), self.cap)))
             if need <= self.cap:
                 break
             cap = self.cap
