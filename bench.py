@@ -538,6 +538,69 @@ def scan_chunk_rates(args, local=0, record_bases=125_000_000, chunk=4_000_000):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def scan_chunk_all_devices(world: int, args, record_bases=125_000_000, chunk=4_000_000):
+    """Several GPUs: the ONE-process form of the drop-in path -- the native worker pool with its workers spread over every
+    device of the job (chunk_workers --devices 0,..,N-1: worker i -> device i mod N through ipcr_scratch_create_on, no
+    collective; internal/pipeline/pipeline.go:60-125).  Run by rank 0 in a child process before it touches the GPU;
+    reported under other_workloads, never `value`.  Any failure is reported as text: it must not take the job down."""
+    import subprocess
+    exe = os.path.join(ROOT, "ipcr_amd", "chunk_workers")
+    try:
+        env = dict(os.environ, GPU_MAX_HW_QUEUES=os.environ.get("IPCR_CHUNK_HW_QUEUES", "8"))
+        if os.environ.get("IPCR_BENCH_ONE_DEVICE"):      # rehearsal on one GPU: device slots instead of devices
+            env["IPCR_DEVICE_SLOTS"] = str(world)
+        r = subprocess.run([exe, "--devices", ",".join(str(d) for d in range(world)), str(min(record_bases, args.record_len)), str(chunk),
+                            str(2 * world), str(4 * world)], capture_output=True, text=True, timeout=300, env=env)
+        if r.returncode != 0:
+            return {"error": "chunk_workers --devices failed (%d): %s" % (r.returncode, r.stderr[-500:])}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:500]}
+
+
+def measure_traffic(workload: str, kernel: str):
+    """HBM bytes per launch of the dominant kernel, measured IN THIS RUN: two rocprofv3 --pmc children (FETCH_SIZE and
+    WRITE_SIZE in passes of their own, nothing else traced, the program directly after `--`) of this script on the same
+    workload, started before this process touches the GPU.  FETCH_SIZE is reported in KiB and, on gfx950, at half the
+    bytes of a 16 B/lane coalesced stream (MI355X_MICROARCH.md, HBM): read = raw KiB x 1024 x 2; WRITE_SIZE is exact.
+    -> (bytes per launch, launches averaged) or None (no rocprofv3, a failed pass: the caller quotes profiles/ instead)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    vals = {}
+    with tempfile.TemporaryDirectory(prefix="ipcr_bench_pmc_") as d:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(d, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--workload", workload, "--no-cpu-baseline", "--no-others",
+                   "--no-traffic", "--steps", "4", "--warmup", "1"]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=d,
+                                   env=dict(os.environ, TMPDIR=d, IPCR_JIT_ASYNC="0", IPCR_BENCH_ONE_WINDOW="1"))
+            except Exception:  # noqa: BLE001
+                return None
+            if r.returncode != 0:
+                return None
+            acc = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        nm = row.get("Kernel_Name", "")
+                        if kernel in nm and not (kernel == "ipcr_filter" and "index" in nm) and row.get("Counter_Name") == counter:
+                            acc.append(float(row["Counter_Value"]))
+            if not acc:
+                return None
+            vals[counter] = (sum(acc) / len(acc), len(acc))
+    rd = vals["FETCH_SIZE"][0] * 1024.0 * 2.0
+    wr = vals["WRITE_SIZE"][0] * 1024.0
+    return int(rd + wr), int(min(vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]))
+
+
 def fasta_to_tsv(ctx, records=8):
     """FASTA file (80-column lines, page cache) -> resident tiles -> scan -> sorted TSV rows, C2 panel."""
     import io
@@ -671,6 +734,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo to rehearse)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every pass before the next one is enqueued")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc children (quote profiles/ instead)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 40 if args.workload == "c4" else 2000
@@ -682,9 +746,15 @@ def main() -> None:
         import subprocess
         raise SystemExit(subprocess.call(cmd, env=dict(os.environ)))
 
-    chunk_rates = None
-    if not args.no_others and "RANK" not in os.environ and args.gpus <= 1 and not os.environ.get("IPCR_EXCHANGE_SELFTEST"):
+    chunk_rates, all_dev_rates, traffic = None, None, None
+    single = "RANK" not in os.environ and args.gpus <= 1 and not os.environ.get("IPCR_EXCHANGE_SELFTEST")
+    if not args.no_others and single:
         chunk_rates = scan_chunk_rates(args)      # child process, before anything here has initialised HIP
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if not args.no_traffic and not under_profiler and single and args.records == RECORDS and args.record_len == RECORD_LEN:
+        traffic = measure_traffic(args.workload, "ipcr_index_filter" if args.workload == "c4" else "ipcr_filter")
+    if not args.no_others and os.environ.get("RANK") == "0" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        all_dev_rates = scan_chunk_all_devices(int(os.environ["WORLD_SIZE"]), args)
 
     import glob
     import torch
@@ -741,6 +811,8 @@ def main() -> None:
                             "steps": r["steps"], "warmup_actual": r["warmup_actual"], "products_per_step": r["nprod"],
                             "device_path": r["device_path"], "exchange_redone": r["exchange_redone"]}
             r["prods"] = None
+        if all_dev_rates is not None:
+            others["scan_chunk_one_process_all_devices"] = all_dev_rates
 
     genome_bases = res["bases_per_gpu"]
     pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_pmc.json" % ("filter" if args.workload == "c2" else args.workload))))
@@ -791,6 +863,11 @@ def main() -> None:
         },
         "roofline": roofline_of(res, pmc[-1] if pmc else None),
     }
+    if traffic is not None:     # measured by this run (measure_traffic), not quoted
+        out["roofline"]["traffic"] = traffic[0]
+        out["roofline"]["traffic_source"] = ("measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE children of this command "
+                                             "(separate passes, %d launches averaged; FETCH_SIZE doubled, MI355X_MICROARCH.md HBM)" % traffic[1])
+        out["roofline"]["traffic_over_algorithmic"] = round(traffic[0] / out["roofline"]["algorithmic_bytes_per_launch"], 4)
     if res["probe_ms"] is not None:
         out["config"]["probe_rescan_ms"] = round(res["probe_ms"], 4)
     if ctx.want_cpu:

@@ -2477,8 +2477,14 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
             const uint64_t c0 = i * SLC, nc = std::min<uint64_t>(SLC, cols - c0), W = nc * 128u;
             const bool lower = (sflags[(size_t)i] & 2u) != 0;
             uint8_t *d = g->staging + c0 * 2048ull;
-            HIPCHK(hipMemcpyAsync(d, slab, W * 4u * (lower ? 4u : 3u), hipMemcpyHostToDevice, g->stream));
-            const uint32_t *dl = reinterpret_cast<const uint32_t *>(d);
+            // A lone caller: the conversion kernel reads the pinned slab over the link itself, no copy operation in between
+            // (whole 150 Mb record: 60 Gbases/s against 51).  A pool of workers keeps the copy engine: their kernels would
+            // otherwise wait on the link with the compute units held (16 workers: 78 Gbases/s against 99).
+            // IPCR_CHUNK_ZEROCOPY=0/1 forces.
+            static const int zc_env = getenv("IPCR_CHUNK_ZEROCOPY") ? atoi(getenv("IPCR_CHUNK_ZEROCOPY")) : -1;
+            const bool zerocopy = zc_env >= 0 ? zc_env != 0 : live <= 1;
+            if (!zerocopy) HIPCHK(hipMemcpyAsync(d, slab, W * 4u * (lower ? 4u : 3u), hipMemcpyHostToDevice, g->stream));
+            const uint32_t *dl = zerocopy ? reinterpret_cast<const uint32_t *>(slab) : reinterpret_cast<const uint32_t *>(d);
             HIPCHK(ipcr::launch_tiles_from_linear(g->stream, dl, dl + W, dl + 2 * W, lower ? dl + 3 * W : nullptr, col0, col0 + c0, nc, len,
                                                   g->planes, g->rst, i == 0 ? g->d_rec_start : nullptr, i == 0 ? g->d_rec_len : nullptr,
                                                   i == 0 ? g->e0 : nullptr, i + 1 == nsl ? g->e1 : nullptr));

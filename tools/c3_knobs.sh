@@ -5,6 +5,6 @@ out=${GRAFT_REPO_ROOT:-.}/gpurun_out
 mkdir -p $out
 while read -r w line; do
   [ -z "$w" ] && continue
-  res=$(env $line timeout -k 10 200 python3 bench.py --workload $w --no-cpu-baseline --no-others --steps 300 --warmup 50 2>$out/knob.err | python3 -c "import sys,json; d=json.loads(sys.stdin.read().splitlines()[-1]); print(d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['ms_per_step'], d['config']['products_per_step'])") || { tail -3 $out/knob.err; exit 1; }
+  res=$(env $line timeout -k 10 200 python3 bench.py --workload $w --no-cpu-baseline --no-others --no-traffic --steps 300 --warmup 50 2>$out/knob.err | python3 -c "import sys,json; d=json.loads(sys.stdin.read().splitlines()[-1]); print(d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['ms_per_step'], d['config']['products_per_step'])") || { tail -3 $out/knob.err; exit 1; }
   echo "$w $line -> $res"
 done

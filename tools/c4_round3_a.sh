@@ -5,7 +5,7 @@ out=${GRAFT_REPO_ROOT:-.}/gpurun_out/r03a
 mkdir -p $out
 run() { # name, env...
   name=$1; shift
-  env "$@" timeout -k 10 300 python3 bench.py --workload c4 --no-cpu-baseline --no-others --steps 12 --warmup 2 > $out/$name.json 2> $out/$name.err || { echo "$name FAILED"; tail -5 $out/$name.err; return 1; }
+  env "$@" timeout -k 10 300 python3 bench.py --workload c4 --no-cpu-baseline --no-others --no-traffic --steps 12 --warmup 2 > $out/$name.json 2> $out/$name.err || { echo "$name FAILED"; tail -5 $out/$name.err; return 1; }
   python3 -c "import sys,json; d=json.loads(open('$out/$name.json').read().splitlines()[-1]); print('$name', 'sweep_ms', d['roofline']['avg_launch_ms'], 'ms_per_step', d['ms_per_step'], 'products', d['config']['products_per_step'])"
 }
 run static IPCR_INDEX_DYNAMIC=0 &&

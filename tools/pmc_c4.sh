@@ -4,7 +4,7 @@ set -o pipefail
 out=$GRAFT_REPO_ROOT/gpurun_out/c4pmc
 mkdir -p "$out"
 export TMPDIR=/tmp
-args="--workload c4 --no-cpu-baseline --no-others --steps 3 --warmup 1"
+args="--workload c4 --no-cpu-baseline --no-others --no-traffic --steps 3 --warmup 1"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d "$out/sq" -- python3 bench.py $args > "$out/sq.log" 2>&1 || { tail -5 "$out/sq.log"; exit 1; }
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY --output-format csv -d "$out/lds" -- python3 bench.py $args > "$out/lds.log" 2>&1 || { tail -5 "$out/lds.log"; exit 1; }
 python3 - <<'PY'

@@ -14,7 +14,7 @@ export IPCR_JIT_ASYNC=0   # every pass on the panel's own kernels, from the firs
 if [ $stage != prof ]; then
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || { tail -5 "$out/bench.err"; exit 1; }
 tail -c 600 "$out/bench.json"; echo
-python3 bench.py --no-pipeline --no-cpu-baseline --no-others > "$out/bench_serial.json" 2> "$out/bench_serial.err" || exit 1
+python3 bench.py --no-pipeline --no-cpu-baseline --no-others --no-traffic > "$out/bench_serial.json" 2> "$out/bench_serial.err" || exit 1
 for w in c3 c4; do
   python3 bench.py --workload $w --no-others > "$out/bench_$w.json" 2> "$out/bench_$w.err" || { tail -5 "$out/bench_$w.err"; exit 1; }
 done
@@ -23,7 +23,7 @@ fi
 for w in c2 c3 c4; do
   steps=400; warm=50; psteps=4
   if [ $w = c4 ]; then steps=20; warm=3; psteps=3; fi
-  args="--workload $w --no-cpu-baseline --no-others"
+  args="--workload $w --no-cpu-baseline --no-others --no-traffic"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_$w" -- python3 bench.py $args --steps $steps --warmup $warm > "$out/stats_$w.log" 2>&1 || { tail -5 "$out/stats_$w.log"; exit 1; }
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch_$w" -- python3 bench.py $args --steps $psteps --warmup 1 > "$out/pmc_fetch_$w.log" 2>&1 || { tail -5 "$out/pmc_fetch_$w.log"; exit 1; }
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write_$w" -- python3 bench.py $args --steps $psteps --warmup 1 > "$out/pmc_write_$w.log" 2>&1 || { tail -5 "$out/pmc_write_$w.log"; exit 1; }
