@@ -79,6 +79,7 @@ SYMBOLS = {
     "ipcr_last_error": (C.c_char_p, []),
     "ipcr_set_device": (C.c_int, [C.c_int]),
     "ipcr_device_count": (C.c_int, []),
+    "ipcr_bind_thread_to_device": (C.c_int, [C.c_int]),
     "ipcr_iupac_mask": (C.c_uint8, [C.c_uint8]),
     "ipcr_base_match": (C.c_int, [C.c_uint8, C.c_uint8]),
     "ipcr_revcomp": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p]),
@@ -161,6 +162,8 @@ def _preload_hip_runtime() -> None:
     would load a second runtime and find no GPU.  So when torch is installed, load ITS copies
     first (same SONAMEs, so libipcr_hip.so binds to them); otherwise /opt/rocm's are used."""
     import importlib.util
+    if os.environ.get("IPCR_HIP_RUNTIME") == "system":   # a process that will never import torch: /opt/rocm's runtime
+        return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):

@@ -1,11 +1,14 @@
 // chunk_workers -- the drop-in entry point under the reference's worker model, driven from native threads.
 //
-//   chunk_workers [--devices d0,d1,...] [record_bases] [chunk_bases] [workers ...]   (defaults: device 0, 125000000 4000000 1 8 16)
+//   chunk_workers [--devices d0,d1,...] [--bind] [record_bases] [chunk_bases] [workers ...]   (defaults: device 0, 125000000 4000000 1 8 16)
 //
 // --devices: worker i creates its scratch on device d[i mod n] (ipcr_scratch_create_on) -- one host process, every GPU of
 // the node, no collective: chunks are independent.  The worker threads never select a device themselves; every entry
 // point of the library does.  A device may be listed twice, and with IPCR_DEVICE_SLOTS=N in the environment devices
 // beyond the physical ones exist as slots with tables of their own (a one-GPU box rehearses the N-device flow).
+// --bind: every worker thread first moves onto the CPUs next to its device (ipcr_bind_thread_to_device).  Not the default:
+// a pool of 16 workers is not limited by the link, and on the shared hosts these numbers come from 16 threads held on
+// one socket lost more to its other tenants (63 Gbases/s) than the scheduler's free choice of both sockets (96).
 //
 // internal/pipeline/pipeline.go:60-125: CompilePanel once, one scratch per worker, every worker pulls rolling chunks
 // (core/fasta/path_ctx.go:83-179: chunk size, overlap = max product length) of a record from one queue and calls
@@ -44,15 +47,17 @@ static std::string bench_primer(unsigned idx, int n = 20) { // core/engine/perfo
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static int usage(const char *why) {
-    fprintf(stderr, "chunk_workers: %s\nusage: chunk_workers [--devices d0,d1,...] [record_bases] [chunk_bases > 2000] [workers >= 1 ...]\n", why);
+    fprintf(stderr, "chunk_workers: %s\nusage: chunk_workers [--devices d0,d1,...] [--bind] [record_bases] [chunk_bases > 2000] [workers >= 1 ...]\n", why);
     return 2;
 }
 
 int main(int argc, char **argv) {
     std::vector<int> devices;
     std::vector<const char *> pos;
+    bool bind = false;
     for (int i = 1; i < argc; ++i) {
-        if (!strcmp(argv[i], "--devices")) {
+        if (!strcmp(argv[i], "--bind")) bind = true;
+        else if (!strcmp(argv[i], "--devices")) {
             if (i + 1 >= argc) return usage("--devices needs a list");
             for (const char *q = argv[++i]; *q;) {
                 char *end = nullptr;
@@ -202,7 +207,9 @@ int main(int argc, char **argv) {
         std::atomic<size_t> next{0};
         std::atomic<long long> nprod{0}, ns[4] = {{0}, {0}, {0}, {0}};
         std::atomic<int> failed{0}, at_gate{0}, finished{0}, pass_no{-1};
+        std::atomic<int> bound{0};
         auto work = [&](ipcr_scratch *sc) {
+            if (bind && ipcr_bind_thread_to_device(ipcr_scratch_device(sc))) bound.fetch_add(1);
             for (int pass = 0; pass < PASSES; ++pass) {
                 at_gate.fetch_add(1);
                 while (pass_no.load(std::memory_order_acquire) < pass) std::this_thread::yield();
@@ -255,12 +262,13 @@ int main(int argc, char **argv) {
         // per call: the rest of `call` is the copy into device memory (through pinned slices under a pool) and the pack enqueue
         printf(", \"call_ms_%d_worker%s\": {\"call\": %.3f, \"enqueue\": %.3f, \"wait\": %.3f, \"sort_join\": %.3f}", W, W == 1 ? "" : "s",
                call_ms[0], call_ms[1], call_ms[2], call_ms[3]);
-        if (W == workers.back()) printf(", \"products_per_pass\": %lld, \"panel_device_slots\": %d", products, ipcr_panel_device_slots(panel));
+        if (W == workers.back()) printf(", \"products_per_pass\": %lld, \"panel_device_slots\": %d, \"workers_on_device_cpus\": %d", products, ipcr_panel_device_slots(panel), bound.load());
         for (auto &sc : scs) ipcr_scratch_destroy(sc);
     }
     {   // one worker, the whole record in one call
         ipcr_scratch *sc = nullptr;
         if (ipcr_scratch_create_on(panel, devices[0], &sc) != IPCR_OK) return 5;
+        if (bind) (void)ipcr_bind_thread_to_device(devices[0]);
         double best = 0;
         for (int r = 0; r < 4; ++r) {
             const double t0 = now();

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <atomic>
 #include <chrono>
@@ -27,6 +28,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "device_types.h"
@@ -64,6 +66,10 @@ extern int ipcr_internal_genome_phys_device(const ipcr_genome *g);
 extern ipcr_status ipcr_internal_genome_add_batch(ipcr_genome *g, const uint8_t *dbase, const uint64_t *offs, const uint64_t *lens,
                                                   const std::string *ids, size_t n, void *d_tmp, size_t tmp_bytes);
 extern size_t ipcr_internal_batch_table_bytes(size_t n);
+// host.cpp: the process's pool of worker threads (created at first use, they live as long as the process)
+extern void ipcr_internal_pool_run(size_t n, const std::function<void(size_t)> &fn, int phys); // phys >= 0: on that device's CPUs
+extern bool ipcr_internal_bind_thread(int phys);
+extern unsigned ipcr_internal_pool_size();
 
 namespace {
 
@@ -152,16 +158,21 @@ void start_record(ipcr_fasta *f, const std::string &header) { // path_ctx.go:100
         if (e_ != hipSuccess) return ipcr_internal_fail(IPCR_ERR_DEVICE, "HIP: %s (%s)", hipGetErrorString(e_), #call); \
     } while (0)
 
-// The loader's big buffers (two pinned slabs, two raw device slabs, the compacted slab) are kept for the next load
+// Pinned slabs the read-ahead cycles through.  Two were one too few: the read of slab j + 2 had to wait until slab j was
+// decoded, i.e. for its copy AND the host's round trips behind it, and the link idled 0.5 ms in every 1.7 (1 GB file:
+// 29.9 ms; the copies alone take 18).  With four the reader only ever waits for the link.
+constexpr int NPIN = 4;
+
+// The loader's big buffers (the pinned slabs, two raw device slabs, the compacted slab) are kept for the next load
 // of the process instead of being freed: allocating and pinning them costs ~9 ms, a fifth of loading a 1 GB file.
 struct FastaBuffers {
     int device = -1;
     size_t slab = 0;
-    uint8_t *pin = nullptr, *pin2 = nullptr, *d_raw = nullptr, *d_raw2 = nullptr, *d_out = nullptr;
+    uint8_t *pin[NPIN] = {}, *d_raw = nullptr, *d_raw2 = nullptr, *d_out = nullptr;
     uint32_t *d_counts = nullptr;
+    bool pinned() const { for (int k = 0; k < NPIN; ++k) if (!pin[k]) return false; return true; }
     void release() {
-        if (pin) (void)hipHostFree(pin);
-        if (pin2) (void)hipHostFree(pin2);
+        for (int k = 0; k < NPIN; ++k) if (pin[k]) (void)hipHostFree(pin[k]);
         if (d_raw) (void)hipFree(d_raw);
         if (d_raw2) (void)hipFree(d_raw2);
         if (d_out) (void)hipFree(d_out);
@@ -181,10 +192,10 @@ struct FastaLoader {
     uint64_t foff = 0;
     size_t slab = 0;
     hipStream_t st = nullptr;
-    uint8_t *pin = nullptr, *pin2 = nullptr, *d_raw = nullptr, *d_raw2 = nullptr, *d_out = nullptr, *d_rec = nullptr;
+    uint8_t *pin[NPIN] = {}, *d_raw = nullptr, *d_raw2 = nullptr, *d_out = nullptr, *d_rec = nullptr;
     int phys_device = 0;
     hipStream_t cs = nullptr;                  // the slabs' host-to-device copies: slab j + 1 crosses the link while slab j is decoded
-    hipEvent_t ev_h2d[2] = {nullptr, nullptr}; // d_raw[k] holds its slab
+    hipEvent_t ev_h2d[NPIN] = {};              // pinned slab k has crossed the link (its device copy is complete)
     hipEvent_t ev_free[2] = {nullptr, nullptr}; // the kernels that read d_raw[k] have run
     uint32_t *d_counts = nullptr, *d_hdr_off = nullptr, *h_small = nullptr; // h_small: pinned, hdr_off[nh] + total
     ipcr_fasta_range *d_hdr = nullptr;
@@ -206,16 +217,15 @@ struct FastaLoader {
         if (gz) gzclose(gz);
         else if (fd >= 0) close(fd);
         if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
-        for (int k = 0; k < 2; ++k) {
-            if (ev_h2d[k]) (void)hipEventDestroy(ev_h2d[k]);
-            if (ev_free[k]) (void)hipEventDestroy(ev_free[k]);
-        }
+        for (int k = 0; k < NPIN; ++k) if (ev_h2d[k]) (void)hipEventDestroy(ev_h2d[k]);
+        for (int k = 0; k < 2; ++k) if (ev_free[k]) (void)hipEventDestroy(ev_free[k]);
         {   // the big buffers go to the cache (a set already there is dropped), or are freed
             FastaBuffers mine;
             mine.device = phys_device; mine.slab = slab;
-            mine.pin = pin; mine.pin2 = pin2; mine.d_raw = d_raw; mine.d_raw2 = d_raw2; mine.d_out = d_out; mine.d_counts = d_counts;
+            for (int k = 0; k < NPIN; ++k) mine.pin[k] = pin[k];
+            mine.d_raw = d_raw; mine.d_raw2 = d_raw2; mine.d_out = d_out; mine.d_counts = d_counts;
             static const bool cache_on = !(getenv("IPCR_FASTA_CACHE") && atoi(getenv("IPCR_FASTA_CACHE")) == 0);
-            const bool complete = pin && pin2 && d_raw && d_raw2 && d_out && d_counts;
+            const bool complete = mine.pinned() && d_raw && d_raw2 && d_out && d_counts;
             if (cache_on && complete) {
                 std::lock_guard<std::mutex> lk(g_fasta_cache_mu);
                 std::swap(mine, g_fasta_cache);
@@ -257,38 +267,40 @@ struct FastaLoader {
         FHIP(hipGetDevice(&phys_device));
         {
             std::lock_guard<std::mutex> lk(g_fasta_cache_mu);
-            if (g_fasta_cache.pin && g_fasta_cache.device == phys_device && g_fasta_cache.slab == slab) {
-                pin = g_fasta_cache.pin; pin2 = g_fasta_cache.pin2; d_raw = g_fasta_cache.d_raw; d_raw2 = g_fasta_cache.d_raw2;
+            if (g_fasta_cache.pinned() && g_fasta_cache.device == phys_device && g_fasta_cache.slab == slab) {
+                for (int k = 0; k < NPIN; ++k) pin[k] = g_fasta_cache.pin[k];
+                d_raw = g_fasta_cache.d_raw; d_raw2 = g_fasta_cache.d_raw2;
                 d_out = g_fasta_cache.d_out; d_counts = g_fasta_cache.d_counts;
                 g_fasta_cache = FastaBuffers();
             }
         }
-        if (!pin) {
-            FHIP(hipHostMalloc((void **)&pin, slab, hipHostMallocDefault));
-            FHIP(hipHostMalloc((void **)&pin2, slab, hipHostMallocDefault));
+        if (!pin[0]) {
+            for (int k = 0; k < NPIN; ++k) FHIP(hipHostMalloc((void **)&pin[k], slab, hipHostMallocDefault));
             FHIP(hipMalloc((void **)&d_raw, slab));
             FHIP(hipMalloc((void **)&d_raw2, slab));
             FHIP(hipMalloc((void **)&d_out, slab));
             FHIP(hipMalloc((void **)&d_counts, (slab / 4096 + 4) * 4));
         }
         FHIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        for (int k = 0; k < 2; ++k) {
-            FHIP(hipEventCreateWithFlags(&ev_h2d[k], hipEventDisableTiming));
-            FHIP(hipEventCreateWithFlags(&ev_free[k], hipEventDisableTiming));
-        }
+        for (int k = 0; k < NPIN; ++k) FHIP(hipEventCreateWithFlags(&ev_h2d[k], hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) FHIP(hipEventCreateWithFlags(&ev_free[k], hipEventDisableTiming));
         t_alloc = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
         return IPCR_OK;
     }
 
-    // fill buf[have, slab) from the file; returns bytes now in the buffer.  Plain files are read by a
-    // few threads at once (one pread stream copies from the page cache at ~8 GB/s, less than PCIe takes)
+    // fill buf[have, slab) from the file; returns bytes now in the buffer.  Plain files are read in pieces of 2 MiB by
+    // the process's pool of threads (one pread stream copies from the page cache at ~10 GB/s, the link takes 57; the
+    // pool reaches ~70).  The threads must be the same from slab to slab: with 16 threads STARTED for every slab (round
+    // 2, and this round until tools/ubench/slab_pipeline.hip took the pipeline apart) every slab copy running meanwhile
+    // took 1.7-1.9 ms instead of 1.2 -- creating and ending threads maps and unmaps their stacks, and every change of the
+    // address space makes the GPU driver revisit the process's pinned ranges.  And they run on the device's own socket
+    // (host.cpp: device_cpus): a slab written by the other socket's cores leaves at 31 GB/s, not 54.
+    // IPCR_FASTA_READERS=1: one stream, no pool.
     ipcr_status fill(uint8_t *buf, size_t have, size_t *n) {
         if (!gz && fsize >= 0) {
             const size_t want = (size_t)std::min<uint64_t>(slab - have, (uint64_t)fsize - foff);
             const size_t piece = (size_t)2 << 20;
-            // (one pread stream copies from the page cache at ~8 GB/s; the link takes 57: IPCR_FASTA_READERS, default 16)
-            static const unsigned max_readers = [] { const char *v = getenv("IPCR_FASTA_READERS"); const int n = v && *v ? atoi(v) : 16; return (unsigned)std::min(std::max(n, 1), 64); }();
-            const unsigned nt = (unsigned)std::min<size_t>(max_readers, (want + piece - 1) / piece);
+            static const bool pooled = [] { const char *v = getenv("IPCR_FASTA_READERS"); return !(v && *v && atoi(v) <= 1); }();
             std::atomic<bool> bad{false};
             auto reader = [&](size_t a, size_t b) {
                 while (a < b) {
@@ -297,16 +309,9 @@ struct FastaLoader {
                     a += (size_t)r;
                 }
             };
-            if (nt <= 1) reader(0, want);
-            else {
-                std::vector<std::thread> th;
-                const size_t per = ((want + nt - 1) / nt + 4095) & ~(size_t)4095;
-                for (unsigned t = 0; t < nt; ++t) {
-                    const size_t a = std::min(want, (size_t)t * per), b = std::min(want, a + per);
-                    if (a < b) th.emplace_back(reader, a, b);
-                }
-                for (auto &t : th) t.join();
-            }
+            const size_t np = (want + piece - 1) / piece;
+            if (np <= 1 || !pooled) reader(0, want);
+            else ipcr_internal_pool_run(np, [&](size_t i) { reader(i * piece, std::min(want, (i + 1) * piece)); }, phys_device);
             if (bad) return ipcr_internal_fail(IPCR_ERR_INVALID, "read error in FASTA input");
             foff += want;
             have += want;
@@ -413,37 +418,53 @@ struct FastaLoader {
         }
     }
 
-    // What the read-ahead thread hands over: slab j sits in pinned buffer j & 1, its bytes [0, cut) are on their way to
-    // d_raw[j & 1] (ev_h2d[j & 1]); what follows the cut is carried into the next slab.
+    // What the read-ahead thread hands over: slab j sits in pinned buffer j % NPIN, its bytes [0, cut) are on their way to
+    // d_raw[j & 1] (ev_h2d[j % NPIN]); what follows the cut is carried into the next slab.
     struct SlabInfo { size_t n = 0, cut = 0; bool last = false; ipcr_status st = IPCR_OK; };
 
     ipcr_status run() {
-        uint8_t *buf[2] = {pin, pin2};
+        uint8_t **buf = pin;
         uint8_t *draw[2] = {d_raw, d_raw2};
         std::mutex mu;
         std::condition_variable cv;
         std::deque<SlabInfo> ready;
         uint64_t consumed = 0; // slabs the main thread has finished with (their pinned buffer may be overwritten)
+        uint64_t freed = 0;    // slabs whose decode has been queued: ev_free of their device slab has been recorded
         bool stop = false;
+        // IPCR_DEBUG_TIMES: a time line of both threads (label, slab, ms since run() began), printed at the end
+        const bool trace = getenv("IPCR_DEBUG_TIMES") != nullptr;
+        const auto t_run0 = std::chrono::steady_clock::now();
+        std::mutex tmu;
+        std::vector<std::tuple<const char *, uint64_t, double>> tl;
+        auto mark = [&](const char *what, uint64_t j) {
+            if (!trace) return;
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count();
+            std::lock_guard<std::mutex> lk(tmu);
+            tl.emplace_back(what, j, ms);
+        };
+        std::vector<hipEvent_t> tev; // trace: start / stop of every slab copy on the copy stream
         // ---- read-ahead: file -> pinned slab (a few pread threads), cut behind the last line end, copy to the device on
-        // the copy stream.  It runs one slab ahead of the decode: the read of slab j + 2 waits for slab j to be consumed.
+        // the copy stream.  It runs up to NPIN - 1 slabs ahead of the decode: the read of slab j + NPIN waits for slab j to be consumed.
         std::thread reader([&]() {
             (void)hipSetDevice(phys_device);
+            (void)ipcr_internal_bind_thread(phys_device); // it reads the file with the pool: on the device's own socket (host.cpp: device_cpus)
             size_t carry = 0, cut_prev = 0;
             for (uint64_t j = 0;; ++j) {
                 SlabInfo si;
-                uint8_t *b = buf[j & 1];
-                if (j >= 2) {
+                uint8_t *b = buf[j % NPIN];
+                if (j >= (uint64_t)NPIN) {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return stop || consumed + 1 >= j; }); // slab j - 2 is done with on the host ...
+                    cv.wait(lk, [&] { return stop || consumed + NPIN > j; }); // slab j - NPIN is done with on the host ...
                     if (stop) return;
                     lk.unlock();
-                    (void)hipEventSynchronize(ev_h2d[j & 1]);                // ... and has left the pinned buffer
+                    (void)hipEventSynchronize(ev_h2d[j % NPIN]);             // ... and has left the pinned buffer
                 }
-                if (carry) memcpy(b, buf[(j - 1) & 1] + cut_prev, carry);
+                if (carry) memcpy(b, buf[(j - 1) % NPIN] + cut_prev, carry);
                 size_t n = 0;
                 const auto t0 = std::chrono::steady_clock::now();
+                mark("fill>", j);
                 si.st = fill(b, carry, &n);
+                mark("fill<", j);
                 t_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 si.n = n;
                 si.last = eof;
@@ -461,9 +482,24 @@ struct FastaLoader {
                 si.cut = cut;
                 if (si.st == IPCR_OK) {
                     hipError_t e = hipSuccess;
-                    if (j >= 2) e = hipStreamWaitEvent(cs, ev_free[j & 1], 0); // the kernels over slab j - 2 have read d_raw[j & 1]
+                    if (j >= 2) { // the kernels over slab j - 2 have read d_raw[j & 1]: their event must have been recorded first
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || freed + 2 > j; });
+                        if (stop) return;
+                        lk.unlock();
+                        e = hipStreamWaitEvent(cs, ev_free[j & 1], 0);
+                    }
+                    if (trace && j < 64) { hipEvent_t a, z; (void)hipEventCreate(&a); (void)hipEventCreate(&z); tev.push_back(a); tev.push_back(z); (void)hipEventRecord(a, cs); }
+                    // One slab copy at a time: a copy queued while the one before is still in flight is given another DMA
+                    // engine by the runtime (the preferred one is busy) and then takes 1.8-2.4 ms instead of 1.2 -- and as
+                    // slow copies are always still in flight when the next slab is ready, that state keeps itself up (1 GB
+                    // file: 31 ms; tools/ubench/slab_pipeline.hip).  The fill of the next slab has long begun: nothing waits.
+                    static const bool one_copy = !(getenv("IPCR_FASTA_COPY_OVERLAP") && atoi(getenv("IPCR_FASTA_COPY_OVERLAP")));
+                    if (one_copy && j >= 1 && e == hipSuccess) e = hipEventSynchronize(ev_h2d[(j - 1) % NPIN]);
                     if (e == hipSuccess && cut) e = hipMemcpyAsync(draw[j & 1], b, cut, hipMemcpyHostToDevice, cs);
-                    if (e == hipSuccess) e = hipEventRecord(ev_h2d[j & 1], cs);
+                    if (trace && j < 64) (void)hipEventRecord(tev.back(), cs);
+                    if (e == hipSuccess) e = hipEventRecord(ev_h2d[j % NPIN], cs);
+                    mark("h2d queued", j);
                     if (e != hipSuccess) si.st = ipcr_internal_fail(IPCR_ERR_DEVICE, "HIP: %s (FASTA slab copy)", hipGetErrorString(e));
                 }
                 const bool end = si.st != IPCR_OK || si.last || n == 0;
@@ -494,29 +530,37 @@ struct FastaLoader {
             const size_t n = si.n, cut = si.cut;
             if (n == 0) break;
             const bool last = si.last;
-            const uint8_t *raw = buf[j & 1];
+            const uint8_t *raw = buf[j % NPIN];
             uint8_t *d_cur = draw[j & 1];
             const auto th0 = std::chrono::steady_clock::now();
-            FHIP(hipStreamWaitEvent(st, ev_h2d[j & 1], 0));
+            mark("slab taken", j);
+            FHIP(hipStreamWaitEvent(st, ev_h2d[j % NPIN], 0));
             s = find_headers(d_cur, cut);
             if (s != IPCR_OK) return s;
             const uint32_t nh = (uint32_t)ranges.size();
             if (nh && !last && ranges.back().end > cut) return ipcr_internal_fail(IPCR_ERR_UNSUPPORTED, "FASTA: a header line longer than the %zu-byte slab", slab);
             uint32_t total = 0;
             const auto td0 = std::chrono::steady_clock::now();
+            mark("headers found", j);
             t_host += std::chrono::duration<double>(td0 - th0).count();
             if (cut) {
                 const uint32_t nb = (uint32_t)((cut + 4095) / 4096);
                 if (nh) FHIP(hipMemcpyAsync(d_hdr, ranges.data(), (size_t)nh * sizeof(ipcr_fasta_range), hipMemcpyHostToDevice, st));
                 FHIP(ipcr::launch_fasta_decode(st, d_cur, cut, d_hdr, nh, (at_line_start || lead_open) ? 1u : 0u, d_counts, d_out, d_hdr_off));
                 FHIP(hipEventRecord(ev_free[j & 1], st));
+                { std::lock_guard<std::mutex> lk(mu); freed = j + 1; }
+                cv.notify_all();
                 if (nh) FHIP(hipMemcpyAsync(h_small, d_hdr_off, (size_t)nh * 4, hipMemcpyDeviceToHost, st));
                 FHIP(hipMemcpyAsync(h_small + nh, d_counts + nb, 4, hipMemcpyDeviceToHost, st));
                 FHIP(hipStreamSynchronize(st));
                 total = h_small[nh];
-            } else
+            } else {
                 FHIP(hipEventRecord(ev_free[j & 1], st));
+                { std::lock_guard<std::mutex> lk(mu); freed = j + 1; }
+                cv.notify_all();
+            }
             const auto tp0 = std::chrono::steady_clock::now();
+            mark("decoded", j);
             t_decode += std::chrono::duration<double>(tp0 - td0).count();
             // hand the compacted bytes to the records.  A record that begins and ends in this slab is packed straight
             // out of d_out with all the others like it (one launch); the one that came in open and the one that stays
@@ -553,6 +597,7 @@ struct FastaLoader {
             if (s != IPCR_OK) return s;
             FHIP(hipStreamSynchronize(st)); // d_out is reused by the next slab
             t_pack += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
+            mark("packed", j);
             if (cut > 0) {
                 at_line_start = raw[cut - 1] == '\n';
                 lead_open = at_line_start; // a cut inside a line is behind one of its non-blank bytes
@@ -568,6 +613,18 @@ struct FastaLoader {
         if (getenv("IPCR_DEBUG_TIMES"))
             fprintf(stderr, "fasta loader: buffers %.3f s, read %.3f s (overlapped), cut + header search %.3f s, h2d + decode %.3f s, copy + pack %.3f s\n",
                     t_alloc, t_read, t_host, t_decode, t_pack);
+        if (trace && getenv("IPCR_DEBUG_TIMES")[0] == '2') {
+            std::sort(tl.begin(), tl.end(), [](const auto &x, const auto &y) { return std::get<2>(x) < std::get<2>(y); });
+            (void)hipStreamSynchronize(cs);
+            for (size_t k = 0; k + 1 < tev.size(); k += 2) {
+                float dur = 0, since0 = 0;
+                (void)hipEventElapsedTime(&dur, tev[k], tev[k + 1]);
+                (void)hipEventElapsedTime(&since0, tev[0], tev[k]);
+                fprintf(stderr, "  copy of slab %2zu: starts %.3f ms after the first, takes %.3f ms\n", k / 2, since0, dur);
+            }
+            for (hipEvent_t e : tev) (void)hipEventDestroy(e);
+            for (const auto &e : tl) fprintf(stderr, "  %8.3f ms  slab %2llu  %s\n", std::get<2>(e), (unsigned long long)std::get<1>(e), std::get<0>(e));
+        }
         return fs;
     }
 };

@@ -12,6 +12,8 @@
 #include "ipcr_hip.h"
 
 #include <emmintrin.h>
+#include <sched.h>
+#include <unistd.h>
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -107,6 +109,59 @@ struct DeviceGuard {
     DeviceGuard(const DeviceGuard &) = delete;
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
+
+// ------------------------------------------------------------ the CPUs next to a device
+// A slab of pinned memory that cores of the OTHER socket have just written crosses the link at 31 GB/s instead of 54: the
+// DMA engine's reads find the lines dirty in caches two hops away (measured round 3, tools/gpu_round3_o.sh -- the FASTA
+// loader's threads bound to the far socket: 40 ms per GB, to the device's own: 26 ms; unbound it was the scheduler's luck).
+// So the threads of this library that fill pinned memory run on the CPUs the kernel lists as local to the device
+// (/sys/bus/pci/devices/<bus id>/local_cpulist), as far as the process is allowed on them.  IPCR_BIND_THREADS=0: never.
+struct CpuSet {
+    cpu_set_t set;
+    bool known = false;
+};
+const CpuSet &device_cpus(int phys) {
+    static std::mutex mu;
+    static std::map<int, CpuSet> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(phys);
+    if (it != cache.end()) return it->second;
+    CpuSet &c = cache[phys];
+    CPU_ZERO(&c.set);
+    if (const char *v = getenv("IPCR_BIND_THREADS")) if (*v && atoi(v) == 0) return c;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, phys) != hipSuccess) return c;
+    for (char *q = bus; *q; ++q) *q = (char)tolower((unsigned char)*q);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+    FILE *fh = fopen(path.c_str(), "r");
+    if (!fh) return c;
+    char line[4096] = {0};
+    const bool got = fgets(line, sizeof line, fh) != nullptr;
+    fclose(fh);
+    if (!got) return c;
+    cpu_set_t allowed, local;
+    CPU_ZERO(&allowed);
+    CPU_ZERO(&local);
+    if (sched_getaffinity(getpid(), sizeof allowed, &allowed) != 0) return c; // the process's mask, not a bound thread's
+    for (const char *q = line; *q;) { // "0-63,128-191"
+        char *e = nullptr;
+        const long a = strtol(q, &e, 10);
+        if (e == q) break;
+        long b = a;
+        if (*e == '-') { q = e + 1; b = strtol(q, &e, 10); }
+        for (long k = a; k <= b && k < CPU_SETSIZE; ++k) if (k >= 0) CPU_SET((int)k, &local);
+        q = (*e == ',') ? e + 1 : e;
+        if (*e != ',') break;
+    }
+    CPU_AND(&c.set, &allowed, &local);
+    c.known = CPU_COUNT(&c.set) > 0 && CPU_COUNT(&c.set) < CPU_COUNT(&allowed); // nothing to choose on a one-socket host
+    return c;
+}
+// the calling thread onto the device's CPUs; false when they are not known (or binding is off)
+bool bind_this_thread(int phys) {
+    const CpuSet &c = device_cpus(phys);
+    return c.known && sched_setaffinity(0, sizeof c.set, &c.set) == 0;
+}
 
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
@@ -641,6 +696,12 @@ ipcr_status ipcr_set_device(int device) {
     g_default_slot.store(device, std::memory_order_relaxed); // what ipcr_scratch_create / ipcr_genome_create use from now on, on any thread
     HIPCHK(hipSetDevice(slot_phys(device)));                 // and the calling thread's own HIP device (a Python host shares it with torch)
     return IPCR_OK;
+}
+
+int ipcr_bind_thread_to_device(int device) {
+    if (device < 0) device = default_slot();
+    if (device >= slot_count()) return 0;
+    return bind_this_thread(slot_phys(device)) ? 1 : 0;
 }
 
 uint8_t ipcr_iupac_mask(uint8_t c) { return T.mask[c]; }
@@ -1407,12 +1468,15 @@ public:
     static PackPool &get() { static PackPool *p = new PackPool; return *p; } // never destroyed: its threads sleep on the condition variable until the process ends
     unsigned size() const { return (unsigned)threads_.size() + 1u; }
     // fn(i) for i in [0, n), on the pool's threads and the caller's; returns when all are done
-    template <class F> void run(size_t n, F fn) {
+    // phys >= 0: what the items write is pinned memory read by that device next -- the pool's own threads move onto its CPUs
+    // (device_cpus; the caller's thread stays where its owner put it)
+    template <class F> void run(size_t n, F fn, int phys = -1) {
         std::unique_lock<std::mutex> big(run_mu_); // one record at a time
         {
             std::lock_guard<std::mutex> lk(mu_);
             fn_ = [&](size_t i) { fn(i); };
             n_ = n; next_.store(0); done_.store(0); ++gen_;
+            want_phys_ = phys;
         }
         cv_.notify_all();
         work();
@@ -1422,9 +1486,9 @@ public:
     }
 private:
     PackPool() {
-        unsigned t = std::thread::hardware_concurrency();
+        unsigned t = std::min(std::thread::hardware_concurrency(), 16u); // IPCR_PACK_THREADS: up to 64
         if (const char *v = getenv("IPCR_PACK_THREADS")) t = (unsigned)std::max(1, atoi(v));
-        t = std::min(std::max(t, 1u), 16u);
+        t = std::min(std::max(t, 1u), 64u);
         for (unsigned i = 1; i < t; ++i) threads_.emplace_back([this] { loop(); });
         for (auto &th : threads_) th.detach(); // they sleep on the condition variable for the rest of the process's life
     }
@@ -1438,12 +1502,16 @@ private:
     }
     void loop() {
         uint64_t seen = 0;
+        int bound = -1;
         for (;;) {
+            int want;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return gen_ != seen; });
                 seen = gen_;
+                want = want_phys_;
             }
+            if (want >= 0 && want != bound) { (void)bind_this_thread(want); bound = want; }
             work();
         }
     }
@@ -1451,10 +1519,20 @@ private:
     std::condition_variable cv_, cv_done_;
     std::function<void(size_t)> fn_;
     size_t n_ = 0;
+    int want_phys_ = -1;
     std::atomic<size_t> next_{0}, done_{0};
     uint64_t gen_ = 0;
     std::vector<std::thread> threads_;
 };
+
+} // namespace
+
+// fasta.cpp: its file reads run on the same threads (threads started per slab slowed the slab copies, see there)
+void ipcr_internal_pool_run(size_t n, const std::function<void(size_t)> &fn, int phys) { PackPool::get().run(n, [&](size_t i) { fn(i); }, phys); }
+bool ipcr_internal_bind_thread(int phys) { return bind_this_thread(phys); }
+unsigned ipcr_internal_pool_size() { return PackPool::get().size(); }
+
+namespace {
 
 struct HitLess {
     bool operator()(const ipcr_hit &a, const ipcr_hit &b) const {
@@ -2514,7 +2592,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
             const uint64_t group = std::max<uint64_t>(PackPool::get().size(), (nsl + 3) / 4);
             for (uint64_t g0 = 0; g0 < nsl; g0 += group) {
                 const uint64_t g1 = std::min(nsl, g0 + group);
-                PackPool::get().run((size_t)(g1 - g0), [&](size_t k) { pack_slice(g0 + k, s->h_planes + (g0 + k) * SLC * 2048ull); });
+                PackPool::get().run((size_t)(g1 - g0), [&](size_t k) { pack_slice(g0 + k, s->h_planes + (g0 + k) * SLC * 2048ull); }, slot_phys(g->device));
                 for (uint64_t i = g0; i < g1; ++i) {
                     st = send_slice(i, s->h_planes + i * SLC * 2048ull);
                     if (st != IPCR_OK) { (void)hipStreamSynchronize(g->stream); return st; }

@@ -80,6 +80,12 @@ __attribute__((target("avx512bw,avx512f"))) uint32_t pack_avx512(const uint8_t *
     const __m512i nib = _mm512_set1_epi8(0x0F), up = _mm512_set1_epi8((char)0xDF), bit1 = _mm512_set1_epi8(2), bit2 = _mm512_set1_epi8(4);
     uint64_t any_rst = 0, any_low = 0;
     const uint64_t pairs = n / 64u;
+    // Non-temporal 8-byte stores (the write-combining buffers make whole lines of them) when all four planes are 8-byte
+    // aligned: pinned planes a core has written the ordinary way stay dirty in its cache, and a device that reads them
+    // next has every line fetched out of that cache -- two hops away if the core sits on the other socket.
+    // IPCR_PACK_NT=0: ordinary stores.
+    static const bool nt_on = !(getenv("IPCR_PACK_NT") && atoi(getenv("IPCR_PACK_NT")) == 0);
+    const bool nt = nt_on && (((uintptr_t)lo | (uintptr_t)hi | (uintptr_t)iv | (uintptr_t)rs) & 7u) == 0;
     for (uint64_t w = 0; w < pairs; ++w) {
         const __m512i c = _mm512_loadu_si512(seq + w * 64u);
         const __m512i want = _mm512_shuffle_epi8(lut, _mm512_and_si512(c, nib));
@@ -87,13 +93,21 @@ __attribute__((target("avx512bw,avx512f"))) uint32_t pack_avx512(const uint8_t *
         const uint64_t m_up = _mm512_cmpeq_epi8_mask(want, c);
         const uint64_t b2 = _mm512_test_epi8_mask(c, bit2), b1 = _mm512_test_epi8_mask(c, bit1);
         const uint64_t l = (b1 ^ b2) & m_acgt, h = b2 & m_acgt, v = ~m_up, r = ~m_acgt;
-        lo[2 * w] = (uint32_t)l; lo[2 * w + 1] = (uint32_t)(l >> 32);
-        hi[2 * w] = (uint32_t)h; hi[2 * w + 1] = (uint32_t)(h >> 32);
-        iv[2 * w] = (uint32_t)v; iv[2 * w + 1] = (uint32_t)(v >> 32);
-        rs[2 * w] = (uint32_t)r; rs[2 * w + 1] = (uint32_t)(r >> 32);
+        if (nt) { // past the caches: the next reader of these words is the device
+            _mm_stream_si64(reinterpret_cast<long long *>(lo + 2 * w), (long long)l);
+            _mm_stream_si64(reinterpret_cast<long long *>(hi + 2 * w), (long long)h);
+            _mm_stream_si64(reinterpret_cast<long long *>(iv + 2 * w), (long long)v);
+            _mm_stream_si64(reinterpret_cast<long long *>(rs + 2 * w), (long long)r);
+        } else {
+            lo[2 * w] = (uint32_t)l; lo[2 * w + 1] = (uint32_t)(l >> 32);
+            hi[2 * w] = (uint32_t)h; hi[2 * w + 1] = (uint32_t)(h >> 32);
+            iv[2 * w] = (uint32_t)v; iv[2 * w + 1] = (uint32_t)(v >> 32);
+            rs[2 * w] = (uint32_t)r; rs[2 * w + 1] = (uint32_t)(r >> 32);
+        }
         any_rst |= r;
         any_low |= m_acgt & ~m_up;
     }
+    if (nt) _mm_sfence();
     return (any_rst ? 1u : 0u) | (any_low ? 2u : 0u);
 }
 

@@ -1141,6 +1141,34 @@ def test_handover_matches_device_memory():
 
 # ---- one host process, several devices through the C ABI ------------------------------------------
 
+def test_bind_thread_to_device_moves_only_the_calling_thread(hip):
+    """ipcr_bind_thread_to_device: the calling thread ends up on a subset of the CPUs it was allowed on (the device's
+    local_cpulist), nobody else moves, and 0 is an honest answer on a host with nothing to choose."""
+    import os
+    import threading
+    from ipcr_amd import _lib as L
+    main_before = os.sched_getaffinity(0)
+    seen = {}
+
+    def worker():
+        before = os.sched_getaffinity(0)
+        r = L.lib().ipcr_bind_thread_to_device(0)
+        seen["r"], seen["before"], seen["after"] = r, before, os.sched_getaffinity(0)
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert seen["r"] in (0, 1)
+    assert seen["after"] <= seen["before"] and len(seen["after"]) > 0
+    if seen["r"] == 1:
+        assert len(seen["after"]) < len(seen["before"])
+    else:
+        assert seen["after"] == seen["before"]
+    assert os.sched_getaffinity(0) == main_before
+    assert L.lib().ipcr_bind_thread_to_device(10_000) == 0      # no such device: nothing happens
+
+
+
 def test_one_process_drives_several_device_slots(hip, monkeypatch):
     """The reference's unit of parallelism is a pool of workers calling ForEachCompiledProduct on independent chunks
     (internal/pipeline/pipeline.go:60-125); over several GPUs that is worker i -> device i mod N with no collective.
