@@ -69,7 +69,7 @@ struct ipcr_index_shape {
     uint32_t tw_mask;   // (1 << tw_bits) - 1
     uint32_t blk_mask;  // (1 << block bits) - 1
     uint8_t group;      // shapes of one (anchored end, protected length) share a group
-    uint8_t reserved0;
+    uint8_t paired;     // 1: the shape's table serves TWO consecutive base steps per 32-bit word (jit.cpp: "two steps per lookup")
     uint8_t fast;       // the group's shapes share their low six key bits (else the whole key is computed per shape)
     uint8_t dl;         // left shapes: the window start lies dl bases behind the newest base
     uint64_t valid_mask; // even bits of the k-mer bases the key reads (a base that gives one bit counts)
@@ -79,6 +79,7 @@ static inline uint32_t ipcr_index_key_bits(const ipcr_index_shape &s) { return (
 // 64-bit words of a shape's bitmap: never below 16 (so that word offsets fit the 11 bits the drain's constants have, in units of 16)
 static inline uint32_t ipcr_index_words64(const ipcr_index_shape &s) {
     const uint32_t kb = ipcr_index_key_bits(s);
+    if (s.paired) return 2048u; // 2^12 words of 32 bits: 16 bits per step of the pair (16-bit keys only)
     return kb <= 10u ? 16u : (1u << (kb - 6u));
 }
 

@@ -403,6 +403,22 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     const size_t lds_budget = 160u * 1024u - 16u * 192u * 16u - 256u;
     size_t lds_used = 0;
     auto shape_bytes = [](unsigned key_bits) { return (size_t)(key_bits <= 10 ? 16u : (1u << (key_bits - 6))) * 10u; };
+    // Two steps per lookup (jit.cpp): possible when EVERY group keys on "3 protected bases + 5 block bases" -- the panel's
+    // tables are then 2^12 32-bit words per shape (18 KiB with the rank prefixes), one ds_read_b32 serves two base steps.
+    bool paired = !groups.empty();
+    {
+        size_t ns_all = 0;
+        int lmax = 0;
+        for (const Group &g : groups) {
+            const int t = std::min(g.t, g.lmin);
+            const int bf = (t >= g.lmin) ? 0 : (g.lmin - t) / (k + 1);
+            if (!(k >= 1 && t >= 3 && bf >= 5)) paired = false;
+            ns_all += (size_t)k + 1;
+            for (uint32_t q : g.members) lmax = std::max(lmax, pats[q].len);
+        }
+        if (ns_all > IPCR_INDEX_MAX_SHAPES || ns_all * (2048u * 9u) > lds_budget) paired = false;
+        if (paired) paired = ipcr::jit_index_pairable(ns_all, lmax - 1);
+    }
     for (Group &g : groups) {
         const int t = std::min(g.t, g.lmin);
         const int bf = (t >= g.lmin) ? 0 : (g.lmin - t) / (k + 1);
@@ -441,7 +457,7 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
             }
         } else
             for (int j = 1; j < ns; ++j) pos[(size_t)j] = pos[(size_t)j - 1] + (b > 0 ? b : 0);
-        for (int j = 0; j < ns; ++j) lds_used += shape_bytes((unsigned)(2 * tu + bits[(size_t)j]));
+        for (int j = 0; j < ns; ++j) lds_used += paired ? (size_t)2048u * 9u : shape_bytes((unsigned)(2 * tu + bits[(size_t)j]));
         // files the group's shapes and keys for one layout; returns its cost (see above)
         auto emit = [&](const std::vector<int> &pos, const std::vector<int> &bits) -> double {
             const size_t ents_before = ents.size();
@@ -451,6 +467,7 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
                 sh.left = g.left ? 1 : 0;
                 sh.group = next_group;
                 sh.fast = fast ? 1 : 0;
+                sh.paired = paired ? 1 : 0;
                 sh.dl = (uint8_t)(g.left ? DL : 0);
                 sh.tw_bits = (uint8_t)(2 * tu);
                 sh.tw_mask = tu ? (uint32_t)((1ull << (2 * tu)) - 1ull) : 0u;
@@ -528,7 +545,7 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
             }
             return cost;
         };
-        if (tri && b == 5 && ns > 1) {
+        if (tri && b == 5 && ns > 1 && !paired) {
             // Measured on the 4096-pattern panel (C4, 3 Gb): blocks of 11, 10, 11 bits are picked (cost 0.13 against 0.18
             // for three 10-bit blocks) and a third fewer hits reach the drain.  The larger bitmaps leave the waves smaller
             // hit queues (round 2, two steps per entry: 1 % slower); with one queue entry per four steps the queues fill
@@ -575,6 +592,13 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     if (ix.uniform_len < 0) ix.uniform_len = 0;
     for (uint32_t q = 0; q < P; ++q)
         if (dropped[q]) ix.leftover.push_back(q);
+    if (paired && !ix.shapes.empty() && !ix.shapes[0].paired) paired = false; // (cannot happen: every shape was filed under the same decision)
+    if (paired) // entries are ranked in the order of the tables' low halves: word = the key's low 4 + 8 bits, bit = its high 2 + 2
+        for (auto &e : ents) {
+            const uint32_t key = e.first & 0xFFFFu, prot = key & 63u, blk = key >> 6;
+            const uint32_t wo = ((blk & 0xFFu) << 4) | (prot & 15u), bo = ((blk >> 8) << 2) | (prot >> 4);
+            e.first = (e.first & ~0xFFFFFu) | (wo << 4) | bo;
+        }
     std::sort(ents.begin(), ents.end());
     ents.erase(std::unique(ents.begin(), ents.end()), ents.end());
     // Direct index instead of a hash table: a set bitmap bit means the key is in the panel, and its rank among
@@ -586,10 +610,11 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     std::vector<uint32_t> off64(NS + 1, 0);
     for (size_t i = 0; i < NS; ++i) off64[i + 1] = off64[i] + ipcr_index_words64(ix.shapes[i]);
     const size_t T64 = off64[NS];
-    const size_t img_words = T64 * 2 + T64 / 2 + NS + 2 * NS;
+    const size_t pfx_words = paired ? T64 / 4 : T64 / 2; // one uint16 per 64 keys: a 64-bit bitmap word, or the low halves of four table words
+    const size_t img_words = T64 * 2 + pfx_words + NS + 2 * NS;
     ix.lds_image.assign(std::max<size_t>(1, img_words), 0u);
     uint16_t *prefix = reinterpret_cast<uint16_t *>(ix.lds_image.data() + T64 * 2);
-    uint32_t *base = ix.lds_image.data() + T64 * 2 + T64 / 2;
+    uint32_t *base = ix.lds_image.data() + T64 * 2 + pfx_words;
     size_t ndistinct = 0;
     for (size_t i = 0; i < ents.size(); ++i)
         if (i == 0 || ents[i].first != ents[i - 1].first) ++ndistinct;
@@ -614,7 +639,15 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     size_t r = 0;
     for (size_t i = 0; i < ents.size();) {
         const uint32_t tag = ents[i].first, sidx = tag >> 20, key = tag & 0xFFFFFu;
-        ix.lds_image[off64[sidx] * 2u + (key >> 5)] |= 1u << (key & 31u);
+        if (paired) {
+            // low half: the key as the older step of a pair looks it up; high half: as the newer one does (word = the key's
+            // high 4 + 8 bits, bit = its low 2 + 2)
+            const uint32_t wo = key >> 4, bo = key & 15u;
+            const uint32_t prot = ((bo & 3u) << 4) | (wo & 15u), blk = ((bo >> 2) << 8) | (wo >> 4);
+            ix.lds_image[off64[sidx] * 2u + wo] |= 1u << bo;
+            ix.lds_image[off64[sidx] * 2u + (((blk >> 2) << 4) | (prot >> 2))] |= 1u << (16u + (((blk & 3u) << 2) | (prot & 3u)));
+        } else
+            ix.lds_image[off64[sidx] * 2u + (key >> 5)] |= 1u << (key & 31u);
         ++shape_count[sidx];
         fill(ix.table[r], ents[i].second);
         uint32_t tail = (uint32_t)r;
@@ -632,6 +665,12 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     for (size_t sidx = 0; sidx < NS; ++sidx) {
         base[sidx] = run;
         uint32_t within = 0;
+        if (paired)
+            for (uint32_t g = off64[sidx] / 2u; g < off64[sidx + 1] / 2u; ++g) { // one prefix per four table words (their low halves: 64 keys)
+                prefix[g] = (uint16_t)within;
+                for (uint32_t w = 0; w < 4; ++w) within += (uint32_t)__builtin_popcount(ix.lds_image[g * 4u + w] & 0xFFFFu);
+            }
+        else
         for (uint32_t g = off64[sidx]; g < off64[sidx + 1]; ++g) { // one prefix per 64-bit word of the bitmap
             prefix[g] = (uint16_t)within; // checked below: a shape files fewer than 65536 keys
             for (uint32_t w = 0; w < 2; ++w) within += (uint32_t)__builtin_popcount(ix.lds_image[g * 2u + w]);
@@ -663,7 +702,7 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
                     ix.shapes[sidx].blk_shift, ix.shapes[sidx].blk_mask, shape_count[sidx], ent_count[sidx], longest[sidx]);
     }
     std::sort(ix.leftover.begin(), ix.leftover.end());
-    ix.usable = !ix.shapes.empty() && !ents.empty() && !prefix_overflow && T64 * 10 + 12 * NS + 16u * 128u * 16u <= 160u * 1024u;
+    ix.usable = !ix.shapes.empty() && !ents.empty() && !prefix_overflow && (size_t)ipcr::jit_index_image_bytes(ix.shapes) + 16u * 128u * 16u <= 160u * 1024u;
 }
 
 void build_dev_pattern(const ipcr_panel &p, const PatternDef &d, uint32_t gid, ipcr_dev_pattern &o) {

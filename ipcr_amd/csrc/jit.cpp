@@ -991,9 +991,27 @@ static unsigned index_words64(const std::vector<ipcr_index_shape> &shapes) {
     for (const ipcr_index_shape &x : shapes) t += ipcr_index_words64(x);
     return t;
 }
-static unsigned index_image_bytes(const std::vector<ipcr_index_shape> &shapes) { // bitmaps + per-word rank prefixes + first entries + shape constants (build_index)
-    const unsigned image = index_words64(shapes) * 10u + (unsigned)shapes.size() * 12u + 32u; // (+ the drain's bit table)
+static bool index_paired(const std::vector<ipcr_index_shape> &shapes) { return !shapes.empty() && shapes[0].paired != 0; } // all of a panel's shapes or none
+static unsigned index_image_bytes(const std::vector<ipcr_index_shape> &shapes) { // bitmaps + rank prefixes (uint16 per 64 keys) + first entries + shape constants (build_index)
+    const unsigned per64 = index_paired(shapes) ? 9u : 10u; // two-step tables: 64 keys are four 32-bit words, half of each a copy for the other step
+    const unsigned image = index_words64(shapes) * per64 + (unsigned)shapes.size() * 12u + 32u; // (+ the drain's bit table)
     return (image + 15u) & ~15u;
+}
+unsigned jit_index_image_bytes(const std::vector<ipcr_index_shape> &shapes) { return index_image_bytes(shapes); }
+// Two steps per lookup: steps per queue entry and entry layout for n shapes and windows that reach TR bases back (0: not possible)
+static unsigned paired_plan(size_t ns, int TR, unsigned *mode_out) {
+    const unsigned ROWB = 7;
+    for (unsigned spe : {4u, 2u}) {
+        if (ns * spe > 31u) continue; // payload bits 0..30, one per (shape, step)
+        const unsigned nb = (unsigned)(TR < 0 ? 0 : TR) + spe;
+        if (2u * nb + 6u + ROWB <= 64u) { if (mode_out) *mode_out = 0; return spe; }
+        if (2u * nb + ROWB <= 64u && nb + 6u <= 32u) { if (mode_out) *mode_out = 1; return spe; }
+    }
+    return 0;
+}
+bool jit_index_pairable(size_t n_shapes, int tail_rows) {
+    if (env_int("IPCR_INDEX_TWO_STEP", 0, 0, 1) == 0 || n_shapes == 0) return false; // off unless asked for: measured 18 % SLOWER (below)
+    return paired_plan(n_shapes, tail_rows, nullptr) != 0;
 }
 static unsigned index_queue_entries(const std::vector<ipcr_index_shape> &shapes) { // per-wave hit queue: what the image leaves of the 160 KiB, in rounds of 64
     const unsigned left = 160u * 1024u - std::min(160u * 1024u, index_image_bytes(shapes));
@@ -1062,7 +1080,22 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
     for (const Pack &p : packs) byte_layout |= p.sh.size() > 1;
     const unsigned ROWB = 7; // rows 0..127 of the unit
     unsigned SPE = 1, mode = 2;
-    {
+    // ---- two steps per lookup (all shapes "3 protected bases + 5 block bases", host.cpp: build_index decides).  The keys of
+    // steps t and t + 1 share two of their three protected bases and four of their five block bases: those twelve bits are
+    // the ADDRESS of a 32-bit word; the base only step t has (the oldest of either field, four bits) picks one of its low 16
+    // bits, the base only step t + 1 has (the newest of either field) one of its high 16 -- ONE ds_read_b32 per shape for
+    // two base steps instead of two ds_read_u8; a shape's table is as large as a 17-bit bitmap: 16 KiB.
+    // MEASURED (C4, 3 Gb): 6.09 ms per sweep against 5.15 with the same 16-bit keys looked up one step at a time (4.99 with
+    // the default 17-bit keys) -- half the LDS lookups and the sweep is 18 % SLOWER.  What the pair saves in addresses
+    // (3 per step instead of 6) it pays twice over in bit indices (one per shape and step, where a pack of byte lookups
+    // shares ONE shift): +10 % VALU instructions, most of them four-cycle v_alignbit.  Splitting the bit collection over
+    // 1 / 2 / 4 / 8 registers changes nothing (6.09 / 6.10 / 6.18 / 6.23): no latency chain -- the sweep follows the VALU
+    // issue count, not the LDS instruction count.  Off by default (IPCR_INDEX_TWO_STEP=1), parity-tested.
+    const bool paired = index_paired(shapes);
+    if (paired) {
+        SPE = paired_plan(NS, TR, &mode);
+        if (SPE == 0) return std::string(); // (build_index asked jit_index_pairable first)
+    } else {
         const unsigned SH0 = (unsigned)packs.size();
         unsigned want = byte_layout ? (SH0 <= 2 ? 4u : (SH0 <= 4 ? 2u : 1u)) : (SH0 * 4u <= 31u ? 4u : (SH0 * 2u <= 31u ? 2u : 1u));
         want = (unsigned)env_int("IPCR_INDEX_STEPS_PER_ENTRY", (int)want, 1, (int)want);
@@ -1085,6 +1118,18 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
     const unsigned KMHI = 2u * NBAS > 32u ? 2u * NBAS - 32u : 0u;
     auto bitpos = [&](unsigned p, unsigned i, unsigned j) { return (byte_layout ? 8u * i : 0u) + p + SHF * j; };
     std::vector<int> tab(32, 0);
+    // the tests of a block shift their bits into NCH registers in turn (one chain of 24 dependent shifts is latency, not work)
+    unsigned NCH = paired ? (unsigned)env_int("IPCR_INDEX_ACC_CHAINS", 1, 1, 8) : 1u;
+    while (paired && ((unsigned)NS * SPE) % NCH) --NCH;
+    const unsigned NPC = paired ? (unsigned)NS * SPE / NCH : 0u; // tests per chain
+    const bool use_add = env_int("IPCR_INDEX_ACC_ADD", 0, 0, 1) != 0; // dev knob: a chain grows by add + v_bitop3 (from bit 0 up) instead of one v_alignbit (from bit 31 down)
+    if (paired) { // the c-th (shape, step) test of an entry's block, in the order the code below makes them -> payload bit (c % NCH) * NPC + c / NCH
+        unsigned c = 0;
+        for (unsigned pi = 0; pi < SPE / 2u; ++pi)
+            for (const Grp &g : groups)
+                for (int si : g.sh)
+                    for (unsigned o = 0; o < 2u; ++o, ++c) tab[(c % NCH) * NPC + (use_add ? NPC - 1u - c / NCH : c / NCH)] = si | (int)((SPE - 1u - (2u * pi + o)) << 4);
+    } else
     for (unsigned p = 0; p < NPK; ++p)
         for (unsigned i = 0; i < packs[p].sh.size(); ++i)
             for (unsigned j = 0; j < SPE; ++j) tab[bitpos(p, i, j)] = packs[p].sh[i] | (int)(j << 4);
@@ -1094,7 +1139,7 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
 
     std::ostringstream s;
     s << "// generated by ipcr_amd/csrc/jit.cpp: seed-index filter (transposed k-mers), " << NS << " key shapes in " << groups.size() << " groups / " << NPK
-      << " packs, 128 rows per strand, " << SPE << " steps per queue entry (entry layout " << "ABC"[mode] << ")\n";
+      << " packs, 128 rows per strand, " << SPE << " steps per queue entry (entry layout " << "ABC"[mode] << ")" << (paired ? ", two steps per lookup" : "") << "\n";
     s << "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
     s << "typedef unsigned int u32;\ntypedef unsigned long long u64;\ntypedef long long i64;\n";
     s << "typedef u32 v4 __attribute__((ext_vector_type(4)));\n";
@@ -1115,14 +1160,16 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
     s << "#define KMHI " << KMHI << "u // k-mer bits an entry keeps in y\n";
     s << "#define NBAS " << NBAS << "u // bases (and invalid flags) an entry keeps\n";
     s << "#define EMODE " << mode << " // entry layout: 0 = lane, row above the k-mer in y; 1 = row in y, lane above the flags in z; 2 = both in w\n";
+    s << "#define PAIRED " << (paired ? "true" : "false") << " // a shape's table: 2^12 words, low half = the keys of the older step of a pair, high half = of the newer\n";
+    s << "#define PFX_WORDS " << (paired ? "(T64N / 4u)" : "(T64N / 2u)") << " // uint16 rank prefixes, one per 64 keys\n";
     s << "__device__ const unsigned char __attribute__((aligned(16))) BITTAB[32] = {";
     for (int b = 0; b < 32; ++b) s << (b ? ", " : "") << tab[(size_t)b];
     s << "}; // payload bit -> shape | steps back << 4\n";
     s << R"SRC(
-// LDS image (host.cpp: build_index): the shapes' bitmaps, T64N 64-bit words | T64N uint16 rank prefixes | NS first-entry
-// indices | NS x 2 words of shape constants; behind it (kernel start) the 32 bytes of BITTAB
+// LDS image (host.cpp: build_index): the shapes' bitmaps, T64N 64-bit words | uint16 rank prefixes, one per 64 keys | NS
+// first-entry indices | NS x 2 words of shape constants; behind it (kernel start) the 32 bytes of BITTAB
 #define PREFIX_WORD0 (T64N * 2u)
-#define BASE_WORD0 (T64N * 2u + T64N / 2u)
+#define BASE_WORD0 (T64N * 2u + PFX_WORDS)
 #define SHAPE_WORD0 (BASE_WORD0 + NS)
 #define TAB_WORD0 (SHAPE_WORD0 + 2u * NS)
 #define LDS_WORDS (TAB_WORD0 + 8u)
@@ -1270,10 +1317,22 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "            const u64 skm = hkm >> (2u * back); // a hit of an earlier step of the entry: its own k-mer\n"
          "            const u32 c0 = lds[SHAPE_WORD0 + 2u * sidx], c1 = lds[SHAPE_WORD0 + 2u * sidx + 1u];\n"
          "            const u32 key = ((u32)(skm >> (c0 & 63u)) & (c1 & 0xFFFFu)) | (((u32)(skm >> ((c0 >> 8) & 63u)) & (c1 >> 16)) << ((c0 >> 16) & 31u));\n"
-         "            const u32 wi = (c0 >> 21) * 16u + (key >> 6); // the shape's bitmap word with this key\n"
-         "            const u64 w = T64[wi];\n"
          "            // the key is in the panel; its rank among the shape's keys is the index of its entry\n"
-         "            idx = lds[BASE_WORD0 + sidx] + (u32)prefix[wi] + (u32)__popcll((w << (63u - (key & 63u))) << 1);\n"
+         "            if (PAIRED) { // keys are ranked as the OLDER step of a pair files them: word = the key's low 4 + 8 bits, bit = its high 2 + 2\n"
+         "              const u32 dw = (c0 >> 21) * 32u + (((key >> 2) & 0xFF0u) | (key & 15u)), bo = ((key >> 14) << 2) | ((key >> 4) & 3u);\n"
+         "              const v4 g4 = *reinterpret_cast<const v4*>(lds + (dw & ~3u)); // the 64 keys (four words' low halves) one prefix covers\n"
+         "              const u32 pos = dw & 3u;\n"
+         "              const u32 own = pos == 0u ? g4.x : (pos == 1u ? g4.y : (pos == 2u ? g4.z : g4.w));\n"
+         "              u32 r = (u32)__builtin_popcount(own & ((1u << bo) - 1u));\n"
+         "              if (pos > 0u) r += (u32)__builtin_popcount(g4.x & 0xFFFFu);\n"
+         "              if (pos > 1u) r += (u32)__builtin_popcount(g4.y & 0xFFFFu);\n"
+         "              if (pos > 2u) r += (u32)__builtin_popcount(g4.z & 0xFFFFu);\n"
+         "              idx = lds[BASE_WORD0 + sidx] + (u32)prefix[dw >> 2] + r;\n"
+         "            } else {\n"
+         "              const u32 wi = (c0 >> 21) * 16u + (key >> 6); // the shape's bitmap word with this key\n"
+         "              const u64 w = T64[wi];\n"
+         "              idx = lds[BASE_WORD0 + sidx] + (u32)prefix[wi] + (u32)__popcll((w << (63u - (key & 63u))) << 1);\n"
+         "            }\n"
          "          }\n"
          "          u32 next = 0xFFFFFFFFu;\n"
          "          if (idx != 0xFFFFFFFFu) {\n"
@@ -1315,6 +1374,7 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "    u32 A = tr32(base[offA], tc), B = tr32(base[offB], tc), I = tr32(base[offI], tc);\n"
          "    u32 rA = 0u, rB = 0u, rI = 0u; // the next chunk's words as loaded\n"
          "    u32 acc = 0u; // the masks of the steps since the last queue entry\n";
+    for (unsigned j = 0; j < NCH && paired; ++j) s << "    u32 acc" << j << " = 0u;\n";
     if (mode == 0) s << "    const u32 lane_y = lane << KMHI; // this lane's part of an entry's y\n";
     if (mode == 1) s << "    const u32 lane_z = lane << NBAS;\n";
     if (mode == 2) s << "    const u32 lane_w = lane << 15;\n";
@@ -1328,6 +1388,54 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
     const bool phased = env_int("IPCR_INDEX_PHASED", 0, 0, 1) != 0;
     for (unsigned k0 = 0; k0 < U; k0 += SPE) {
         std::ostringstream pa, pb; // phase A (addresses, reads), phase B (tests)
+        if (paired) {
+            unsigned cc = 0; // tests made so far in this block
+            auto test = [&](const std::string &word, const std::string &idx) {
+                const std::string a = "acc" + std::to_string(cc % NCH);
+                if (use_add) pb << "        " << a << " = ANDOR(" << word << " >> " << idx << ", 1u, " << a << " + " << a << ");\n";
+                else pb << "        " << a << " = __builtin_amdgcn_alignbit(" << word << " >> " << idx << ", " << a << ", 1u);\n";
+                ++cc;
+            };
+            for (unsigned kn = k0 + 1u; kn < k0 + SPE; kn += 2u) { // the pair (kn - 1, kn), every field taken in the frame of step kn
+                const unsigned half = kn / 16u, tq = kn % 16u, P0 = 2u * (15u - tq);
+                const char *W[3] = {half ? "B" : "A", half ? "A" : "PB", half ? "PB" : "PA"};
+                auto shifted = [&](unsigned f, unsigned width) { // (km >> f), valid in its low `width` bits at least; km = {W2, W1, W0} >> P0
+                    const unsigned P = P0 + f, q = P / 32u, r = P % 32u;
+                    if (q > 2u) return std::string("0u");
+                    if (r == 0u) return std::string(W[q]);
+                    if (r + width <= 32u || q == 2u) return "(" + std::string(W[q]) + " >> " + std::to_string(r) + "u)";
+                    return "__builtin_amdgcn_alignbit(" + std::string(W[q + 1]) + ", " + W[q] + ", " + std::to_string(r) + "u)";
+                };
+                auto width_of = [](unsigned mask) { unsigned w = 0; while (mask >> w) ++w; return w; };
+                auto field = [&](unsigned f, unsigned mask) { return "(" + shifted(f, width_of(mask)) + " & " + std::to_string(mask) + "u)"; };
+                const std::string K = std::to_string(kn);
+                pa << "        // steps " << kn - 1u << ", " << kn << "\n";
+                for (size_t gi = 0; gi < groups.size(); ++gi) {
+                    const unsigned c = (unsigned)groups[gi].c_off; // the protected bases: 8 bits of the two steps together
+                    const std::string G = std::to_string(gi) + "_" + K;
+                    pa << "        const u32 cp" << G << " = " << field(c, 0x3Cu) << ", un" << G << " = ANDOR(" << shifted(c, 2u) << ", 3u, 16u), uo" << G << " = " << field(c + 6u, 3u) << ";\n";
+                    for (int si : groups[gi].sh) {
+                        const unsigned b = (unsigned)shapes[(size_t)si].blk_shift; // the block: 12 bits of the two steps together
+                        const std::string S = std::to_string(si) + "_" + K;
+                        const std::string addr = b >= 4u ? "ANDOR(" + shifted(b - 4u, 14u) + ", 16320u, cp" + G + ")" : "((" + field(b + 2u, 255u) + " << 6) | cp" + G + ")";
+                        const std::string inew = b >= 2u ? "ANDOR(" + shifted(b - 2u, 4u) + ", 12u, un" + G + ")" : "((" + field(b, 3u) + " << 2) | un" + G + ")";
+                        const std::string iold = "ANDOR(" + shifted(b + 8u, 4u) + ", 12u, uo" + G + ")";
+                        pa << "        const u32 w" << S << " = *reinterpret_cast<const u32*>(ldsb + " << off64[(size_t)si] * 8u << "u + " << addr << ");\n";
+                        test("w" + S, iold);
+                        test("w" + S, inew);
+                    }
+                }
+            }
+            if (use_add) {
+                pb << "        acc = (acc0 & " << ((1u << NPC) - 1u) << "u)";
+                for (unsigned j = 1; j < NCH; ++j) pb << " | ((acc" << j << " & " << ((1u << NPC) - 1u) << "u) << " << j * NPC << "u)";
+                pb << ";\n";
+            } else {
+                pb << "        acc = (acc0 >> " << 32u - NPC << "u)";
+                for (unsigned j = 1; j < NCH; ++j) pb << " | ((acc" << j << " >> " << 32u - NPC << "u) << " << j * NPC << "u)";
+                pb << ";\n";
+            }
+        } else
         for (unsigned k = k0; k < k0 + SPE; ++k) {
             const unsigned half = k / 16u, tq = k % 16u, P0 = 2u * (15u - tq);
             const char *W[3] = {half ? "B" : "A", half ? "A" : "PB", half ? "PB" : "PA"};

@@ -68,6 +68,11 @@ struct IndexGeom {
     uint32_t table_entries = 0; // entries of the panel's table: chained patterns of a key go back into the queue when an entry index fits the bits a queue entry has for it
 };
 std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom);
+// can a panel of n_shapes shapes (all "3 protected bases + 5 block bases") whose windows reach tail_rows bases back take
+// the two-steps-per-lookup tables?  (host.cpp: build_index asks before it lays the tables out; IPCR_INDEX_TWO_STEP=0: no)
+bool jit_index_pairable(size_t n_shapes, int tail_rows);
+// bytes of the LDS image of a set of shapes (tables + rank prefixes + constants)
+unsigned jit_index_image_bytes(const std::vector<ipcr_index_shape> &shapes);
 JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom, std::string &err);
 hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t block0, uint64_t nblocks, uint32_t nshapes,
                             const uint32_t *lds_image, const void *table, uint32_t max_mm, void *queue,

@@ -574,12 +574,14 @@ def test_index_filter_random(hip, force_index, monkeypatch, seed):
     assert 3 in kinds
 
 
-@pytest.mark.parametrize("half_bases", [0, 1])
-def test_config_c4_large_panel_index(hip, monkeypatch, half_bases):
-    """256 TSV rows -> 768 pairs / 1024 distinct patterns: seed-index filter, vs the oracle; also with the 17-bit keys
-    (a block takes one bit of a spare sixth base: host.cpp build_index, off by default)"""
+@pytest.mark.parametrize("half_bases,two_step", [(0, 0), (1, 0), (0, 1)])
+def test_config_c4_large_panel_index(hip, monkeypatch, half_bases, two_step):
+    """256 TSV rows -> 768 pairs / 1024 distinct patterns: seed-index filter, vs the oracle; with 16-bit keys, with the
+    17-bit keys (a block takes one bit of a spare sixth base: host.cpp build_index, the default), and with the tables
+    that serve two base steps per lookup (jit.cpp, IPCR_INDEX_TWO_STEP: measured slower, kept as a knob)"""
     from ipcr_amd import workloads
     monkeypatch.setenv("IPCR_INDEX_HALF_BASES", str(half_bases))
+    monkeypatch.setenv("IPCR_INDEX_TWO_STEP", str(two_step))
     rng = random.Random(26)
     pairs = workloads.c4_pairs(256)
     g, seqs = build_planted_genome(hip, rng, 3, 400_000, pairs[:256], 0x5eed1239)

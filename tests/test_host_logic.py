@@ -478,7 +478,11 @@ def test_seed_index_source_compiles_for_gfx950(k, tw, lens, iupac, tmp_path):
     src = cp.filter_source(2)
     cp.close()
     assert "ipcr_index_filter" in src
-    if tw >= 3 and k >= 1 and "(entry layout C)" not in src:   # (primers beyond 26 nt: one bit per shape, see jit.cpp)
+    if "two steps per lookup" in src:                          # 3 protected + 5 block bases throughout: one ds_read_b32 per shape and PAIR of steps
+        assert re.search(r"const u32 cp0_1 = \(.*& 60u\), un0_1 = ANDOR\(.*, 3u, 16u\), uo0_1 = ", src), \
+            "the protected bases two consecutive steps share must be taken once per pair and group"
+        assert len(re.findall(r"reinterpret_cast<const u32\*>\(ldsb \+", src)) == 16 * src.count("#define NS ") * int(re.search(r"#define NS (\d+)", src).group(1))
+    elif tw >= 3 and k >= 1 and "(entry layout C)" not in src:   # (primers beyond 26 nt: one bit per shape, see jit.cpp)
         assert re.search(r"const u32 cb0_0 = \(.*& 7u\), cw0_0 = ", src), \
             "a panel with >= 3 protected bases must take its shapes' common six key bits once per step"
     path = tmp_path / "index.hip"
