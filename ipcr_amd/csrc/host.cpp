@@ -606,12 +606,12 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     // comes from a per-256-bit-group prefix (uint16, LDS) plus popcounts inside the group.
     const size_t NS = ix.shapes.size();
     // LDS image: the shapes' bitmaps one after the other (64-bit words) | a uint16 rank prefix per bitmap word |
-    // NS first-entry indices | NS x 2 words of shape constants
+    // NS x 4 words of shape constants (shifts, masks, first bitmap word, first entry)
     std::vector<uint32_t> off64(NS + 1, 0);
     for (size_t i = 0; i < NS; ++i) off64[i + 1] = off64[i] + ipcr_index_words64(ix.shapes[i]);
     const size_t T64 = off64[NS];
     const size_t pfx_words = paired ? T64 / 4 : T64 / 2; // one uint16 per 64 keys: a 64-bit bitmap word, or the low halves of four table words
-    const size_t img_words = T64 * 2 + pfx_words + NS + 2 * NS;
+    const size_t img_words = T64 * 2 + pfx_words + 4 * NS; // (T64 is a multiple of 16: the constants are 16-byte aligned)
     ix.lds_image.assign(std::max<size_t>(1, img_words), 0u);
     uint16_t *prefix = reinterpret_cast<uint16_t *>(ix.lds_image.data() + T64 * 2);
     uint32_t *base = ix.lds_image.data() + T64 * 2 + pfx_words;
@@ -662,8 +662,9 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     }
     uint32_t run = 0;
     bool prefix_overflow = false;
+    std::vector<uint32_t> first_entry(NS, 0);
     for (size_t sidx = 0; sidx < NS; ++sidx) {
-        base[sidx] = run;
+        first_entry[sidx] = run;
         uint32_t within = 0;
         if (paired)
             for (uint32_t g = off64[sidx] / 2u; g < off64[sidx + 1] / 2u; ++g) { // one prefix per four table words (their low halves: 64 keys)
@@ -679,11 +680,13 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         run += shape_count[sidx];
     }
     // the shapes' constants for the drain, which handles a hit's shape as a run-time value:
-    // {tw_shift | blk_shift << 8 | tw_bits << 16 | (first bitmap word / 16) << 21, tw_mask | blk_mask << 16}
+    // {tw_shift | blk_shift << 8 | tw_bits << 16, tw_mask | blk_mask << 16, first 64-bit bitmap word, first entry}
     for (size_t sidx = 0; sidx < NS; ++sidx) {
         const ipcr_index_shape &sh = ix.shapes[sidx];
-        base[NS + 2 * sidx] = (uint32_t)sh.tw_shift | ((uint32_t)sh.blk_shift << 8) | ((uint32_t)sh.tw_bits << 16) | ((off64[sidx] / 16u) << 21);
-        base[NS + 2 * sidx + 1] = (sh.tw_mask & 0xFFFFu) | ((sh.blk_mask & 0xFFFFu) << 16);
+        base[4 * sidx] = (uint32_t)sh.tw_shift | ((uint32_t)sh.blk_shift << 8) | ((uint32_t)sh.tw_bits << 16);
+        base[4 * sidx + 1] = (sh.tw_mask & 0xFFFFu) | ((sh.blk_mask & 0xFFFFu) << 16);
+        base[4 * sidx + 2] = off64[sidx];
+        base[4 * sidx + 3] = first_entry[sidx];
     }
     static const bool debug = env_flag("IPCR_INDEX_DEBUG", false);
     if (debug) { // per shape: key bits, distinct keys, filed patterns, longest chain

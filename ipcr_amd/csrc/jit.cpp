@@ -994,7 +994,7 @@ static unsigned index_words64(const std::vector<ipcr_index_shape> &shapes) {
 static bool index_paired(const std::vector<ipcr_index_shape> &shapes) { return !shapes.empty() && shapes[0].paired != 0; } // all of a panel's shapes or none
 static unsigned index_image_bytes(const std::vector<ipcr_index_shape> &shapes) { // bitmaps + rank prefixes (uint16 per 64 keys) + first entries + shape constants (build_index)
     const unsigned per64 = index_paired(shapes) ? 9u : 10u; // two-step tables: 64 keys are four 32-bit words, half of each a copy for the other step
-    const unsigned image = index_words64(shapes) * per64 + (unsigned)shapes.size() * 12u + 32u; // (+ the drain's bit table)
+    const unsigned image = index_words64(shapes) * per64 + (unsigned)shapes.size() * 16u + 32u; // (+ the drain's bit table)
     return (image + 15u) & ~15u;
 }
 unsigned jit_index_image_bytes(const std::vector<ipcr_index_shape> &shapes) { return index_image_bytes(shapes); }
@@ -1166,12 +1166,12 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
     for (int b = 0; b < 32; ++b) s << (b ? ", " : "") << tab[(size_t)b];
     s << "}; // payload bit -> shape | steps back << 4\n";
     s << R"SRC(
-// LDS image (host.cpp: build_index): the shapes' bitmaps, T64N 64-bit words | uint16 rank prefixes, one per 64 keys | NS
-// first-entry indices | NS x 2 words of shape constants; behind it (kernel start) the 32 bytes of BITTAB
+// LDS image (host.cpp: build_index): the shapes' bitmaps, T64N 64-bit words | uint16 rank prefixes, one per 64 keys | NS x
+// 4 words of shape constants (one ds_read_b128 in the drain: field shifts, field masks, first bitmap word, first entry);
+// behind it (kernel start) the 32 bytes of BITTAB
 #define PREFIX_WORD0 (T64N * 2u)
-#define BASE_WORD0 (T64N * 2u + PFX_WORDS)
-#define SHAPE_WORD0 (BASE_WORD0 + NS)
-#define TAB_WORD0 (SHAPE_WORD0 + 2u * NS)
+#define SHAPE_WORD0 (T64N * 2u + PFX_WORDS)
+#define TAB_WORD0 (SHAPE_WORD0 + 4u * NS)
 #define LDS_WORDS (TAB_WORD0 + 8u)
 #define ANDOR(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA) /* (a & b) | c: v_bitop3_b32 issues in two cycles, v_and_or_b32 in four */
 __device__ __forceinline__ u32 LSHL_OR(u32 a, u32 sh, u32 b) { u32 r; asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(8), "v"(b)); (void)sh; return r; }
@@ -1296,8 +1296,8 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "        };\n"
          "        for (u32 qb = 0; qb < n; qb += 64u) {\n"
          "          const u32 i = qb + lane;\n"
-         "          v4 e; e.x = 0u; e.y = 0u; e.z = 0u; e.w = 0u;\n"
-         "          if (i < n) e = *reinterpret_cast<const v4*>(wq + i * 4u);\n"
+         "          v4 e = *reinterpret_cast<const v4*>(wq + i * 4u); // (a slot behind the last entry is still inside the queue: n <= QCAP, a multiple of 64)\n"
+         "          if (i >= n) e.w = 0u; // nothing pending, no chain: the lane idles through the round\n"
          "          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // every lane has read its slot: slots up to qb + 63 may be rewritten\n"
          "          u32 pend = 0u, idx = 0xFFFFFFFFu, back = 0u, keep = 0u; // keep: what of w a handed-back entry keeps (layout C: lane and row)\n"
          "          u32 elane, erow0;\n"
@@ -1315,11 +1315,11 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "            const u32 sidx = t & 15u;\n"
          "            back = t >> 4;\n"
          "            const u64 skm = hkm >> (2u * back); // a hit of an earlier step of the entry: its own k-mer\n"
-         "            const u32 c0 = lds[SHAPE_WORD0 + 2u * sidx], c1 = lds[SHAPE_WORD0 + 2u * sidx + 1u];\n"
-         "            const u32 key = ((u32)(skm >> (c0 & 63u)) & (c1 & 0xFFFFu)) | (((u32)(skm >> ((c0 >> 8) & 63u)) & (c1 >> 16)) << ((c0 >> 16) & 31u));\n"
+         "            const v4 sc = *reinterpret_cast<const v4*>(lds + SHAPE_WORD0 + 4u * sidx); // {shifts, masks, first bitmap word, first entry}\n"
+         "            const u32 key = ((u32)(skm >> (sc.x & 63u)) & (sc.y & 0xFFFFu)) | (((u32)(skm >> ((sc.x >> 8) & 63u)) & (sc.y >> 16)) << ((sc.x >> 16) & 31u));\n"
          "            // the key is in the panel; its rank among the shape's keys is the index of its entry\n"
          "            if (PAIRED) { // keys are ranked as the OLDER step of a pair files them: word = the key's low 4 + 8 bits, bit = its high 2 + 2\n"
-         "              const u32 dw = (c0 >> 21) * 32u + (((key >> 2) & 0xFF0u) | (key & 15u)), bo = ((key >> 14) << 2) | ((key >> 4) & 3u);\n"
+         "              const u32 dw = sc.z * 2u + (((key >> 2) & 0xFF0u) | (key & 15u)), bo = ((key >> 14) << 2) | ((key >> 4) & 3u);\n"
          "              const v4 g4 = *reinterpret_cast<const v4*>(lds + (dw & ~3u)); // the 64 keys (four words' low halves) one prefix covers\n"
          "              const u32 pos = dw & 3u;\n"
          "              const u32 own = pos == 0u ? g4.x : (pos == 1u ? g4.y : (pos == 2u ? g4.z : g4.w));\n"
@@ -1327,11 +1327,11 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "              if (pos > 0u) r += (u32)__builtin_popcount(g4.x & 0xFFFFu);\n"
          "              if (pos > 1u) r += (u32)__builtin_popcount(g4.y & 0xFFFFu);\n"
          "              if (pos > 2u) r += (u32)__builtin_popcount(g4.z & 0xFFFFu);\n"
-         "              idx = lds[BASE_WORD0 + sidx] + (u32)prefix[dw >> 2] + r;\n"
+         "              idx = sc.w + (u32)prefix[dw >> 2] + r;\n"
          "            } else {\n"
-         "              const u32 wi = (c0 >> 21) * 16u + (key >> 6); // the shape's bitmap word with this key\n"
+         "              const u32 wi = sc.z + (key >> 6); // the shape's bitmap word with this key\n"
          "              const u64 w = T64[wi];\n"
-         "              idx = lds[BASE_WORD0 + sidx] + (u32)prefix[wi] + (u32)__popcll((w << (63u - (key & 63u))) << 1);\n"
+         "              idx = sc.w + (u32)prefix[wi] + (u32)__popcll((w << (63u - (key & 63u))) << 1);\n"
          "            }\n"
          "          }\n"
          "          u32 next = 0xFFFFFFFFu;\n"
