@@ -490,10 +490,10 @@ struct FastaLoader {
                         e = hipStreamWaitEvent(cs, ev_free[j & 1], 0);
                     }
                     if (trace && j < 64) { hipEvent_t a, z; (void)hipEventCreate(&a); (void)hipEventCreate(&z); tev.push_back(a); tev.push_back(z); (void)hipEventRecord(a, cs); }
-                    // One slab copy at a time: a copy queued while the one before is still in flight is given another DMA
-                    // engine by the runtime (the preferred one is busy) and then takes 1.8-2.4 ms instead of 1.2 -- and as
-                    // slow copies are always still in flight when the next slab is ready, that state keeps itself up (1 GB
-                    // file: 31 ms; tools/ubench/slab_pipeline.hip).  The fill of the next slab has long begun: nothing waits.
+                    // One slab copy at a time: the next one is queued when the one before has finished.  Queued behind a
+                    // copy still in flight it was slower on every box tried (1 GB file: 37 -> 46-52 ms on a slow one,
+                    // tools/gpu_round3_n.sh); why, the runtime does not say.  The fill of the next slab has long begun
+                    // by the time this thread waits here, so the link idles only for the few microseconds of the hand-over.
                     static const bool one_copy = !(getenv("IPCR_FASTA_COPY_OVERLAP") && atoi(getenv("IPCR_FASTA_COPY_OVERLAP")));
                     if (one_copy && j >= 1 && e == hipSuccess) e = hipEventSynchronize(ev_h2d[(j - 1) % NPIN]);
                     if (e == hipSuccess && cut) e = hipMemcpyAsync(draw[j & 1], b, cut, hipMemcpyHostToDevice, cs);
