@@ -88,6 +88,8 @@ int main(int argc, char **argv) {
     for (int d : devices)
         if (d >= ipcr_device_count()) { fprintf(stderr, "chunk_workers: device %d of %d\n", d, ipcr_device_count()); return 2; }
 
+    // --bind: this thread too, before it makes the record -- the bytes the workers pack then live next to the device as well
+    if (bind) (void)ipcr_bind_thread_to_device(devices[0]);
     // the record: benchDNA (performance_benchmark_test.go:67-76) + an amplicon of pair 0 every 1 Mb
     std::vector<uint8_t> seq(n);
     unsigned x = 0x5eed1234u;
