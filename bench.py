@@ -524,7 +524,8 @@ def scan_chunk_rates(args, local=0, record_bases=125_000_000, chunk=4_000_000):
     record from a queue.  PCIe-inclusive; reported next to the raw pinned H2D rate; never `value`.  Measured by the
     native driver ipcr_amd/chunk_workers (csrc/chunk_workers.cpp) in a child process: the call takes ~0.1 ms, and a
     Python thread pool would add its own per-call interpreter work to it.  It runs BEFORE this process touches the GPU
-    and with GPU_MAX_HW_QUEUES=8: with 16 queues per process a worker pool is fast or slow from run to run."""
+    and with GPU_MAX_HW_QUEUES=4, the runtime's default and the best setting for a pool of packing workers (chunk_workers.cpp;
+    this process itself runs with 16, one queue per stream, for the resident-genome lanes and the collective)."""
     import subprocess
     exe = os.path.join(ROOT, "ipcr_amd", "chunk_workers")
     if not os.path.exists(exe):
@@ -532,7 +533,7 @@ def scan_chunk_rates(args, local=0, record_bases=125_000_000, chunk=4_000_000):
     n = min(record_bases, args.record_len)
     r = subprocess.run([exe, str(n), str(chunk), "1", "8", "16"], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local)),
-                                GPU_MAX_HW_QUEUES=os.environ.get("IPCR_CHUNK_HW_QUEUES", "8")))   # see chunk_workers.cpp
+                                GPU_MAX_HW_QUEUES=os.environ.get("IPCR_CHUNK_HW_QUEUES", "4")))   # see chunk_workers.cpp
     if r.returncode != 0:
         raise SystemExit("chunk_workers failed (%d): %s" % (r.returncode, r.stderr[-2000:]))
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -546,7 +547,7 @@ def scan_chunk_all_devices(world: int, args, record_bases=125_000_000, chunk=4_0
     import subprocess
     exe = os.path.join(ROOT, "ipcr_amd", "chunk_workers")
     try:
-        env = dict(os.environ, GPU_MAX_HW_QUEUES=os.environ.get("IPCR_CHUNK_HW_QUEUES", "8"))
+        env = dict(os.environ, GPU_MAX_HW_QUEUES=os.environ.get("IPCR_CHUNK_HW_QUEUES", "4"))
         if os.environ.get("IPCR_BENCH_ONE_DEVICE"):      # rehearsal on one GPU: device slots instead of devices
             env["IPCR_DEVICE_SLOTS"] = str(world)
         r = subprocess.run([exe, "--devices", ",".join(str(d) for d in range(world)), str(min(record_bases, args.record_len)), str(chunk),
