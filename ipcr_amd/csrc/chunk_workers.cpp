@@ -194,7 +194,7 @@ int main(int argc, char **argv) {
     printf("{\"pinned_h2d_GBps\": %.1f, \"record_bases\": %llu, \"chunk_bases\": %llu, \"chunks\": %zu, \"planted\": %llu, \"devices\": [",
            h2d, (unsigned long long)n, (unsigned long long)chunk, jobs.size(), (unsigned long long)planted);
     for (size_t i = 0; i < devices.size(); ++i) printf("%s%d", i ? ", " : "", devices[i]);
-    printf("]");
+    printf("], \"hw_queues\": %d", atoi(getenv("GPU_MAX_HW_QUEUES")));
     int rc = 0;
     for (int W : workers) {
         std::vector<ipcr_scratch *> scs((size_t)W, nullptr);
