@@ -1407,6 +1407,10 @@ struct ipcr_scratch {
     uint8_t *d_amps = nullptr; uint64_t amps_cap = 0;
     ipcr_genome *nest = nullptr; // amplicons of a nested-PCR batch, one record each (ipcr_nested_windows)
     void *d_probe_misc = nullptr; uint64_t probe_misc_cap = 0;
+    // ipcr_probe_products: its own lane, and ONE pinned block the two kernels read their arguments from and write the
+    // results to (no copy operation in either direction)
+    hipStream_t probe_stream = nullptr;
+    uint8_t *h_probe = nullptr; uint64_t h_probe_cap = 0;
 };
 
 namespace {
@@ -2403,6 +2407,8 @@ void ipcr_scratch_destroy(ipcr_scratch *s) {
         if (e) (void)hipEventDestroy(e);
     if (s->ev_done) (void)hipEventDestroy(s->ev_done);
     if (s->cstream) (void)hipStreamDestroy(s->cstream);
+    if (s->probe_stream) (void)hipStreamDestroy(s->probe_stream);
+    if (s->h_probe) (void)hipHostFree(s->h_probe);
     // the stream goes with the last scratch that shares it (own_lane / lane_used references)
     delete s;
 }
@@ -2790,10 +2796,24 @@ ipcr_status ipcr_probe_products(ipcr_scratch *s, const ipcr_genome *g, const cha
     ipcr_status st = normalize_probe(probe, prb);
     if (st != IPCR_OK) return st;
     if (prb.empty()) return IPCR_OK;
+    // The rescan runs on a lane of its own and its kernels take their arguments straight out of pinned host memory and
+    // put the results there: chained scratches share ONE in-order stream on which the next pass's sweep is already
+    // queued when the host gets here, and three small pageable copies + one back cost more than the two kernels.
+    // pinned block: [0, 256) probe / rc masks | results | segments | offsets
+    const uint64_t res_off = 256, seg_off = (res_off + n * sizeof(ipcr_probe_rec) + 15) & ~15ull;
+    const uint64_t off_off = seg_off + n * sizeof(ipcr_amp_seg), hbytes = off_off + (n + 1) * 8;
+    if (hbytes > s->h_probe_cap) {
+        if (s->h_probe) (void)hipHostFree(s->h_probe);
+        s->h_probe = nullptr;
+        s->h_probe_cap = hbytes * 2;
+        HIPCHK(hipHostMalloc((void **)&s->h_probe, s->h_probe_cap, hipHostMallocDefault));
+    }
+    if (!s->probe_stream) HIPCHK(hipStreamCreateWithFlags(&s->probe_stream, hipStreamNonBlocking));
     // amplicon = record[start:end], or record[start:] ++ record[:end] for wrap-around products
     // (internal/pipeline/pipeline.go:80-89)
-    std::vector<ipcr_amp_seg> segs(n);
-    std::vector<uint64_t> offs(n + 1, 0);
+    ipcr_amp_seg *segs = reinterpret_cast<ipcr_amp_seg *>(s->h_probe + seg_off);
+    uint64_t *offs = reinterpret_cast<uint64_t *>(s->h_probe + off_off);
+    offs[0] = 0;
     for (size_t i = 0; i < n; ++i) {
         const ipcr_product &pr = s->products[i];
         if ((size_t)pr.record >= g->rec_start.size()) return fail(IPCR_ERR_INVALID, "product record outside genome");
@@ -2812,24 +2832,24 @@ ipcr_status ipcr_probe_products(ipcr_scratch *s, const ipcr_genome *g, const cha
         s->amps_cap = amp_bytes + (amp_bytes >> 2);
         HIPCHK(hipMalloc((void **)&s->d_amps, s->amps_cap));
     }
-    const uint64_t misc_bytes = 512 + n * sizeof(ipcr_probe_rec) + n * sizeof(ipcr_amp_seg) + (n + 1) * 8 + 64;
-    if (misc_bytes > s->probe_misc_cap) {
-        if (s->d_probe_misc) (void)hipFree(s->d_probe_misc);
-        s->d_probe_misc = nullptr;
-        s->probe_misc_cap = misc_bytes * 2;
-        HIPCHK(hipMalloc(&s->d_probe_misc, s->probe_misc_cap));
+    std::string rc;
+    revcomp(prb, rc, nullptr);
+    uint8_t *masks = s->h_probe;
+    memset(masks, 0, 256);
+    bool strict = true;
+    for (size_t i = 0; i < prb.size(); ++i) {
+        masks[i] = T.mask[(uint8_t)prb[i]];
+        masks[128 + i] = T.mask[(uint8_t)rc[i]];
+        if (prb[i] != 'A' && prb[i] != 'C' && prb[i] != 'G' && prb[i] != 'T') strict = false;
     }
-    uint8_t *base = static_cast<uint8_t *>(s->d_probe_misc);
-    uint8_t *misc = base; // 256 masks + results
-    uint64_t o = 256 + n * sizeof(ipcr_probe_rec);
-    o = (o + 15) & ~15ull;
-    ipcr_amp_seg *dsegs = reinterpret_cast<ipcr_amp_seg *>(base + o);
-    o += n * sizeof(ipcr_amp_seg);
-    uint64_t *doffs = reinterpret_cast<uint64_t *>(base + o);
-    HIPCHK(hipMemcpyAsync(dsegs, segs.data(), n * sizeof(ipcr_amp_seg), hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(doffs, offs.data(), (n + 1) * 8, hipMemcpyHostToDevice, s->stream));
-    HIPCHK(ipcr::launch_gather(s->stream, g->planes, g->rst, dsegs, (uint32_t)n, s->d_amps));
-    return run_probe(s->stream, s->d_amps, doffs, (uint32_t)n, prb, max_mm, misc, out);
+    const uint32_t fast = (max_mm == 0 && strict) ? 1u : 0u; // oligo.go:33-42
+    ipcr_probe_rec *res = reinterpret_cast<ipcr_probe_rec *>(s->h_probe + res_off);
+    HIPCHK(ipcr::launch_gather(s->probe_stream, g->planes, g->rst, segs, (uint32_t)n, s->d_amps));
+    HIPCHK(ipcr::launch_probe(s->probe_stream, s->d_amps, offs, (uint32_t)n, masks, masks + 128, (uint32_t)prb.size(),
+                              (uint32_t)(max_mm < 0 ? 0 : max_mm), fast, res));
+    HIPCHK(hipStreamSynchronize(s->probe_stream));
+    memcpy(out, res, n * sizeof(ipcr_probe_hit)); // (ipcr_probe_rec is layout-identical)
+    return IPCR_OK;
 }
 
 // ------------------------------------------------------------------------------ nested PCR
