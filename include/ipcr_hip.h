@@ -346,6 +346,12 @@ ipcr_status ipcr_probe_best_hit(const uint8_t *amplicon, uint64_t len, const cha
                                 ipcr_probe_hit *out);
 /* batched form for ipcr-probe: every product of the last scan on `s` against the resident
  * genome; out[i] corresponds to product i (internal/visitors/probe.go:18-33) */
+/* the same in two halves: _begin queues the rescan of the scratch's current products on a lane of its own and returns,
+ * _end waits for it and hands the results out -- the collector's work on the NEXT chunk's products can run in between
+ * (internal/pipeline/pipeline.go:127-161 merges while the workers scan).  The scratch must not be scanned with between
+ * the two; one rescan per scratch at a time. */
+ipcr_status ipcr_probe_products_begin(ipcr_scratch *s, const ipcr_genome *g, const char *probe, int32_t max_mm);
+ipcr_status ipcr_probe_products_end(ipcr_scratch *s, ipcr_probe_hit *out, int64_t n_out);
 ipcr_status ipcr_probe_products(ipcr_scratch *s, const ipcr_genome *g, const char *probe, int32_t max_mm,
                                 ipcr_probe_hit *out, int64_t n_out);
 

@@ -149,6 +149,8 @@ SYMBOLS = {
     "ipcr_exchange_redone": (C.c_uint64, [C.c_void_p]),
     "ipcr_probe_best_hit": (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_int32, C.POINTER(ProbeHit)]),
     "ipcr_probe_products": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(ProbeHit), C.c_int64]),
+    "ipcr_probe_products_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32]),
+    "ipcr_probe_products_end": (C.c_int, [C.c_void_p, C.POINTER(ProbeHit), C.c_int64]),
     "ipcr_nested_windows": (C.c_int, [C.c_void_p, C.POINTER(Window), C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(NestedHit)]),
     "ipcr_nested_products": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NestedHit), C.c_int64]),
 }

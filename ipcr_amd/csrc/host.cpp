@@ -1411,6 +1411,8 @@ struct ipcr_scratch {
     // results to (no copy operation in either direction)
     hipStream_t probe_stream = nullptr;
     uint8_t *h_probe = nullptr; uint64_t h_probe_cap = 0;
+    int64_t probe_pending = -1;     // ipcr_probe_products_begin: products whose rescan is in flight (-1: none)
+    uint64_t probe_res_off = 0;     // ... and where in h_probe its results arrive
 };
 
 namespace {
@@ -2784,18 +2786,36 @@ ipcr_status ipcr_probe_best_hit(const uint8_t *amplicon, uint64_t len, const cha
 
 ipcr_status ipcr_probe_products(ipcr_scratch *s, const ipcr_genome *g, const char *probe, int32_t max_mm,
                                 ipcr_probe_hit *out, int64_t n_out) {
-    if (!s || !g || !probe || (!out && n_out)) return fail(IPCR_ERR_INVALID, "ipcr_probe_products: null argument");
+    const ipcr_status st = ipcr_probe_products_begin(s, g, probe, max_mm);
+    return st != IPCR_OK ? st : ipcr_probe_products_end(s, out, n_out);
+}
+
+ipcr_status ipcr_probe_products_end(ipcr_scratch *s, ipcr_probe_hit *out, int64_t n_out) {
+    if (!s || (!out && n_out)) return fail(IPCR_ERR_INVALID, "ipcr_probe_products_end: null argument");
+    if (s->probe_pending < 0) return fail(IPCR_ERR_INVALID, "ipcr_probe_products_end without ipcr_probe_products_begin");
+    const int64_t n = s->probe_pending;
+    s->probe_pending = -1;
+    if (n != n_out) return fail(IPCR_ERR_INVALID, "n_out (%lld) != products the rescan was begun for (%lld)", (long long)n_out, (long long)n);
+    if (n == 0) return IPCR_OK;
+    if (s->probe_res_off == 0) { memset(out, 0, (size_t)n * sizeof *out); return IPCR_OK; } // empty probe: nothing found (oligo.go:21-23)
+    DeviceGuard dg(s->device);
+    HIPCHK(hipStreamSynchronize(s->probe_stream));
+    memcpy(out, s->h_probe + s->probe_res_off, (size_t)n * sizeof(ipcr_probe_hit)); // (ipcr_probe_rec is layout-identical)
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_probe_products_begin(ipcr_scratch *s, const ipcr_genome *g, const char *probe, int32_t max_mm) {
+    if (!s || !g || !probe) return fail(IPCR_ERR_INVALID, "ipcr_probe_products: null argument");
     if (!s->stream) return fail(IPCR_ERR_DEVICE, "host-only scratch: the probe rescan has no CPU fallback");
+    if (s->probe_pending >= 0) return fail(IPCR_ERR_INVALID, "ipcr_probe_products_begin: the rescan begun before has not been ended");
     { const ipcr_status ds = same_device(s, g); if (ds != IPCR_OK) return ds; }
     DeviceGuard dg(s->device);
     const size_t n = s->products.size();
-    if ((int64_t)n != n_out) return fail(IPCR_ERR_INVALID, "n_out (%lld) != products of the last scan (%zu)", (long long)n_out, n);
-    if (n == 0) return IPCR_OK;
-    memset(out, 0, n * sizeof *out);
     std::string prb;
     ipcr_status st = normalize_probe(probe, prb);
     if (st != IPCR_OK) return st;
-    if (prb.empty()) return IPCR_OK;
+    s->probe_res_off = 0;
+    if (n == 0 || prb.empty()) { s->probe_pending = (int64_t)n; return IPCR_OK; }
     // The rescan runs on a lane of its own and its kernels take their arguments straight out of pinned host memory and
     // put the results there: chained scratches share ONE in-order stream on which the next pass's sweep is already
     // queued when the host gets here, and three small pageable copies + one back cost more than the two kernels.
@@ -2847,8 +2867,8 @@ ipcr_status ipcr_probe_products(ipcr_scratch *s, const ipcr_genome *g, const cha
     HIPCHK(ipcr::launch_gather(s->probe_stream, g->planes, g->rst, segs, (uint32_t)n, s->d_amps));
     HIPCHK(ipcr::launch_probe(s->probe_stream, s->d_amps, offs, (uint32_t)n, masks, masks + 128, (uint32_t)prb.size(),
                               (uint32_t)(max_mm < 0 ? 0 : max_mm), fast, res));
-    HIPCHK(hipStreamSynchronize(s->probe_stream));
-    memcpy(out, res, n * sizeof(ipcr_probe_hit)); // (ipcr_probe_rec is layout-identical)
+    s->probe_res_off = res_off;
+    s->probe_pending = (int64_t)n; // (set last: a begin that failed leaves nothing to end)
     return IPCR_OK;
 }
 

@@ -517,6 +517,14 @@ def test_config_c5_probe_rescan(hip):
             w = O.best_hit(amp, prb, k)                # core/oligo/oligo.go:19-77 on Product.Seq
             assert (bool(out[i].found), chr(out[i].strand) if out[i].found else "", out[i].pos, out[i].mm) == \
                 (w.found, w.strand, w.pos if w.found else 0, w.mm if w.found else 0)
+        # the two-halves form: begin returns at once, the same results come out of end; one rescan per scratch at a time
+        L = hip.lib.lib()
+        out2 = (hip.lib.ProbeHit * len(got))()
+        hip.lib.check(L.ipcr_probe_products_begin(sc._h, g._h, prb.encode(), k))
+        assert L.ipcr_probe_products_begin(sc._h, g._h, prb.encode(), k) != 0          # not ended yet
+        hip.lib.check(L.ipcr_probe_products_end(sc._h, out2, len(got)))
+        assert bytes(out2) == bytes(out)
+        assert L.ipcr_probe_products_end(sc._h, out2, len(got)) != 0                     # nothing begun
     g.close()
 
 
