@@ -1277,7 +1277,85 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
              "    const u64 cp = cp0 + (u64)(u32)__builtin_amdgcn_readfirstlane((int)take);\n";
     else
         s << "  for (u64 cp = cp0 + wave0; cp < cp0 + ncolpairs; cp += nwaves) { // one unit = one column pair = 64 strands\n";
-    s << "    auto flush = [&]() __attribute__((always_inline)) {\n"
+    // The drain.  The queue is a STACK: a round takes the newest 64 entries, and what it hands back (an entry's further key
+    // hits, a key's further patterns) goes into the slots it has just read, on top of the older entries -- so the next round
+    // is again 64 entries wide.  A drain in the middle of a unit stops below 64 entries (they wait for company); only the
+    // unit's last drain runs rounds that are not full.  (Until late in round 3 the queue was emptied front to back at every
+    // drain and the handed-back entries -- a fifth of a pass -- in passes of their own, at a fifth of the lanes and less:
+    // 0.23 rounds per base step where the hits fill 0.13.  IPCR_INDEX_STACK_DRAIN=0 is that form.)
+    const bool stack_drain = env_int("IPCR_INDEX_STACK_DRAIN", 1, 0, 1) != 0;
+    if (stack_drain) {
+    s << "    auto flush = [&](bool all) __attribute__((always_inline)) {\n"
+         "      u32 n = qn;\n"
+         "      const u64 unit_base = cp * 8192u; // first position of this unit\n"
+         "      const u32 shard = (u32)cp & 255u;\n"
+         "      const u32 floor_n = all ? 0u : 63u;\n"
+         "      while (n > floor_n) {\n"
+         "        const u32 qb = n > 64u ? n - 64u : 0u; // the round: entries [qb, n)\n"
+         "        const u32 i = qb + lane;\n"
+         "        v4 e = *reinterpret_cast<const v4*>(wq + i * 4u); // (slots up to 63 are inside the queue whatever n is)\n"
+         "        if (i >= n) e.w = 0u; // nothing pending, no chain: the lane idles through the round\n"
+         "        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // every lane has read its slot: slots from qb up may be rewritten\n"
+         "        u32 pend = 0u, idx = 0xFFFFFFFFu, back = 0u, keep = 0u; // keep: what of w a handed-back entry keeps (layout C: lane and row)\n"
+         "        u32 elane, erow0;\n"
+         "        u64 hkm; u32 hbad;\n"
+         "        if (EMODE == 0) { hkm = ((u64)(KMHI ? (e.y & ((1u << KMHI) - 1u)) : 0u) << 32) | e.x; hbad = e.z; elane = (e.y >> KMHI) & 63u; erow0 = (e.y >> (KMHI + 6u)) & ((1u << ROWB) - 1u); }\n"
+         "        else if (EMODE == 1) { hkm = ((u64)(KMHI ? (e.y & ((1u << KMHI) - 1u)) : 0u) << 32) | e.x; hbad = e.z & ((1u << NBAS) - 1u); elane = e.z >> NBAS; erow0 = (e.y >> KMHI) & ((1u << ROWB) - 1u); }\n"
+         "        else { hkm = ((u64)e.y << 32) | e.x; hbad = e.z; elane = (e.w >> 15) & 63u; erow0 = (e.w >> 21) & ((1u << ROWB) - 1u); keep = e.w & 0x7FFF8000u; }\n"
+         "        const u32 pay = EMODE == 2 ? (e.w & 0x7FFFu) : (e.w & 0x7FFFFFFFu);\n"
+         "        if (e.w & 0x80000000u) { idx = pay >> 2; back = pay & 3u; }\n"
+         "        else pend = pay;\n"
+         "        const u32 rest = pend & (pend - 1u);\n"
+         "        if (pend != 0u) {\n"
+         "          const u32 t = reinterpret_cast<const unsigned char*>(lds + TAB_WORD0)[__builtin_ctz(pend)];\n"
+         "          const u32 sidx = t & 15u;\n"
+         "          back = t >> 4;\n"
+         "          const u64 skm = hkm >> (2u * back); // a hit of an earlier step of the entry: its own k-mer\n"
+         "          const v4 sc = *reinterpret_cast<const v4*>(lds + SHAPE_WORD0 + 4u * sidx); // {shifts, masks, first bitmap word, first entry}\n"
+         "          const u32 key = ((u32)(skm >> (sc.x & 63u)) & (sc.y & 0xFFFFu)) | (((u32)(skm >> ((sc.x >> 8) & 63u)) & (sc.y >> 16)) << ((sc.x >> 16) & 31u));\n"
+         "          // the key is in the panel; its rank among the shape's keys is the index of its entry\n"
+         "          if (PAIRED) { // keys are ranked as the OLDER step of a pair files them: word = the key's low 4 + 8 bits, bit = its high 2 + 2\n"
+         "            const u32 dw = sc.z * 2u + (((key >> 2) & 0xFF0u) | (key & 15u)), bo = ((key >> 14) << 2) | ((key >> 4) & 3u);\n"
+         "            const v4 g4 = *reinterpret_cast<const v4*>(lds + (dw & ~3u)); // the 64 keys (four words' low halves) one prefix covers\n"
+         "            const u32 pos = dw & 3u;\n"
+         "            const u32 own = pos == 0u ? g4.x : (pos == 1u ? g4.y : (pos == 2u ? g4.z : g4.w));\n"
+         "            u32 r = (u32)__builtin_popcount(own & ((1u << bo) - 1u));\n"
+         "            if (pos > 0u) r += (u32)__builtin_popcount(g4.x & 0xFFFFu);\n"
+         "            if (pos > 1u) r += (u32)__builtin_popcount(g4.y & 0xFFFFu);\n"
+         "            if (pos > 2u) r += (u32)__builtin_popcount(g4.z & 0xFFFFu);\n"
+         "            idx = sc.w + (u32)prefix[dw >> 2] + r;\n"
+         "          } else {\n"
+         "            const u32 wi = sc.z + (key >> 6); // the shape's bitmap word with this key\n"
+         "            const u64 w = T64[wi];\n"
+         "            idx = sc.w + (u32)prefix[wi] + (u32)__popcll((w << (63u - (key & 63u))) << 1);\n"
+         "          }\n"
+         "        }\n"
+         "        u32 next = 0xFFFFFFFFu;\n"
+         "        if (idx != 0xFFFFFFFFu) {\n"
+         "          const u64 skm = hkm >> (2u * back);\n"
+         "          const u32 sbad = hbad >> back;\n"
+         "          const u32 strand_off = elane << 7;\n"
+         "          const int erow = (int)erow0 - (int)back;\n"
+         "          next = check_entry(idx, skm, sbad, erow, unit_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
+         "          if (!CHAIN_CARRY || rest != 0u)\n"
+         "            while (next != 0xFFFFFFFFu) next = check_entry(next, skm, sbad, erow, unit_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
+         "        }\n"
+         "        // a lane hands back at most one entry per round: the rest of its mask (any chain under the key it took was\n"
+         "        // walked above), or the next pattern of its key\n"
+         "        const bool again = rest != 0u || (CHAIN_CARRY && next != 0xFFFFFFFFu);\n"
+         "        const u64 rb = __ballot(again);\n"
+         "        if (again) {\n"
+         "          const u32 slot = qb + __builtin_amdgcn_mbcnt_hi((u32)(rb >> 32), __builtin_amdgcn_mbcnt_lo((u32)rb, 0u));\n"
+         "          e.w = rest != 0u ? (keep | rest) : (keep | 0x80000000u | (next << 2) | back); // (k-mer, flags and row as filed)\n"
+         "          *reinterpret_cast<v4*>(wq + slot * 4u) = e;\n"
+         "        }\n"
+         "        n = qb + (u32)__popcll(rb);\n"
+         "        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // the entries handed back are read by other lanes next\n"
+         "      }\n"
+         "      qn = n;\n"
+         "    };\n";
+    } else
+    s << "    auto flush = [&](bool) __attribute__((always_inline)) {\n"
          "      u32 n = qn;\n"
          "      const u64 unit_base = cp * 8192u; // first position of this unit\n"
          "      const u32 shard = (u32)cp & 255u;\n"
@@ -1545,7 +1623,7 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "        if (it == 4u) done = true;\n"
          "        else { PA = A; PB = B; PI = I; if (it == 3u) { A = SA; B = SB; I = SI; } else { A = tr32(rA, tc); B = tr32(rB, tc); I = tr32(rI, tc); } }\n"
          "      }\n"
-         "      if (full || done) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); flush(); }\n"
+         "      if (full || done) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); flush(done); }\n"
          "    }\n";
     s << "  }\n"; // (rows are relative to the unit: the queue is always empty when a unit ends)
     if (dynamic)
