@@ -499,9 +499,10 @@ def roofline_of(res, traffic_file=None):
         except Exception:
             pass
     if res["kernel"] == "ipcr_index_filter":
-        lim = ("not HBM: VALU issue and the LDS together (per 64-base step ~29 instructions of walk -- one random 1-byte bitmap "
-               "lookup per key shape -- and ~22 of drain: ~0.12 key hits per lane and step are checked exactly and nearly all "
-               "rejected); halving the lookups at +43 % instructions made the sweep 18 % slower; see DESIGN.md section 4.3")
+        lim = ("not HBM: the LDS first, VALU issue behind it (per 64-base step ~29 instructions of walk -- one random 1-byte "
+               "bitmap lookup per key shape, 3.4 lanes of 32 on the busiest bank -- and ~11 of drain: ~0.12 key hits per lane and "
+               "step are checked exactly, in rounds of 64 that the stack-ordered queue keeps full, and nearly all rejected); "
+               "halving the lookups at +43 % instructions made the sweep 18 % slower; see DESIGN.md section 4.3")
         try:
             d = json.load(open(traffic_file))
             dv = d.get("derived")

@@ -758,8 +758,11 @@ def test_k4_medium_panel_is_specialised_in_groups(hip):
     g.close()
 
 
-def test_index_drain_under_chains_and_crowded_rounds(hip, force_index):
-    """worst case for the seed-index drain: three families of 16 primers that differ only in two bases of one block
+@pytest.mark.parametrize("stack", [1, 0])
+def test_index_drain_under_chains_and_crowded_rounds(hip, force_index, monkeypatch, stack):
+    """(stack = 1: the drain takes the newest 64 entries per round and leaves fewer than 64 for the next drain of the
+    unit, jit.cpp: stack_drain; 0: the front-to-back form it replaced, still behind IPCR_INDEX_STACK_DRAIN=0)
+    worst case for the seed-index drain: three families of 16 primers that differ only in two bases of one block
     (every key of the other blocks is shared by the whole family: entry chains of 16; an exact site is filed under
     all three shapes, and with k = 2 every site matches all 16 members) on a sequence
     of period 128 = one strand, so that all 64 lanes of a wave hit in the same base step and every lane hands entries
@@ -782,6 +785,7 @@ def test_index_drain_under_chains_and_crowded_rounds(hip, force_index):
     unit[100:120] = rc
     seq = ("".join(unit) * 600).encode()            # 76 800 bases: 600 strands, each with the same sites
     cfg = E.Config(MaxMM=2, TerminalWindow=3, MinLen=0, MaxLen=120, HitCap=0, SeedLen=12)
+    monkeypatch.setenv("IPCR_INDEX_STACK_DRAIN", str(stack))   # read when the kernel's source is generated (first scan)
     eng = E.New(cfg)
     cp = eng.CompilePanel(pairs)
     sc = eng.NewSimulationScratch(cp)
