@@ -64,9 +64,13 @@ def main():
                        "--workload %s --no-cpu-baseline --no-others --steps 3..4 --warmup 1`; averages per launch of %s. "
                        "FETCH_SIZE is reported in KiB and, on gfx950, at half the bytes of a 16 B/lane coalesced stream "
                        "(MI355X_MICROARCH.md, HBM): hbm_read = raw_kb*1024*2; WRITE_SIZE exact." % (w, kernel)}
+        found = 0
         for name in ("fetch", "write", "sq", "lds", "grbm"):
             for k, v in counters(os.path.join(src, f"pmc_{name}_{w}"), kernel).items():
                 out[k] = v
+                found += 1
+        if not found:   # this workload was not profiled in this collection (profile_round.sh <tag> prof "c4"): its files stay
+            continue
         if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
             rd = int(out["FETCH_SIZE"]["avg"] * 1024 * 2)
             wr = int(out["WRITE_SIZE"]["avg"] * 1024)

@@ -7,6 +7,7 @@
 set -o pipefail
 tag=${1:-r03}
 stage=${2:-all}   # bench | prof | all (a gpurun call is limited to 20 minutes: two calls for one round)
+wls=${3:-"c2 c3 c4"}   # workloads of the prof stage (a kernel that has not changed keeps its profile)
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
@@ -20,7 +21,7 @@ for w in c3 c4; do
 done
 fi
 [ $stage = bench ] && { echo done; exit 0; }
-for w in c2 c3 c4; do
+for w in $wls; do
   steps=400; warm=50; psteps=4
   if [ $w = c4 ]; then steps=20; warm=3; psteps=3; fi
   args="--workload $w --no-cpu-baseline --no-others --no-traffic"
