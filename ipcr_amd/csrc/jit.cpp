@@ -1266,7 +1266,29 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "  const u32 offB = ((rowB >> 2) * 3u + (jh & 1u)) * 256u + (rowB & 3u);\n"
          "  const u32 offI = ((rowI >> 2) * 3u + 2u) * 256u + (rowI & 3u);\n";
     const bool dynamic = env_int("IPCR_INDEX_DYNAMIC", 1, 0, 1) != 0;
-    if (dynamic)
+    // Which counter?  A 128-byte line of the tiles holds four rows of EIGHT columns, a unit reads two of them: four
+    // consecutive units share every line they load.  With one counter for the chip those four go to whichever waves ask
+    // next -- usually on four different XCDs, each with an L2 of its own, and the line is fetched four times (PMC: 1.7-3.4 x
+    // the algorithmic bytes).  So the groups of four units are dealt to the XCDs in turn, one counter per XCD (work[8 +
+    // 32 x]), and a wave asks the counter of the XCD it runs on (HW_REG_XCC_ID: speed only -- every unit is taken exactly
+    // once whatever the placement); a wave whose counter has run out moves on to the next one, so the sweep still ends
+    // with every wave busy.  IPCR_INDEX_XCD=0: the one counter.
+    const bool per_xcd = dynamic && env_int("IPCR_INDEX_XCD", 1, 0, 1) != 0;
+    if (per_xcd)
+        s << "  u32 xq = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u, xtries = 0u; // HW_REG_XCC_ID, bits 3:0\n"
+             "  for (;;) { // one unit = one column pair = 64 strands\n"
+             "    u64 unit;\n"
+             "    for (;;) {\n"
+             "      u32 take = 0u;\n"
+             "      if (lane == 0u) take = atomicAdd(work + 8u + 32u * xq, 1u);\n"
+             "      take = (u32)__builtin_amdgcn_readfirstlane((int)take);\n"
+             "      unit = ((u64)(take >> 2) * 8u + xq) * 4u + (take & 3u); // ascending in take: a counter that has run out stays so\n"
+             "      if (unit < ncolpairs || ++xtries == 8u) break;\n"
+             "      xq = (xq + 1u) & 7u;\n"
+             "    }\n"
+             "    if (unit >= ncolpairs) break;\n"
+             "    const u64 cp = cp0 + unit;\n";
+    else if (dynamic)
         // Units are handed out by a counter (work[0]): the waves of a persistent grid do not all run at the same pace (with a
         // fixed share each, the 16 waves of a CU ended between 67 % and 100 % of the sweep: 7.29 ms per 3 Gb, 6.30 ms with the
         // counter).  The last wave to leave zeroes the counters again (work[32] counts the leavers): nothing to clear between launches.
@@ -1629,7 +1651,10 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
     if (dynamic)
         s << "  if (lane == 0u) {\n"
              "    const u32 left = atomicAdd(work + 32u, 1u);\n"
-             "    if ((u64)left + 1ull == nwaves) { __hip_atomic_store(work, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(work + 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n"
+             "    if ((u64)left + 1ull == nwaves) {\n"
+             "      __hip_atomic_store(work, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(work + 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+          << (per_xcd ? "      for (u32 x = 0; x < 8u; ++x) __hip_atomic_store(work + 8u + 32u * x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n" : "") <<
+             "    }\n"
              "  }\n";
     s << "  if (stamps && lane == 0u) stamps[wave0 * 2u + 1u] = __builtin_amdgcn_s_memrealtime();\n";
     s << "}\n";
