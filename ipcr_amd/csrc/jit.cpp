@@ -1274,9 +1274,12 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
     // once whatever the placement); a wave whose counter has run out moves on to the next one, so the sweep still ends
     // with every wave busy.  IPCR_INDEX_XCD=0: the one counter.
     const bool per_xcd = dynamic && env_int("IPCR_INDEX_XCD", 1, 0, 1) != 0;
-    if (per_xcd)
+    // The next unit is taken, and its first nine loads issued, under the walk of the current unit's last chunk
+    // (IPCR_INDEX_AHEAD=0: at the unit's start, where the wave waits for the counter and then for the loads).
+    const bool ahead = per_xcd && env_int("IPCR_INDEX_AHEAD", 1, 0, 1) != 0;
+    if (per_xcd) {
         s << "  u32 xq = (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u, xtries = 0u; // HW_REG_XCC_ID, bits 3:0\n"
-             "  for (;;) { // one unit = one column pair = 64 strands\n"
+             "  auto take_unit = [&]() __attribute__((always_inline)) { // -> a unit of [0, ncolpairs), or something beyond: no unit is left\n"
              "    u64 unit;\n"
              "    for (;;) {\n"
              "      u32 take = 0u;\n"
@@ -1286,8 +1289,33 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
              "      if (unit < ncolpairs || ++xtries == 8u) break;\n"
              "      xq = (xq + 1u) & 7u;\n"
              "    }\n"
-             "    if (unit >= ncolpairs) break;\n"
-             "    const u64 cp = cp0 + unit;\n";
+             "    return unit;\n"
+             "  };\n";
+        if (ahead)
+            s << "  // a unit's first words as loaded: its last chunk (the history of lane + 1), its first chunk, bit 31 of the column before\n"
+                 "  u32 nSA = 0u, nSB = 0u, nSI = 0u, nA = 0u, nB = 0u, nI = 0u, nH0 = 0u, nH1 = 0u;\n"
+                 "  auto issue_unit = [&](u64 unit) __attribute__((always_inline)) {\n"
+                 "    const u64 ncp = cp0 + unit, ncol = ncp * 2u + (lane >> 5);\n"
+                 "    const u32* const nbase = planes + (((ncol >> 6) * 6144u + (ncol & 63u)) << 2);\n"
+                 "    nSA = nbase[offA + 18432u]; nSB = nbase[offB + 18432u]; nSI = nbase[offI + 18432u];\n"
+                 "    nA = nbase[offA]; nB = nbase[offB]; nI = nbase[offI];\n"
+                 "    if (ncp != 0ull) {\n"
+                 "      const u64 pcol = ncp * 2u - 1u;\n"
+                 "      const u32* const pbase = planes + (((pcol >> 6) * 6144u + (pcol & 63u)) << 2);\n"
+                 "      nH0 = pbase[(lane < 32u ? offA : offB) + 18432u]; nH1 = pbase[offI + 18432u];\n"
+                 "    }\n"
+                 "  };\n"
+                 "  u64 nunit = take_unit();\n"
+                 "  if (nunit < ncolpairs) issue_unit(nunit);\n"
+                 "  for (;;) { // one unit = one column pair = 64 strands\n"
+                 "    if (nunit >= ncolpairs) break;\n"
+                 "    const u64 cp = cp0 + nunit;\n";
+        else
+            s << "  for (;;) { // one unit = one column pair = 64 strands\n"
+                 "    const u64 unit = take_unit();\n"
+                 "    if (unit >= ncolpairs) break;\n"
+                 "    const u64 cp = cp0 + unit;\n";
+    }
     else if (dynamic)
         // Units are handed out by a counter (work[0]): the waves of a persistent grid do not all run at the same pace (with a
         // fixed share each, the 16 waves of a CU ended between 67 % and 100 % of the sweep: 7.29 ms per 3 Gb, 6.30 ms with the
@@ -1453,6 +1481,23 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, \"wavefront\"); // queue slots are rewritten by other lanes next\n"
          "    };\n";
     // the unit's tiles: column 2 cp + (lane >> 5)
+    if (ahead)
+    s << "    const u64 col = cp * 2u + (lane >> 5);\n"
+         "    const u32* const base = planes + (((col >> 6) * 6144u + (col & 63u)) << 2);\n"
+         "    // (the words were loaded under the unit before: issue_unit)\n"
+         "    const u32 SA = tr32(nSA, tc), SB = tr32(nSB, tc), SI = tr32(nSI, tc);\n"
+         "    u32 PA = (u32)__shfl_up((int)SA, 1), PB = (u32)__shfl_up((int)SB, 1), PI = (u32)__shfl_up((int)SI, 1);\n"
+         "    {\n"
+         "      u32 hA = 0u, hB = 0u, hI = 0xFFFFFFFFu; // the very first strand: nothing but invalid bases in front of it\n"
+         "      if (cp != 0ull) {\n"
+         "        const u64 bk = __ballot((nH0 >> 31) != 0u);\n"
+         "        const u64 bi = __ballot((nH1 >> 31) != 0u);\n"
+         "        hA = (u32)bk; hB = (u32)(bk >> 32); hI = (u32)bi;\n"
+         "      }\n"
+         "      if (lane == 0u) { PA = hA; PB = hB; PI = hI; }\n"
+         "    }\n"
+         "    u32 A = tr32(nA, tc), B = tr32(nB, tc), I = tr32(nI, tc);\n";
+    else
     s << "    const u64 col = cp * 2u + (lane >> 5);\n"
          "    const u32* const base = planes + (((col >> 6) * 6144u + (col & 63u)) << 2);\n"
          "    // history: the strand before mine ended with its chunk 3 -- lane - 1's, which is loaded and transposed first (and kept: the\n"
@@ -1471,8 +1516,8 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "      }\n"
          "      if (lane == 0u) { PA = hA; PB = hB; PI = hI; }\n"
          "    }\n"
-         "    u32 A = tr32(base[offA], tc), B = tr32(base[offB], tc), I = tr32(base[offI], tc);\n"
-         "    u32 rA = 0u, rB = 0u, rI = 0u; // the next chunk's words as loaded\n"
+         "    u32 A = tr32(base[offA], tc), B = tr32(base[offB], tc), I = tr32(base[offI], tc);\n";
+    s << "    u32 rA = 0u, rB = 0u, rI = 0u; // the next chunk's words as loaded\n"
          "    u32 acc = 0u; // the masks of the steps since the last queue entry\n";
     for (unsigned j = 0; j < NCH && paired; ++j) s << "    u32 acc" << j << " = 0u;\n";
     if (mode == 0) s << "    const u32 lane_y = lane << KMHI; // this lane's part of an entry's y\n";
@@ -1608,8 +1653,11 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
         const unsigned half = k / 16u, tq = k % 16u, P0 = 2u * (15u - tq);
         const char *W[3] = {half ? "B" : "A", half ? "A" : "PB", half ? "PB" : "PA"};
         s << "      if (u == " << k0 << "u) {\n";
-        if (k0 == 0)
+        if (k0 == 0) {
             s << "        if (it < 2u) { rA = base[offA + (it + 1u) * 6144u]; rB = base[offB + (it + 1u) * 6144u]; rI = base[offI + (it + 1u) * 6144u]; }\n";
+            if (ahead)
+                s << "        if (it == 3u) { nunit = take_unit(); if (nunit < ncolpairs) issue_unit(nunit); } // the next unit, under this chunk's walk\n";
+        }
         s << pa.str();
         if (phased) s << "        __builtin_amdgcn_sched_barrier(0);\n";
         s << pb.str();
