@@ -470,24 +470,77 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
         const std::string a = std::to_string(i), b2 = std::to_string(i + 1);
         shift += "p" + a + "lo = p" + b2 + "lo; p" + a + "hi = p" + b2 + "hi; p" + a + "iv = p" + b2 + "iv; ";
     }
-    std::ostringstream body; // rolled main loop: quads [0, QM)
+    // IPCR_JIT_ROLL=1: ONE loop over all the quads -- the strand's 32 and the wrap rows behind them; what a quad loads ahead
+    // (tiles, or the stashed head quads shifted by one strand) and whether a row's windows are evaluated are wave-uniform
+    // branches on the iteration number.  By default the loop stops where its prefetch reaches the strand's end and quads
+    // [QM, QTOTAL) -- 7 of 37 for a 20-row window -- are emitted a second time as a static epilogue: 57 % of the generated
+    // source, and hiprtc's time is proportional to it.  MEASURED (C2 / C3, 3 Gb): the rolled form builds in 0.46 / 0.50 s
+    // instead of 0.82 / 0.86 -- and sweeps 10-13 % slower (0.203 against 0.183 ms, 0.226 against 0.200): with the tile
+    // loads inside a branch the compiler no longer knows how many loads are in flight where the paths meet and waits with
+    // vmcnt(0..2) where the straight-line loop waits with vmcnt(6..8) -- the two quads of prefetch are gone.  A kernel
+    // that is built once per panel and swept for as long as the run lasts keeps the fast loop; the build is off the
+    // critical path anyway (the first scans take the table-driven kernel).  Parity-tested (test_random_differential).
+    const bool roll = env_int("IPCR_JIT_ROLL", 0, 0, 1) != 0;
+    const int NIT = roll ? (QTOTAL + QPI - 1) / QPI : NFULL;
+    auto load_wrap_dyn = [&](const std::string &kq) { // load_wrap for a quad number known at run time (wave-uniform)
+        std::ostringstream b;
+        b << "{ const u32 kq = " << kq << ";\n";
+        b << "        v4 nlo = st[kq * 3u][(lane + 1u) & 63u], nhi = st[kq * 3u + 1u][(lane + 1u) & 63u], niv = st[kq * 3u + 2u][(lane + 1u) & 63u];\n";
+        b << "        if (lane == 63u) { nlo = nblk[kq * 192u]; nhi = nblk[kq * 192u + 64u]; niv = nblk[kq * 192u + 128u]; }\n";
+        b << "        p" << D << "lo = (st[kq * 3u][lane] >> 1) | (nlo << 31); p" << D << "hi = (st[kq * 3u + 1u][lane] >> 1) | (nhi << 31); p" << D
+          << "iv = (st[kq * 3u + 2u][lane] >> 1) | (niv << 31); }";
+        return b.str();
+    };
+    // IPCR_JIT_PEEL=1: iteration 0 of the main loop -- the rows that only fill the window, their windows would start
+    // before the strand -- is emitted by itself (a row there is its four expansion instructions), and the loop that
+    // follows has no "it > 0" test in front of its first LM1 rows and no "it == 0" in front of the stash stores: 19 + 5
+    // wave-uniform branches fewer per 20 rows, and straight-line code for the scheduler.
+    const bool peel = !roll && NFULL >= 2 && env_int("IPCR_JIT_PEEL", 1, 0, 1) != 0;
+    std::ostringstream pro; // iteration 0 by itself
+    for (int u4 = 0; u4 < QPI && peel; ++u4) {
+        pro << "  { // quad " << u4 << "\n";
+        pro << "      const v4 clo = p1lo, chi = p1hi, civ = p1iv;\n";
+        pro << "      " << shift << "\n";
+        pro << "      " << load_normal(std::to_string(u4 + D) + "u") << "\n";
+        if (u4 < QW)
+            pro << "      st[" << u4 * 3 << "][lane] = clo; st[" << u4 * 3 + 1 << "][lane] = chi; st[" << u4 * 3 + 2 << "][lane] = civ;\n";
+        for (int c = 0; c < 4; ++c) {
+            const int step = u4 * 4 + c;
+            pro << row_code(step, "xyzw"[c], std::to_string(step) + "u", step < LM1 ? "never" : "");
+        }
+        pro << "  }\n";
+    }
+    std::ostringstream body; // rolled main loop: quads [0, QM), or all of them
     for (int u4 = 0; u4 < QPI; ++u4) {
         body << "    { // quad " << u4 << " of the iteration\n";
         body << "      const u32 qi = it * " << QPI << "u + " << u4 << "u;\n";
+        const bool cut = roll && (NIT - 1) * QPI + u4 >= QTOTAL; // the last iteration has no such quad
+        if (cut) body << "      if (it < " << NIT - 1 << "u) {\n";
         body << "      const v4 clo = p1lo, chi = p1hi, civ = p1iv;\n";
         body << "      " << shift << "\n";
-        body << "      " << load_normal("qi + " + std::to_string(D) + "u") << "\n";
-        if (u4 < QW)
+        if (roll) {
+            body << "      if (qi + " << D << "u < 32u) { " << load_normal("qi + " + std::to_string(D) + "u") << " }\n";
+            body << "      else if (qi + " << D << "u < " << QTOTAL << "u) " << load_wrap_dyn("qi + " + std::to_string(D) + "u - 32u") << "\n";
+        } else
+            body << "      " << load_normal("qi + " + std::to_string(D) + "u") << "\n";
+        if (u4 < QW && !peel)
             body << "      if (it == 0u) { st[" << u4 * 3 << "][lane] = clo; st[" << u4 * 3 + 1 << "][lane] = chi; st[" << u4 * 3 + 2
                  << "][lane] = civ; }\n";
         for (int c = 0; c < 4; ++c) {
             const int step = u4 * 4 + c;
-            body << row_code(step, "xyzw"[c], "(qi * 4u + " + std::to_string(c) + "u)", step < LM1 ? "it > 0u" : "");
+            std::string guard = step < LM1 && !peel ? "it > 0u" : "";
+            if (roll) { // row x = it * W + step ends a window of this strand iff LM1 <= x < 128 + LM1
+                const int it_max = (128 + LM1 - 1 - step) / W;
+                if (it_max < 0) guard = "never";
+                else if (it_max < NIT - 1) guard += std::string(guard.empty() ? "" : " && ") + "it < " + std::to_string(it_max + 1) + "u";
+            }
+            body << row_code(step, "xyzw"[c], "(qi * 4u + " + std::to_string(c) + "u)", guard);
         }
+        if (cut) body << "      }\n";
         body << "    }\n";
     }
     std::ostringstream epi; // static epilogue: quads [QM, QTOTAL)
-    for (int qi = QM; qi < QTOTAL; ++qi) {
+    for (int qi = QM; qi < QTOTAL && !roll; ++qi) {
         epi << "  { // quad " << qi << "\n";
         epi << "      const v4 clo = p1lo, chi = p1hi, civ = p1iv;\n";
         epi << "      " << shift << "\n";
@@ -619,7 +672,8 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     for (int i = 1; i <= D; ++i)
         s << "  v4 p" << i << "lo = own[" << (i - 1) * 192 << "], p" << i << "hi = own[" << (i - 1) * 192 + 64 << "], p" << i
           << "iv = own[" << (i - 1) * 192 + 128 << "];\n";
-    s << "  for (u32 it = 0; it < " << NFULL << "u; ++it) {\n" << body.str() << "  }\n";
+    s << pro.str();
+    s << "  for (u32 it = " << (peel ? 1 : 0) << "u; it < " << NIT << "u; ++it) {\n" << body.str() << "  }\n";
     s << epi.str();
     // ---- exact verification of this wave's survivors (verifyAt, core/engine/ac.go:186-213 / the
     // inner loop of FindMatches, core/primer/match.go:67-84): lane j compares window position j

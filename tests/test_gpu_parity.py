@@ -202,6 +202,32 @@ def test_random_differential(hip, spec, seed):
         check(hip, cfg, "".join(seq).encode(), pairs, specialize=spec)
 
 
+@pytest.mark.parametrize("roll", [0, 1])
+def test_windows_across_strand_and_block_ends(hip, monkeypatch, roll):
+    """sites planted so that their windows start in the last rows of a strand (p % 128 in 100..127: the wrap rows, read
+    from the stashed head quads of the neighbour column) and across block ends (p % 8192 near 8191: lane 63's neighbour
+    is column 0 of the next block), forward and reverse, 0-2 mismatches, with junk bytes; the specialised filter in
+    its default form (main loop + static epilogue) and as one rolled loop over all quads (IPCR_JIT_ROLL=1, jit.cpp);
+    vs the oracle"""
+    monkeypatch.setenv("IPCR_JIT_ROLL", str(roll))   # read when the kernel's source is generated (first scan)
+    rng = random.Random(4242 + roll)
+    E, P = hip.engine, hip.primer.Pair
+    for n, k, tw in ((70000, 2, 5), (40000, 3, 3), (70000, 0, 0)):
+        seq = rand_case(rng, n, with_junk=True)
+        pairs = [P("a", "ACGTTGCATGGATCCTAACG", "TTGACCGTAGGCATTCAGGA", 0, 0), P("b", "AGAGTTTGATCMTGGCTCAG", "TACGGYTACCTTGTTAYGACTT", 0, 0)]
+        starts = [s0 + r for s0 in range(0, n - 9000, 8192) for r in (100, 109, 118, 127, 8064 + 120, 8191 - 10, 8191)]
+        for i, a in enumerate(starts):
+            p = pairs[i % 2]
+            ln = rng.randint(60, 150)
+            if a + ln > n:
+                continue
+            plant(rng, seq, p.Forward, a, rng.choice([0, 1, 2]) if k else 0)
+            rc = O.revcomp(p.Reverse).decode()
+            plant(rng, seq, rc, a + ln - len(rc), rng.choice([0, 0, 1]) if k else 0)
+        cfg = E.Config(MaxMM=k, TerminalWindow=tw, MinLen=0, MaxLen=400, HitCap=0, SeedLen=12)
+        check(hip, cfg, "".join(seq).encode(), hip.primer.AddSelfPairs(pairs), specialize=True)
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_long_primers_take_the_specialised_filter(hip, seed):
     """primers of 33..128 nt: the specialised kernel filters on the 20 positions next to the protected end, every
@@ -758,10 +784,11 @@ def test_k4_medium_panel_is_specialised_in_groups(hip):
     g.close()
 
 
-@pytest.mark.parametrize("stack", [1, 0])
+@pytest.mark.parametrize("stack", [1, 0, 2])
 def test_index_drain_under_chains_and_crowded_rounds(hip, force_index, monkeypatch, stack):
     """(stack = 1: the drain takes the newest 64 entries per round and leaves fewer than 64 for the next drain of the
-    unit, jit.cpp: stack_drain; 0: the front-to-back form it replaced, still behind IPCR_INDEX_STACK_DRAIN=0)
+    unit, jit.cpp: stack_drain; 0: the front-to-back form it replaced, still behind IPCR_INDEX_STACK_DRAIN=0, with the
+    units taken at their start; 2: the stack drain with one unit counter for the chip, IPCR_INDEX_XCD=0)
     worst case for the seed-index drain: three families of 16 primers that differ only in two bases of one block
     (every key of the other blocks is shared by the whole family: entry chains of 16; an exact site is filed under
     all three shapes, and with k = 2 every site matches all 16 members) on a sequence
@@ -785,7 +812,10 @@ def test_index_drain_under_chains_and_crowded_rounds(hip, force_index, monkeypat
     unit[100:120] = rc
     seq = ("".join(unit) * 600).encode()            # 76 800 bases: 600 strands, each with the same sites
     cfg = E.Config(MaxMM=2, TerminalWindow=3, MinLen=0, MaxLen=120, HitCap=0, SeedLen=12)
-    monkeypatch.setenv("IPCR_INDEX_STACK_DRAIN", str(stack))   # read when the kernel's source is generated (first scan)
+    monkeypatch.setenv("IPCR_INDEX_STACK_DRAIN", str(min(stack, 1)))   # read when the kernel's source is generated (first scan)
+    if stack == 2:   # the unit hand-out it replaced too: one counter for the chip, a unit's loads at its start
+        monkeypatch.setenv("IPCR_INDEX_XCD", "0")
+    monkeypatch.setenv("IPCR_INDEX_AHEAD", "0" if stack == 0 else "1")   # (no effect without the per-XCD counters)
     eng = E.New(cfg)
     cp = eng.CompilePanel(pairs)
     sc = eng.NewSimulationScratch(cp)
