@@ -314,12 +314,21 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
         }
         Lmax = std::max<int>(Lmax, p.len);
     }
-    const int W = (Lmax + 3) / 4 * 4;        // window rows, multiple of the row-quad
+    // IPCR_JIT_MERGE=1: ONE rare-branch test per row quad instead of one per row.  The rare branch (some window passed the
+    // block test: exact count, push) reads the window's rows, and the row after a window's last one overwrites its first --
+    // unless the register window has spare slots: with three of them a quad's four rows can all be expanded and tested
+    // before any of their rare branches runs.  W = 24 slots for windows of 17..20 rows (20 more registers, no spill at
+    // two waves per SIMD) buys 15 fewer v_cmp + s_cbranch_vccz pairs per 20 rows.  Needs the peeled loop (no row guards).
+    // MEASURED (3 Gb): C3 0.1958 / 0.1994 ms against 0.1970 / 0.2002 without, C2 0.1806 / 0.1876 against 0.1830 / 0.1815 --
+    // inside the run-to-run spread, for 15 % more generated source (a 24-row loop body): off by default, parity-tested.
+    const bool roll = env_int("IPCR_JIT_ROLL", 0, 0, 1) != 0;
+    const bool want_merge = !roll && env_int("IPCR_JIT_PEEL", 1, 0, 1) != 0 && env_int("IPCR_JIT_MERGE", 0, 0, 1) != 0 && Lmax <= 20;
+    const int W = (Lmax + 3 + (want_merge ? 3 : 0)) / 4 * 4; // window rows, multiple of the row-quad (merge: at least three spare)
     // tuning knobs; defaults = best of the sweeps on MI355X (tools/sweep_jit.py): windows up to
     // 20 rows leave registers for two quads of prefetch, wider ones spill unless it is one
-    const int D = env_int("IPCR_JIT_DEPTH", W <= 20 ? 2 : 1, 1, 4);    // row-quads prefetched ahead
+    const int D = env_int("IPCR_JIT_DEPTH", Lmax <= 20 ? 2 : 1, 1, 4); // row-quads prefetched ahead
     const int WPS = env_int("IPCR_JIT_WAVES", 2, 1, 4);                // __launch_bounds__ waves per SIMD
-    const int WPG = env_int("IPCR_JIT_WG", W <= 20 ? 2 : 4, 1, 4);     // waves per workgroup
+    const int WPG = env_int("IPCR_JIT_WG", Lmax <= 20 ? 2 : 4, 1, 4);  // waves per workgroup
     const int QPI = W / 4;                   // quads per unrolled main-loop iteration
     const int LM1 = Lmax - 1;                // rows of the next strand a window can reach
     const int QTOTAL = (128 + LM1 + 3) / 4;  // quads streamed: 32 of the strand + the wrap rows
@@ -337,7 +346,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     std::vector<Plan> plans;
     for (const auto &p : pats) plans.push_back(choose_plan(p, k, exact_stage));
     // evaluation of every pattern for the window that starts at slot sr
-    auto eval_code = [&](int sr) {
+    auto eval_code = [&](int sr, const std::string &sfx) {
         std::ostringstream o;
         for (size_t q = 0; q < pats.size(); ++q) {
             const Plan &pl = plans[q];
@@ -388,7 +397,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
                 for (int i = 0; i < B; ++i) { const std::string e = orchain(pl.blocks[(size_t)i]); o << "            const u32 e" << i << " = " << e << ";\n"; }
                 o << count_code(B, k);
             }
-            o << "            f" << q << " = f;\n          }\n";
+            o << "            f" << q << sfx << " = f;\n          }\n";
         }
         return o.str();
     };
@@ -406,7 +415,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
         b << "        {\n          u32 ";
         for (size_t q = 0; q < pats.size(); ++q) b << (q ? ", f" : "f") << q;
         b << ";\n";
-        b << eval_code(((slot - LM1) % W + W) % W);
+        b << eval_code(((slot - LM1) % W + W) % W, "");
         b << "          u32 all = f0";
         for (size_t q = 1; q < pats.size(); ++q) b << " & f" << q;
         b << ";\n";
@@ -441,6 +450,82 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
             b << "            }\n";
         }
         b << "          }\n        }\n      }\n";
+        return b.str();
+    };
+    // ---- the merged form: a quad's rows are expanded and tested first (row_head: f<q>_<c>, all_<c>), then ONE branch
+    // covers the rare work of all four (row_rare)
+    auto row_head = [&](int slot, char comp, int c, bool ev) {
+        std::ostringstream b;
+        const std::string sl = std::to_string(slot), cs = "_" + std::to_string(c);
+        b << "      { // window slot " << slot << "\n";
+        b << "        const u32 lo = clo." << comp << ", hi = chi." << comp << ", iv = civ." << comp << ";\n";
+        b << "        a" << sl << " = OR3(lo, hi, iv); c" << sl << " = __builtin_amdgcn_bitop3_b32(lo, hi, iv, 0xEF); g" << sl
+          << " = __builtin_amdgcn_bitop3_b32(lo, hi, iv, 0xFB); t" << sl << " = __builtin_amdgcn_bitop3_b32(lo, hi, iv, 0xBF); n" << sl << " = iv;\n";
+        if (ev) {
+            b << eval_code(((slot - LM1) % W + W) % W, cs);
+            b << "          all" << cs << " = f0" << cs;
+            for (size_t q = 1; q < pats.size(); ++q) b << " & f" << q << cs;
+            b << ";\n";
+        }
+        b << "      }\n";
+        return b.str();
+    };
+    auto row_rare = [&](int slot, int c, const std::string &xexpr) {
+        std::ostringstream b;
+        const std::string cs = "_" + std::to_string(c);
+        b << "          if (all" << cs << " != 0xFFFFFFFFu) {\n";
+        b << "            const u64 pos = posbase + (u64)(" << xexpr << " - " << LM1 << "u);\n";
+        const int sr0 = ((slot - LM1) % W + W) % W;
+        for (size_t q = 0; q < pats.size(); ++q) {
+            const Plan &pl = plans[q];
+            size_t U = 0;
+            for (const auto &blk : pl.blocks) U += blk.size();
+            const bool exact_already = !pl.counted || pl.blocks.size() == U;
+            b << "            if (f" << q << cs << " != 0xFFFFFFFFu) {\n";
+            b << "              u32 f = f" << q << cs << ";\n";
+            if (!exact_already && exact_stage) {
+                b << "              {\n";
+                int e = 0;
+                for (const auto &blk : pl.blocks)
+                    for (int j : blk) b << "            const u32 e" << e++ << " = " << plane_expr(pats[q].mask[j], (sr0 + j) % W, uses_n) << ";\n";
+                b << count_code((int)U, k);
+                b << "              }\n";
+            }
+            if (offs[q] == 0)
+                b << "              if (f != 0xFFFFFFFFu) push(" << pid(q) << "ull, pos, ~f, lcnt, lkey, lbits, queue, qcap, qcount, counts);\n";
+            else
+                b << "              if (f != 0xFFFFFFFFu) { u64 wp = pos; u32 wm = ~f; if (wp >= " << offs[q] << "ull) wp -= " << offs[q]
+                  << "ull; else { wp += " << 128 - offs[q] << "ull; wm >>= 1; } if (wm) push(" << pid(q)
+                  << "ull, wp, wm, lcnt, lkey, lbits, queue, qcap, qcount, counts); }\n";
+            b << "            }\n";
+        }
+        b << "          }\n";
+        return b.str();
+    };
+    // the four rows of a quad: slot0 = the first row's slot, xs = each row's number as an expression, ev = is a window of this strand tested there
+    auto quad_rows_merged = [&](int slot0, const std::string xs[4], const bool ev[4]) {
+        std::ostringstream b;
+        int nev = 0;
+        for (int c = 0; c < 4; ++c) nev += ev[c] ? 1 : 0;
+        if (nev) {
+            b << "      u32 ";
+            bool first = true;
+            for (int c = 0; c < 4; ++c) {
+                if (!ev[c]) continue;
+                for (size_t q = 0; q < pats.size(); ++q) { b << (first ? "" : ", ") << "f" << q << "_" << c; first = false; }
+                b << ", all_" << c;
+            }
+            b << ";\n";
+        }
+        for (int c = 0; c < 4; ++c) b << row_head(slot0 + c, "xyzw"[c], c, ev[c]);
+        if (nev) {
+            b << "      {\n        u32 any = ";
+            bool first = true;
+            for (int c = 0; c < 4; ++c) if (ev[c]) { b << (first ? "" : " & ") << "all_" << c; first = false; }
+            b << ";\n        if (__builtin_expect(any != 0xFFFFFFFFu, 0)) {\n";
+            for (int c = 0; c < 4; ++c) if (ev[c]) b << row_rare(slot0 + c, c, xs[c]);
+            b << "        }\n      }\n";
+        }
         return b.str();
     };
     auto load_normal = [&](const std::string &q) {
@@ -480,7 +565,6 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     // vmcnt(0..2) where the straight-line loop waits with vmcnt(6..8) -- the two quads of prefetch are gone.  A kernel
     // that is built once per panel and swept for as long as the run lasts keeps the fast loop; the build is off the
     // critical path anyway (the first scans take the table-driven kernel).  Parity-tested (test_random_differential).
-    const bool roll = env_int("IPCR_JIT_ROLL", 0, 0, 1) != 0;
     const int NIT = roll ? (QTOTAL + QPI - 1) / QPI : NFULL;
     auto load_wrap_dyn = [&](const std::string &kq) { // load_wrap for a quad number known at run time (wave-uniform)
         std::ostringstream b;
@@ -496,6 +580,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     // follows has no "it > 0" test in front of its first LM1 rows and no "it == 0" in front of the stash stores: 19 + 5
     // wave-uniform branches fewer per 20 rows, and straight-line code for the scheduler.
     const bool peel = !roll && NFULL >= 2 && env_int("IPCR_JIT_PEEL", 1, 0, 1) != 0;
+    const bool merge = want_merge && peel && W - Lmax >= 3;
     std::ostringstream pro; // iteration 0 by itself
     for (int u4 = 0; u4 < QPI && peel; ++u4) {
         pro << "  { // quad " << u4 << "\n";
@@ -504,6 +589,12 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
         pro << "      " << load_normal(std::to_string(u4 + D) + "u") << "\n";
         if (u4 < QW)
             pro << "      st[" << u4 * 3 << "][lane] = clo; st[" << u4 * 3 + 1 << "][lane] = chi; st[" << u4 * 3 + 2 << "][lane] = civ;\n";
+        if (merge) {
+            std::string xs[4];
+            bool ev[4];
+            for (int c = 0; c < 4; ++c) { xs[c] = std::to_string(u4 * 4 + c) + "u"; ev[c] = u4 * 4 + c >= LM1; }
+            pro << quad_rows_merged(u4 * 4, xs, ev);
+        } else
         for (int c = 0; c < 4; ++c) {
             const int step = u4 * 4 + c;
             pro << row_code(step, "xyzw"[c], std::to_string(step) + "u", step < LM1 ? "never" : "");
@@ -526,6 +617,12 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
         if (u4 < QW && !peel)
             body << "      if (it == 0u) { st[" << u4 * 3 << "][lane] = clo; st[" << u4 * 3 + 1 << "][lane] = chi; st[" << u4 * 3 + 2
                  << "][lane] = civ; }\n";
+        if (merge) {
+            std::string xs[4];
+            bool ev[4];
+            for (int c = 0; c < 4; ++c) { xs[c] = "(qi * 4u + " + std::to_string(c) + "u)"; ev[c] = true; }
+            body << quad_rows_merged(u4 * 4, xs, ev);
+        } else
         for (int c = 0; c < 4; ++c) {
             const int step = u4 * 4 + c;
             std::string guard = step < LM1 && !peel ? "it > 0u" : "";
@@ -547,6 +644,12 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
         const int qn = qi + D;
         if (qn < 32) epi << "      " << load_normal(std::to_string(qn) + "u") << "\n";
         else if (qn < QTOTAL) epi << "      " << load_wrap(qn - 32) << "\n";
+        if (merge) {
+            std::string xs[4];
+            bool ev[4];
+            for (int c = 0; c < 4; ++c) { const int x = qi * 4 + c; xs[c] = std::to_string(x) + "u"; ev[c] = x >= LM1 && x < 128 + LM1; }
+            epi << quad_rows_merged((qi % QPI) * 4, xs, ev);
+        } else
         for (int c = 0; c < 4; ++c) {
             const int x = qi * 4 + c;
             const int slot = (qi % QPI) * 4 + c;

@@ -202,17 +202,18 @@ def test_random_differential(hip, spec, seed):
         check(hip, cfg, "".join(seq).encode(), pairs, specialize=spec)
 
 
-@pytest.mark.parametrize("roll", [0, 1])
+@pytest.mark.parametrize("roll", [0, 1, 2])
 def test_windows_across_strand_and_block_ends(hip, monkeypatch, roll):
     """sites planted so that their windows start in the last rows of a strand (p % 128 in 100..127: the wrap rows, read
     from the stashed head quads of the neighbour column) and across block ends (p % 8192 near 8191: lane 63's neighbour
     is column 0 of the next block), forward and reverse, 0-2 mismatches, with junk bytes; the specialised filter in
-    its default form (main loop + static epilogue) and as one rolled loop over all quads (IPCR_JIT_ROLL=1, jit.cpp);
-    vs the oracle"""
-    monkeypatch.setenv("IPCR_JIT_ROLL", str(roll))   # read when the kernel's source is generated (first scan)
+    its default form (iteration 0, main loop, static epilogue), as one rolled loop over all quads (IPCR_JIT_ROLL=1) and
+    with a 24-slot window and one rare-branch test per quad (IPCR_JIT_MERGE=1; jit.cpp); vs the oracle"""
+    monkeypatch.setenv("IPCR_JIT_ROLL", str(roll & 1))   # read when the kernel's source is generated (first scan)
+    monkeypatch.setenv("IPCR_JIT_MERGE", str(roll >> 1))  # 2: a 24-slot register window, one rare-branch test per row quad
     rng = random.Random(4242 + roll)
     E, P = hip.engine, hip.primer.Pair
-    for n, k, tw in ((70000, 2, 5), (40000, 3, 3), (70000, 0, 0)):
+    for n, k, tw in ((34000, 2, 5), (18000, 3, 3), (34000, 0, 0)):
         seq = rand_case(rng, n, with_junk=True)
         pairs = [P("a", "ACGTTGCATGGATCCTAACG", "TTGACCGTAGGCATTCAGGA", 0, 0), P("b", "AGAGTTTGATCMTGGCTCAG", "TACGGYTACCTTGTTAYGACTT", 0, 0)]
         starts = [s0 + r for s0 in range(0, n - 9000, 8192) for r in (100, 109, 118, 127, 8064 + 120, 8191 - 10, 8191)]
