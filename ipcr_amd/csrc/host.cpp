@@ -1794,9 +1794,11 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
         s->stats.kernel_kind = 2;
     }
     if (!pd.fused) {
+        // (the seed index files one window per queue entry; its leftover filters and the table-driven kernel 32 strands)
+        const uint32_t single = s->stats.kernel_kind == 3 && s->stats.leftover_kernels == 0 && s->stats.leftover_patterns == 0 ? 1u : 0u;
         HIPCHK(ipcr::launch_verify(lane, g->planes, g->rst, sd.dev, (uint32_t)p->cfg.max_mm, g->d_rec_start,
                                    g->d_rec_len, pd.nrec, pd.check_rst, s->d_queue, s->qcap, qc, s->d_hits,
-                                   s->hcap, cnt + 1, cnt + 2, cnt_next, qc_next, s->ev[2], s->ev[3]));
+                                   s->hcap, cnt + 1, cnt + 2, cnt_next, qc_next, s->ev[2], s->ev[3], single));
         pd.verified = true;
     }
     if (!pd.published) {

@@ -354,7 +354,9 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint32_t *__restrict_
                                                      unsigned long long *__restrict__ hcount,
                                                      unsigned long long *__restrict__ ccount,
                                                      unsigned long long *__restrict__ next_counters,
-                                                     unsigned long long *__restrict__ next_qcount) {
+                                                     unsigned long long *__restrict__ next_qcount, uint32_t single) {
+    // single != 0: every queue entry holds ONE candidate (the seed index files a window at a time, bits == 1): one thread
+    // per entry instead of one per (entry, strand bit) -- 25 000 threads with work instead of 800 000 of which one in 32 has.
     // The candidate queue is cut into IPCR_QUEUE_SHARDS segments with a counter each (a single
     // counter serialises the filters' pushes at ~12 ns apiece, MI355X_MICROARCH.md "dequeue").
     // qcount = this scan's shard counters, qcap = capacity of one segment.
@@ -383,7 +385,8 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint32_t *__restrict_
     }
     // hit slots and the candidate count are aggregated per workgroup in LDS: thousands of
     // same-address global atomics would serialise (see above)
-    unsigned long long n = (unsigned long long)s_pref[IPCR_QUEUE_SHARDS - 1u] * 32ull; // one thread per (entry, strand bit)
+    const uint32_t per = single ? 0u : 5u; // log2 of the threads per entry
+    unsigned long long n = (unsigned long long)s_pref[IPCR_QUEUE_SHARDS - 1u] << per; // one thread per (entry, strand bit)
     for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
         if (threadIdx.x == 0) { s_hits = 0; s_cands = 0; }
         __syncthreads();
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint32_t *__restrict_
         bool hit = false;
         ipcr_hit_rec h;
         if (i < n) {
-            const uint32_t eidx = (uint32_t)(i >> 5);
+            const uint32_t eidx = (uint32_t)(i >> per);
             uint32_t slo = 0, shi = IPCR_QUEUE_SHARDS - 1u; // first shard whose inclusive prefix exceeds eidx
             while (slo < shi) {
                 const uint32_t mid = (slo + shi) >> 1;
@@ -399,8 +402,8 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint32_t *__restrict_
             }
             const uint32_t within = eidx - (slo ? s_pref[slo - 1u] : 0u);
             const ipcr_queue_entry ent = queue[(uint64_t)slo * qcap + within];
-            const uint32_t bit = (uint32_t)(i & 31u);
-            if (bit == 0u) atomicAdd(&s_cands, (uint32_t)__builtin_popcount(ent.bits));
+            const uint32_t bit = single ? (ent.bits ? (uint32_t)__builtin_ctz(ent.bits) : 0u) : (uint32_t)(i & 31u);
+            if (single || bit == 0u) atomicAdd(&s_cands, (uint32_t)__builtin_popcount(ent.bits));
             if ((ent.bits >> bit) & 1u) {
                 const uint32_t q = (uint32_t)(ent.key >> 48);
                 const uint64_t P = (ent.key & 0xFFFFFFFFFFFFull) + ((uint64_t)bit << IPCR_TILE_LOG_N);
@@ -620,11 +623,11 @@ hipError_t launch_verify(hipStream_t st, const uint32_t *planes, const uint32_t 
                          const uint64_t *rec_len, uint32_t nrec, uint32_t check_rst, const ipcr_queue_entry *queue,
                          uint64_t qcap, const unsigned long long *qcount, ipcr_hit_rec *hits, uint64_t hcap,
                          unsigned long long *hcount, unsigned long long *ccount, unsigned long long *next_counters,
-                         unsigned long long *next_qcount, hipEvent_t start, hipEvent_t stop) {
+                         unsigned long long *next_qcount, hipEvent_t start, hipEvent_t stop, uint32_t single) {
     if (nrec == 0) return hipSuccess;
     hipExtLaunchKernelGGL(verify_kernel, dim3(IPCR_VERIFY_BLOCKS), dim3(256), 0, st, start, stop, 0, planes, rst, pats, max_mm,
                           rec_start, rec_len, nrec, check_rst, queue, qcap, qcount, hits, hcap, hcount, ccount,
-                          next_counters, next_qcount);
+                          next_counters, next_qcount, single);
     return hipGetLastError();
 }
 

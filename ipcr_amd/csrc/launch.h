@@ -31,7 +31,8 @@ hipError_t launch_verify(hipStream_t st, const uint32_t *planes, const uint32_t 
                          const uint64_t *rec_len, uint32_t nrec, uint32_t check_rst, const ipcr_queue_entry *queue,
                          uint64_t qcap, const unsigned long long *qcount, ipcr_hit_rec *hits, uint64_t hcap,
                          unsigned long long *hcount, unsigned long long *ccount, unsigned long long *next_counters,
-                         unsigned long long *next_qcount, hipEvent_t start, hipEvent_t stop);
+                         unsigned long long *next_qcount, hipEvent_t start, hipEvent_t stop,
+                         uint32_t single = 0); // single: every queue entry holds one candidate (bits has one bit set)
 hipError_t launch_unpack(hipStream_t st, const uint32_t *planes, const uint32_t *rst, uint64_t P0, uint64_t n,
                          uint8_t *out);
 hipError_t launch_gather(hipStream_t st, const uint32_t *planes, const uint32_t *rst, const ipcr_amp_seg *segs,
