@@ -80,6 +80,22 @@ double pass_prob(const ipcr_dev_pattern &p, const Plan &pl, int k) {
     return pp * ok;
 }
 
+// VALU instructions of one block's OR (jit_source: orchain emits exactly this): a position that allows one base -- or any
+// base: the invalid plane -- is one input, an IUPAC code of two bases an AND of two planes that rides along in an
+// and-or with another input, a code of three bases an instruction of its own; three inputs per OR.
+int block_ops(const ipcr_dev_pattern &p, const std::vector<int> &blk) {
+    int singles = 0, and2 = 0, ops = 0;
+    for (int j : blk) {
+        const int n = __builtin_popcount(p.mask[j] & 15u);
+        if (n == 0) return 0;          // matches nothing: the block is a constant
+        if (n == 2) ++and2;
+        else { if (n == 3) ++ops; ++singles; }
+    }
+    for (int i = 0; i < and2; ++i) { ++ops; if (singles == 0) singles = 1; }
+    while (singles > 3) { ++ops; singles -= 2; }
+    return ops + (singles >= 2 ? 1 : 0);
+}
+
 Plan make_plan(const ipcr_dev_pattern &p, int k, int B) {
     Plan pl;
     pl.L = p.len;
@@ -95,6 +111,38 @@ Plan make_plan(const ipcr_dev_pattern &p, int k, int B) {
     if (B < k + 1) B = k + 1;
     pl.blocks.resize((size_t)B);
     for (int i = 0; i < U; ++i) pl.blocks[(size_t)((long)i * B / U)].push_back(un[(size_t)i]);
+    // Which positions share a block is free (<= k mismatches spoil <= k blocks whatever the partition), and an OR of 2 n + 1
+    // inputs costs n instructions where one of 2 n + 2 costs n + 1: a block that holds a two-base IUPAC code beside two
+    // plain positions (four inputs, two instructions) gives one of them to the panel's two-position block (three plain
+    // positions: still one instruction).  Greedy: move one position at a time while the instruction count falls.
+    // C3 (27F / 1492R, codes M and Y): one instruction per pattern and row step fewer, 67 -> 63 in the loop.
+    static const bool rebalance = !getenv("IPCR_JIT_REBALANCE") || atoi(getenv("IPCR_JIT_REBALANCE")) != 0;
+    for (int round = 0; rebalance && round < 64; ++round) {
+        int best_gain = 0, bx = -1, by = -1, bi = -1;
+        for (int x = 0; x < B; ++x) {
+            if (pl.blocks[(size_t)x].size() < 2) continue;
+            const int ox = block_ops(p, pl.blocks[(size_t)x]);
+            for (size_t i = 0; i < pl.blocks[(size_t)x].size(); ++i) {
+                std::vector<int> xs = pl.blocks[(size_t)x];
+                const int j = xs[i];
+                xs.erase(xs.begin() + (long)i);
+                const int nx = block_ops(p, xs);
+                for (int y = 0; y < B; ++y) {
+                    if (y == x) continue;
+                    std::vector<int> ys = pl.blocks[(size_t)y];
+                    ys.push_back(j);
+                    const int gain = ox + block_ops(p, pl.blocks[(size_t)y]) - nx - block_ops(p, ys);
+                    // (ties: the move that leaves the blocks' sizes closest, so that no block becomes a lone position)
+                    if (gain > best_gain || (gain == best_gain && gain > 0 && ys.size() < pl.blocks[(size_t)by].size() + 1)) { best_gain = gain; bx = x; by = y; bi = (int)i; }
+                }
+            }
+        }
+        if (best_gain <= 0) break;
+        const int j = pl.blocks[(size_t)bx][(size_t)bi];
+        pl.blocks[(size_t)bx].erase(pl.blocks[(size_t)bx].begin() + bi);
+        pl.blocks[(size_t)by].push_back(j);
+    }
+    for (auto &b : pl.blocks) std::sort(b.begin(), b.end());
     return pl;
 }
 
@@ -129,7 +177,7 @@ Plan choose_plan(const ipcr_dev_pattern &p, int k, bool exact_stage) {
         int counter = 0;
         (void)count_code((int)pl.blocks.size(), k, &counter);
         double main_ops = counter;
-        for (const auto &blk : pl.blocks) main_ops += (double)((blk.size() - 1 + 1) / 2);
+        for (const auto &blk : pl.blocks) main_ops += (double)block_ops(p, blk);
         const bool exact = (int)pl.blocks.size() == U;
         const double rare = exact ? 0.0 : 2048.0 * pass_prob(p, pl, k) * (exact_ops + 24.0);
         const double cost = main_ops + rare;
@@ -178,17 +226,23 @@ std::string count_code(int B, int k, int *cost) {
                 if (t < k + 1 - (B - 1 - i)) continue; // cannot reach level k+1 any more: dead
                 const std::string prev = (t == 1) ? "" : "u" + std::to_string(t - 1) + " & ";
                 if (t >= 2 && !live[(size_t)t - 1]) continue;
-                if (!live[(size_t)t]) {
+                // (u & e) | u' as ONE v_bitop3_b32 (two issue cycles): left to itself the compiler takes v_and_or_b32 (four).
+                // The top level goes straight into the verdict: f |= u_k & e
+                if (t == k + 1 && t >= 2) {
+                    th << "            f = ANDOR(u" << t - 1 << ", e" << i << ", f);\n";
+                    live[(size_t)t] = true;
+                } else if (!live[(size_t)t]) {
                     th << "            u32 u" << t << " = " << prev << "e" << i << ";\n";
                     live[(size_t)t] = true;
+                } else if (t >= 2) {
+                    th << "            u" << t << " = ANDOR(u" << t - 1 << ", e" << i << ", u" << t << ");\n";
                 } else {
-                    th << "            u" << t << " |= " << prev << "e" << i << ";\n";
+                    th << "            u" << t << " |= e" << i << ";\n";
                 }
                 ++th_cost;
             }
         }
-        th << "            f |= u" << (k + 1) << ";\n";
-        ++th_cost;
+        if (k + 1 < 2) { th << "            f |= u" << (k + 1) << ";\n"; ++th_cost; }
     }
     // Carry-save adder tree.  gfx950 has v_bitop3_b32 (any function of three words in one instruction), so a full
     // adder is TWO instructions (xor3, majority) and a half adder two (xor, and); outputs that do not reach the verdict

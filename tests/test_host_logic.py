@@ -355,8 +355,11 @@ def _counter_blocks(src):
         if re.match(r"(const u32 x\d+|u32 u\d+|u\d+ \|?=) ", t) or re.match(r"const u32 x\d+ = .*, x\d+ = ", t):
             stmts.append(t)
             continue
-        if t.startswith("f |= ") and flags:
-            out.append((flags, stmts + [t]))
+        if t.startswith("f = ANDOR(") and flags:   # thermometer: the top level goes straight into the verdict, once per flag
+            stmts.append(t)
+            continue
+        if (t.startswith("f |= ") or t.startswith("f0 = f") or re.match(r"f\d+(_\d)? = f;", t) or t == "}") and flags and (t.startswith("f |= ") or any(x.startswith("f = ANDOR(") for x in stmts)):
+            out.append((flags, stmts + ([t] if t.startswith("f |= ") else [])))
             flags, stmts, in_pat = 0, [], False
     return out
 
@@ -395,7 +398,8 @@ def test_generated_block_counters_are_exact(k, tw, primers, monkeypatch):
             seen.add(key)
             n = 1 << flags
             full = (1 << n) - 1
-            env = {"f": 0, "FULL": full, "XOR3": lambda a, b, c: a ^ b ^ c, "MAJ3": lambda a, b, c: (a & b) | (c & (a | b))}
+            env = {"f": 0, "FULL": full, "XOR3": lambda a, b, c: a ^ b ^ c, "MAJ3": lambda a, b, c: (a & b) | (c & (a | b)),
+                   "ANDOR": lambda a, b, c: (a & b) | c}
             assign = np.arange(n, dtype=np.uint32)      # every assignment of the flags, as a number
             as_int = lambda bits: int.from_bytes(np.packbits(bits, bitorder="little").tobytes(), "little")
             for i in range(flags):     # flag i as a truth-table column over all 2^flags assignments
