@@ -593,10 +593,17 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     // bit 31 coming from the neighbour column (lane + 1, or lane 0 of the next block).  The head
     // quads were stashed in LDS when first streamed (each wave its own slice, so no barrier), so
     // nothing is fetched from HBM twice and the neighbour word is just the next lane's LDS slot.
+    // Lane 63's neighbour is column 0 of the NEXT block.  IPCR_JIT_NEIGHBOUR=1 (default): its head words (QW quads x 3
+    // planes) are loaded at the kernel's start, one by each of the first lanes, and kept as a 65th column of the stash --
+    // the wrap quads then read LDS only.  0: lane 63 loads them where they are needed, a divergent branch with three global
+    // loads per wrap quad whose round trip the wave waits for.
+    const bool nb_lds = env_int("IPCR_JIT_NEIGHBOUR", 1, 0, 1) != 0;
     auto load_wrap = [&](int kq) {
         std::ostringstream b;
-        b << "{ v4 nlo = st[" << kq * 3 << "][(lane + 1u) & 63u], nhi = st[" << kq * 3 + 1 << "][(lane + 1u) & 63u], niv = st["
-          << kq * 3 + 2 << "][(lane + 1u) & 63u];\n";
+        const std::string nl = nb_lds ? "lane + 1u" : "(lane + 1u) & 63u";
+        b << "{ v4 nlo = st[" << kq * 3 << "][" << nl << "], nhi = st[" << kq * 3 + 1 << "][" << nl << "], niv = st["
+          << kq * 3 + 2 << "][" << nl << "];\n";
+        if (!nb_lds)
         b << "        if (lane == 63u) { nlo = nblk[" << kq * 192 << "]; nhi = nblk[" << kq * 192 + 64 << "]; niv = nblk["
           << kq * 192 + 128 << "]; }\n";
         b << "        p" << D << "lo = (st[" << kq * 3 << "][lane] >> 1) | (nlo << 31); p" << D << "hi = (st[" << kq * 3 + 1
@@ -623,7 +630,9 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     auto load_wrap_dyn = [&](const std::string &kq) { // load_wrap for a quad number known at run time (wave-uniform)
         std::ostringstream b;
         b << "{ const u32 kq = " << kq << ";\n";
-        b << "        v4 nlo = st[kq * 3u][(lane + 1u) & 63u], nhi = st[kq * 3u + 1u][(lane + 1u) & 63u], niv = st[kq * 3u + 2u][(lane + 1u) & 63u];\n";
+        const std::string nl = nb_lds ? "lane + 1u" : "(lane + 1u) & 63u";
+        b << "        v4 nlo = st[kq * 3u][" << nl << "], nhi = st[kq * 3u + 1u][" << nl << "], niv = st[kq * 3u + 2u][" << nl << "];\n";
+        if (!nb_lds)
         b << "        if (lane == 63u) { nlo = nblk[kq * 192u]; nhi = nblk[kq * 192u + 64u]; niv = nblk[kq * 192u + 128u]; }\n";
         b << "        p" << D << "lo = (st[kq * 3u][lane] >> 1) | (nlo << 31); p" << D << "hi = (st[kq * 3u + 1u][lane] >> 1) | (nhi << 31); p" << D
           << "iv = (st[kq * 3u + 2u][lane] >> 1) | (niv << 31); }";
@@ -824,13 +833,20 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
         s << "a" << i << " = 0, c" << i << " = 0, g" << i << " = 0, t" << i << " = 0, n" << i << " = 0";
     }
     s << ";\n";
-    s << "  __shared__ v4 stash[" << WPG << "][" << QW * 3 << "][64]; // head quads of each wave's block, for the wrap rows\n";
-    s << "  v4 (*st)[64] = stash[wv];\n";
+    const int SC = nb_lds ? 65 : 64; // stash columns: the wave's 64 + column 0 of the next block
+    s << "  __shared__ v4 stash[" << WPG << "][" << QW * 3 << "][" << SC << "]; // head quads of each wave's block, for the wrap rows\n";
+    s << "  v4 (*st)[" << SC << "] = stash[wv];\n";
     for (int i = 1; i <= D; ++i)
         s << "  v4 p" << i << "lo = own[" << (i - 1) * 192 << "], p" << i << "hi = own[" << (i - 1) * 192 + 64 << "], p" << i
           << "iv = own[" << (i - 1) * 192 + 128 << "];\n";
+    if (nb_lds)
+        s << "  v4 nbv = {0u, 0u, 0u, 0u}; // word (lane / 3, lane % 3) of the next block's column 0\n"
+             "  if (lane < " << QW * 3 << "u) nbv = nblk[(lane / 3u) * 192u + (lane % 3u) * 64u];\n";
     s << pro.str();
-    s << "  for (u32 it = " << (peel ? 1 : 0) << "u; it < " << NIT << "u; ++it) {\n" << body.str() << "  }\n";
+    if (nb_lds && peel) s << "  if (lane < " << QW * 3 << "u) st[lane][64] = nbv; // (loaded before iteration 0: it has long arrived)\n";
+    s << "  for (u32 it = " << (peel ? 1 : 0) << "u; it < " << NIT << "u; ++it) {\n";
+    if (nb_lds && !peel) s << "    if (it == 1u && lane < " << QW * 3 << "u) st[lane][64] = nbv;\n";
+    s << body.str() << "  }\n";
     s << epi.str();
     // ---- exact verification of this wave's survivors (verifyAt, core/engine/ac.go:186-213 / the
     // inner loop of FindMatches, core/primer/match.go:67-84): lane j compares window position j
