@@ -416,6 +416,99 @@ def test_generated_block_counters_are_exact(k, tw, primers, monkeypatch):
             assert env["f"] & full == want, (k, flags, force, stmts)
 
 
+def _slot0_patterns(src):
+    """the generated main loop's code for the windows that end at register slot 0: per pattern the leaves -- (plane letter,
+    slot) -- of its protected OR and of every block flag, temporaries resolved"""
+    lines = src.splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith("  for (u32 it = "))
+    start = next(i for i in range(start, len(lines)) if "// window slot 0" in lines[i])
+    out, cur, tmp = [], None, {}
+    leaf = re.compile(r"\b([acgtn])(\d+)\b")
+    ref = re.compile(r"\bo\d+_\d+\b")
+    def leaves(expr):
+        got = [(m.group(1), int(m.group(2))) for m in leaf.finditer(expr)]
+        for r in ref.findall(expr):
+            got += tmp[r]
+        return got
+    for l in lines[start:]:
+        if "// window slot 1" in l:
+            break
+        t = l.strip()
+        m = re.match(r"\{ // pattern (\d+): len (\d+), (\d+) protected, (\d+) blocks", t)
+        if m:
+            cur = {"q": int(m.group(1)), "len": int(m.group(2)), "nprot": int(m.group(3)), "nblocks": int(m.group(4)), "prot": [], "blocks": []}
+            tmp = {}
+            continue
+        if cur is None:
+            continue
+        m = re.match(r"const u32 (o\d+_\d+) = (.*);", t)
+        if m:
+            tmp[m.group(1)] = leaves(m.group(2))
+            continue
+        m = re.match(r"u32 f = (.*);", t)
+        if m:
+            cur["prot"] = leaves(m.group(1))
+            continue
+        m = re.match(r"const u32 e\d+ = (.*);", t)
+        if m:
+            cur["blocks"].append(leaves(m.group(1)))
+            continue
+        if re.match(r"f\d+ = f;", t):
+            out.append(cur)
+            cur = None
+    return out
+
+
+@pytest.mark.parametrize("rebalance", ["1", "0"])
+@pytest.mark.parametrize("k,tw,primers", [
+    (2, 5, ("ACGTTGCATGGATCCTAACG", "TTGACCGTAGGCATTCAGGA")),
+    (3, 3, ("AGAGTTTGATCMTGGCTCAG", "TACGGYTACCTTGTTAYGAC")),
+    (1, 3, ("ACGTNGCATGCAAGCTAGCT", "GGCCTTRAGGCCATATGGYA")),
+    (3, 0, ("ACBTTGCATGCAAGDTAGCT", "GGMCTTAAGGCCWTATGGCA")),
+    (4, 2, ("ACGTTGCATSCAAGCTAG", "GGCCTKAAGGCCATATGGCA")),
+    (2, 3, ("ACGTTGCATGCAAG", "GGMCTYAAGGCCRTAT")),
+])
+def test_filter_blocks_partition_the_window(k, tw, primers, rebalance, monkeypatch):
+    """the specialised filter is sound only if every position of a pattern's window is tested exactly once -- in the
+    protected OR or in exactly one block -- through exactly the mismatch planes its IUPAC code calls for (`x` = base is
+    not X; a code of several bases is the AND of their planes, N the invalid plane).  Which positions share a block is
+    the generator's choice (jit.cpp: make_plan moves positions between blocks while the instruction count falls,
+    IPCR_JIT_REBALANCE): read it back from the generated source, for windows ending at slot 0 of the main loop"""
+    monkeypatch.setenv("IPCR_JIT_REBALANCE", rebalance)
+    cfg = engine.Config(MaxMM=k, TerminalWindow=tw, MaxLen=2000)
+    cp = engine.New(cfg).CompilePanel(primer.AddSelfPairs([primer.Pair("p", primers[0], primers[1], 0, 0)]))
+    src = cp.filter_source(0)
+    assert src
+    ids = cp.scanned_patterns(0)
+    pats = _slot0_patterns(src)
+    assert len(pats) == len(ids) >= 2
+    infos = [cp.pattern_info(i) for i in ids]
+    lmax = max(len(x[0]) for x in infos)
+    assert lmax <= 20
+    W = (lmax + 3) // 4 * 4
+    sr = (0 - (lmax - 1)) % W
+    for pat, (seq, left, tw_dev, _so, _sl) in zip(pats, infos):
+        L = len(seq)
+        assert pat["len"] == L
+        want = {}
+        for j, ch in enumerate(seq):
+            allowed = [b for b in "ACGT" if O.base_match(b, ch)]
+            slot = (sr + j) % W
+            want[j] = {("n", slot)} if len(allowed) == 4 else {(b.lower(), slot) for b in allowed}
+        groups = [pat["prot"]] + pat["blocks"]
+        flat = [x for g in groups for x in g]
+        assert len(flat) == len(set(flat)), (seq, "a plane is read twice")
+        assert set(flat) == set().union(*want.values()), (seq, "the window's positions and planes")
+        for j in range(L):   # a position's planes stay together: one group holds them all
+            assert sum(1 for g in groups if want[j] <= set(g)) == 1, (seq, j)
+        prot_pos = set(range(tw_dev)) if left else set(range(L - tw_dev, L))
+        got_prot = {j for j in range(L) if want[j] <= set(pat["prot"])}
+        if k > 0 and L - len(prot_pos) > k:
+            assert got_prot == prot_pos, (seq, left, tw_dev, got_prot)
+            assert len(pat["blocks"]) == pat["nblocks"] >= k + 1
+    cp.close()
+
+
 def test_pattern_shards_join_to_the_unsharded_result():
     """ipcr_panel_set_shard: the distinct patterns are dealt round-robin over `count` panel objects; their hit lists
     over the same records, concatenated in any order, join (full panel) to exactly the unsharded products -- the
