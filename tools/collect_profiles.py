@@ -76,6 +76,17 @@ def main():
             wr = int(out["WRITE_SIZE"]["avg"] * 1024)
             out.update(hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
                        algorithmic_bytes_per_launch=alg)
+        if w in ("c2", "c3") and alg and "SQ_INSTS_VALU" in out and "GRBM_GUI_ACTIVE" in out:
+            # the specialised filter: one wave per block of 64 columns x 32 strands x 128 bases, 128 + 19 row steps each
+            blocks = -(-int(alg / 0.375) // 262144)
+            cu_cycles = 256.0 * out["GRBM_GUI_ACTIVE"]["avg"] / 8.0
+            out["derived"] = {
+                "blocks": blocks,
+                "row_steps_per_launch": blocks * 147,
+                "valu_instructions_per_row_step": round(out["SQ_INSTS_VALU"]["avg"] / (blocks * 147), 1),
+                "valu_issue_busy_frac_upper_bound": round(out["SQ_INSTS_VALU"]["avg"] * 4.0 / (4.0 * cu_cycles), 3),
+                "hbm_bytes_over_algorithmic": round(out["hbm_bytes_per_launch"] / alg, 4) if "hbm_bytes_per_launch" in out else None,
+            }
         if w == "c4" and all(k in out for k in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")):
             # the index kernel is not HBM-bound: say what binds it, from the counters themselves.  One wave-level base step =
             # 64 bases (lane = strand, no tail rows): the genome of the profiled run / 64 (its size is in the bench line's
