@@ -116,7 +116,7 @@ Plan make_plan(const ipcr_dev_pattern &p, int k, int B) {
     // plain positions (four inputs, two instructions) gives one of them to the panel's two-position block (three plain
     // positions: still one instruction).  Greedy: move one position at a time while the instruction count falls.
     // C3 (27F / 1492R, codes M and Y): one instruction per pattern and row step fewer, 67 -> 63 in the loop.
-    static const bool rebalance = !getenv("IPCR_JIT_REBALANCE") || atoi(getenv("IPCR_JIT_REBALANCE")) != 0;
+    const bool rebalance = !getenv("IPCR_JIT_REBALANCE") || atoi(getenv("IPCR_JIT_REBALANCE")) != 0; // (read per panel: tests switch it)
     for (int round = 0; rebalance && round < 64; ++round) {
         int best_gain = 0, bx = -1, by = -1, bi = -1;
         for (int x = 0; x < B; ++x) {
