@@ -38,7 +38,7 @@ RECORDS = 24
 RECORD_LEN = 125_000_000
 N_PLANTS = 1000
 PRODUCT_LEN = 180
-MIN_WARM_PASSES = {"c2": 300, "c3": 300, "c5": 300, "c4": 12}   # the first ~50 sweeps after idle run 15-25 % slower (clock ramp)
+MIN_WARM_PASSES = {"c2": 300, "c2n": 300, "c3": 300, "c5": 300, "c4": 12}   # the first ~50 sweeps after idle run 15-25 % slower (clock ramp)
 PROBE = "TGGACCTTAGCAGGTCATTCAG"
 
 
@@ -121,8 +121,36 @@ def plant_stride(records: int, record_len: int) -> int:
     return max((record_len - 4096) // (per_rec + 1), 400)
 
 
+def n_runs(record_len: int, genome_idx: int, record: int, keep_clear):
+    """SURVEY.md 8(d), variant +N: 0.1 % of a record's positions overwritten with 'N' in runs of 1..1000 (own xorshift32,
+    fixed seed per genome and record) -- the reference's forceFallback condition for every record (core/engine/compiled.go:185-190)
+    and its halo path (halo.go:76-108).  keep_clear: sorted (lo, hi) windows no run may touch (the planted amplicons: the
+    same plants are verified as in the N-free genome).  -> [(start, length)], in generation order."""
+    import bisect
+    x = (0x2545F491 ^ ((genome_idx * 0x9E3779B9 + record * 0x85EBCA6B) & 0xFFFFFFFF)) or 1
+    los = [w[0] for w in keep_clear]
+    runs, covered, target = [], 0, record_len // 1000
+    while covered < target:
+        x ^= (x << 13) & 0xFFFFFFFF
+        x ^= x >> 17
+        x ^= (x << 5) & 0xFFFFFFFF
+        ln = 1 + x % 1000
+        x ^= (x << 13) & 0xFFFFFFFF
+        x ^= x >> 17
+        x ^= (x << 5) & 0xFFFFFFFF
+        if record_len <= ln + 1:
+            break
+        pos = x % (record_len - ln)
+        i = bisect.bisect_right(los, pos + ln)
+        if i > 0 and keep_clear[i - 1][1] > pos:
+            continue
+        runs.append((pos, ln))
+        covered += ln
+    return runs
+
+
 def build_genome(torch, engine, workloads, revcomp_fn, genome_idx: int, records: int, record_len: int,
-                 keep_host_record0: bool, probe: str = ""):
+                 keep_host_record0: bool, probe: str = "", with_n: bool = False):
     """C2 / C4 / C5 genome of SURVEY.md 8(d): LCG stream seed 0x5eed1234+g cut into records, amplicons of pair 0
     planted as makeEngineBenchFixture does (performance_benchmark_test.go:47-62); with `probe` (C5) every amplicon
     also carries the probe at offset 60: as is, reverse-complemented, with 1 or 2 substitutions, or not at all."""
@@ -164,6 +192,10 @@ def build_genome(torch, engine, workloads, revcomp_fn, genome_idx: int, records:
                 if kind != 4:
                     _put(torch, buf, start + 60, rc_probe if kind == 1 else "".join(ps))
             plants.append((r, start, nm))
+        if with_n:
+            clear = sorted((s0 - 64, s0 + PRODUCT_LEN + 64) for (rr, s0, _) in plants if rr == r)
+            for (pos, ln) in n_runs(record_len, genome_idx, r, clear):
+                buf[pos:pos + ln] = 78   # 'N'
         torch.cuda.synchronize()
         if keep_host_record0 and r == 0:
             host0 = buf.cpu().numpy().copy()
@@ -224,6 +256,14 @@ def workload_spec(name, engine, workloads):
                     pairs=workloads.c2_pairs(), genome="c2", kernel="ipcr_filter",
                     text="C2: 1 primer pair (+self pairs: 12 orientation slots, 4 distinct patterns), k=2, 3'-window=5, "
                          "hit-cap 10000, max-length 2000")
+    if name == "c2n":
+        return dict(cfg=E.Config(MaxMM=2, TerminalWindow=5, MinLen=0, MaxLen=2000, HitCap=10000, SeedLen=12),
+                    pairs=workloads.c2_pairs(), genome="c2n", kernel="ipcr_filter",
+                    text="C2 on the +N genome (SURVEY 8d: 0.1 % of positions in runs of 1-1000 N): every record holds reset bytes, "
+                         "so with k > 0 and a hit cap the reference takes FindMatches for every orientation "
+                         "(core/engine/compiled.go:185-190,238-258) and caps the rc orientations before their 5' window filter -- "
+                         "the device scans those two patterns unprotected and the host filters (the kernel every "
+                         "ipcr_scan_chunk call and every real genome runs)")
     if name == "c3":
         return dict(cfg=E.Config(MaxMM=3, TerminalWindow=3, MinLen=0, MaxLen=2000, HitCap=10000, SeedLen=12, Circular=True),
                     pairs=workloads.c3_pairs(), genome="c3", kernel="ipcr_filter",
@@ -254,7 +294,7 @@ def get_genome(ctx, key):
     else:
         want_host = key == "c2" and ctx.want_cpu
         g, plants, host0 = build_genome(torch, engine, workloads, ctx.revcomp, ctx.rank, a.records, a.record_len,
-                                        want_host, probe=PROBE if key == "c5" else "")
+                                        want_host, probe=PROBE if key == "c5" else "", with_n=key == "c2n")
     nrec = g.num_records
     lens = [g.record_len(r) for r in range(nrec)]
     flags = [g.record_flags(r) for r in range(nrec)]
@@ -265,7 +305,7 @@ def get_genome(ctx, key):
 
 def check_products(name, prods, plants):
     """every planted amplicon of rank 0's genome must come back exactly (coordinates, mismatch counts and positions)"""
-    if name in ("c2", "c4", "c5"):
+    if name in ("c2", "c2n", "c4", "c5"):
         found = {(p.Record, p.Start): p for p in prods
                  if p.ExperimentID == "bench_000" and p.Type == "forward" and p.Length == PRODUCT_LEN}
         for (r, start, nm) in plants:
@@ -519,7 +559,7 @@ def roofline_of(res, traffic_file=None):
 
 
 # ----------------------------------------------------------------------------------------------- other measurements
-def scan_chunk_rates(args, local=0, record_bases=125_000_000, chunk=4_000_000):
+def scan_chunk_rates(args, local=0, record_bases=125_000_000, chunk=4_000_000, probe=False):
     """Drop-in entry point (what the cgo shim binds): ipcr_scan_chunk on host ASCII under the reference's worker model
     (internal/pipeline/pipeline.go:60-125): W threads, one scratch each, one shared panel, rolling chunks of one
     record from a queue.  PCIe-inclusive; reported next to the raw pinned H2D rate; never `value`.  Measured by the
@@ -532,7 +572,10 @@ def scan_chunk_rates(args, local=0, record_bases=125_000_000, chunk=4_000_000):
     if not os.path.exists(exe):
         raise SystemExit(exe + " is missing: build first (python -c 'import __graft_entry__ as g; g.build()')")
     n = min(record_bases, args.record_len)
-    r = subprocess.run([exe, str(n), str(chunk), "1", "8", "16"], capture_output=True, text=True, timeout=600,
+    # probe: BASELINE C5 over the drop-in call -- every worker annotates its chunk's products (ipcr_probe_scratch_products),
+    # a collector thread calls ipcr_probe_best_hit per amplicon beside them (chunk_workers.cpp: --probe)
+    argv = [exe, "--probe", str(n), str(chunk), "16"] if probe else [exe, str(n), str(chunk), "1", "8", "16"]
+    r = subprocess.run(argv, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local)),
                                 GPU_MAX_HW_QUEUES=os.environ.get("IPCR_CHUNK_HW_QUEUES", "4")))   # see chunk_workers.cpp
     if r.returncode != 0:
@@ -725,7 +768,7 @@ def main() -> None:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2n", "c3", "c4", "c5"])
     # one C2 step is ~0.2 ms: the default region (about half a second) is long enough for the clocks to settle
     ap.add_argument("--steps", type=int, default=None, help="timed passes (default 2000; 40 for c4)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed passes before them (default 200; 5 for c4)")
@@ -748,10 +791,11 @@ def main() -> None:
         import subprocess
         raise SystemExit(subprocess.call(cmd, env=dict(os.environ)))
 
-    chunk_rates, all_dev_rates, traffic = None, None, None
+    chunk_rates, c5_chunk, all_dev_rates, traffic = None, None, None, None
     single = "RANK" not in os.environ and args.gpus <= 1 and not os.environ.get("IPCR_EXCHANGE_SELFTEST")
     if not args.no_others and single:
         chunk_rates = scan_chunk_rates(args)      # child process, before anything here has initialised HIP
+        c5_chunk = scan_chunk_rates(args, probe=True)
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if not args.no_traffic and not under_profiler and single and args.records == RECORDS and args.record_len == RECORD_LEN:
         traffic = measure_traffic(args.workload, "ipcr_index_filter" if args.workload == "c4" else "ipcr_filter")
@@ -787,7 +831,7 @@ def main() -> None:
     others = {}
     if not args.no_others:
         if world == 1 and not ctx.multi:
-            for nm, st, wu in (("c3", 400, 100), ("c4", 30, 5), ("c5", 300, 50)):
+            for nm, st, wu in (("c2n", 400, 100), ("c3", 400, 100), ("c4", 30, 5), ("c5", 300, 50)):
                 if nm == args.workload:
                     continue
                 r = run_workload(ctx, nm, st, wu)
@@ -805,6 +849,8 @@ def main() -> None:
                 r["prods"] = None
             if chunk_rates is not None:
                 others["scan_chunk"] = chunk_rates
+            if c5_chunk is not None:    # ipcr-probe over ipcr_scan_chunk + ipcr_probe_scratch_products, 16 workers; ipcr_probe_best_hit latency
+                others["c5_chunk"] = c5_chunk
             others["fasta_to_tsv"] = fasta_to_tsv(ctx)
         elif args.workload != "c4":   # several GPUs: the scaling target north_star names rides along
             r = run_workload(ctx, "c4", 30, 5)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IPCR_ABI_VERSION 3
+#define IPCR_ABI_VERSION 4
 #define IPCR_MAX_PRIMER_LEN 128 /* longest primer/probe the device path accepts */
 #define IPCR_MAX_MM 16          /* largest --mismatches the device path accepts */
 
@@ -225,7 +225,9 @@ ipcr_status ipcr_scratch_hits(const ipcr_scratch *s, const ipcr_hit **out, int64
  * order (unsorted, and a window found through several keys may appear twice: ipcr_join_hits sorts
  * and removes duplicates).  Header = two sets of four uint64 {queue words, hits, candidate windows,
  * fullest queue segment}; the set the last scan used is the non-zero one.  Valid until the next scan
- * on this scratch; the address changes when the buffer regrows. */
+ * on this scratch; the address changes when the buffer regrows.  IPCR_ERR_UNSUPPORTED after a scan that ran in segments
+ * (ipcr_scan_stats.segmented: a capped scan with more raw matches than the buffer may take): the device buffer then holds the
+ * last range only and the hits live in the host list (ipcr_scratch_hits); ipcr_exchange_begin sends them from there. */
 ipcr_status ipcr_scratch_device_hits(const ipcr_scratch *s, const void **dev_block, uint64_t *n_hits, uint64_t *capacity);
 
 /* ---- Engine.ForEachCompiledProduct / SimulateCompiledWithScratch -- compiled.go:141-267 ----
@@ -323,6 +325,11 @@ uint8_t ipcr_genome_record_flags(const ipcr_genome *g, uint32_t record);
  * exchange together inside ipcr_exchange_end (ipcr_exchange_redone counts those). */
 #define IPCR_EXCHANGE_ID_BYTES 128
 typedef struct ipcr_exchange ipcr_exchange;
+/* 1 when ipcr_exchange_create can reach ncclCommInitRank on this rank: librccl opens and has the entry points, the device
+ * exists (ipcr_last_error says why not).  Local, no side effect on the job.  Take the MINIMUM over all ranks on the host's own
+ * channel before ANY rank calls ipcr_exchange_create: a rank that fails early while the others are already inside
+ * ncclCommInitRank leaves them waiting for ever. */
+int32_t ipcr_exchange_available(int32_t device);
 ipcr_status ipcr_exchange_unique_id(uint8_t *id_out /* IPCR_EXCHANGE_ID_BYTES */);
 /* same_records: every rank scanned the SAME records (pattern shards): record indices are not rebased */
 ipcr_status ipcr_exchange_create(const uint8_t *id, int32_t world, int32_t rank, int32_t device, uint64_t cap_hits,
@@ -335,15 +342,37 @@ ipcr_status ipcr_exchange_begin(ipcr_exchange *x, const ipcr_scratch *s, int32_t
  * [rank_hit_start[r], rank_hit_start[r + 1]), its records start at rank_record_offset[r].  Valid until the next end. */
 ipcr_status ipcr_exchange_end(ipcr_exchange *x, int32_t ticket, const ipcr_hit **hits, int64_t *n_hits,
                               const uint64_t **rank_hit_start, const uint32_t **rank_record_offset);
+/* The host side of ipcr_exchange_end as a pure function over a gathered buffer in HOST memory -- `world` blocks of
+ * 64 + cap * 32 bytes (header: two sets of four uint64, the hit count is word 1 of the non-zero set; then cap ipcr_hit slots),
+ * as ncclAllGather of every rank's ipcr_scratch_device_hits block leaves them.  rec_counts[r] = records of rank r (ignored with
+ * same_records).  Writes rank r's valid records to out[rank_hit_start[r] .. rank_hit_start[r + 1]) with `record` rebased by
+ * rank_record_offset[r] (both arrays: world + 1 entries, may be NULL).  *need = the largest count any rank reported.
+ * IPCR_ERR_CAPACITY: some rank reported more than cap -- every rank reads the same headers, gets the same status and repeats
+ * the exchange with a capacity >= *need -- or the records do not fit out_cap.  No device, no communicator. */
+ipcr_status ipcr_exchange_unpack(const void *gathered, int32_t world, uint64_t cap, const uint32_t *rec_counts, int32_t same_records,
+                                 ipcr_hit *out, uint64_t out_cap, uint64_t *rank_hit_start, uint32_t *rank_record_offset, uint64_t *need);
 /* hit slots every rank sends: grows by itself on overflow; a host that knows what it needs says so (the SAME value on every rank) */
 ipcr_status ipcr_exchange_reserve(ipcr_exchange *x, uint64_t cap_hits);
 uint64_t ipcr_exchange_capacity(const ipcr_exchange *x);
 uint64_t ipcr_exchange_redone(const ipcr_exchange *x);
 
 /* ---- oligo.BestHit / probe.AnnotateAmplicon -- core/oligo/oligo.go:19-77 ----
- * amplicon in host memory; runs the probe rescan on the device. */
+ * amplicon in host memory; runs the probe rescan on the default device (ipcr_set_device).  Safe to call from any thread
+ * next to running scans, and cheap enough to call per product as visitors.Probe.Visit does on the collector goroutine
+ * (internal/visitors/probe.go:18-33): no device allocation, no copy operation, not the null stream -- the call borrows
+ * a pinned block and a stream from a free list, the kernel stages the amplicon in LDS straight out of pinned memory and
+ * the caller spins on the tagged 16-byte result.  (ipcr_probe_scratch_products is the batched form for a worker.) */
 ipcr_status ipcr_probe_best_hit(const uint8_t *amplicon, uint64_t len, const char *probe, int32_t max_mm,
                                 ipcr_probe_hit *out);
+/* ipcr-probe behind the drop-in call: every product of the LAST ipcr_scan_chunk on `s`, rescanned for the probe from the
+ * tiles that call packed (the scratch's private chunk genome keeps them until its next scan; no allocation in steady
+ * state; the scratch's device and probe lane).  out[i] corresponds to product i of ipcr_scratch_products.  The amplicon
+ * is what the pipeline would slice into Product.Seq on the worker (internal/pipeline/pipeline.go:80-89): chunk-local
+ * [start, end), or record[start:] ++ record[:end] for a wrap-around product of a circular record -- so a worker
+ * annotates its own chunk's products and the collector only formats (hipprobe).  _begin / ipcr_probe_products_end
+ * split it as below.  IPCR_ERR_INVALID when the scratch's last scan was not an ipcr_scan_chunk. */
+ipcr_status ipcr_probe_scratch_products_begin(ipcr_scratch *s, const char *probe, int32_t max_mm);
+ipcr_status ipcr_probe_scratch_products(ipcr_scratch *s, const char *probe, int32_t max_mm, ipcr_probe_hit *out, int64_t n_out);
 /* batched form for ipcr-probe: every product of the last scan on `s` against the resident
  * genome; out[i] corresponds to product i (internal/visitors/probe.go:18-33) */
 /* the same in two halves: _begin queues the rescan of the scratch's current products on a lane of its own and returns,

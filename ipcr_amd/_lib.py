@@ -136,6 +136,9 @@ SYMBOLS = {
     "ipcr_scan_genome_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipcr_join_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_uint64),
                                  C.POINTER(C.c_uint8), C.c_uint32, C.c_void_p, C.c_void_p]),
+    "ipcr_exchange_available": (C.c_int32, [C.c_int32]),
+    "ipcr_exchange_unpack": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_uint32), C.c_int32, C.c_void_p, C.c_uint64,
+                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "ipcr_exchange_unique_id": (C.c_int, [C.c_char_p]),
     "ipcr_exchange_create": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
     "ipcr_exchange_destroy": (None, [C.c_void_p]),
@@ -151,6 +154,8 @@ SYMBOLS = {
     "ipcr_probe_products": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(ProbeHit), C.c_int64]),
     "ipcr_probe_products_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32]),
     "ipcr_probe_products_end": (C.c_int, [C.c_void_p, C.POINTER(ProbeHit), C.c_int64]),
+    "ipcr_probe_scratch_products_begin": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    "ipcr_probe_scratch_products": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(ProbeHit), C.c_int64]),
     "ipcr_nested_windows": (C.c_int, [C.c_void_p, C.POINTER(Window), C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(NestedHit)]),
     "ipcr_nested_products": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NestedHit), C.c_int64]),
 }

@@ -224,8 +224,6 @@ def run(argv: Optional[Sequence[str]] = None, stdout=None, stderr=None) -> int:
     rows = []
     max_primer_len = max((max(len(p.Forward), len(p.Reverse)) for p in pairs), default=0)
     chunk, overlap, warns = validate_chunking(o.circular, o.chunk_size, cfg.MaxLen, max_primer_len)
-    if chunk and o.probe:
-        chunk, warns = 0, warns + ["chunking disabled: the probe rescan reads amplicons from the resident genome"]
     for w in warns:
         print(f"warning: {w}", file=stderr)
     collector = Collector(o.dedup_cap)
@@ -236,10 +234,23 @@ def run(argv: Optional[Sequence[str]] = None, stdout=None, stderr=None) -> int:
             from . import fasta
             try:
                 for rec in fasta.StreamChunks(path, chunk, overlap):
-                    for p in eng.SimulateCompiledWithScratch(rec.ID, rec.Seq, cp, sc):
+                    prods = eng.SimulateCompiledWithScratch(rec.ID, rec.Seq, cp, sc)
+                    # ipcr-probe keeps --chunk-size (internal/probeapp/app.go:108): the worker that scanned the chunk
+                    # annotates its products from the chunk's own tiles, chunk-local coordinates, before the
+                    # collector rebases them (pipeline.go:80-89 slices Product.Seq chunk-locally too)
+                    hits = sc.probe_products(o.probe, o.probe_max_mm) if o.probe and prods else [None] * len(prods)
+                    for p, h in zip(prods, hits):
+                        ph = None
+                        if h is not None:
+                            if o.require_probe and not h.found:             # internal/visitors/probe.go:20-22
+                                continue
+                            site = ""
+                            if h.found:
+                                site = bytes(rec.Seq[p.Start:p.End]).upper()[h.pos:h.pos + len(primer.Normalize(o.probe))].decode()
+                            ph = (h, site)
                         p = collector.add(path, p)
                         if p is not None:
-                            rows.append((path, p, None))
+                            rows.append((path, p, ph))
             except _lib.IpcrError as e:
                 print(f"error: {e}", file=stderr)
             continue

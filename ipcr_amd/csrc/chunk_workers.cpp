@@ -1,6 +1,12 @@
 // chunk_workers -- the drop-in entry point under the reference's worker model, driven from native threads.
 //
-//   chunk_workers [--devices d0,d1,...] [--bind] [record_bases] [chunk_bases] [workers ...]   (defaults: device 0, 125000000 4000000 1 8 16)
+//   chunk_workers [--devices d0,d1,...] [--bind] [--probe] [record_bases] [chunk_bases] [workers ...]   (defaults: device 0, 125000000 4000000 1 8 16)
+//
+// --probe: ipcr-probe (BASELINE C5) as the Go pipeline would run it over the drop-in call -- every planted amplicon carries
+// an internal probe, every worker annotates the products of the chunk it has just scanned with ipcr_probe_scratch_products
+// (--probe-max-mm 2) and checks the planted ones; beside the pool one "collector" thread calls ipcr_probe_best_hit per
+// amplicon the whole time (internal/visitors/probe.go:18-33: the form a host without the batched call uses) and its latency
+// under the sweeping workers is reported next to the latency on an idle device.
 //
 // --devices: worker i creates its scratch on device d[i mod n] (ipcr_scratch_create_on) -- one host process, every GPU of
 // the node, no collective: chunks are independent.  The worker threads never select a device themselves; every entry
@@ -54,9 +60,10 @@ static int usage(const char *why) {
 int main(int argc, char **argv) {
     std::vector<int> devices;
     std::vector<const char *> pos;
-    bool bind = false;
+    bool bind = false, probe_on = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--bind")) bind = true;
+        else if (!strcmp(argv[i], "--probe")) probe_on = true;
         else if (!strcmp(argv[i], "--devices")) {
             if (i + 1 >= argc) return usage("--devices needs a list");
             for (const char *q = argv[++i]; *q;) {
@@ -101,9 +108,11 @@ int main(int argc, char **argv) {
     std::string rc_rev(rev.size(), 'A');
     ipcr_revcomp(rev.data(), rev.size(), &rc_rev[0]);
     uint64_t planted = 0;
+    static const char PROBE[] = "TGGACCTTAGCAGGTCATTCAG"; // bench.py: PROBE
     for (uint64_t a = 500000; a + 180 < n; a += 1000000, ++planted) {
         memcpy(&seq[a], fwd.data(), 20);
         memcpy(&seq[a + 160], rc_rev.data(), 20);
+        if (probe_on) memcpy(&seq[a + 60], PROBE, sizeof PROBE - 1);
     }
 
     // the link: pinned host -> device, 256 MiB, best of 4
@@ -210,10 +219,11 @@ int main(int argc, char **argv) {
         // the pool lives as long as the run, as the reference's worker goroutines do: the threads start once
         // and meet at a barrier before every timed pass (best of three: a thread's first HIP call falls into the first)
         std::atomic<size_t> next{0};
-        std::atomic<long long> nprod{0}, ns[4] = {{0}, {0}, {0}, {0}};
+        std::atomic<long long> nprod{0}, nannot{0}, probe_ns{0}, ns[4] = {{0}, {0}, {0}, {0}};
         std::atomic<int> failed{0}, at_gate{0}, finished{0}, pass_no{-1};
         std::atomic<int> bound{0};
         auto work = [&](ipcr_scratch *sc) {
+            std::vector<ipcr_probe_hit> ph;
             if (bind && ipcr_bind_thread_to_device(ipcr_scratch_device(sc))) bound.fetch_add(1);
             for (int pass = 0; pass < PASSES; ++pass) {
                 at_gate.fetch_add(1);
@@ -227,6 +237,18 @@ int main(int argc, char **argv) {
                     int64_t np = 0;
                     (void)ipcr_scratch_products(sc, &pr, &np);
                     nprod.fetch_add(np);
+                    if (probe_on) { // the worker annotates its own chunk's products: the chunk's tiles are still in its scratch
+                        const double tp = now();
+                        ph.resize((size_t)np + 1);
+                        if (ipcr_probe_scratch_products(sc, PROBE, 2, ph.data(), np) != IPCR_OK) { failed.store(1); break; }
+                        probe_ns.fetch_add((long long)((now() - tp) * 1e9));
+                        for (int64_t i = 0; i < np; ++i)
+                            if (pr[i].pair == 0 && pr[i].type == 0 && pr[i].length == 180) {
+                                const ipcr_probe_hit &h = ph[(size_t)i];
+                                if (h.found && h.strand == '+' && h.pos == 60 && h.mm == 0) nannot.fetch_add(1);
+                                else failed.store(2);
+                            }
+                    }
                     ipcr_scan_stats stt;
                     if (ipcr_scratch_stats(sc, &stt) == IPCR_OK) {
                         ns[0].fetch_add((long long)(stt.total_ms * 1e6));
@@ -240,11 +262,27 @@ int main(int argc, char **argv) {
         };
         std::vector<std::thread> th;
         for (int w = 0; w < W; ++w) th.emplace_back(work, scs[(size_t)w]);
-        double best = 0, call_ms[4] = {0, 0, 0, 0}; // of the best pass: whole call, enqueue, wait, host sort + join
-        long long products = -1;
+        // --probe: the collector's form of the rescan, one ipcr_probe_best_hit per amplicon, the whole time the pool sweeps
+        std::atomic<int> collector_stop{0};
+        std::atomic<long long> bh_calls{0}, bh_ns{0}, bh_bad{0};
+        std::thread collector;
+        if (probe_on && W == workers.back())
+            collector = std::thread([&] {
+                while (pass_no.load(std::memory_order_acquire) < 0 && !collector_stop.load()) std::this_thread::yield();
+                const uint8_t *amp = &seq[500000];
+                while (!collector_stop.load(std::memory_order_relaxed)) {
+                    ipcr_probe_hit h;
+                    const double t0 = now();
+                    if (ipcr_probe_best_hit(amp, 180, PROBE, 2, &h) != IPCR_OK || !h.found || h.pos != 60 || h.mm != 0 || h.strand != '+') bh_bad.fetch_add(1);
+                    bh_ns.fetch_add((long long)((now() - t0) * 1e9));
+                    bh_calls.fetch_add(1);
+                }
+            });
+        double best = 0, call_ms[4] = {0, 0, 0, 0}, probe_call_ms = 0; // of the best pass: whole call, enqueue, wait, host sort + join
+        long long products = -1, annotated = 0;
         for (int pass = 0; pass < PASSES; ++pass) {
             while (at_gate.load() < (pass + 1) * W) std::this_thread::yield(); // everyone is at the gate
-            next.store(0); nprod.store(0);
+            next.store(0); nprod.store(0); nannot.store(0); probe_ns.store(0);
             for (auto &x : ns) x.store(0);
             const double t0 = now();
             pass_no.store(pass, std::memory_order_release);
@@ -255,21 +293,42 @@ int main(int argc, char **argv) {
             if (rate > best) {
                 best = rate;
                 for (int i = 0; i < 4; ++i) call_ms[i] = (double)ns[i].load() / 1e6 / (double)total;
+                probe_call_ms = (double)probe_ns.load() / 1e6 / (double)total;
             }
+            annotated = nannot.load() / (long long)reps;
             const long long per_pass = nprod.load() / (long long)reps;
             if (products >= 0 && per_pass != products) { fprintf(stderr, "product count changed between passes\n"); rc = 7; }
             products = per_pass;
         }
         for (auto &t : th) t.join();
+        collector_stop.store(1);
+        if (collector.joinable()) collector.join();
+        if (probe_on && annotated < (long long)planted) { fprintf(stderr, "%lld annotated amplicons for %llu planted\n", annotated, (unsigned long long)planted); rc = 9; }
+        if (bh_bad.load()) { fprintf(stderr, "ipcr_probe_best_hit: %lld wrong results\n", bh_bad.load()); rc = 10; }
         if (products < (long long)planted) { fprintf(stderr, "%lld products for %llu planted amplicons\n", products, (unsigned long long)planted); rc = 8; }
         printf(", \"gbases_per_s_%d_worker%s\": %.2f", W, W == 1 ? "" : "s", best);
         if (W > 1) printf(", \"pinned_h2d_GBps_%d_streams\": %.1f", W, pool_h2d(W));
         // per call: the rest of `call` is the copy into device memory (through pinned slices under a pool) and the pack enqueue
         printf(", \"call_ms_%d_worker%s\": {\"call\": %.3f, \"enqueue\": %.3f, \"wait\": %.3f, \"sort_join\": %.3f}", W, W == 1 ? "" : "s",
                call_ms[0], call_ms[1], call_ms[2], call_ms[3]);
+        if (probe_on) printf(", \"probe_rescan_ms_per_call_%d_worker%s\": %.4f", W, W == 1 ? "" : "s", probe_call_ms);
+        if (probe_on && W == workers.back())
+            printf(", \"probe\": \"%s\", \"probe_annotated_per_pass\": %lld, \"probe_best_hit_us_under_%d_workers\": %.2f, \"probe_best_hit_calls\": %lld", PROBE, annotated, W,
+                   bh_calls.load() ? (double)bh_ns.load() / 1e3 / (double)bh_calls.load() : 0.0, bh_calls.load());
         if (W == workers.back()) printf(", \"products_per_pass\": %lld, \"panel_device_slots\": %d, \"workers_on_device_cpus\": %d", products, ipcr_panel_device_slots(panel), bound.load());
         for (auto &sc : scs) ipcr_scratch_destroy(sc);
     }
+    if (probe_on) { // ipcr_probe_best_hit on an idle device: amplicons of 180 and 2000 bases, 2000 calls each after 200 to warm
+        for (uint64_t alen : {180ull, 2000ull}) {
+            if (500000 + alen > n) continue;
+            ipcr_probe_hit h;
+            for (int i = 0; i < 200; ++i) (void)ipcr_probe_best_hit(&seq[500000], alen, PROBE, 2, &h);
+            const double t0 = now();
+            for (int i = 0; i < 2000; ++i)
+                if (ipcr_probe_best_hit(&seq[500000], alen, PROBE, 2, &h) != IPCR_OK || !h.found || h.pos != 60) { rc = 10; break; }
+            printf(", \"probe_best_hit_us_idle_%llu\": %.2f", (unsigned long long)alen, (now() - t0) * 1e6 / 2000.0);
+        }
+    } else
     {   // one worker, the whole record in one call
         ipcr_scratch *sc = nullptr;
         if (ipcr_scratch_create_on(panel, devices[0], &sc) != IPCR_OK) return 5;

@@ -23,12 +23,18 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
 ipcr_status ipcr_internal_fail(ipcr_status st, const char *fmt, ...);
+// host.cpp: what a scratch sends -- its device hit block (header + slots), or, when that block does not hold the scan's
+// results (*authoritative == 0), the host list that does
+ipcr_status ipcr_internal_scratch_send_block(const ipcr_scratch *s, const void **dev_block, uint64_t *hcap, const ipcr_hit **host_hits,
+                                             uint64_t *n_host, int *authoritative);
 int ipcr_internal_slot_phys(int slot);
 int ipcr_internal_slot_count();
 
@@ -87,6 +93,11 @@ constexpr int SLOTS = 2; // exchanges in flight
 struct ipcr_exchange {
     Rccl *lib = nullptr;
     ncclComm_t comm = nullptr;
+    // IPCR_TEST_EXCHANGE_FAKE=1 (tests on a one-GPU box): no communicator -- the "all-gather" copies this rank's block into
+    // every rank's place of the receive buffer, rank r's header rewritten to hold (hits >> r) records: everything around the
+    // collective (shape agreement, strided header read-back, per-rank prefix copies, lock-step redo, rebasing) runs with world > 1
+    bool fake = false;
+    void *h_fake = nullptr; // pinned: world x 16 bytes, the rewritten header words
     int world = 1, rank = 0, device = 0, phys = 0;
     bool same_records = false;
     hipStream_t stream = nullptr;
@@ -149,17 +160,46 @@ ipcr_status ensure_host(ipcr_exchange *x, uint64_t cap) {
 // enqueue one all-gather of the scratch's device hit block into receive slot `slot`
 ipcr_status enqueue(ipcr_exchange *x, const ipcr_scratch *s, int slot) {
     const void *dev_block = nullptr;
-    uint64_t n_hits = 0, hcap = 0;
-    ipcr_status st = ipcr_scratch_device_hits(s, &dev_block, &n_hits, &hcap);
+    const ipcr_hit *host_hits = nullptr;
+    uint64_t n_host = 0, hcap = 0;
+    int authoritative = 1;
+    ipcr_status st = ipcr_internal_scratch_send_block(s, &dev_block, &hcap, &host_hits, &n_host, &authoritative);
     if (st == IPCR_OK) st = ensure_slot(x, slot);
     if (st != IPCR_OK) return st;
     const size_t nb = block_bytes(x->cap);
     const void *send = dev_block;
-    if (hcap < x->cap) { // this rank's buffer is smaller than the agreed shape: the same bytes through the staging buffer
+    if (!authoritative) {
+        // The scan's results live in the HOST list only: a capped scan with far more raw matches than the hit buffer may
+        // take ran range of blocks by range of blocks (host.cpp: scan_segmented) and the device buffer holds the last
+        // range's records.  The block is rebuilt in the staging buffer -- header with the true count, then the first `cap`
+        // records -- and sent from there: same shape, same lock-step overflow handling as any other rank's block.
+        uint64_t hdr[8] = {0, n_host, 0, 0, 0, 0, 0, 0};
+        const uint64_t n_send = std::min<uint64_t>(n_host, x->cap);
+        XHIP(hipMemcpyAsync(x->d_stage, hdr, sizeof hdr, hipMemcpyHostToDevice, x->stream));
+        if (n_send) XHIP(hipMemcpyAsync(static_cast<uint8_t *>(x->d_stage) + 64, host_hits, (size_t)n_send * sizeof(ipcr_hit), hipMemcpyHostToDevice, x->stream));
+        XHIP(hipStreamSynchronize(x->stream)); // (pageable sources: the list may change once this call has returned)
+        send = x->d_stage;
+    } else if (hcap < x->cap) { // this rank's buffer is smaller than the agreed shape: the same bytes through the staging buffer
         XHIP(hipMemcpyAsync(x->d_stage, dev_block, block_bytes(hcap), hipMemcpyDeviceToDevice, x->stream));
         send = x->d_stage;
     }
-    XNCCL(x->lib, x->lib->AllGather(send, x->d_recv[slot], nb, ncclUint8, x->comm, x->stream));
+    if (!x->fake) {
+        XNCCL(x->lib, x->lib->AllGather(send, x->d_recv[slot], nb, ncclUint8, x->comm, x->stream));
+    } else { // tests: see ipcr_exchange::fake
+        uint64_t hdr[8];
+        XHIP(hipMemcpyAsync(hdr, send, sizeof hdr, hipMemcpyDeviceToHost, x->stream));
+        XHIP(hipStreamSynchronize(x->stream));
+        const uint64_t n = std::max(hdr[1], hdr[5]);
+        uint64_t *hf = static_cast<uint64_t *>(x->h_fake);
+        for (int r = 0; r < x->world; ++r) {
+            uint8_t *dst = static_cast<uint8_t *>(x->d_recv[slot]) + nb * (size_t)r;
+            XHIP(hipMemcpyAsync(dst, send, nb, hipMemcpyDeviceToDevice, x->stream));
+            hf[2 * r] = n >> r; // "rank r found half of what rank r - 1 found": uneven counts, zero-hit ranks for small n
+            hf[2 * r + 1] = 0;
+            XHIP(hipMemcpyAsync(dst + 8, hf + 2 * r, 8, hipMemcpyHostToDevice, x->stream));      // counter set 0: hits
+            XHIP(hipMemcpyAsync(dst + 40, hf + 2 * r + 1, 8, hipMemcpyHostToDevice, x->stream)); // counter set 1: zero
+        }
+    }
     XHIP(hipEventRecord(x->done[slot], x->stream));
     x->pend[slot].active = true;
     x->pend[slot].scratch = s;
@@ -174,12 +214,63 @@ uint64_t header_hits(const uint8_t *block) {
     return std::max(h[1], h[5]);
 }
 
+// ---- the host side of ipcr_exchange_end, free of HIP and RCCL (ipcr_exchange_unpack runs it on the CPU for world > 1) ----
+// What every rank derives from the gathered HEADERS alone -- all ranks read the same bytes, so all take the same decision.
+struct GatherPlan {
+    std::vector<uint64_t> counts;     // hits rank r reported (its true count, also when it exceeds the capacity)
+    std::vector<uint64_t> hit_start;  // world + 1: where rank r's records go in the gathered list
+    std::vector<uint32_t> rec_offset; // world + 1: what is added to rank r's record indices
+    uint64_t need = 0;                // largest count: > cap means every rank regrows and repeats the exchange
+};
+// headers: rank r's 64-byte header at headers + r * stride
+void plan_gather(const uint8_t *headers, size_t stride, int world, const std::vector<uint64_t> &rec_counts, bool same_records, GatherPlan &pl) {
+    pl.counts.assign((size_t)world, 0);
+    pl.hit_start.assign((size_t)world + 1, 0);
+    pl.rec_offset.assign((size_t)world + 1, 0);
+    pl.need = 0;
+    for (int r = 0; r < world; ++r) {
+        pl.counts[(size_t)r] = header_hits(headers + stride * (size_t)r);
+        pl.need = std::max(pl.need, pl.counts[(size_t)r]);
+    }
+    for (int r = 0; r < world; ++r) {
+        pl.hit_start[(size_t)r + 1] = pl.hit_start[(size_t)r] + pl.counts[(size_t)r];
+        pl.rec_offset[(size_t)r + 1] = pl.rec_offset[(size_t)r] + (same_records ? 0u : (uint32_t)rec_counts[(size_t)r]);
+    }
+}
+// byte offset of rank r's first record inside a gathered buffer of `world` blocks of block_bytes(cap)
+size_t records_offset(uint64_t cap, int r) { return block_bytes(cap) * (size_t)r + 64u; }
+// record indices -> job-global (rank r's records start at rec_offset[r])
+void rebase_records(ipcr_hit *hits, const GatherPlan &pl, int world) {
+    for (int r = 0; r < world; ++r)
+        for (uint64_t i = pl.hit_start[(size_t)r]; i < pl.hit_start[(size_t)r + 1]; ++i) hits[(size_t)i].record += pl.rec_offset[(size_t)r];
+}
+
 } // namespace
 
 extern "C" {
 
+static bool fake_transport() {
+    const char *v = getenv("IPCR_TEST_EXCHANGE_FAKE");
+    return v && *v && atoi(v) != 0;
+}
+
+// Everything ipcr_exchange_create can fail on BEFORE it enters ncclCommInitRank, checked locally and without side effects
+// on the job: librccl opens and has the entry points, the device exists.  A host takes the minimum of this over all ranks
+// first (its own channel: an all-reduce, a barrier with a flag) and calls ipcr_exchange_create only when it is 1 on every
+// rank -- a rank that failed here while the others were already inside ncclCommInitRank would leave them waiting for ever.
+int32_t ipcr_exchange_available(int32_t device) {
+    if (device < 0 || device >= ipcr_internal_slot_count()) {
+        (void)ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_available: device %d of %d", device, ipcr_internal_slot_count());
+        return 0;
+    }
+    if (fake_transport()) return 1;
+    if (!rccl()) { (void)ipcr_internal_fail(IPCR_ERR_DEVICE, "RCCL is not available"); return 0; }
+    return 1;
+}
+
 ipcr_status ipcr_exchange_unique_id(uint8_t *id_out) {
     if (!id_out) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_unique_id: null argument");
+    if (fake_transport()) { memset(id_out, 0, IPCR_EXCHANGE_ID_BYTES); return IPCR_OK; }
     Rccl *r = rccl();
     if (!r) return ipcr_internal_fail(IPCR_ERR_DEVICE, "RCCL is not available");
     ncclUniqueId id;
@@ -194,10 +285,14 @@ ipcr_status ipcr_exchange_create(const uint8_t *id, int32_t world, int32_t rank,
     if (!id || !out || world < 1 || rank < 0 || rank >= world) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_create: bad argument");
     *out = nullptr;
     if (device < 0 || device >= ipcr_internal_slot_count()) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_create: device %d of %d", device, ipcr_internal_slot_count());
-    Rccl *r = rccl();
-    if (!r) return ipcr_internal_fail(IPCR_ERR_DEVICE, "RCCL is not available");
-    ipcr_exchange *x = new ipcr_exchange;
+    const bool fake = fake_transport();
+    Rccl *r = fake ? nullptr : rccl();
+    if (!r && !fake) return ipcr_internal_fail(IPCR_ERR_DEVICE, "RCCL is not available");
+    // everything that can fail locally comes BEFORE the communicator: once a rank is inside ncclCommInitRank the others must follow
+    ipcr_exchange *x = new (std::nothrow) ipcr_exchange;
+    if (!x) return ipcr_internal_fail(IPCR_ERR_DEVICE, "out of memory");
     x->lib = r;
+    x->fake = fake;
     x->world = world;
     x->rank = rank;
     x->device = device;
@@ -206,14 +301,17 @@ ipcr_status ipcr_exchange_create(const uint8_t *id, int32_t world, int32_t rank,
     x->rec_counts.assign((size_t)world, 0);
     OnDevice on(x->phys);
     auto build = [&]() -> ipcr_status {
-        ncclUniqueId uid;
-        memcpy(&uid, id, sizeof uid);
-        XNCCL(r, r->CommInitRank(&x->comm, world, uid, rank)); // synchronises with the other ranks
         XHIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
         for (int i = 0; i < SLOTS; ++i) XHIP(hipEventCreateWithFlags(&x->done[i], hipEventDisableTiming));
         XHIP(hipMalloc(&x->d_meta, 8u * (size_t)(world + 1)));
         XHIP(hipHostMalloc(&x->h_meta, 8u * (size_t)(world + 1), hipHostMallocDefault));
-        return set_capacity(x, std::max<uint64_t>(cap_hits, 1));
+        if (fake) XHIP(hipHostMalloc(&x->h_fake, 16u * (size_t)world, hipHostMallocDefault));
+        const ipcr_status cs = set_capacity(x, std::max<uint64_t>(cap_hits, 1));
+        if (cs != IPCR_OK || fake) return cs;
+        ncclUniqueId uid;
+        memcpy(&uid, id, sizeof uid);
+        XNCCL(r, r->CommInitRank(&x->comm, world, uid, rank)); // synchronises with the other ranks: the last thing that can fail
+        return IPCR_OK;
     };
     const ipcr_status st = build();
     if (st != IPCR_OK) { ipcr_exchange_destroy(x); return st; }
@@ -234,6 +332,7 @@ void ipcr_exchange_destroy(ipcr_exchange *x) {
     if (x->h_recv) (void)hipHostFree(x->h_recv);
     if (x->d_meta) (void)hipFree(x->d_meta);
     if (x->h_meta) (void)hipHostFree(x->h_meta);
+    if (x->h_fake) (void)hipHostFree(x->h_fake);
     if (x->stream) (void)hipStreamDestroy(x->stream);
     delete x;
 }
@@ -246,7 +345,8 @@ ipcr_status ipcr_exchange_set_records(ipcr_exchange *x, uint32_t n_local_records
     hm[x->world] = n_local_records;
     uint64_t *dm = static_cast<uint64_t *>(x->d_meta);
     XHIP(hipMemcpyAsync(dm + x->world, hm + x->world, 8, hipMemcpyHostToDevice, x->stream));
-    XNCCL(x->lib, x->lib->AllGather(dm + x->world, dm, 8, ncclUint8, x->comm, x->stream));
+    if (x->fake) { for (int r = 0; r < x->world; ++r) XHIP(hipMemcpyAsync(dm + r, dm + x->world, 8, hipMemcpyDeviceToDevice, x->stream)); }
+    else XNCCL(x->lib, x->lib->AllGather(dm + x->world, dm, 8, ncclUint8, x->comm, x->stream));
     XHIP(hipMemcpyAsync(hm, dm, 8u * (size_t)x->world, hipMemcpyDeviceToHost, x->stream));
     XHIP(hipStreamSynchronize(x->stream));
     for (int r = 0; r < x->world; ++r) x->rec_counts[(size_t)r] = hm[r];
@@ -286,16 +386,12 @@ ipcr_status ipcr_exchange_end(ipcr_exchange *x, int32_t ticket, const ipcr_hit *
         // every rank's header first: all ranks read the same counts and take the same decision
         XHIP(hipMemcpy2DAsync(x->h_recv, 64, x->d_recv[ticket], nb, 64, (size_t)x->world, hipMemcpyDeviceToHost, x->stream));
         XHIP(hipStreamSynchronize(x->stream));
-        uint64_t need = 0;
-        std::vector<uint64_t> counts((size_t)x->world);
-        for (int r = 0; r < x->world; ++r) {
-            counts[(size_t)r] = header_hits(static_cast<const uint8_t *>(x->h_recv) + 64u * (size_t)r);
-            need = std::max(need, counts[(size_t)r]);
-        }
-        if (need > pd.cap) { // some rank overflowed: every rank regrows and repeats the exchange (the scratch still holds the scan)
+        GatherPlan pl;
+        plan_gather(static_cast<const uint8_t *>(x->h_recv), 64, x->world, x->rec_counts, x->same_records, pl);
+        if (pl.need > pd.cap) { // some rank overflowed: every rank regrows and repeats the exchange (the scratch still holds the scan)
             ++x->redone;
             uint64_t cap = std::max(pd.cap, x->cap);
-            while (cap < need) cap *= 2;
+            while (cap < pl.need) cap *= 2;
             ipcr_status st = set_capacity(x, cap); // (an exchange in flight in the other slot keeps its own buffers and shape)
             if (st != IPCR_OK) return st;
             st = enqueue(x, pd.scratch, ticket);
@@ -305,20 +401,15 @@ ipcr_status ipcr_exchange_end(ipcr_exchange *x, int32_t ticket, const ipcr_hit *
             continue;
         }
         // the records: only the valid prefix of every rank's block
-        x->hit_start.assign((size_t)x->world + 1, 0);
-        x->rec_offset.assign((size_t)x->world + 1, 0);
-        for (int r = 0; r < x->world; ++r) {
-            x->hit_start[(size_t)r + 1] = x->hit_start[(size_t)r] + counts[(size_t)r];
-            x->rec_offset[(size_t)r + 1] = x->rec_offset[(size_t)r] + (x->same_records ? 0u : (uint32_t)x->rec_counts[(size_t)r]);
-        }
-        x->hits.resize((size_t)x->hit_start[(size_t)x->world]);
+        x->hit_start = pl.hit_start;
+        x->rec_offset = pl.rec_offset;
+        x->hits.resize((size_t)pl.hit_start[(size_t)x->world]);
         for (int r = 0; r < x->world; ++r)
-            if (counts[(size_t)r])
-                XHIP(hipMemcpyAsync(x->hits.data() + x->hit_start[(size_t)r], static_cast<const uint8_t *>(x->d_recv[ticket]) + nb * (size_t)r + 64,
-                                    (size_t)counts[(size_t)r] * sizeof(ipcr_hit), hipMemcpyDeviceToHost, x->stream));
+            if (pl.counts[(size_t)r])
+                XHIP(hipMemcpyAsync(x->hits.data() + pl.hit_start[(size_t)r], static_cast<const uint8_t *>(x->d_recv[ticket]) + records_offset(pd.cap, r),
+                                    (size_t)pl.counts[(size_t)r] * sizeof(ipcr_hit), hipMemcpyDeviceToHost, x->stream));
         XHIP(hipStreamSynchronize(x->stream));
-        for (int r = 0; r < x->world; ++r) // job-global record index
-            for (uint64_t i = x->hit_start[(size_t)r]; i < x->hit_start[(size_t)r + 1]; ++i) x->hits[(size_t)i].record += x->rec_offset[(size_t)r];
+        rebase_records(x->hits.data(), pl, x->world); // job-global record index
         if (hits) *hits = x->hits.data();
         if (n_hits) *n_hits = (int64_t)x->hits.size();
         if (rank_hit_start) *rank_hit_start = x->hit_start.data();
@@ -326,6 +417,32 @@ ipcr_status ipcr_exchange_end(ipcr_exchange *x, int32_t ticket, const ipcr_hit *
         return IPCR_OK;
     }
     return ipcr_internal_fail(IPCR_ERR_CAPACITY, "ipcr_exchange_end: the exchange kept overflowing");
+}
+
+// The host side of ipcr_exchange_end over a gathered buffer in HOST memory: `world` blocks of 64 + cap * 32 bytes, as
+// ncclAllGather leaves them.  Pure function (no device, no communicator): what the tests drive with synthetic buffers for
+// world = 2, 3, 8, and what a host that runs the collective itself (MPI, its own RCCL communicator) can use.  *need = the
+// largest count any rank reported; IPCR_ERR_CAPACITY when it exceeds cap (every rank sees the same headers, so every rank
+// gets this status and repeats the exchange with a capacity >= *need) or when the records do not fit out_cap.
+ipcr_status ipcr_exchange_unpack(const void *gathered, int32_t world, uint64_t cap, const uint32_t *rec_counts, int32_t same_records,
+                                 ipcr_hit *out, uint64_t out_cap, uint64_t *rank_hit_start, uint32_t *rank_record_offset, uint64_t *need) {
+    if (!gathered || world < 1 || (!rec_counts && !same_records)) return ipcr_internal_fail(IPCR_ERR_INVALID, "ipcr_exchange_unpack: bad argument");
+    std::vector<uint64_t> rc((size_t)world, 0);
+    for (int r = 0; r < world && rec_counts; ++r) rc[(size_t)r] = rec_counts[r];
+    GatherPlan pl;
+    plan_gather(static_cast<const uint8_t *>(gathered), block_bytes(cap), world, rc, same_records != 0, pl);
+    if (need) *need = pl.need;
+    if (rank_hit_start) memcpy(rank_hit_start, pl.hit_start.data(), ((size_t)world + 1) * sizeof(uint64_t));
+    if (rank_record_offset) memcpy(rank_record_offset, pl.rec_offset.data(), ((size_t)world + 1) * sizeof(uint32_t));
+    if (pl.need > cap) return ipcr_internal_fail(IPCR_ERR_CAPACITY, "a rank reported %llu hits, the exchange carries %llu: repeat it with a larger capacity on every rank",
+                                                 (unsigned long long)pl.need, (unsigned long long)cap);
+    const uint64_t total = pl.hit_start[(size_t)world];
+    if (total > out_cap || (total && !out)) return ipcr_internal_fail(IPCR_ERR_CAPACITY, "%llu gathered hits do not fit the output (%llu)", (unsigned long long)total, (unsigned long long)out_cap);
+    for (int r = 0; r < world; ++r)
+        if (pl.counts[(size_t)r])
+            memcpy(out + pl.hit_start[(size_t)r], static_cast<const uint8_t *>(gathered) + records_offset(cap, r), (size_t)pl.counts[(size_t)r] * sizeof(ipcr_hit));
+    rebase_records(out, pl, world);
+    return IPCR_OK;
 }
 
 // a capacity every rank already knows it needs (e.g. from a first, synchronous exchange): the same value on every rank

@@ -1395,6 +1395,8 @@ struct ipcr_scratch {
     std::vector<uint64_t> last_rec_start;
     ipcr_scan_stats stats{};
     ipcr_genome *chunk = nullptr; // private genome of ipcr_scan_chunk
+    bool dev_hits_stale = false;  // the device hit buffer does NOT hold the last scan's hits (scan_segmented: only its last range): hits_raw does
+    bool last_was_chunk = false;  // the products in `products` are those of an ipcr_scan_chunk: their amplicons lie in `chunk`
     // ipcr_scan_chunk with several workers: the caller's (pageable) bytes go through two pinned slices of this
     // scratch -- the CPU copy of slice i+1 runs under the DMA of slice i, and workers do not meet in the runtime's
     // own pageable-copy path
@@ -1822,6 +1824,8 @@ ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g, b
     pd.t0 = std::chrono::steady_clock::now();
     s->hits.clear();
     s->products.clear();
+    s->last_was_chunk = false;
+    s->dev_hits_stale = false;
     const double pack_ms_keep = s->stats.pack_ms;
     memset(&s->stats, 0, sizeof s->stats);
     s->stats.pack_ms = pack_ms_keep;
@@ -2073,6 +2077,7 @@ ipcr_status scan_segmented(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g,
     s->stats.candidates = cand;
     s->stats.hits = s->hits.size();
     s->stats.segmented = 1;
+    s->dev_hits_stale = true; // the device buffer and its header hold the last range only (ipcr_scratch_device_hits, the exchange)
     s->stats.total_ms = ms_since(pd.t0);
     return IPCR_OK;
 }
@@ -2440,11 +2445,27 @@ ipcr_status ipcr_scratch_hits(const ipcr_scratch *s, const ipcr_hit **out, int64
 ipcr_status ipcr_scratch_device_hits(const ipcr_scratch *s, const void **dev_block, uint64_t *n_hits, uint64_t *capacity) {
     if (!s || !dev_block || !n_hits || !capacity) return fail(IPCR_ERR_INVALID, "null argument");
     if (!s->d_hitbuf) return fail(IPCR_ERR_DEVICE, "host-only scratch has no device hit buffer");
+    if (s->dev_hits_stale)
+        return fail(IPCR_ERR_UNSUPPORTED, "the device hit buffer does not hold this scan's hits: a capped scan that ran in segments keeps them on the host "
+                                          "(ipcr_scratch_hits; ipcr_exchange_begin sends them from there)");
     *dev_block = s->d_hitbuf;
     *n_hits = s->hits_raw.size();
     *capacity = s->hcap;
     return IPCR_OK;
 }
+
+} // extern "C"
+ipcr_status ipcr_internal_scratch_send_block(const ipcr_scratch *s, const void **dev_block, uint64_t *hcap, const ipcr_hit **host_hits,
+                                             uint64_t *n_host, int *authoritative) {
+    if (!s || !s->d_hitbuf) return fail(IPCR_ERR_DEVICE, "host-only scratch has no device hit buffer");
+    *dev_block = s->d_hitbuf;
+    *hcap = s->hcap;
+    *host_hits = s->hits_raw.data();
+    *n_host = s->hits_raw.size();
+    *authoritative = s->dev_hits_stale ? 0 : 1;
+    return IPCR_OK;
+}
+extern "C" {
 
 ipcr_status ipcr_scan_genome_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g) {
     ipcr_status st = scratch_ready(p, s);
@@ -2515,6 +2536,7 @@ ipcr_status ipcr_join_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_hit 
     s->hits_raw.assign(hits, hits + n_hits);
     sort_hits(s->hits_raw, s->hits, n_records, (uint32_t)p->defs.size());
     s->products.clear();
+    s->last_was_chunk = false;
     return join_sorted_hits(p, s, record_len, record_flags, n_records, emit, user);
 }
 
@@ -2549,6 +2571,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
     s->hits.clear();
     s->products.clear();
     memset(&s->stats, 0, sizeof s->stats);
+    s->last_was_chunk = p->id.empty();
     if (p->id.empty()) return IPCR_OK; // compiled.go:163-165
     DeviceGuard dg(s->device); // the worker's thread may never have selected a device (a goroutine on any thread)
     const uint64_t need_cols = record_cols(len) + 64;
@@ -2716,6 +2739,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
     g->flags_valid = true;
     const uint8_t fl = (uint8_t)((g->flags[0] & 1u) | (p->modes_equal ? 0u : 2u));
     st = join_sorted_hits(p, s, g->rec_len.data(), &fl, 1, emit, user);
+    s->last_was_chunk = st == IPCR_OK; // the products' amplicons lie in s->chunk until the next scan (ipcr_probe_scratch_products)
     s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return st;
 }
@@ -2737,28 +2761,70 @@ static ipcr_status normalize_probe(const char *probe, std::string &prb) {
     return IPCR_OK;
 }
 
-static ipcr_status run_probe(hipStream_t st, const uint8_t *d_amps, const uint64_t *d_off, uint32_t namp,
-                             const std::string &prb, int32_t max_mm, void *d_misc, ipcr_probe_hit *out) {
-    // d_misc: [0,128) probe masks, [128,256) rc masks, [256, ...) results
+// probe and rc(probe) as the two rows of IUPAC masks the probe kernel reads; returns the kernel's fast-path flag
+static uint32_t probe_masks(const std::string &prb, int32_t max_mm, uint8_t *masks /* 256 bytes */) {
     std::string rc;
     revcomp(prb, rc, nullptr);
-    uint8_t masks[256];
-    memset(masks, 0, sizeof masks);
+    memset(masks, 0, 256);
     bool strict = !prb.empty();
     for (size_t i = 0; i < prb.size(); ++i) {
         masks[i] = T.mask[(uint8_t)prb[i]];
         masks[128 + i] = T.mask[(uint8_t)rc[i]];
         if (prb[i] != 'A' && prb[i] != 'C' && prb[i] != 'G' && prb[i] != 'T') strict = false;
     }
-    uint8_t *dm = static_cast<uint8_t *>(d_misc);
-    HIPCHK(hipMemcpyAsync(dm, masks, 256, hipMemcpyHostToDevice, st));
-    ipcr_probe_rec *dres = reinterpret_cast<ipcr_probe_rec *>(dm + 256);
-    const uint32_t fast = (max_mm == 0 && strict) ? 1u : 0u; // oligo.go:33-42
-    HIPCHK(ipcr::launch_probe(st, d_amps, d_off, namp, dm, dm + 128, (uint32_t)prb.size(),
-                              (uint32_t)(max_mm < 0 ? 0 : max_mm), fast, dres));
-    HIPCHK(hipMemcpyAsync(out, dres, (uint64_t)namp * sizeof(ipcr_probe_hit), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    return (max_mm == 0 && strict) ? 1u : 0u; // oligo.go:33-42
+}
+
+// ipcr_probe_best_hit is what a host without the batched form calls once per product (visitors.Probe.Visit runs on the
+// collector goroutine, internal/visitors/probe.go:18-33), next to a pool of workers that sweep on the same device.  So it
+// must not allocate or free device memory (hipFree waits for the whole device: every worker's sweep), use the null stream
+// or a copy operation.  A call borrows one of these from a free list (one per concurrent caller ever seen, per device
+// slot; they live as long as the process): a non-blocking stream and ONE pinned block the kernel reads its arguments
+// and the amplicon from (it stages them in LDS) and writes its 16-byte result to, tagged, where the caller spins.
+struct ProbeCtx {
+    int slot = 0;
+    hipStream_t st = nullptr;
+    uint8_t *h = nullptr; // [0, 256) masks | [256, 272) result | [272, 288) the two offsets | [320, ...) amplicon + 16 spare bytes
+    uint64_t hcap = 0;
+    uint32_t tag = 0;
+};
+static std::mutex g_probe_mu;
+static std::vector<ProbeCtx *> g_probe_free;
+static constexpr uint64_t PROBE_CTX_AMP_OFF = 320;
+
+static ipcr_status probe_ctx_acquire(int slot, uint64_t amp_len, ProbeCtx **out) {
+    ProbeCtx *c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_probe_mu);
+        for (size_t i = 0; i < g_probe_free.size(); ++i)
+            if (g_probe_free[i]->slot == slot) { c = g_probe_free[i]; g_probe_free.erase(g_probe_free.begin() + (long)i); break; }
+    }
+    if (!c) {
+        c = new ProbeCtx;
+        c->slot = slot;
+        const hipError_t e = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(IPCR_ERR_DEVICE, "hipStreamCreateWithFlags: %s", hipGetErrorString(e)); }
+    }
+    const uint64_t need = PROBE_CTX_AMP_OFF + amp_len + 64;
+    if (need > c->hcap) { // (first use, or an amplicon beyond 64 KB: --max-length is 2000 by default)
+        if (c->h) (void)hipHostFree(c->h);
+        c->h = nullptr;
+        c->hcap = std::max<uint64_t>(need + (need >> 2), 64u << 10);
+        const hipError_t e = hipHostMalloc((void **)&c->h, c->hcap, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            c->hcap = 0;
+            std::lock_guard<std::mutex> lk(g_probe_mu);
+            g_probe_free.push_back(c);
+            return fail(IPCR_ERR_DEVICE, "hipHostMalloc: %s", hipGetErrorString(e));
+        }
+        memset(c->h, 0, PROBE_CTX_AMP_OFF);
+    }
+    *out = c;
     return IPCR_OK;
+}
+static void probe_ctx_release(ProbeCtx *c) {
+    std::lock_guard<std::mutex> lk(g_probe_mu);
+    g_probe_free.push_back(c);
 }
 
 ipcr_status ipcr_probe_best_hit(const uint8_t *amplicon, uint64_t len, const char *probe, int32_t max_mm,
@@ -2770,20 +2836,52 @@ ipcr_status ipcr_probe_best_hit(const uint8_t *amplicon, uint64_t len, const cha
     if (st != IPCR_OK) return st;
     if (prb.empty()) return IPCR_OK; // oligo.go:21-23
     if (slot_count() == 0) return fail(IPCR_ERR_DEVICE, "no HIP device visible: the probe rescan has no CPU fallback");
-    DeviceGuard dg(default_slot());
-    uint8_t *d = nullptr;
-    const uint64_t bytes = len + 16 + 16 + 256 + sizeof(ipcr_probe_rec);
-    HIPCHK(hipMalloc((void **)&d, bytes + 64));
-    // layout: offsets (16 B) | misc (256 + result, 16-aligned) | amplicon
-    uint64_t offs[2] = {0, len};
-    hipError_t e = hipMemcpy(d, offs, 16, hipMemcpyHostToDevice);
-    uint8_t *misc = d + 16;
-    uint8_t *amps = d + 16 + 256 + 32;
-    if (e == hipSuccess && len) e = hipMemcpy(amps, amplicon, len, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(d); HIPCHK(e); }
-    st = run_probe(nullptr, amps, reinterpret_cast<const uint64_t *>(d), 1, prb, max_mm, misc, out);
-    (void)hipFree(d);
-    return st;
+    if (len < prb.size()) return IPCR_OK; // no window fits (core/primer/match.go:31-34)
+    if (len > 0x7FFFFFFFull) return fail(IPCR_ERR_UNSUPPORTED, "amplicon of %llu bases: ipcr_probe_hit positions are 32-bit", (unsigned long long)len);
+    const int slot = default_slot();
+    DeviceGuard dg(slot);
+    ProbeCtx *c = nullptr;
+    st = probe_ctx_acquire(slot, len, &c);
+    if (st != IPCR_OK) return st;
+    const uint32_t fast = probe_masks(prb, max_mm, c->h);
+    uint64_t *offs = reinterpret_cast<uint64_t *>(c->h + 272);
+    offs[0] = 0;
+    offs[1] = len;
+    memcpy(c->h + PROBE_CTX_AMP_OFF, amplicon, len);
+    c->tag = (c->tag % 0x3FFFFFFFu) + 1u; // never 0, never the tag the result slot still holds
+    const uint32_t tag = c->tag;
+    volatile int32_t *res = reinterpret_cast<volatile int32_t *>(c->h + 256);
+    const hipError_t le = ipcr::launch_probe(c->st, c->h + PROBE_CTX_AMP_OFF, offs, 1, c->h, c->h + 128, (uint32_t)prb.size(),
+                                             (uint32_t)(max_mm < 0 ? 0 : max_mm), fast, reinterpret_cast<ipcr_probe_rec *>(c->h + 256), tag);
+    if (le != hipSuccess) { probe_ctx_release(c); return fail(IPCR_ERR_DEVICE, "probe kernel: %s", hipGetErrorString(le)); }
+    // the record is one 16-byte store into pinned memory: spin on its tag (a kernel of one wave: microseconds)
+    bool got = false;
+    for (uint64_t spin = 1;; ++spin) {
+        if (((uint32_t)__atomic_load_n(res, __ATOMIC_ACQUIRE) >> 1) == tag) { got = true; break; }
+        if (spin < 0x4000u) __builtin_ia32_pause();
+        else std::this_thread::yield();
+        if ((spin & 0x3FFFu) == 0) {
+            const hipError_t q = hipStreamQuery(c->st);
+            if (q == hipErrorNotReady) continue;
+            got = ((uint32_t)__atomic_load_n(res, __ATOMIC_ACQUIRE) >> 1) == tag; // the stream has drained
+            if (!got) {
+                probe_ctx_release(c);
+                return fail(IPCR_ERR_DEVICE, "probe kernel: %s", q == hipSuccess ? "its result did not reach pinned memory" : hipGetErrorString(q));
+            }
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    out->found = res[0] & 1;
+    out->strand = res[1];
+    out->pos = res[2];
+    out->mm = res[3];
+    if (!out->found) memset(out, 0, sizeof *out);
+    // (the kernel reads nothing of the block after lane 0's store: the next call may rewrite it.  A wait for the stream
+    // now and then lets the runtime retire its bookkeeping of the launches.)
+    if ((tag & 0xFFu) == 0u) (void)hipStreamSynchronize(c->st);
+    probe_ctx_release(c);
+    return IPCR_OK;
 }
 
 ipcr_status ipcr_probe_products(ipcr_scratch *s, const ipcr_genome *g, const char *probe, int32_t max_mm,
@@ -2806,11 +2904,10 @@ ipcr_status ipcr_probe_products_end(ipcr_scratch *s, ipcr_probe_hit *out, int64_
     return IPCR_OK;
 }
 
-ipcr_status ipcr_probe_products_begin(ipcr_scratch *s, const ipcr_genome *g, const char *probe, int32_t max_mm) {
-    if (!s || !g || !probe) return fail(IPCR_ERR_INVALID, "ipcr_probe_products: null argument");
-    if (!s->stream) return fail(IPCR_ERR_DEVICE, "host-only scratch: the probe rescan has no CPU fallback");
+// the batched rescan of the scratch's current products against the tiles of `g`: the resident genome the scan ran over, or
+// the scratch's own chunk genome (ipcr_probe_scratch_products)
+static ipcr_status probe_begin(ipcr_scratch *s, const ipcr_genome *g, const char *probe, int32_t max_mm) {
     if (s->probe_pending >= 0) return fail(IPCR_ERR_INVALID, "ipcr_probe_products_begin: the rescan begun before has not been ended");
-    { const ipcr_status ds = same_device(s, g); if (ds != IPCR_OK) return ds; }
     DeviceGuard dg(s->device);
     const size_t n = s->products.size();
     std::string prb;
@@ -2840,6 +2937,7 @@ ipcr_status ipcr_probe_products_begin(ipcr_scratch *s, const ipcr_genome *g, con
         const ipcr_product &pr = s->products[i];
         if ((size_t)pr.record >= g->rec_start.size()) return fail(IPCR_ERR_INVALID, "product record outside genome");
         const uint64_t rs = g->rec_start[(size_t)pr.record], rl = g->rec_len[(size_t)pr.record];
+        if (pr.start < 0 || pr.end < 0 || (uint64_t)pr.start > rl || (uint64_t)pr.end > rl) return fail(IPCR_ERR_INVALID, "product outside its record");
         ipcr_amp_seg sg{};
         if (pr.start <= pr.end) { sg.pa = rs + (uint64_t)pr.start; sg.len_a = (uint64_t)(pr.end - pr.start); sg.pb = rs; sg.len_b = 0; }
         else { sg.pa = rs + (uint64_t)pr.start; sg.len_a = rl - (uint64_t)pr.start; sg.pb = rs; sg.len_b = (uint64_t)pr.end; }
@@ -2849,29 +2947,46 @@ ipcr_status ipcr_probe_products_begin(ipcr_scratch *s, const ipcr_genome *g, con
     }
     const uint64_t amp_bytes = offs[n] + 16;
     if (amp_bytes > s->amps_cap) {
+        // (grows to the largest batch seen and stays: hipFree waits for the device, so a steady state must not come here)
         if (s->d_amps) (void)hipFree(s->d_amps);
         s->d_amps = nullptr;
-        s->amps_cap = amp_bytes + (amp_bytes >> 2);
+        s->amps_cap = std::max<uint64_t>(amp_bytes + (amp_bytes >> 1), 1u << 20);
         HIPCHK(hipMalloc((void **)&s->d_amps, s->amps_cap));
     }
-    std::string rc;
-    revcomp(prb, rc, nullptr);
-    uint8_t *masks = s->h_probe;
-    memset(masks, 0, 256);
-    bool strict = true;
-    for (size_t i = 0; i < prb.size(); ++i) {
-        masks[i] = T.mask[(uint8_t)prb[i]];
-        masks[128 + i] = T.mask[(uint8_t)rc[i]];
-        if (prb[i] != 'A' && prb[i] != 'C' && prb[i] != 'G' && prb[i] != 'T') strict = false;
-    }
-    const uint32_t fast = (max_mm == 0 && strict) ? 1u : 0u; // oligo.go:33-42
+    const uint32_t fast = probe_masks(prb, max_mm, s->h_probe);
     ipcr_probe_rec *res = reinterpret_cast<ipcr_probe_rec *>(s->h_probe + res_off);
     HIPCHK(ipcr::launch_gather(s->probe_stream, g->planes, g->rst, segs, (uint32_t)n, s->d_amps));
-    HIPCHK(ipcr::launch_probe(s->probe_stream, s->d_amps, offs, (uint32_t)n, masks, masks + 128, (uint32_t)prb.size(),
+    HIPCHK(ipcr::launch_probe(s->probe_stream, s->d_amps, offs, (uint32_t)n, s->h_probe, s->h_probe + 128, (uint32_t)prb.size(),
                               (uint32_t)(max_mm < 0 ? 0 : max_mm), fast, res));
     s->probe_res_off = res_off;
     s->probe_pending = (int64_t)n; // (set last: a begin that failed leaves nothing to end)
     return IPCR_OK;
+}
+
+ipcr_status ipcr_probe_products_begin(ipcr_scratch *s, const ipcr_genome *g, const char *probe, int32_t max_mm) {
+    if (!s || !g || !probe) return fail(IPCR_ERR_INVALID, "ipcr_probe_products: null argument");
+    if (!s->stream) return fail(IPCR_ERR_DEVICE, "host-only scratch: the probe rescan has no CPU fallback");
+    { const ipcr_status ds = same_device(s, g); if (ds != IPCR_OK) return ds; }
+    return probe_begin(s, g, probe, max_mm);
+}
+
+// ipcr-probe behind the drop-in call: the products of the scratch's last ipcr_scan_chunk, rescanned from the tiles that
+// call has just packed (they stay in the scratch's private genome until its next scan) -- what visitors.Probe.Visit
+// computes from p.Seq (internal/visitors/probe.go:18-33), which the pipeline slices chunk-locally on the worker
+// (internal/pipeline/pipeline.go:80-89; wrap-around products of a circular record included)
+ipcr_status ipcr_probe_scratch_products_begin(ipcr_scratch *s, const char *probe, int32_t max_mm) {
+    if (!s || !probe) return fail(IPCR_ERR_INVALID, "ipcr_probe_scratch_products: null argument");
+    if (!s->stream) return fail(IPCR_ERR_DEVICE, "host-only scratch: the probe rescan has no CPU fallback");
+    if (!s->last_was_chunk || !s->chunk) {
+        if (s->products.empty() && s->last_was_chunk) { s->probe_pending = 0; s->probe_res_off = 0; return IPCR_OK; } // (an empty panel's chunk scan packs nothing)
+        return fail(IPCR_ERR_INVALID, "ipcr_probe_scratch_products: the scratch's last scan was not an ipcr_scan_chunk");
+    }
+    return probe_begin(s, s->chunk, probe, max_mm);
+}
+
+ipcr_status ipcr_probe_scratch_products(ipcr_scratch *s, const char *probe, int32_t max_mm, ipcr_probe_hit *out, int64_t n_out) {
+    const ipcr_status st = ipcr_probe_scratch_products_begin(s, probe, max_mm);
+    return st != IPCR_OK ? st : ipcr_probe_products_end(s, out, n_out);
 }
 
 // ------------------------------------------------------------------------------ nested PCR

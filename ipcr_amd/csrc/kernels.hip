@@ -498,26 +498,62 @@ __global__ void gather_amplicons_kernel(const uint32_t *__restrict__ planes, con
 // oligo.BestHit (core/oligo/oligo.go:19-77): one wavefront per amplicon, lanes stride the
 // start offsets; both strands; best = fewest mismatches, then leftmost; '+' wins exact
 // ties; the k=0 strict-ACGT fast path returns the first '+' occurrence when one exists.
+// The wave first stages its amplicon in LDS as one-hot codes (A 1, C 2, G 4, T 8, anything else 0 = matches
+// nothing; strings.ToUpper folded in: oligo.go:20) with dword loads, and the two mask rows beside it: the
+// arguments may lie in pinned HOST memory (ipcr_probe_best_hit hands the amplicon over that way: no copy
+// operation, no device allocation), which a lane must not read a byte at a time per comparison.
+// tag != 0: the record's `found` word carries it above bit 0 (one 16-byte store; the host spins on it).
+#define IPCR_PROBE_LDS_BYTES 16384u
+__device__ __forceinline__ uint32_t probe_onehot(uint32_t b) {
+    b &= 0xDFu;
+    return (b == 'A') ? 1u : (b == 'C') ? 2u : (b == 'G') ? 4u : (b == 'T') ? 8u : 0u;
+}
 __global__ __launch_bounds__(64) void probe_kernel(const uint8_t *__restrict__ amps,
                                                    const uint64_t *__restrict__ amp_off, // n+1 offsets
                                                    const uint8_t *__restrict__ pmask,    // probe IUPAC masks
                                                    const uint8_t *__restrict__ rmask,    // rc(probe) masks
-                                                   uint32_t plen, uint32_t max_mm, uint32_t fastpath,
+                                                   uint32_t plen, uint32_t max_mm, uint32_t fastpath, uint32_t tag,
                                                    ipcr_probe_rec *__restrict__ out) {
+    __shared__ uint8_t s_mask[256];
+    __shared__ uint32_t s_amp[IPCR_PROBE_LDS_BYTES / 4u];
     const uint64_t a0 = amp_off[blockIdx.x], a1 = amp_off[blockIdx.x + 1];
     const uint64_t n = a1 - a0;
     const uint32_t lane = threadIdx.x;
+    if (plen > 128u) plen = 128u; // (the host refuses longer probes)
+    for (uint32_t i = lane; i < 256u; i += 64u) s_mask[i] = (i < 128u) ? (i < plen ? pmask[i] : 0) : (i - 128u < plen ? rmask[i - 128u] : 0);
+    const bool staged = n <= IPCR_PROBE_LDS_BYTES;
+    if (staged && n > 0) {
+        // dwords of the buffer that cover [a0, a1): the first may begin up to 3 bytes in front of the amplicon, the last
+        // end up to 3 behind it (inside the buffer: every amplicon buffer carries 16 spare bytes)
+        const uintptr_t p0 = reinterpret_cast<uintptr_t>(amps + a0);
+        const uint32_t head = (uint32_t)(p0 & 3u);
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(p0 - head);
+        const uint32_t nw = (uint32_t)((n + head + 3u) / 4u);
+        uint8_t *sb = reinterpret_cast<uint8_t *>(s_amp);
+        for (uint32_t i = lane; i < nw; i += 64u) {
+            const uint32_t v = w[i];
+#pragma unroll
+            for (uint32_t b = 0; b < 4u; ++b) {
+                const int64_t idx = (int64_t)(4u * i + b) - (int64_t)head;
+                if (idx >= 0 && (uint64_t)idx < n) sb[idx] = (uint8_t)probe_onehot((v >> (8u * b)) & 0xFFu);
+            }
+        }
+    }
+    __syncthreads();
     unsigned long long best[2] = {~0ull, ~0ull}; // key = mm<<40 | pos
     if (plen > 0 && n >= plen) {
+        const uint8_t *sb = reinterpret_cast<const uint8_t *>(s_amp);
         for (uint64_t pos = lane; pos + plen <= n; pos += 64u) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const uint8_t *mk = s ? rmask : pmask;
+                const uint8_t *mk = s_mask + (s ? 128 : 0);
                 uint32_t mm = 0;
-                for (uint32_t j = 0; j < plen; ++j) {
-                    const uint32_t b = amps[a0 + pos + j] & 0xDFu; // strings.ToUpper (oligo.go:20)
-                    uint32_t oh = (b == 'A') ? 1u : (b == 'C') ? 2u : (b == 'G') ? 4u : (b == 'T') ? 8u : 0u;
-                    if ((mk[j] & oh) == 0u && ++mm > max_mm) break;
+                if (staged) {
+                    for (uint32_t j = 0; j < plen; ++j)
+                        if ((mk[j] & sb[pos + j]) == 0u && ++mm > max_mm) break;
+                } else {
+                    for (uint32_t j = 0; j < plen; ++j)
+                        if ((mk[j] & probe_onehot(amps[a0 + pos + j])) == 0u && ++mm > max_mm) break;
                 }
                 if (mm <= max_mm) {
                     const unsigned long long key = ((unsigned long long)mm << 40) | pos;
@@ -545,7 +581,9 @@ __global__ __launch_bounds__(64) void probe_kernel(const uint8_t *__restrict__ a
             r.pos = (int32_t)(best[pick] & 0xFFFFFFFFFFull);
             r.mm = (int32_t)(best[pick] >> 40);
         }
-        out[blockIdx.x] = r;
+        r.found |= (int32_t)(tag << 1);
+        // ONE 16-byte store: a host that spins on the tag never sees half a record
+        *reinterpret_cast<int4 *>(out + blockIdx.x) = make_int4(r.found, r.strand, r.pos, r.mm);
     }
 }
 
@@ -647,9 +685,9 @@ hipError_t launch_gather(hipStream_t st, const uint32_t *planes, const uint32_t 
 
 hipError_t launch_probe(hipStream_t st, const uint8_t *amps, const uint64_t *amp_off, uint32_t namp,
                         const uint8_t *pmask, const uint8_t *rmask, uint32_t plen, uint32_t max_mm,
-                        uint32_t fastpath, ipcr_probe_rec *out) {
+                        uint32_t fastpath, ipcr_probe_rec *out, uint32_t tag) {
     if (namp == 0) return hipSuccess;
-    probe_kernel<<<dim3(namp), dim3(64), 0, st>>>(amps, amp_off, pmask, rmask, plen, max_mm, fastpath, out);
+    probe_kernel<<<dim3(namp), dim3(64), 0, st>>>(amps, amp_off, pmask, rmask, plen, max_mm, fastpath, tag, out);
     return hipGetLastError();
 }
 

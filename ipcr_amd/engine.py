@@ -244,6 +244,15 @@ class SimulationScratch:
         _lib.check(_lib.lib().ipcr_scratch_products(self._h, C.byref(ptr), C.byref(n)))
         return [_product(self._cp, ptr[i], seq_ids) for i in range(n.value)]
 
+    def probe_products(self, probe: str, max_mm: int):
+        """ipcr_probe_scratch_products: oligo.BestHit (core/oligo/oligo.go:19-77) for every product of the last
+        ipcr_scan_chunk on this scratch, rescanned from the chunk's own tiles -- what visitors.Probe.Visit computes
+        from Product.Seq (internal/visitors/probe.go:18-33).  List of _lib.ProbeHit, one per product."""
+        n = self.num_products()
+        out = (_lib.ProbeHit * max(n, 1))()
+        _lib.check(_lib.lib().ipcr_probe_scratch_products(self._h, probe.encode(), max_mm, out, n))
+        return [out[i] for i in range(n)]
+
 
 def _fill_sites(pr: Product, seq: bytes) -> None:
     """FwdSite / RevSite as core/engine/engine.go:175-183 slices them (NeedSites, pretty text only):

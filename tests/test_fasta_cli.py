@@ -148,6 +148,25 @@ def test_cli_end_to_end_matches_oracle(tmp_path):
     lines = out.getvalue().splitlines()
     assert rc == 0 and lines[0] == cli.TSV_HEADER_PROBE and len(lines) >= 2
     assert all(l.split("\t")[13] == "true" for l in lines[1:])
+    # ipcr-probe keeps --chunk-size (internal/probeapp/app.go:108): chunked output == unchunked output, annotation
+    # columns included (integration_test.go:125-225 makes the claim for ipcr; every chunk's products are annotated
+    # from the chunk's own tiles by ipcr_probe_scratch_products)
+    for extra in ([], ["--no-require-probe"], ["--probe-max-mm", "2"]):
+        a, b = io.StringIO(), io.StringIO()
+        prb = probe if not extra or extra[0] != "--probe-max-mm" else probe[:8] + ("A" if probe[8] != "A" else "C") + probe[9:]
+        base = ["-f", fwd, "-r", rev, "-m", "1", "--sort", "--probe", prb] + extra
+        assert cli.run(base + [str(fa)], stdout=a) == 0
+        err = io.StringIO()
+        assert cli.run(base + ["--chunk-size", "3000", str(fa)], stdout=b, stderr=err) == 0
+        assert "chunking disabled" not in err.getvalue()
+        assert a.getvalue() == b.getvalue() and len(a.getvalue().splitlines()) >= 2
+        rows = [l.split("\t") for l in a.getvalue().splitlines()[1:]]
+        for r in rows:                                                   # and both equal oligo.BestHit on the amplicon
+            rec = dict(recs)[r[1]]
+            w = O.best_hit(rec[int(r[3]):int(r[4])], prb, 2 if extra and extra[0] == "--probe-max-mm" else 0)
+            assert r[13] == ("true" if w.found else "false")
+            if w.found:
+                assert (r[14], r[15], r[16], r[17]) == (w.strand, str(w.pos), str(w.mm), w.site)
 
 
 def test_chunking_rules():  # internal/runutil/runutil_test.go:20-59

@@ -57,6 +57,55 @@ def test_config_c2_full_size_properties():
     genome.close()
 
 
+def test_config_c2_reference_n_full_size():
+    """SURVEY 8(d)'s +N variant of C2 at its full size: 0.1 % of the positions of every record are 'N', in runs of 1-1000
+    (bench.n_runs) -- for the reference that is forceFallback on every record (core/engine/compiled.go:185-190,238-258:
+    FindMatches for all four orientations, the rc ones capped before their 5' window filter), for the device the kernel
+    variant that scans the rc patterns unprotected and leaves the window to the host.  It is what every real genome and
+    every ipcr_scan_chunk call run.  Same plants as the N-free genome; whole record 0 against the oracle with the
+    default hit cap and with --hit-cap 0 (seeded path + halo rescue, collector order "automaton hits, then halo hits",
+    compiled.go:211-232)."""
+    torch = pytest.importorskip("torch")
+    sys.path.insert(0, ROOT)
+    import bench
+    from ipcr_amd import engine, primer, workloads
+
+    pairs = workloads.c2_pairs()
+    genome, plants, host0 = bench.build_genome(torch, engine, workloads, primer.RevComp, 0, 24, 125_000_000, True, with_n=True)
+    assert genome.total_bases == 3_000_000_000 and len(plants) == 1000
+    n_count = int((host0 == 78).sum())
+    assert 120_000 <= n_count <= 130_000                       # 0.1 % of 125 Mb
+    assert all(genome.record_flags(r) & 1 for r in range(24))  # every record holds reset bytes
+    opairs = [O.Pair(p.ID, p.Forward, p.Reverse, p.MinProduct, p.MaxProduct) for p in pairs]
+    for cap in (10000, 0):
+        cfg = engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=cap, SeedLen=12)
+        eng = engine.New(cfg)
+        cp = eng.CompilePanel(pairs)
+        sc = eng.NewSimulationScratch(cp)
+        prods = eng.ScanGenome(genome, cp, sc)
+        assert sc.stats().kernel_kind == 1
+        if cap:   # the rc orientations are scanned without their protected window: patterns of their own
+            assert cp.scanned_patterns(1) != cp.scanned_patterns(0)
+        found = {(p.Record, p.Start): p for p in prods if p.ExperimentID == "bench_000" and p.Type == "forward" and p.Length == 180}
+        for (r, start, nm) in plants:
+            p = found[(r, start)]
+            assert (p.FwdMM, p.FwdMismatchIdx, p.RevMM) == (nm, () if nm == 0 else ((10,) if nm == 1 else (3, 10)), 0)
+        hits = sc.hits()
+        keys = [(h.Record, h.Pattern, h.Pos) for h in hits]
+        assert keys == sorted(keys) and len(set(keys)) == len(keys)
+        assert all(h.Pos + 20 <= 125_000_000 and h.Mismatches <= 2 for h in hits)
+        # unprotected rc patterns accept 1 + 60 + 1710 variants instead of 991: still a handful of chance hits per 3 Gb
+        assert 2000 <= len(hits) <= 2100
+        assert [p.sig() for p in eng.ScanGenome(genome, cp, sc)] == [p.sig() for p in prods]
+        op = O.Panel(O.Config(max_mm=2, terminal_window=5, max_len=2000, hit_cap=cap, seed_len=12), opairs)
+        want = op.scan_ptr(host0.ctypes.data, int(host0.shape[0]))
+        assert [p.sig() for p in prods if p.Record == 0] == [w.sig() for w in want] and len(want) >= 40
+        op.close()
+        sc.close()
+        cp.close()
+    genome.close()
+
+
 def test_config_c3_full_size_properties():
     """BASELINE.json configs[2]: 27F/1492R with IUPAC codes, k=3, --circular, 3.0 Gb.  Planted sites use
     concrete bases for the ambiguity codes (M -> A/C, Y -> C/T) and up to three substitutions outside the 3'

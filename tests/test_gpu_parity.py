@@ -555,6 +555,155 @@ def test_config_c5_probe_rescan(hip):
     g.close()
 
 
+def _probe_tuple(h):
+    return (bool(h.found), chr(h.strand) if h.found else "", h.pos if h.found else 0, h.mm if h.found else 0)
+
+
+def _want_probe(amp, prb, k):
+    w = O.best_hit(amp, prb, k)                        # core/oligo/oligo.go:19-77 on Product.Seq
+    return (w.found, w.strand, w.pos if w.found else 0, w.mm if w.found else 0)
+
+
+def test_probe_on_the_chunk_path(hip):
+    """ipcr-probe behind the drop-in call (BASELINE C5 as the Go pipeline runs it): ipcr_scan_chunk, then
+    ipcr_probe_scratch_products rescans the chunk's products from the tiles that call packed -- against oligo.BestHit
+    on the amplicon the pipeline would slice into Product.Seq (internal/pipeline/pipeline.go:80-89,
+    internal/visitors/probe.go:18-33).  k = 0 / 1 / 2; probe on '+', on '-', absent, IUPAC; lower-case amplicon bases
+    (BestHit upper-cases the amplicon, oligo.go:20); several chunks through one scratch; a panel without products."""
+    from ipcr_amd import workloads
+    rng = random.Random(41)
+    pairs = workloads.c2_pairs()
+    cfg = hip.engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12)
+    eng = hip.engine.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    sc = eng.NewSimulationScratch(cp)
+    fwd, rcrev = pairs[0].Forward, O.revcomp(pairs[0].Reverse).decode()
+    total = 0
+    for chunk_no, n in enumerate((300_000, 120_000, 1_000_000, 4_000)):
+        s = bytearray(O.bench_dna(n, 0x5eed2000 + chunk_no))
+        starts = list(range(1000, n - 400, max(2500, n // 12)))
+        for t, a in enumerate(starts):
+            f = fwd if t % 3 == 0 else fwd[:7] + O.different_base(fwd[7]) + fwd[8:]
+            s[a:a + len(f)] = f.encode()
+            s[a + 180 - len(rcrev):a + 180] = rcrev.encode()
+            if t % 4 == 1:   # lower-case bases in the amplicon's interior: they match a probe, never a primer
+                s[a + 60:a + 100] = bytes(s[a + 60:a + 100]).lower()
+            if t % 5 == 2:
+                s[a + 75] = ord("N")
+        seq = bytes(s)
+        got = eng.SimulateCompiledWithScratch("chunk%d" % chunk_no, seq, cp, sc)
+        want = O.simulate_batch(ocfg(cfg), seq, opairs(pairs))
+        assert [g.sig() for g in got] == [w.sig() for w in want] and len(got) >= len(starts)
+        total += len(got)
+        a0 = starts[0]
+        inner = seq[a0 + 70:a0 + 91].decode().upper()
+        mut = inner[:9] + O.different_base(inner[9]) + inner[10:]
+        for prb, k in [(inner, 0), (inner, 2), (mut, 0), (mut, 1), (mut, 2), (O.revcomp(inner).decode(), 0),
+                       (O.revcomp(mut).decode(), 2), ("ACGTNNRYACGTACGTACGTT", 2), ("GGGGGGGGGGGGGGGGGGGGGGGGG", 0),
+                       (inner[:6] + "R" + inner[7:12] + "N" + inner[13:], 1)]:
+            out = sc.probe_products(prb, k)
+            assert len(out) == len(got)
+            for h, p in zip(out, got):
+                assert _probe_tuple(h) == _want_probe(seq[p.Start:p.End], prb, k), (chunk_no, prb, k, p)
+        # the two halves: begin returns at once, end hands the same records out; one rescan per scratch at a time
+        import ctypes as C
+        L = hip.lib.lib()
+        ref = sc.probe_products(inner, 2)
+        out2 = (hip.lib.ProbeHit * len(got))()
+        hip.lib.check(L.ipcr_probe_scratch_products_begin(sc._h, inner.encode(), 2))
+        assert L.ipcr_probe_scratch_products_begin(sc._h, inner.encode(), 2) != 0
+        hip.lib.check(L.ipcr_probe_products_end(sc._h, out2, len(got)))
+        assert [_probe_tuple(out2[i]) for i in range(len(got))] == [_probe_tuple(h) for h in ref]
+        assert L.ipcr_probe_scratch_products(sc._h, inner.encode(), 2, out2, len(got) + 1) != 0   # n_out must match
+    assert total >= 30
+    # a chunk without products, and an invalid probe
+    assert eng.SimulateCompiledWithScratch("empty", b"ACGT" * 1000, cp, sc) == [] and sc.probe_products("ACGTACGT", 1) == []
+    with pytest.raises(hip.lib.IpcrError):
+        sc.probe_products("ACGU", 0)
+    # a scratch whose last scan was a resident genome's has no chunk tiles to read
+    g = hip.engine.Genome(100_000, 1)
+    g.add_record("r", O.bench_dna(50_000, 7))
+    eng.ScanGenome(g, cp, sc)
+    with pytest.raises(hip.lib.IpcrError):
+        sc.probe_products("ACGTACGT", 1)
+    g.close()
+    cp.close()
+
+
+def test_probe_on_the_chunk_path_wrap_product(hip):
+    """--circular: the record goes through ipcr_scan_chunk whole (chunking is off, internal/runutil/runutil.go:46-49) and an
+    origin-spanning product's amplicon is record[start:] ++ record[:end] (pipeline.go:82-84): probes that lie across the
+    junction, on either strand, and one that lies before it."""
+    P = hip.primer.Pair
+    fwd, rev = "ACGTTGCATGCAAGCTTGCA", "GGCCTTAAGGCCATATCCGG"
+    n = 60_000
+    s = bytearray(O.bench_dna(n, 0x77aa))
+    s[n - 100:n - 100 + len(fwd)] = fwd.encode()
+    rc = O.revcomp(rev)
+    s[80 - len(rc):80] = rc
+    s[20_000:20_000 + len(fwd)] = fwd.encode()            # and an ordinary product
+    s[20_000 + 300 - len(rc):20_000 + 300] = rc
+    seq = bytes(s)
+    pairs = [P("w", fwd, rev, 0, 0)]
+    cfg = hip.engine.Config(MaxMM=1, TerminalWindow=3, MaxLen=1000, HitCap=10000, SeedLen=12, Circular=True)
+    eng = hip.engine.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    sc = eng.NewSimulationScratch(cp)
+    got = eng.SimulateCompiledWithScratch("plasmid", seq, cp, sc)
+    want = O.simulate_batch(ocfg(cfg), seq, opairs(pairs))
+    assert [g.sig() for g in got] == [w.sig() for w in want]
+    wraps = [p for p in got if p.Start > p.End]
+    assert wraps and any(p.Start <= p.End for p in got)
+    amp_of = lambda p: seq[p.Start:p.End] if p.Start <= p.End else seq[p.Start:] + seq[:p.End]
+    w0 = amp_of(wraps[0])
+    junction = n - wraps[0].Start
+    across = w0[junction - 10:junction + 11].decode()     # 21-mer over the origin
+    before = w0[30:51].decode()
+    for prb, k in [(across, 0), (O.revcomp(across).decode(), 0), (across[:5] + O.different_base(across[5]) + across[6:], 1),
+                   (before, 0), ("TTTTTTTTTTTTTTTTTTTTTT", 0)]:
+        out = sc.probe_products(prb, k)
+        for h, p in zip(out, got):
+            assert _probe_tuple(h) == _want_probe(amp_of(p), prb, k), (prb, k, p)
+    assert _probe_tuple(sc.probe_products(across, 0)[got.index(wraps[0])])[0]
+    cp.close()
+
+
+def test_probe_best_hit_from_many_threads(hip):
+    """ipcr_probe_best_hit is what a collector calls per product next to the workers' sweeps: no allocation, no
+    null-stream work, one pinned block and stream per concurrent caller.  Eight threads, amplicons of 5..20 000 bases
+    (beyond the kernel's LDS stage: read from pinned memory directly), against the oracle."""
+    import threading
+    errs = []
+
+    def worker(seed):
+        rng = random.Random(seed)
+        try:
+            for it in range(40):
+                n = rng.choice([5, 40, 180, 700, 2000, 2000, 6000]) if it else 20_000
+                amp = "".join(rng.choice("ACGTACGTACGTacgtN") for _ in range(n))
+                L = rng.randint(3, 30)
+                prb = "".join(rng.choice("ACGTACGTACGTRYN") for _ in range(L))
+                if rng.random() < 0.6 and n > L + 2:
+                    q = rng.randrange(0, n - L)
+                    src = prb if rng.random() < 0.5 else O.revcomp(prb).decode()
+                    conc = "".join(rng.choice([b for b in "ACGT" if O.base_match(b, ch)]) for ch in src)
+                    amp = amp[:q] + conc + amp[q + L:]
+                k = rng.choice([0, 0, 1, 2])
+                w = O.best_hit(amp, prb, k)
+                g = hip.oligo.BestHit(amp, prb, k)
+                if (g.Found, g.Strand, g.Pos, g.MM, g.Site) != (w.found, w.strand, w.pos, w.mm, w.site):
+                    errs.append((seed, it, n, prb, k, g, w))
+        except Exception as e:  # noqa: BLE001
+            errs.append((seed, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(100 + i,)) for i in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs[:3]
+
+
 # ---- seed-index filter (large panels) ------------------------------------------------------------
 
 @pytest.fixture
