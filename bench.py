@@ -352,6 +352,10 @@ def run_workload(ctx, name, steps, warmup):
         eng.ScanGenomeHits(genome, cp, scs[0])      # one synchronous exchange: sizes the buffers on every rank
         xchg.allgather(dist.hits_from_scratch(scs[0]), nrec, size_hint=int(scs[0].device_hits()[1] * 1.25) + 64)
         xchg.agree_on_device_path(scs[0])           # zero-copy view of the device hit buffer on every rank, or the host copy on all
+        # the library's own exchange against the torch.distributed form of the same hits, once, on every rank; all ranks fall
+        # back together if they differ anywhere (dist.py: verify_native) -- the first job with a real multi-rank communicator
+        # checks the path that one-GPU boxes can only run with one rank
+        xchg.verify_native(scs[0], nrec)
     expect = None
     for s_ in scs:  # untimed set-up: kernel specialisation (hiprtc) and buffer sizing happen here
         n_ = eng.ScanGenomeCount(genome, cp, s_)
@@ -457,7 +461,8 @@ def run_workload(ctx, name, steps, warmup):
         pack_ms=genome.pack_ms, breakdown={k: round(getattr(st, k), 4) for k in
                                            ("filter_ms", "verify_ms", "enqueue_ms", "wait_ms", "sort_ms", "join_ms", "total_ms")},
         device_path=bool(xchg.device_path) if multi else None, exchange_redone=xchg.redone if multi else 0,
-        native_exchange=bool(xchg.native) if multi else None, compile_times=compile_times,
+        native_exchange=bool(xchg.native) if multi else None, native_exchange_verified=xchg.native_verified if multi else None,
+        compile_times=compile_times,
         windows=len(windows), window_ms_min=min(windows) * 1e3, window_ms_max=max(windows) * 1e3,
         probe_ms=(sum(probe_ms[-steps:]) / max(1, len(probe_ms[-steps:]))) if probe_ms else None,
         prods=prods)
@@ -857,7 +862,8 @@ def main() -> None:
             others["c4"] = {"workload": r["text"], "ms_per_step": round(r["ms_per_step"], 4), "gbases_per_s": round(r["value"], 1),
                             "sweep_ms_rank0": round(r["filter_ms"], 4), "kernel": r["kernel"], "n_gpus": world, "scaling": "weak",
                             "steps": r["steps"], "warmup_actual": r["warmup_actual"], "products_per_step": r["nprod"],
-                            "device_path": r["device_path"], "exchange_redone": r["exchange_redone"]}
+                            "device_path": r["device_path"], "exchange_redone": r["exchange_redone"],
+                            "native_exchange": r["native_exchange"], "native_exchange_verified": r["native_exchange_verified"]}
             r["prods"] = None
         if all_dev_rates is not None:
             others["scan_chunk_one_process_all_devices"] = all_dev_rates
@@ -901,6 +907,8 @@ def main() -> None:
             "backend": backend if ctx.multi else None,
             "device_path": res["device_path"],
             "native_exchange": res["native_exchange"],   # ncclAllGather inside libipcr_hip.so (csrc/exchange.cpp), not torch.distributed
+            "native_exchange_verified": res["native_exchange_verified"],   # ... and its first result equal to torch.distributed's on every rank
+            "exchange_redone": res["exchange_redone"],
             "panel_compile": res["compile_times"],
             "parallelism": ("1 genome per GPU (weak scaling); one all-gatherv of hit records per step (%s, %s; %d exchanges redone "
                             "after an overflow); every rank joins its own records inside the step, the gathered records are "

@@ -199,6 +199,7 @@ ipcr_status enqueue(ipcr_exchange *x, const ipcr_scratch *s, int slot) {
             XHIP(hipMemcpyAsync(dst + 8, hf + 2 * r, 8, hipMemcpyHostToDevice, x->stream));      // counter set 0: hits
             XHIP(hipMemcpyAsync(dst + 40, hf + 2 * r + 1, 8, hipMemcpyHostToDevice, x->stream)); // counter set 1: zero
         }
+        XHIP(hipStreamSynchronize(x->stream)); // (h_fake is rewritten by the next enqueue)
     }
     XHIP(hipEventRecord(x->done[slot], x->stream));
     x->pend[slot].active = true;

@@ -2445,12 +2445,12 @@ ipcr_status ipcr_scratch_hits(const ipcr_scratch *s, const ipcr_hit **out, int64
 ipcr_status ipcr_scratch_device_hits(const ipcr_scratch *s, const void **dev_block, uint64_t *n_hits, uint64_t *capacity) {
     if (!s || !dev_block || !n_hits || !capacity) return fail(IPCR_ERR_INVALID, "null argument");
     if (!s->d_hitbuf) return fail(IPCR_ERR_DEVICE, "host-only scratch has no device hit buffer");
-    if (s->dev_hits_stale)
-        return fail(IPCR_ERR_UNSUPPORTED, "the device hit buffer does not hold this scan's hits: a capped scan that ran in segments keeps them on the host "
-                                          "(ipcr_scratch_hits; ipcr_exchange_begin sends them from there)");
     *dev_block = s->d_hitbuf;
     *n_hits = s->hits_raw.size();
     *capacity = s->hcap;
+    if (s->dev_hits_stale) // (the outputs are filled all the same: the buffer exists, it just is not this scan's result)
+        return fail(IPCR_ERR_UNSUPPORTED, "the device hit buffer does not hold this scan's hits: a capped scan that ran in segments keeps them on the host "
+                                          "(ipcr_scratch_hits; ipcr_exchange_begin sends them from there)");
     return IPCR_OK;
 }
 

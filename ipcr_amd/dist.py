@@ -149,7 +149,10 @@ class HitExchanger:
     device staging buffer of the agreed size instead of the zero-copy view -- the collective's shape
     never depends on a local condition."""
 
-    def __init__(self, device=None, cap_hits: int = 4096, group=None, same_records: bool = False):
+    def __init__(self, device=None, cap_hits: int = 4096, group=None, same_records: bool = False, native_lib=None):
+        """native_lib: an object with the ipcr_exchange_* entry points to use instead of libipcr_hip.so's (tests: the native
+        caller of this class under a world-size-2 gloo job, tests/test_dist_gloo.py); with it the native form is used on
+        any device."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -166,18 +169,32 @@ class HitExchanger:
         self._alloc(cap_hits)
         self._native = None                  # ipcr_exchange handle (csrc/exchange.cpp): RCCL inside the library
         self._native_redone0 = 0
-        if self.active and self.device.type == "cuda" and not os.environ.get("IPCR_EXCHANGE_TORCH"):
+        self.native_verified = None          # verify_native: True / False once it has run
+        self._L = native_lib
+        if self.active and (native_lib is not None or (self.device.type == "cuda" and not os.environ.get("IPCR_EXCHANGE_TORCH"))):
             self._native_create(cap_hits)
 
     def _native_create(self, cap_hits: int) -> None:
         """The library's own all-gather (ncclAllGather straight out of the scratch's device hit buffer, the same one a
-        Go or C++ host calls).  Collective: every rank constructs its exchanger at the same point.  Rank 0 makes the
-        RCCL id and broadcasts it (with an ok flag: nobody enters ncclCommInitRank alone); the ranks then take the minimum
-        of their verdicts, so all of them use the native form or none does."""
+        Go or C++ host calls).  Collective: every rank constructs its exchanger at the same point.  Three agreements, each
+        a MIN over the ranks, so that all of them use the native form or none does and NOBODY enters ncclCommInitRank
+        alone: (1) ipcr_exchange_available -- everything ipcr_exchange_create can fail on locally (librccl, the device),
+        checked before any rank creates anything; (2) rank 0's RCCL id, broadcast with an ok flag; (3) the result of
+        ipcr_exchange_create itself."""
         import ctypes as C
         from . import _lib
         torch, dist = self.torch, self.dist
-        L = _lib.lib()
+        L = self._lib()
+        dev_index = self.device.index if self.device.index is not None else (torch.cuda.current_device() if self.device.type == "cuda" else 0)
+
+        def all_min(v: int) -> int:
+            t = torch.tensor([v], dtype=torch.int32, device=self.device)
+            if self.world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            return int(t.item())
+
+        if all_min(int(L.ipcr_exchange_available(int(dev_index)))) != 1:
+            return
         buf = torch.zeros(1 + 128, dtype=torch.uint8, device=self.device)
         if self.rank == 0:
             raw = C.create_string_buffer(128)
@@ -187,23 +204,62 @@ class HitExchanger:
         if self.world > 1:
             dist.broadcast(buf, src=0, group=self.group)
         got = bytes(buf.cpu().numpy().tobytes())
-        ok, handle = 0, C.c_void_p()
-        if got[0] == 1:
-            dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-            st = L.ipcr_exchange_create(got[1:], self.world, self.rank, int(dev_index), int(cap_hits), int(self.same_records), C.byref(handle))
-            ok = int(st == _lib.OK)
-        t = torch.tensor([ok], dtype=torch.int32, device=self.device)
-        if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
-        if int(t.item()) == 1:
+        if got[0] != 1:
+            return
+        handle = C.c_void_p()
+        st = L.ipcr_exchange_create(got[1:], self.world, self.rank, int(dev_index), int(cap_hits), int(self.same_records), C.byref(handle))
+        ok = int(st == _lib.OK)
+        if all_min(ok) == 1:
             self._native = handle
         elif ok:
             L.ipcr_exchange_destroy(handle)
 
+    def verify_native(self, scratch, n_local_records: int) -> bool:
+        """Collective, once per job (bench.py: after the first synchronous exchange): the native exchange of `scratch`'s
+        hits against the torch.distributed form of the same hits, on every rank -- the native path's multi-rank logic
+        (per-rank counts from the gathered headers, record rebasing) has unit tests on the CPU and a fake-transport test
+        on one GPU, but a pool of one-GPU boxes cannot run it over a real communicator of several ranks; the first job
+        that can checks it against the path that the world-size-2 tests cover, and all ranks fall back together
+        (MIN) if the two disagree anywhere."""
+        if self._native is None:
+            return False
+        want, want_ranges, want_offs = self.allgather(hits_from_scratch(scratch), n_local_records)
+        ok = 1
+        try:
+            self.finish(self.start_scratch(scratch, n_local_records))
+            got, got_ranges, got_offs = self.gathered()
+            if list(got_offs) != list(want_offs) or len(got_ranges) != len(want_ranges):
+                ok = 0
+            else:
+                for (a0, a1), (b0, b1) in zip(got_ranges, want_ranges):
+                    # (the device list is in append order and may hold a window twice -- the seed index reports it once per key --
+                    # the host list is sorted and de-duplicated: compare the sets of records)
+                    if set(map(bytes, got[a0:a1])) != set(map(bytes, want[b0:b1])):
+                        ok = 0
+        except Exception:  # noqa: BLE001
+            ok = 0
+        t = self.torch.tensor([ok], dtype=self.torch.int32, device=self.device)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        self.native_verified = bool(int(t.item()))
+        if not self.native_verified:
+            self.close()
+        return self.native_verified
+
+    def _lib(self):
+        if self._L is None:
+            from . import _lib
+            self._L = _lib.lib()
+        return self._L
+
+    def _check(self, status: int) -> None:
+        if status != 0:
+            from . import _lib
+            raise _lib.IpcrError(status, self._lib().ipcr_last_error().decode(errors="replace"))
+
     def close(self) -> None:
         if self._native is not None:
-            from . import _lib
-            _lib.lib().ipcr_exchange_destroy(self._native)
+            self._lib().ipcr_exchange_destroy(self._native)
             self._native = None
 
     def __del__(self):
@@ -218,9 +274,8 @@ class HitExchanger:
 
     def _native_counts(self) -> None:
         import ctypes as C
-        from . import _lib
         arr = (C.c_uint32 * self.world)(*[int(c) for c in self._rec_counts])
-        _lib.check(_lib.lib().ipcr_exchange_set_record_counts(self._native, arr))
+        self._check(self._lib().ipcr_exchange_set_record_counts(self._native, arr))
 
     def _alloc(self, cap: int) -> None:
         torch = self.torch
@@ -306,15 +361,30 @@ class HitExchanger:
             return None
         if self._native is not None:
             import ctypes as C
-            from . import _lib
             ticket = C.c_int32(-1)
-            _lib.check(_lib.lib().ipcr_exchange_begin(self._native, scratch._h, C.byref(ticket)))
+            self._check(self._lib().ipcr_exchange_begin(self._native, scratch._h, C.byref(ticket)))
             return ("native", ticket.value, scratch, n_local_records)
         if self.device.type != "cuda" or not self.device_path:
             return self.start(hits_from_scratch(scratch), n_local_records)
-        ptr, n, cap = scratch.device_hits()
         nbytes = 64 + self.cap * 32
-        if cap >= self.cap:
+        from . import _lib
+        try:
+            ptr, n, cap = scratch.device_hits()
+        except _lib.IpcrError:
+            # a capped scan that ran in segments keeps its hits on the host (ipcr_scratch_device_hits refuses: the device
+            # buffer holds the last range only): the same block shape -- header with the true count, the first `cap`
+            # records -- rebuilt in the staging buffer, so the collective this rank enters is the one the others enter
+            local = hits_from_scratch(scratch)
+            blk = np.zeros(nbytes, dtype=np.uint8)
+            blk[:64].view(np.uint64)[1] = len(local)
+            m = min(len(local), self.cap)
+            if m:
+                blk[64:64 + m * 32] = local[:m].view(np.uint8).reshape(-1)
+            self.d_stage.copy_(self.torch.from_numpy(blk))
+            ptr, cap, send = None, 0, self.d_stage
+        if ptr is None:
+            pass
+        elif cap >= self.cap:
             send = self._view(ptr, nbytes)
         else:   # this rank's buffer is smaller than the agreed shape: same bytes through a staging buffer
             m = 64 + cap * 32
@@ -344,10 +414,10 @@ class HitExchanger:
         if work[0] == "native":
             import ctypes as C
             from . import _lib
-            L = _lib.lib()
+            L = self._lib()
             hits, n = C.POINTER(_lib.Hit)(), C.c_int64(0)
             starts, offs = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)()
-            _lib.check(L.ipcr_exchange_end(self._native, work[1], C.byref(hits), C.byref(n), C.byref(starts), C.byref(offs)))
+            self._check(L.ipcr_exchange_end(self._native, work[1], C.byref(hits), C.byref(n), C.byref(starts), C.byref(offs)))
             if n.value:
                 raw = (C.c_uint8 * (n.value * 32)).from_address(C.addressof(hits.contents))
                 arr = np.frombuffer(raw, dtype=HIT_DTYPE, count=n.value).copy()
@@ -464,9 +534,8 @@ class HitExchanger:
             need = int(max(meta3[:, 0].max(), meta3[:, 2].max()))
             self._rec_counts = [int(c) for c in meta[:, 1]]
             if self._native is not None:   # every rank has read the same `need`: the native exchange is sized for it too
-                from . import _lib
                 self._native_counts()
-                _lib.check(_lib.lib().ipcr_exchange_reserve(self._native, max(int(need), self.cap)))
+                self._check(self._lib().ipcr_exchange_reserve(self._native, max(int(need), self.cap)))
             if need <= self.cap:
                 break
             cap = self.cap

@@ -175,3 +175,148 @@ def test_two_rank_gloo_pattern_shards(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert f"SHARD_OK {rank}" in out, out
+
+
+NATIVE_WORKER = r'''
+import os, sys, random, ctypes as C
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle")); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import torch, torch.distributed as tdist
+from ipcr_amd import _lib, dist
+
+rank, world, local, backend = dist.init_process_group("gloo")
+assert world == 2
+REAL = _lib.lib()
+
+class FakeScratch:                      # what ipcr_exchange_begin reads of a scratch: its device hit block
+    def __init__(self, hits): self.hits = hits; self._h = id(self)
+SCRATCHES = {{}}
+
+class FakeExchangeLib:
+    """ipcr_exchange_* with the collective carried by gloo and everything after it by the REAL ipcr_exchange_unpack:
+    the entry points HitExchanger's native caller uses, with the semantics of csrc/exchange.cpp (true count in the header,
+    first cap records, lock-step redo inside end, two slots)."""
+    def __init__(self): self.x = None
+    def ipcr_last_error(self): return REAL.ipcr_last_error()
+    def ipcr_exchange_available(self, dev): return 1
+    def ipcr_exchange_unique_id(self, buf): return 0
+    def ipcr_exchange_create(self, uid, world, rank, dev, cap, same, out):
+        self.x = dict(world=world, rank=rank, cap=max(int(cap), 1), same=int(same), counts=[0] * world, pend={{}}, next=0, redone=0, keep=None)
+        out._obj.value = 1
+        return 0
+    def ipcr_exchange_destroy(self, x): self.x = None
+    def ipcr_exchange_set_record_counts(self, x, arr): self.x["counts"] = [int(arr[r]) for r in range(self.x["world"])]; return 0
+    def ipcr_exchange_reserve(self, x, cap): self.x["cap"] = max(self.x["cap"], int(cap)); return 0
+    def ipcr_exchange_capacity(self, x): return self.x["cap"]
+    def ipcr_exchange_redone(self, x): return self.x["redone"]
+    def _gather(self, hits, cap):
+        blk = np.zeros(64 + cap * 32, dtype=np.uint8)
+        blk[:64].view(np.uint64)[1] = len(hits)
+        m = min(len(hits), cap)
+        if m: blk[64:64 + m * 32] = hits[:m].view(np.uint8).reshape(-1)
+        recv = torch.empty(self.x["world"] * len(blk), dtype=torch.uint8)
+        tdist.all_gather_into_tensor(recv, torch.from_numpy(blk))
+        return recv.numpy()
+    def ipcr_exchange_begin(self, x, scratch_h, ticket):
+        slot = self.x["next"]
+        if slot in self.x["pend"]: return 1
+        hits = SCRATCHES[scratch_h].hits
+        self.x["pend"][slot] = (hits, self.x["cap"], self._gather(hits, self.x["cap"]))
+        self.x["next"] = (slot + 1) % 2
+        ticket._obj.value = slot
+        return 0
+    def ipcr_exchange_end(self, x, t, hits_p, n_p, starts_p, offs_p):
+        hits, cap, gathered = self.x["pend"].pop(t)
+        w = self.x["world"]
+        for _ in range(24):
+            out = np.zeros(max(w * cap, 1), dtype=dist.HIT_DTYPE)
+            starts, offs, need = (C.c_uint64 * (w + 1))(), (C.c_uint32 * (w + 1))(), C.c_uint64()
+            st = REAL.ipcr_exchange_unpack(gathered.ctypes.data, w, cap, (C.c_uint32 * w)(*self.x["counts"]), self.x["same"],
+                                           out.ctypes.data, w * cap, starts, offs, C.byref(need))
+            if st == _lib.ERR_CAPACITY:
+                self.x["redone"] += 1
+                cap = max(cap, self.x["cap"])
+                while cap < need.value: cap *= 2
+                self.x["cap"] = cap
+                gathered = self._gather(hits, cap)
+                continue
+            assert st == 0
+            self.x["keep"] = (out, starts, offs)
+            C.memmove(C.addressof(hits_p._obj), C.addressof(C.c_void_p(out.ctypes.data)), C.sizeof(C.c_void_p))
+            n_p._obj.value = int(starts[w])
+            C.memmove(C.addressof(starts_p._obj), C.addressof(C.c_void_p(C.addressof(starts))), C.sizeof(C.c_void_p))
+            C.memmove(C.addressof(offs_p._obj), C.addressof(C.c_void_p(C.addressof(offs))), C.sizeof(C.c_void_p))
+            return 0
+        return _lib.ERR_CAPACITY
+
+rng = np.random.default_rng(100 + rank)
+def mk(n, nrec):
+    h = np.zeros(n, dtype=dist.HIT_DTYPE)
+    h["pos"] = rng.integers(0, 1 << 30, n); h["record"] = rng.integers(0, nrec, n); h["pattern"] = rng.integers(0, 8, n)
+    return h
+nrec = 3 if rank == 0 else 2
+mine = mk(40 if rank == 0 else 9, nrec)          # uneven: rank 0 holds more than four times rank 1's
+ref_all, ref_off = dist.allgather_hits(mine, nrec)                          # the plain two-collective form: the reference
+x = dist.HitExchanger(cap_hits=64, native_lib=FakeExchangeLib())
+assert x.native
+sc = FakeScratch(mine); SCRATCHES[sc._h] = sc
+x.set_record_counts([3, 2])
+w0 = x.start_scratch(sc, nrec); x.finish(w0)
+hits, ranges, offs = x.gathered()
+assert np.array_equal(hits, ref_all) and offs == ref_off == [0, 3] and ranges == [(0, 40), (40, 49)] and x.redone == 0
+# two in flight, ended in order; then a capacity only rank 0 exceeds: both ranks redo together inside finish()
+sc2 = FakeScratch(mine[::-1].copy()); SCRATCHES[sc2._h] = sc2
+wa, wb = x.start_scratch(sc, nrec), x.start_scratch(sc2, nrec)
+x.finish(wa); a_hits = x.gathered()[0]
+x.finish(wb); b_hits = x.gathered()[0]
+assert np.array_equal(a_hits, ref_all) and not np.array_equal(b_hits, ref_all) and len(b_hits) == len(ref_all)
+small = dist.HitExchanger(cap_hits=16, native_lib=FakeExchangeLib())
+small.set_record_counts([3, 2])
+small.finish(small.start_scratch(sc, nrec))
+h2, r2, o2 = small.gathered()
+assert small.redone == 1 and small.cap >= 40 and np.array_equal(h2, ref_all) and r2 == ranges and o2 == [0, 3]
+small.finish(small.start_scratch(sc, nrec))
+assert small.redone == 1 and np.array_equal(small.gathered()[0], ref_all)
+# the synchronous form sizes the native exchange too (reserve), and verify_native compares the two forms on every rank
+x3 = dist.HitExchanger(cap_hits=4, native_lib=FakeExchangeLib())
+x3.scratch_hits = None
+orig = dist.hits_from_scratch
+dist.hits_from_scratch = lambda s: s.hits
+try:
+    assert x3.verify_native(sc, nrec) is True and x3.native and x3.native_verified
+    assert x3._L.ipcr_exchange_capacity(None) >= 40
+    # a native exchange that loses a record on ONE rank: every rank falls back together
+    class Lossy(FakeExchangeLib):
+        def ipcr_exchange_end(self, x_, t, hits_p, n_p, starts_p, offs_p):
+            st = super().ipcr_exchange_end(x_, t, hits_p, n_p, starts_p, offs_p)
+            if rank == 1: self.x["keep"][0][0]["pos"] ^= 1
+            return st
+    x4 = dist.HitExchanger(cap_hits=64, native_lib=Lossy())
+    assert x4.verify_native(sc, nrec) is False and not x4.native and x4.native_verified is False
+    x4.finish(x4.start_scratch(sc, nrec))                                   # the torch form serves from here on
+    assert np.array_equal(x4.gathered()[0], ref_all)
+finally:
+    dist.hits_from_scratch = orig
+tdist.barrier()
+print("NATIVE_OK", rank)
+'''
+
+
+def test_two_rank_gloo_native_exchange_caller(tmp_path):
+    """HitExchanger's NATIVE form (what a multi-GPU job runs by default: ipcr_exchange_begin / _end) under a world-size-2
+    job: the library table is replaced by one whose collective is gloo and whose unpack is the real ipcr_exchange_unpack --
+    uneven counts, two exchanges in flight, the lock-step redo when only one rank overflows, the capacity agreed through
+    the synchronous form, and verify_native (all ranks fall back together when one rank's native result is wrong)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "native_worker.py"
+    script.write_text(NATIVE_WORKER.format(root=ROOT))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f"NATIVE_OK {rank}" in out, out

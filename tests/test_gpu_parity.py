@@ -1172,6 +1172,109 @@ def test_device_hit_exchange_one_rank_rccl(hip, monkeypatch):
     g.close()
 
 
+def _raw_hit_records(hip, sc):
+    """the scratch's host hit list (sorted, unique) as a HIT_DTYPE array"""
+    from ipcr_amd import dist
+    return dist.hits_from_scratch(sc)
+
+
+def _fake_exchange(hip, world, rank, cap, rec_counts, same_records=False):
+    import ctypes as C
+    L = hip.lib.lib()
+    uid = C.create_string_buffer(128)
+    hip.lib.check(L.ipcr_exchange_unique_id(uid))
+    x = C.c_void_p()
+    hip.lib.check(L.ipcr_exchange_create(uid.raw, world, rank, 0, cap, int(same_records), C.byref(x)))
+    hip.lib.check(L.ipcr_exchange_set_record_counts(x, (C.c_uint32 * world)(*rec_counts)))
+    return x
+
+
+def _exchange_end(hip, x, ticket, world):
+    import ctypes as C
+    import numpy as np
+    from ipcr_amd.dist import HIT_DTYPE
+    L = hip.lib.lib()
+    hits, n = C.POINTER(hip.lib.Hit)(), C.c_int64(0)
+    starts, offs = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)()
+    hip.lib.check(L.ipcr_exchange_end(x, ticket, C.byref(hits), C.byref(n), C.byref(starts), C.byref(offs)))
+    arr = np.zeros(0, dtype=HIT_DTYPE)
+    if n.value:
+        raw = (C.c_uint8 * (n.value * 32)).from_address(C.addressof(hits.contents))
+        arr = np.frombuffer(raw, dtype=HIT_DTYPE, count=n.value).copy()
+    return arr, [int(starts[r]) for r in range(world + 1)], [int(offs[r]) for r in range(world + 1)]
+
+
+def _exchange_once(hip, x, sc, world=2):
+    import ctypes as C
+    t = C.c_int32(-1)
+    hip.lib.check(hip.lib.lib().ipcr_exchange_begin(x, sc._h, C.byref(t)))
+    return _exchange_end(hip, x, t.value, world)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_exchange_multi_rank_logic_over_a_fake_transport(hip, monkeypatch, world):
+    """ipcr_exchange_begin / _end with world > 1 on one GPU: IPCR_TEST_EXCHANGE_FAKE replaces ncclAllGather by copies of this
+    rank's block into every rank's place of the receive buffer, rank r's header rewritten to (hits >> r) records -- uneven
+    counts, and for small scans zero-hit ranks.  Everything around the collective is the code a multi-GPU job runs, on
+    device memory: shape agreement through the staging buffer, the strided read-back of the headers, the per-rank prefix
+    copies, lock-step overflow + redo (two slots in flight), record rebasing, same_records.  (The collective itself runs
+    with one rank in test_device_hit_exchange_one_rank_rccl; the unpack arithmetic alone on the CPU: test_exchange_unpack.py.)"""
+    import ctypes as C
+    import numpy as np
+    from ipcr_amd import workloads
+    monkeypatch.setenv("IPCR_TEST_EXCHANGE_FAKE", "1")
+    L = hip.lib.lib()
+    rng = random.Random(78)
+    pairs = workloads.c2_pairs()
+    g, _ = build_planted_genome(hip, rng, 3, 600_000, pairs[:1], 0x5eed4445, junk_every=2)
+    eng = hip.engine.New(hip.engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12))
+    cp = eng.CompilePanel(pairs)
+    scs = [eng.NewSimulationScratch(cp) for _ in range(2)]
+    nrec = g.num_records
+    want_products = [p.sig() for p in eng.ScanGenome(g, cp, scs[0])]
+    eng.ScanGenomeHits(g, cp, scs[1])
+    n = len(_raw_hit_records(hip, scs[0]))
+    assert n >= 8
+    # world 1: the device list as it is (append order) -- the reference for every rank's part below
+    x1 = _fake_exchange(hip, 1, 0, 4 * n, [nrec])
+    dev_list, st1, _ = _exchange_once(hip, x1, scs[0], world=1)
+    assert st1 == [0, n] and {bytes(h) for h in dev_list} == {bytes(h) for h in _raw_hit_records(hip, scs[0])}
+    L.ipcr_exchange_destroy(x1)
+    counts = [n >> r for r in range(world)]
+    rec_counts = [nrec + r for r in range(world)]           # (ranks of a real job may hold different numbers of records)
+    for same in (False, True):
+        for cap in (4 * n, max(1, n // 3)):                 # the second overflows on rank 0 (and 1): every rank redoes
+            x = _fake_exchange(hip, world, world - 1, cap, rec_counts, same_records=same)
+            t0, t1 = C.c_int32(-1), C.c_int32(-1)
+            hip.lib.check(L.ipcr_exchange_begin(x, scs[0]._h, C.byref(t0)))      # two in flight, ended in the order begun
+            hip.lib.check(L.ipcr_exchange_begin(x, scs[1]._h, C.byref(t1)))
+            assert L.ipcr_exchange_begin(x, scs[0]._h, C.byref(C.c_int32())) != 0  # a third is refused
+            for t in (t0.value, t1.value):
+                hits, starts, offs = _exchange_end(hip, x, t, world)
+                assert starts == [sum(counts[:r]) for r in range(world + 1)]
+                assert offs == ([0] * (world + 1) if same else [sum(rec_counts[:r]) for r in range(world + 1)])
+                if t == t0.value:
+                    for r in range(world):
+                        part = hits[starts[r]:starts[r + 1]].copy()
+                        part["record"] -= np.uint32(offs[r])
+                        assert part.tobytes() == dev_list[:counts[r]].tobytes(), (world, same, cap, r)
+            assert L.ipcr_exchange_redone(x) == (2 if cap < n else 0)
+            assert L.ipcr_exchange_capacity(x) >= min(cap, n)
+            if not same:   # rank 0's part joins to the single-GPU products; the whole list to `world` shifted copies of them
+                host = hip.engine.SimulationScratch(cp, host_only=True)
+                lens, flags = [], []
+                for r in range(world):
+                    lens += [g.record_len(i) for i in range(nrec)] + [1000] * r
+                    flags += [g.record_flags(i) for i in range(nrec)] + [0] * r
+                hits0, starts0, _ = _exchange_once(hip, x, scs[0], world)
+                prods = eng.JoinHits(cp, host, hits0[:starts0[1]], lens, flags)
+                assert [p.sig() for p in prods] == want_products
+                host.close()
+            L.ipcr_exchange_destroy(x)
+    assert L.ipcr_exchange_available(0) == 1 and L.ipcr_exchange_available(99) == 0
+    g.close()
+
+
 def test_many_tiny_records_in_one_block(hip):
     """hundreds of short records (empty, shorter than a primer, a few kb) share tile blocks: the in-kernel
     verifier starts from the block's first record and walks to the candidate's; every record vs the oracle"""
@@ -1547,8 +1650,26 @@ def test_hit_cap_bounds_device_memory(hip, monkeypatch, k, tw, cap):
     got = eng.ScanGenome(g, cp, sc)
     st = sc.stats()
     assert st.segmented == 1
-    _, _, hcap = sc.device_hits()
-    assert hcap <= (1 << 20)                    # the initial buffer: never regrown towards the raw match count
+    import ctypes as C
+    L = hip.lib.lib()
+    ptr, nh, hcap = C.c_void_p(), C.c_uint64(), C.c_uint64()
+    # the device buffer holds the LAST range only: a caller that would read it (an all-gather straight out of it) is told so
+    assert L.ipcr_scratch_device_hits(sc._h, C.byref(ptr), C.byref(nh), C.byref(hcap)) == hip.lib.ERR_UNSUPPORTED
+    assert hcap.value <= (1 << 20)              # the initial buffer: never regrown towards the raw match count
+    # ... and the library's own exchange sends the host list instead (fake transport: rank r reports hits >> r)
+    monkeypatch.setenv("IPCR_TEST_EXCHANGE_FAKE", "1")
+    kept = {bytes(h) for h in _raw_hit_records(hip, sc)}
+    for xcap in (1 << 16, 16):                  # the second: smaller than the list -> lock-step redo from the host list again
+        x = _fake_exchange(hip, world=2, rank=0, cap=xcap, rec_counts=[3, 3])
+        hits, starts, offs = _exchange_once(hip, x, sc)
+        assert starts[1] == len(kept) and starts[2] - starts[1] == len(kept) >> 1 and offs[:2] == [0, 3]
+        assert {bytes(h) for h in hits[:starts[1]]} == kept
+        second = hits[starts[1]:starts[2]].copy()
+        second["record"] -= 3
+        assert second.tobytes() == hits[:len(second)].tobytes()
+        assert L.ipcr_exchange_redone(x) == (1 if xcap == 16 else 0)
+        L.ipcr_exchange_destroy(x)
+    monkeypatch.delenv("IPCR_TEST_EXCHANGE_FAKE")
     want = []
     for r, s in enumerate(recs):
         for w in O.simulate_batch(ocfg(cfg), s, opairs(pairs)):
