@@ -1765,8 +1765,39 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
     } else if (sd.index_jit) {
         const IndexPlan &ix = set.index;
         const bool more = !ix.leftover.empty();
+        // The index's exact check serves every pattern of this panel: its lanes write the hit records themselves and the last
+        // wave to leave publishes the counters -- ONE kernel per scan, as with the specialised filter (no candidate queue, no
+        // verify kernel, no copy operation: a chunk's scan under a large panel is a conversion launch and a sweep).
+        const bool fuse = !more && publish_enabled() && ipcr::jit_index_fusable();
+        ipcr::JitVerify fv;
+        if (fuse) {
+            fv.rst = g->rst;
+            fv.pats = sd.dev;
+            fv.rec_start = g->d_rec_start;
+            fv.block_rec = g->d_block_rec;
+            fv.rec_len = g->d_rec_len;
+            fv.nrec = pd.nrec;
+            fv.max_mm = (uint32_t)p->cfg.max_mm;
+            fv.check_rst = pd.check_rst;
+            fv.hits = s->d_hits;
+            fv.hcap = s->hcap;
+            fv.counts = cnt;
+            fv.next_counts = cnt_next;
+            fv.next_qcount = qc_next;
+            pd.pre = std::min<uint64_t>(PREFIX_HITS, s->hcap);
+            ++s->seq;
+            fv.seq = s->seq;
+            fv.pub = static_cast<unsigned long long *>(s->pinned) + 4u * pd.cset_used;
+            fv.pub_hits = reinterpret_cast<ipcr_hit_rec *>(static_cast<unsigned long long *>(s->pinned) + 8);
+            fv.pre = (uint32_t)pd.pre;
+            fv.pub_seq = pinned_seq(s);
+            static const bool break_it = env_flag("IPCR_TEST_BREAK_PUBLISH", false); // tests: the word never reaches the host
+            if (break_it) fv.pub_seq = s->d_tickets + 2064;
+        }
         HIPCHK(ipcr::jit_launch_index(sd.index_jit, lane, g->planes, block0, nblocks, (uint32_t)ix.shapes.size(), sd.d_lds_image, sd.d_table,
-                                      (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, qc, s->d_tickets, s->ev[0], more ? nullptr : s->ev[1]));
+                                      (uint32_t)p->cfg.max_mm, s->d_queue, s->qcap, qc, s->d_tickets, s->ev[0], more ? nullptr : s->ev[1],
+                                      fuse ? &fv : nullptr));
+        if (fuse) { pd.fused = true; pd.published = true; }
         if (more && !sd.leftover_jit.empty()) { // patterns the index cannot key: specialised filters that only fill the queue
             ipcr::JitVerify v;
             v.rst = g->rst;

@@ -1371,6 +1371,31 @@ std::string jit_index_source(const std::vector<ipcr_index_shape> &shapes, const 
     s << "typedef unsigned int u32;\ntypedef unsigned long long u64;\ntypedef long long i64;\n";
     s << "typedef u32 v4 __attribute__((ext_vector_type(4)));\n";
     s << "struct qent { u64 key; u32 bits; u32 pad; };\n";
+    s << "struct hitrec { u64 pos; u32 record; u32 pattern; u64 m0, m1; };\n";
+    s << "struct dpat { unsigned short len, seed_off, seed_len, reserved; u32 global_id; unsigned char mask[128]; };\n";
+    // FUSED (hits != null): the index's check is exact for every pattern it serves (<= 32 nt), so a window that passes IS a
+    // match unless it crosses a record end -- the lane that found it looks the record up, turns the mismatch word into
+    // positions, reads the seed span's reset bits where the window holds an invalid base at all, and appends the hit record
+    // itself (device buffer + the tagged copy in the host's pinned buffer, as the specialised filter does): no global
+    // candidate queue, no verify kernel, no copy operation behind the sweep.
+    s << "struct fuse { const u32* rst; const dpat* pats; const u64* rec_start; const u64* rec_len; const u32* block_rec; u32 nrec, check_rst;\n"
+         "  hitrec* hits; u64 hcap; u64* counts; hitrec* pub_hits; u32 pre, seq; };\n";
+    s << "__device__ __forceinline__ u32 rst_bit(const u32* __restrict__ rst, u64 P) {\n"
+         "  const u64 strand = P >> 7, col = strand >> 5;\n"
+         "  const u32 row = (u32)P & 127u, bit = (u32)strand & 31u;\n"
+         "  return (rst[((((col >> 6) * 32u + (row >> 2)) * 64u + (col & 63u)) << 2) + (row & 3u)] >> bit) & 1u;\n"
+         "}\n"
+         "// hand-over of one hit record to the host's pinned buffer: each 16-byte half carries the scan's tag and is ONE store\n"
+         "// (jit_source: publish; host.cpp: scan_collect takes a record only when both tags are this scan's)\n"
+         "__device__ __forceinline__ void publish(hitrec* __restrict__ pub_hits, u64 slot, u64 pos, u32 record, u32 pattern, u64 m0, u32 seq) {\n"
+         "  const u64 tpos = pos | ((u64)(seq & 0xFFFFFFu) << 40);\n"
+         "  v4 a, b;\n"
+         "  a.x = (u32)tpos; a.y = (u32)(tpos >> 32); a.z = record; a.w = pattern;\n"
+         "  b.x = (u32)m0; b.y = (u32)(m0 >> 32); b.z = (u32)slot; b.w = seq;\n"
+         "  v4* dst = (v4*)(pub_hits + slot);\n"
+         "  dst[0] = a;\n"
+         "  dst[1] = b;\n"
+         "}\n";
     s << "#define NS " << NS << "\n";
     s << "#define T64N " << T64N << "u // 64-bit words of all bitmaps\n";
     s << "#define QCAP " << QCAP << "u // per-wave queue of hits (16-byte entries), drained in rounds of 64 at full lane occupancy\n";
@@ -1433,7 +1458,8 @@ __device__ __forceinline__ u32 tr32(u32 x, const trc& c) {
 // next pattern with the same key (0xFFFFFFFF: none).
 // Entry (device_types.h: ipcr_index_entry): {next, pattern, seq2 | prot2, len, flags | okA, okC | okG, okT}
 __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u64 unit_base, u32 strand_off,
-    u32 shard, const v4* __restrict__ table, u32 max_mm, qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount) {
+    u32 shard, const v4* __restrict__ table, u32 max_mm, qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount,
+    const fuse& fu, u32& ncand) {
   const v4 e0 = table[idx * 4u], e1 = table[idx * 4u + 1u];
   const u64 seq2 = ((u64)e0.w << 32) | e0.z, prot2 = ((u64)e1.y << 32) | e1.x;
   const u32 left = e1.w & 1u;
@@ -1458,17 +1484,55 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
   if (bw) mm2 |= spread2(bw);                        // rare: the window holds an invalid base
   const int srow = left ? erow - (int)DL : erow - (int)L + 1; // may lie in the strand before (the padded coordinate is continuous)
   if ((mm2 & prot2) == 0ull && (u32)__popcll(mm2) <= max_mm) {
-    const u64 qi = atomicAdd(qcount + shard * 16u, 1ull);
     // position = (the unit's first strand + the lane) * 128 + row
-    if (qi < qcap) { qent qe; qe.key = ((u64)e0.y << 48) | (u64)((i64)unit_base + (i64)((int)strand_off + srow)); qe.bits = 1u; qe.pad = 0u; queue[(u64)shard * qcap + qi] = qe; }
+    const i64 Ps = (i64)unit_base + (i64)((int)strand_off + srow);
+    if (fu.hits) { // the match is written here: record, bounds (core/engine/ac.go:188-190), mismatch positions, seed-span flag
+      ++ncand;
+      if (Ps >= 0) {
+        const u64 P = (u64)Ps;
+        u32 r = fu.block_rec[P >> 18]; // last record that starts at or before the block's first base
+        u64 rs = fu.rec_start[r];
+        while (r + 1u < fu.nrec) { const u64 rn = fu.rec_start[r + 1u]; if (P < rn) break; ++r; rs = rn; } // a block holds few records
+        if (P >= rs && P - rs + L <= fu.rec_len[r]) { // (P < rs: a window that starts in the padding in front of the record)
+          u64 m = 0ull; // mm2: position j at bit 2 (L - 1 - j)
+          for (u64 t2 = mm2; t2 != 0ull; t2 &= t2 - 1ull) m |= 1ull << (L - 1u - ((u32)__builtin_ctzll(t2) >> 1));
+          const dpat* pp = fu.pats + e0.y;
+          u32 flag = 0u;
+          if (fu.check_rst && bw) { // a reset byte is an invalid base: only a window that holds one can have one in its seed span
+            const u32 soff = pp->seed_off, slen = pp->seed_len;
+            for (u32 j = 0; j < slen; ++j) if (rst_bit(fu.rst, P + soff + j)) { flag = 1u; break; }
+          }
+          const u64 slot = atomicAdd(fu.counts + 1, 1ull);
+          hitrec h; h.pos = P - rs; h.record = r; h.pattern = pp->global_id | (flag << 31); h.m0 = m; h.m1 = 0ull;
+          if (slot < fu.hcap) fu.hits[slot] = h;
+          if (fu.pub_hits && slot < (u64)fu.pre) publish(fu.pub_hits, slot, h.pos, h.record, h.pattern, h.m0, fu.seq);
+        }
+      }
+    } else {
+      const u64 qi = atomicAdd(qcount + shard * 16u, 1ull);
+      if (qi < qcap) { qent qe; qe.key = ((u64)e0.y << 48) | (u64)Ps; qe.bits = 1u; qe.pad = 0u; queue[(u64)shard * qcap + qi] = qe; }
+    }
   }
   return e0.x;
 }
 )SRC";
     s << "extern \"C\" __global__ void __launch_bounds__(" << IPCR_INDEX_WAVES * 64u << ", " << IPCR_INDEX_WAVES / 4u << ") ipcr_index_filter(const u32* __restrict__ planes, u64 cp0, u64 ncolpairs, // units [cp0, cp0 + ncolpairs)\n"
          "    const u32* __restrict__ lds_image, const v4* __restrict__ table, u32 max_mm,\n"
-         "    qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount, u32* __restrict__ work, u64* __restrict__ stamps) {\n"
+         "    qent* __restrict__ queue, u64 qcap, u64* __restrict__ qcount, u32* __restrict__ work, u64* __restrict__ stamps,\n"
+         "    const u32* __restrict__ rst, const dpat* __restrict__ pats, const u64* __restrict__ rec_start, const u64* __restrict__ rec_len,\n"
+         "    const u32* __restrict__ block_rec, u32 nrec, u32 check_rst, hitrec* __restrict__ hits, u64 hcap, u64* __restrict__ counts,\n"
+         "    u64* __restrict__ next_counts, u64* __restrict__ next_qcount, u64* __restrict__ pub, hitrec* __restrict__ pub_hits, u32 pre,\n"
+         "    u32* __restrict__ pub_seq, u32 seq) {\n"
          "  __shared__ u32 lds[((LDS_WORDS + 3u) & ~3u) + " << IPCR_INDEX_WAVES << "u * QCAP * 4u]; // static: every LDS address is a compile-time offset\n"
+         "  __shared__ u32 wg_cand; // windows this workgroup's exact checks passed (fused form)\n"
+         "  if (threadIdx.x == 0u) wg_cand = 0u;\n"
+         "  // the counters alternate between two sets; workgroup 0 clears the set the NEXT scan will use\n"
+         "  if (blockIdx.x == 0u && next_counts) {\n"
+         "    if (threadIdx.x < 4u) next_counts[threadIdx.x] = 0ull;\n"
+         "    if (threadIdx.x < 256u) next_qcount[threadIdx.x * 16u] = 0ull;\n"
+         "  }\n"
+         "  const fuse fu = {rst, pats, rec_start, rec_len, block_rec, nrec, check_rst, hits, hcap, counts, pub_hits, pre, seq};\n"
+         "  u32 ncand = 0u;\n"
          "  for (u32 i = threadIdx.x; i < TAB_WORD0; i += blockDim.x) lds[i] = lds_image[i];\n"
          "  if (threadIdx.x < 8u) lds[TAB_WORD0 + threadIdx.x] = reinterpret_cast<const u32*>(BITTAB)[threadIdx.x];\n"
          "  __syncthreads();\n"
@@ -1613,9 +1677,9 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "          const u32 sbad = hbad >> back;\n"
          "          const u32 strand_off = elane << 7;\n"
          "          const int erow = (int)erow0 - (int)back;\n"
-         "          next = check_entry(idx, skm, sbad, erow, unit_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
+         "          next = check_entry(idx, skm, sbad, erow, unit_base, strand_off, shard, table, max_mm, queue, qcap, qcount, fu, ncand);\n"
          "          if (!CHAIN_CARRY || rest != 0u)\n"
-         "            while (next != 0xFFFFFFFFu) next = check_entry(next, skm, sbad, erow, unit_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
+         "            while (next != 0xFFFFFFFFu) next = check_entry(next, skm, sbad, erow, unit_base, strand_off, shard, table, max_mm, queue, qcap, qcount, fu, ncand);\n"
          "        }\n"
          "        // a lane hands back at most one entry per round: the rest of its mask (any chain under the key it took was\n"
          "        // walked above), or the next pattern of its key\n"
@@ -1695,9 +1759,9 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "            const u32 sbad = hbad >> back;\n"
          "            const u32 strand_off = elane << 7;\n"
          "            const int erow = (int)erow0 - (int)back;\n"
-         "            next = check_entry(idx, skm, sbad, erow, unit_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
+         "            next = check_entry(idx, skm, sbad, erow, unit_base, strand_off, shard, table, max_mm, queue, qcap, qcount, fu, ncand);\n"
          "            if (!CHAIN_CARRY || rest != 0u)\n"
-         "              while (next != 0xFFFFFFFFu) next = check_entry(next, skm, sbad, erow, unit_base, strand_off, shard, table, max_mm, queue, qcap, qcount);\n"
+         "              while (next != 0xFFFFFFFFu) next = check_entry(next, skm, sbad, erow, unit_base, strand_off, shard, table, max_mm, queue, qcap, qcount, fu, ncand);\n"
          "          }\n"
          "          if (CHAIN_CARRY) hand_back(next != 0xFFFFFFFFu, e, keep | 0x80000000u | (next << 2) | back);\n"
          "        }\n"
@@ -1924,12 +1988,28 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "    }\n";
     s << "  }\n"; // (rows are relative to the unit: the queue is always empty when a unit ends)
     if (dynamic)
-        s << "  if (lane == 0u) {\n"
+        s << "  if (hits) { // fused: the candidate statistics (one atomic per workgroup), and every record of this wave on its way before it leaves\n"
+             "    u32 cs = ncand;\n"
+             "    for (int off = 32; off > 0; off >>= 1) cs += __shfl_down(cs, off);\n"
+             "    if (lane == 0u && cs != 0u) atomicAdd(&wg_cand, cs);\n"
+             "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
+             "    __syncthreads();\n"
+             "    if (threadIdx.x == 0u && wg_cand != 0u) { atomicAdd(counts + 2, (u64)wg_cand); asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); }\n"
+             "  }\n"
+             "  u32 last = 0u;\n"
+             "  if (lane == 0u) {\n"
              "    const u32 left = atomicAdd(work + 32u, 1u);\n"
              "    if ((u64)left + 1ull == nwaves) {\n"
+             "      last = 1u;\n"
              "      __hip_atomic_store(work, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(work + 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
           << (per_xcd ? "      for (u32 x = 0; x < 8u; ++x) __hip_atomic_store(work + 8u + 32u * x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n" : "") <<
              "    }\n"
+             "  }\n"
+             "  if (__builtin_amdgcn_readfirstlane((int)last) != 0 && pub) { // every other wave of the scan has left: hand the counters to the host\n"
+             "    __threadfence();\n"
+             "    if (lane < 4u) pub[lane] = __hip_atomic_load(counts + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+             "    __threadfence_system();\n"
+             "    if (lane == 0u) __hip_atomic_store(pub_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);\n"
              "  }\n";
     s << "  if (stamps && lane == 0u) stamps[wave0 * 2u + 1u] = __builtin_amdgcn_s_memrealtime();\n";
     s << "}\n";
@@ -1960,9 +2040,11 @@ JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, const In
     return f; // the kernel's LDS (image + hit queues, up to 160 KiB) is static: nothing to request at launch
 }
 
+bool jit_index_fusable() { return env_int("IPCR_INDEX_DYNAMIC", 1, 0, 1) != 0 && env_int("IPCR_INDEX_FUSED", 1, 0, 1) != 0; }
+
 hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t block0, uint64_t nblocks, uint32_t /*nshapes*/,
                             const uint32_t *lds_image, const void *table, uint32_t max_mm, void *queue,
-                            uint64_t qcap, unsigned long long *qcount, uint32_t *work, hipEvent_t start, hipEvent_t stop) {
+                            uint64_t qcap, unsigned long long *qcount, uint32_t *work, hipEvent_t start, hipEvent_t stop, const JitVerify *fused) {
     if (nblocks == 0) return hipSuccess;
     uint64_t cp0 = block0 * 32u, ncolpairs = nblocks * 32u; // one unit = one column pair
     // one persistent 16-wave workgroup per CU: the bitmaps are staged into LDS once per CU
@@ -1976,8 +2058,12 @@ hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes
         if (hipMalloc((void **)&stamps, nstamp * 8u) != hipSuccess) stamps = nullptr;
         else (void)hipMemsetAsync(stamps, 0, nstamp * 8u, st);
     }
+    JitVerify a = fused ? *fused : JitVerify(); // (all null without: survivors go to the candidate queue, the stand-alone verifier follows)
     void *args[] = {(void *)&planes, (void *)&cp0, (void *)&ncolpairs, (void *)&lds_image, (void *)&table,
-                    (void *)&max_mm, (void *)&queue, (void *)&qcap, (void *)&qcount, (void *)&work, (void *)&stamps};
+                    (void *)&max_mm, (void *)&queue, (void *)&qcap, (void *)&qcount, (void *)&work, (void *)&stamps,
+                    (void *)&a.rst, (void *)&a.pats, (void *)&a.rec_start, (void *)&a.rec_len, (void *)&a.block_rec, (void *)&a.nrec, (void *)&a.check_rst,
+                    (void *)&a.hits, (void *)&a.hcap, (void *)&a.counts, (void *)&a.next_counts, (void *)&a.next_qcount, (void *)&a.pub,
+                    (void *)&a.pub_hits, (void *)&a.pre, (void *)&a.pub_seq, (void *)&a.seq};
     const hipError_t e = hipExtModuleLaunchKernel(f->fn, (unsigned)grid * IPCR_INDEX_WAVES * 64u, 1, 1, IPCR_INDEX_WAVES * 64u, 1, 1, 0, st, args, nullptr, start, stop, 0);
     if (stamps) {
         std::vector<unsigned long long> h(nstamp);

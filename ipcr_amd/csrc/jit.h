@@ -76,8 +76,13 @@ unsigned jit_index_image_bytes(const std::vector<ipcr_index_shape> &shapes);
 JitFilter *jit_build_index(const std::vector<ipcr_index_shape> &shapes, const IndexGeom &geom, std::string &err);
 hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t block0, uint64_t nblocks, uint32_t nshapes,
                             const uint32_t *lds_image, const void *table, uint32_t max_mm, void *queue,
-                            uint64_t qcap, unsigned long long *qcount, uint32_t *work, hipEvent_t start, hipEvent_t stop);
+                            uint64_t qcap, unsigned long long *qcount, uint32_t *work, hipEvent_t start, hipEvent_t stop,
+                            const JitVerify *fused = nullptr);
 // work: two zeroed counters 128 B apart (unit counter, leavers); the kernel leaves them zeroed again
+// fused: the index kernel writes the hit records itself and its last wave hands the counters to the host (as the specialised
+// filter does: JitVerify; tickets / withhold unused) -- for panels whose every pattern the index serves (no leftovers) and
+// when jit_index_fusable() (the dynamic unit hand-out is on: the last wave to leave is what publishes)
+bool jit_index_fusable();
 void jit_destroy(JitFilter *f);
 
 } // namespace ipcr
