@@ -38,7 +38,7 @@ RECORDS = 24
 RECORD_LEN = 125_000_000
 N_PLANTS = 1000
 PRODUCT_LEN = 180
-MIN_WARM_PASSES = {"c2": 300, "c2n": 300, "c3": 300, "c5": 300, "c4": 12}   # the first ~50 sweeps after idle run 15-25 % slower (clock ramp)
+MIN_WARM_PASSES = {"c2": 300, "c2n": 300, "c3": 300, "c5": 300, "c4": 12, "c4n": 12}   # the first ~50 sweeps after idle run 15-25 % slower (clock ramp)
 PROBE = "TGGACCTTAGCAGGTCATTCAG"
 
 
@@ -274,6 +274,12 @@ def workload_spec(name, engine, workloads):
                     pairs=workloads.c4_pairs(1024), genome="c2", kernel="ipcr_index_filter",
                     text="C4: 1024-row ipcr-multiplex panel (unique self pairs added: 3072 pairs, 4096 distinct patterns), "
                          "k=2, 3'-window=3, hit-cap 10000, max-length 2000")
+    if name == "c4n":
+        return dict(cfg=E.Config(MaxMM=2, TerminalWindow=3, MinLen=0, MaxLen=2000, HitCap=10000, SeedLen=12),
+                    pairs=workloads.c4_pairs(1024), genome="c2n", kernel="ipcr_index_filter",
+                    text="C4 on the +N genome: the 1024-row panel where every record holds reset bytes -- the rc orientations are scanned "
+                         "without their 5' window (the reference caps them before the window filter), filed under split keys: "
+                         "window exact + one of k+1 blocks, or a mismatch in the window + one of k longer blocks")
     if name == "c5":
         return dict(cfg=E.Config(MaxMM=2, TerminalWindow=5, MinLen=0, MaxLen=2000, HitCap=10000, SeedLen=12),
                     pairs=workloads.c2_pairs(), genome="c5", kernel="ipcr_filter", probe=PROBE,
@@ -290,9 +296,9 @@ def get_genome(ctx, key):
     a = ctx.args
     if key == "c3":
         g, plants, host0 = build_genome_c3(torch, engine, workloads, ctx.revcomp, ctx.rank, a.records, a.record_len,
-                                           keep_host_record0=ctx.want_cpu)
+                                           keep_host_record0=ctx.want_cpu or ctx.want_cpu_others)
     else:
-        want_host = key == "c2" and ctx.want_cpu
+        want_host = key == "c2" and (ctx.want_cpu or ctx.want_cpu_others)
         g, plants, host0 = build_genome(torch, engine, workloads, ctx.revcomp, ctx.rank, a.records, a.record_len,
                                         want_host, probe=PROBE if key == "c5" else "", with_n=key == "c2n")
     nrec = g.num_records
@@ -305,7 +311,7 @@ def get_genome(ctx, key):
 
 def check_products(name, prods, plants):
     """every planted amplicon of rank 0's genome must come back exactly (coordinates, mismatch counts and positions)"""
-    if name in ("c2", "c2n", "c4", "c5"):
+    if name in ("c2", "c2n", "c4", "c4n", "c5"):
         found = {(p.Record, p.Start): p for p in prods
                  if p.ExperimentID == "bench_000" and p.Type == "forward" and p.Length == PRODUCT_LEN}
         for (r, start, nm) in plants:
@@ -713,13 +719,14 @@ def fasta_to_tsv(ctx, records=8):
             os.unlink(path)
 
 
-def cpu_baseline(name, spec, host0, budget_s: float, gpu_products):
+def cpu_baseline(name, spec, host0, budget_s: float, gpu_products, sample_bases: int = 0, chunk_bases: int = 4_000_000):
     """Reference algorithm restated in C (oracle/: approximate-seed Aho-Corasick scan + verify + join) timed on this box's
-    host cores over a bounded sample of the SAME workload: record 0 of the same genome, as many passes queued to ONE worker
-    pool as fill the budget (every thread busy).  One worker per 4 Mb rolling chunk like internal/pipeline/pipeline.go:60-125;
-    a --circular run (C3) cannot be chunked (internal/runutil/runutil.go:46-49), so there one worker scans one whole
-    record, i.e. the pool scans as many copies of record 0 as it has threads.  Checker/baseline only -- never on the
-    product path.  The sample's product count must equal the GPU's for that record."""
+    host cores over a bounded sample of the SAME workload: record 0 of the same genome (or its first `sample_bases` bases,
+    a record of its own), as many passes queued to ONE worker pool as fill the budget (every thread busy).  One worker per
+    rolling chunk like internal/pipeline/pipeline.go:60-125 (4 Mb unless said otherwise); a --circular run (C3) cannot be
+    chunked (internal/runutil/runutil.go:46-49), so there one worker scans one whole record, i.e. the pool scans as many
+    copies of the sample as it has threads.  Checker/baseline only -- never on the product path.  The sample's product
+    count must equal the GPU's for the same bases (gpu_products: the products of record 0, or a count)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ipcr_oracle as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -729,9 +736,9 @@ def cpu_baseline(name, spec, host0, budget_s: float, gpu_products):
     panel = O.Panel(O.Config(max_mm=c.MaxMM, terminal_window=c.TerminalWindow, min_len=c.MinLen, max_len=c.MaxLen, hit_cap=c.HitCap,
                              seed_len=c.SeedLen, circular=c.Circular), pairs)
     compile_s = time.perf_counter() - t0
-    n = int(host0.shape[0])
+    n = int(host0.shape[0]) if not sample_bases else min(int(sample_bases), int(host0.shape[0]))
     ptr = host0.ctypes.data
-    chunk, overlap = (0, 0) if c.Circular else (4_000_000, 2000)
+    chunk, overlap = (0, 0) if c.Circular else (chunk_bases, 2000)
     nch = 1 if c.Circular else max(1, -(-max(n - overlap, 1) // (chunk - overlap)))
     passes = max(1, -(-cores // nch))                           # calibration round: every thread gets a chunk
     t0 = time.perf_counter()
@@ -745,10 +752,11 @@ def cpu_baseline(name, spec, host0, budget_s: float, gpu_products):
         el = time.perf_counter() - t0
         rate, passes = n * passes2 / el, passes2
     panel.close()
-    gpu_rec0 = len([p for p in gpu_products if p.Record == 0])
-    assert nprod == gpu_rec0, f"CPU baseline found {nprod} products in record 0, GPU path {gpu_rec0}"
+    gpu_n = gpu_products if isinstance(gpu_products, int) else len([p for p in gpu_products if p.Record == 0])
+    assert nprod == gpu_n, f"CPU baseline found {nprod} products in its sample, the GPU path {gpu_n}"
     how = ("whole records (a --circular run is not chunked), one worker per record" if c.Circular
-           else "%d chunks of 4 Mb, overlap 2000, per pass" % nch)
+           else "%d chunks of %.1f Mb, overlap 2000, per pass" % (nch, chunk / 1e6))
+    what = "record 0 (%d bases)" % n if not sample_bases else "the first %d bases of record 0, as a record of its own," % n
     return {
         "value": round(rate / 1e9, 4),
         "unit": "Gbases/s",
@@ -757,11 +765,29 @@ def cpu_baseline(name, spec, host0, budget_s: float, gpu_products):
         "kind": "port",
         "workload": name,
         "panel_compile_s": round(compile_s, 3),
-        "sample": "record 0 (%d bases) of the same genome, %d passes queued to one pool of %d threads (%s = %d scans in all, "
+        "sample": "%s of the same genome, %d passes queued to one pool of %d threads (%s = %d scans in all, "
                   "%.1f s); C restatement of the reference's seeded AC scan + verify + join (not the Go binary)"
-                  % (n, passes, cores, how, nch * passes, el),
+                  % (what, passes, cores, how, nch * passes, el),
         "products_in_sample": int(nprod),
     }
+
+
+def cpu_baseline_bounded(ctx, name, seconds: float = 3.0):
+    """cpu_baseline for a workload that is not the main line (other_workloads.<name>.cpu_baseline), bounded to a few
+    seconds: a prefix of record 0 sized so that one pool run of every host thread fits -- C3 (k = 3, whole records per
+    worker) 8 Mb per thread; C4 (the 1024-row panel: a DRAM-resident automaton, ~0.1 Mb/s per thread) 4 Mb in rolling
+    chunks of 0.5 Mb.  The GPU path scans the same bytes (ipcr_scan_chunk) for the product count the sample must match."""
+    engine = ctx.engine
+    spec = workload_spec(name, engine, ctx.workloads)
+    G = get_genome(ctx, spec["genome"])
+    host0 = G["host0"]
+    if host0 is None:
+        return None
+    n, chunk = (8_000_000, 0) if name == "c3" else (4_000_000, 500_000)
+    n = min(n, int(host0.shape[0]))
+    sample = host0[:n].tobytes()
+    gpu_n = len(engine.New(spec["cfg"]).SimulateBatch("sample", sample, spec["pairs"]))
+    return cpu_baseline(name, spec, host0, seconds, gpu_n, sample_bases=n, chunk_bases=chunk or 4_000_000)
 
 
 # ----------------------------------------------------------------------------------------------- main
@@ -773,7 +799,7 @@ def main() -> None:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2n", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2n", "c3", "c4", "c4n", "c5"])
     # one C2 step is ~0.2 ms: the default region (about half a second) is long enough for the clocks to settle
     ap.add_argument("--steps", type=int, default=None, help="timed passes (default 2000; 40 for c4)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed passes before them (default 200; 5 for c4)")
@@ -787,9 +813,9 @@ def main() -> None:
     ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc children (quote profiles/ instead)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 40 if args.workload == "c4" else 2000
+        args.steps = 40 if args.workload in ("c4", "c4n") else 2000
     if args.warmup is None:
-        args.warmup = 5 if args.workload == "c4" else 200
+        args.warmup = 5 if args.workload in ("c4", "c4n") else 200
 
     cmd = launch_plan(args.gpus, os.environ, sys.argv[1:])
     if cmd is not None:   # launcher only: no torch import, no HIP call in this process
@@ -803,7 +829,7 @@ def main() -> None:
         c5_chunk = scan_chunk_rates(args, probe=True)
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if not args.no_traffic and not under_profiler and single and args.records == RECORDS and args.record_len == RECORD_LEN:
-        traffic = measure_traffic(args.workload, "ipcr_index_filter" if args.workload == "c4" else "ipcr_filter")
+        traffic = measure_traffic(args.workload, "ipcr_index_filter" if args.workload in ("c4", "c4n") else "ipcr_filter")
     if not args.no_others and os.environ.get("RANK") == "0" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         all_dev_rates = scan_chunk_all_devices(int(os.environ["WORLD_SIZE"]), args)
 
@@ -829,6 +855,7 @@ def main() -> None:
     ctx.revcomp = primer.RevComp
     ctx.genomes = {}
     ctx.want_cpu = (not args.no_cpu_baseline) and rank == 0 and world == 1 and args.workload in ("c2", "c3", "c4")
+    ctx.want_cpu_others = (not args.no_cpu_baseline) and (not args.no_others) and rank == 0 and world == 1 and not ctx.multi
     ctx.compile_done = set()
 
     res = run_workload(ctx, args.workload, args.steps, args.warmup)
@@ -836,7 +863,7 @@ def main() -> None:
     others = {}
     if not args.no_others:
         if world == 1 and not ctx.multi:
-            for nm, st, wu in (("c2n", 400, 100), ("c3", 400, 100), ("c4", 30, 5), ("c5", 300, 50)):
+            for nm, st, wu in (("c2n", 400, 100), ("c3", 400, 100), ("c4", 30, 5), ("c4n", 20, 3), ("c5", 300, 50)):
                 if nm == args.workload:
                     continue
                 r = run_workload(ctx, nm, st, wu)
@@ -851,6 +878,8 @@ def main() -> None:
                     others[nm]["probe_rescan_ms"] = round(r["probe_ms"], 4)
                 if "limiter" in rf:
                     others[nm]["limiter"] = rf["limiter"]
+                if nm in ("c3", "c4") and ctx.want_cpu_others:   # the driver's record carries every workload's CPU baseline
+                    others[nm]["cpu_baseline"] = cpu_baseline_bounded(ctx, nm)
                 r["prods"] = None
             if chunk_rates is not None:
                 others["scan_chunk"] = chunk_rates

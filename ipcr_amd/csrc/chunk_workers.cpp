@@ -88,7 +88,7 @@ int main(int argc, char **argv) {
         if (W < 1 || W > 1024) return usage("a worker count must be in 1..1024");
     // HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues in creation order.  With the chunks packed on the host (round 3:
     // one 1.5 MB copy, one conversion launch and one sweep per call) the runtime's default of 4 is the best setting --
-    // 8 / 16 / 24 workers, three runs each (tools/gpu_round3_w.sh): 2 queues 76-79 / 72-74 / 85-87 Gbases/s; 3 queues
+    // 8 / 16 / 24 workers, three runs each (tools/knobs.sh: chunk GPU_MAX_HW_QUEUES=q): 2 queues 76-79 / 72-74 / 85-87 Gbases/s; 3 queues
     // 95-102 / 93-98 / 95-97; 4 queues 94-105 / 110-116 / 106-110; 5 queues 93-112 / 103-114 / 101-107; 8 queues
     // 51-92 / 99-100 / 93-96; 12 and 16: 81-90 / 97-107.  (Round 2, ASCII over the link: 4 queues 44 / 27, 8 queues
     // 44 / 49 / 51 -- the setting this driver forced until now.)  An explicit GPU_MAX_HW_QUEUES in the environment stays.

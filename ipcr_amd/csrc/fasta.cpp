@@ -420,7 +420,7 @@ struct FastaLoader {
 
     // What the read-ahead thread hands over: slab j sits in pinned buffer j % NPIN, its bytes [0, cut) are on their way to
     // d_raw[j & 1] (ev_h2d[j % NPIN]); what follows the cut is carried into the next slab.
-    struct SlabInfo { size_t n = 0, cut = 0; bool last = false; ipcr_status st = IPCR_OK; };
+    struct SlabInfo { size_t n = 0, cut = 0; bool last = false, has_nl = true; ipcr_status st = IPCR_OK; };
 
     ipcr_status run() {
         uint8_t **buf = pin;
@@ -475,6 +475,7 @@ struct FastaLoader {
                     const void *nl = memrchr(b, '\n', n);
                     if (nl) cut = (size_t)((const uint8_t *)nl - b) + 1;
                     else {
+                        si.has_nl = false; // no line ends in this slab: a header that begins in it does not end in it
                         while (cut > 0 && is_space(b[cut - 1])) --cut;
                         if (cut == 0 && n == slab) si.st = ipcr_internal_fail(IPCR_ERR_UNSUPPORTED, "FASTA: a run of white space longer than the %zu-byte slab", slab);
                     }
@@ -492,7 +493,7 @@ struct FastaLoader {
                     if (trace && j < 64) { hipEvent_t a, z; (void)hipEventCreate(&a); (void)hipEventCreate(&z); tev.push_back(a); tev.push_back(z); (void)hipEventRecord(a, cs); }
                     // One slab copy at a time: the next one is queued when the one before has finished.  Queued behind a
                     // copy still in flight it was slower on every box tried (1 GB file: 37 -> 46-52 ms on a slow one,
-                    // tools/gpu_round3_n.sh); why, the runtime does not say.  The fill of the next slab has long begun
+                    // round 3); why, the runtime does not say.  The fill of the next slab has long begun
                     // by the time this thread waits here, so the link idles only for the few microseconds of the hand-over.
                     static const bool one_copy = !(getenv("IPCR_FASTA_COPY_OVERLAP") && atoi(getenv("IPCR_FASTA_COPY_OVERLAP")));
                     if (one_copy && j >= 1 && e == hipSuccess) e = hipEventSynchronize(ev_h2d[(j - 1) % NPIN]);
@@ -538,7 +539,10 @@ struct FastaLoader {
             s = find_headers(d_cur, cut);
             if (s != IPCR_OK) return s;
             const uint32_t nh = (uint32_t)ranges.size();
-            if (nh && !last && ranges.back().end > cut) return ipcr_internal_fail(IPCR_ERR_UNSUPPORTED, "FASTA: a header line longer than the %zu-byte slab", slab);
+            // A slab is cut behind its last line end, so a header that begins in it ends in it -- unless the slab holds no line
+            // end at all: then the header line is longer than the slab (the kernel has clamped its range to the cut: the ID
+            // would be truncated and the rest of the line decoded as sequence).
+            if (nh && !last && !si.has_nl) return ipcr_internal_fail(IPCR_ERR_UNSUPPORTED, "FASTA: a header line longer than the %zu-byte slab", slab);
             uint32_t total = 0;
             const auto td0 = std::chrono::steady_clock::now();
             mark("headers found", j);

@@ -112,7 +112,7 @@ struct DeviceGuard {
 
 // ------------------------------------------------------------ the CPUs next to a device
 // A slab of pinned memory that cores of the OTHER socket have just written crosses the link at 31 GB/s instead of 54: the
-// DMA engine's reads find the lines dirty in caches two hops away (measured round 3, tools/gpu_round3_o.sh -- the FASTA
+// DMA engine's reads find the lines dirty in caches two hops away (measured round 3 -- the FASTA
 // loader's threads bound to the far socket: 40 ms per GB, to the device's own: 26 ms; unbound it was the scheduler's luck).
 // So the threads of this library that fill pinned memory run on the CPUs the kernel lists as local to the device
 // (/sys/bus/pci/devices/<bus id>/local_cpulist), as far as the process is allowed on them.  IPCR_BIND_THREADS=0: never.
@@ -120,6 +120,16 @@ struct CpuSet {
     cpu_set_t set;
     bool known = false;
 };
+// What the process may run on, captured ONCE when the library is loaded: sched_getaffinity later would return the mask of
+// whichever thread asks -- after ipcr_bind_thread_to_device has narrowed the main thread to one device's CPUs, every other
+// device's set (allowed AND local) would come out empty and stay cached so.
+const CpuSet g_initial_cpus = [] {
+    CpuSet c;
+    CPU_ZERO(&c.set);
+    c.known = sched_getaffinity(0, sizeof c.set, &c.set) == 0;
+    return c;
+}();
+
 const CpuSet &device_cpus(int phys) {
     static std::mutex mu;
     static std::map<int, CpuSet> cache;
@@ -139,10 +149,9 @@ const CpuSet &device_cpus(int phys) {
     const bool got = fgets(line, sizeof line, fh) != nullptr;
     fclose(fh);
     if (!got) return c;
-    cpu_set_t allowed, local;
-    CPU_ZERO(&allowed);
+    cpu_set_t allowed = g_initial_cpus.set, local; // the process's mask as it was when the library was loaded, before anybody was bound
     CPU_ZERO(&local);
-    if (sched_getaffinity(getpid(), sizeof allowed, &allowed) != 0) return c; // the process's mask, not a bound thread's
+    if (!g_initial_cpus.known) return c;
     for (const char *q = line; *q;) { // "0-63,128-191"
         char *e = nullptr;
         const long a = strtol(q, &e, 10);
@@ -361,7 +370,8 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     ix.built = true;
     const int k = p.cfg.max_mm;
     const size_t P = set.host.size();
-    struct Group { bool left; int t; int lmin; std::vector<uint32_t> members; };
+    // nblk: blocks the bases behind the first t are cut into (k + 1, or k: see "split" below); noprot: the keys hold no protected base
+    struct Group { bool left; int t; int lmin; std::vector<uint32_t> members; int nblk; bool noprot; };
     std::vector<Group> groups;
     struct Pat { uint64_t ok[4]; uint64_t prot2; int len; bool left; };
     std::vector<Pat> pats(P);
@@ -384,10 +394,26 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         pt.left = d.left;
         int t = k == 0 ? L : std::min(d.tw_dev, L);
         if (t < 0) t = 0;
-        bool found = false;
-        for (Group &g : groups)
-            if (g.left == d.left && g.t == std::min(t, 32)) { g.members.push_back(q); g.lmin = std::min(g.lmin, L); found = true; break; }
-        if (!found) groups.push_back(Group{d.left, std::min(t, 32), L, {q}});
+        auto join = [&](int gt, int nblk, bool noprot) {
+            for (Group &g : groups)
+                if (g.left == d.left && g.t == gt && g.nblk == nblk && g.noprot == noprot) { g.members.push_back(q); g.lmin = std::min(g.lmin, L); return; }
+            groups.push_back(Group{d.left, gt, L, {q}, nblk, noprot});
+        };
+        // SPLIT.  An rc orientation that the device scans WITHOUT its 5' window (the reference caps it before the window
+        // filter: core/engine/compiled.go:249-256 -- every chunk, and every record of a genome that holds an N) has nothing
+        // protected to key on: 20-mers at k = 2 would go under three keys of 6-7 bases, 2048 patterns in 2^12..2^14 slots, and
+        // a third of all lane steps would hit (measured: 33 ms per 3 Gb against 4.1).  But the window is still there in the
+        // panel, and a match either has its first tw bases exact -- then <= k mismatches lie behind them: "3 window bases +
+        // one of k + 1 blocks", the protected orientation's own 16-17-bit keys -- or it has a mismatch among them -- then
+        // <= k - 1 lie behind: one of only k blocks, twice as long (8 bases at k = 2), is exact.  The pattern is filed under
+        // both families; the exact check accepts any window with <= k mismatches, so the union is exactly the raw matches.
+        static const bool split_on = env_flag("IPCR_INDEX_SPLIT", true);
+        const int twp = std::min(p.tw, L);
+        if (split_on && d.left && d.tw_dev == 0 && k >= 1 && twp >= 1 && L - twp >= k + 1) {
+            join(std::min(twp, 32), k + 1, false);
+            join(std::min(twp, 32), k, true);
+        } else
+            join(std::min(t, 32), k + 1, false);
     }
     std::vector<std::pair<uint32_t, uint32_t>> ents; // (tag, pattern)
     std::vector<char> dropped(P, 0);
@@ -411,9 +437,9 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         int lmax = 0;
         for (const Group &g : groups) {
             const int t = std::min(g.t, g.lmin);
-            const int bf = (t >= g.lmin) ? 0 : (g.lmin - t) / (k + 1);
-            if (!(k >= 1 && t >= 3 && bf >= 5)) paired = false;
-            ns_all += (size_t)k + 1;
+            const int bf = (t >= g.lmin) ? 0 : (g.lmin - t) / g.nblk;
+            if (!(k >= 1 && t >= 3 && bf >= 5) || g.noprot) paired = false;
+            ns_all += (size_t)g.nblk;
             for (uint32_t q : g.members) lmax = std::max(lmax, pats[q].len);
         }
         if (ns_all > IPCR_INDEX_MAX_SHAPES || ns_all * (2048u * 9u) > lds_budget) paired = false;
@@ -421,14 +447,15 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     }
     for (Group &g : groups) {
         const int t = std::min(g.t, g.lmin);
-        const int bf = (t >= g.lmin) ? 0 : (g.lmin - t) / (k + 1);
+        const int bf = (t >= g.lmin) ? 0 : (g.lmin - t) / g.nblk;
         // With k >= 1 and at least three protected bases the key is "3 protected bases next to the anchor + 5 block
         // bases" for every block: the protected part is then the low six key bits of all the group's shapes, which
         // the kernel extracts once per step (device_types.h).  Otherwise: as many protected bases as fit.
-        const bool tri = k >= 1 && t >= 3 && bf >= 1;
-        const int tu = tri ? 3 : std::min(t, 8);
+        // (A split group of the second family, noprot, keys on its blocks alone: the first t bases hold a mismatch.)
+        const bool tri = !g.noprot && k >= 1 && t >= 3 && bf >= 1;
+        const int tu = g.noprot ? 0 : (tri ? 3 : std::min(t, 8));
         const int b = tri ? std::min(5, bf) : ((tu >= 8) ? 0 : std::min(8 - tu, bf));
-        const int ns = b > 0 ? k + 1 : 1;
+        const int ns = b > 0 ? g.nblk : 1;
         if ((tu == 0 && b == 0) || ix.shapes.size() + (size_t)ns > IPCR_INDEX_MAX_SHAPES) { // nothing exact to key on
             for (uint32_t q : g.members) dropped[q] = 1;
             continue;
@@ -1413,6 +1440,8 @@ struct ipcr_scratch {
     // results to (no copy operation in either direction)
     hipStream_t probe_stream = nullptr;
     uint8_t *h_probe = nullptr; uint64_t h_probe_cap = 0;
+    uint32_t probe_tag = 0;         // the rescan in flight marks its records with it (the host spins on the tags in h_probe)
+    hipStream_t probe_on = nullptr; // the stream it was queued on
     int64_t probe_pending = -1;     // ipcr_probe_products_begin: products whose rescan is in flight (-1: none)
     uint64_t probe_res_off = 0;     // ... and where in h_probe its results arrive
 };
@@ -1521,20 +1550,35 @@ public:
     // phys >= 0: what the items write is pinned memory read by that device next -- the pool's own threads move onto its CPUs
     // (device_cpus; the caller's thread stays where its owner put it)
     template <class F> void run(size_t n, F fn, int phys = -1) {
+        if (n == 0) return;
         std::unique_lock<std::mutex> big(run_mu_); // one record at a time
+        // Every run is an object of its own: a pool thread that wakes late still holds the run it woke for -- whose
+        // items are all taken, so it does nothing -- and never reads the fields of the run that has begun since.
+        auto job = std::make_shared<Job>();
+        job->fn = [&fn](size_t i) { fn(i); };
+        job->n = n;
+        job->phys = phys;
         {
             std::lock_guard<std::mutex> lk(mu_);
-            fn_ = [&](size_t i) { fn(i); };
-            n_ = n; next_.store(0); done_.store(0); ++gen_;
-            want_phys_ = phys;
+            job_ = job;
+            gen_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
-        work();
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_done_.wait(lk, [&] { return done_.load() >= n_; });
-        fn_ = nullptr;
+        work(*job);
+        // (an item that has been taken is finished before `done` reaches n: fn is not called once this returns)
+        for (unsigned spin = 0; job->done.load(std::memory_order_acquire) < n; ++spin) {
+            if (spin < 2000u) { __builtin_ia32_pause(); continue; }
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_done_.wait_for(lk, std::chrono::microseconds(200), [&] { return job->done.load(std::memory_order_acquire) >= n; });
+        }
     }
 private:
+    struct Job {
+        std::function<void(size_t)> fn;
+        size_t n = 0;
+        int phys = -1;
+        std::atomic<size_t> next{0}, done{0};
+    };
     PackPool() {
         unsigned t = std::min(std::thread::hardware_concurrency(), 16u); // IPCR_PACK_THREADS: up to 64
         if (const char *v = getenv("IPCR_PACK_THREADS")) t = (unsigned)std::max(1, atoi(v));
@@ -1542,36 +1586,41 @@ private:
         for (unsigned i = 1; i < t; ++i) threads_.emplace_back([this] { loop(); });
         for (auto &th : threads_) th.detach(); // they sleep on the condition variable for the rest of the process's life
     }
-    void work() {
+    void work(Job &j) {
         for (;;) {
-            const size_t i = next_.fetch_add(1);
-            if (i >= n_) break;
-            fn_(i);
-            if (done_.fetch_add(1) + 1 >= n_) { std::lock_guard<std::mutex> lk(mu_); cv_done_.notify_all(); }
+            const size_t i = j.next.fetch_add(1);
+            if (i >= j.n) break;
+            j.fn(i);
+            if (j.done.fetch_add(1, std::memory_order_acq_rel) + 1 >= j.n) { std::lock_guard<std::mutex> lk(mu_); cv_done_.notify_all(); }
         }
     }
     void loop() {
         uint64_t seen = 0;
         int bound = -1;
         for (;;) {
-            int want;
+            // a lone worker that scans chunk after chunk comes back every ~100 us: poll for that long before sleeping (a
+            // wake-up through the condition variable costs 20-50 us of the ~25 us a 4 Mb chunk takes to pack)
+            const auto t0 = std::chrono::steady_clock::now();
+            while (gen_.load(std::memory_order_acquire) == seen) {
+                __builtin_ia32_pause();
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) break;
+            }
+            std::shared_ptr<Job> job;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
-                want = want_phys_;
+                cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                seen = gen_.load(std::memory_order_acquire);
+                job = job_;
             }
-            if (want >= 0 && want != bound) { (void)bind_this_thread(want); bound = want; }
-            work();
+            if (!job) continue;
+            if (job->phys >= 0 && job->phys != bound) { (void)bind_this_thread(job->phys); bound = job->phys; }
+            work(*job);
         }
     }
     std::mutex mu_, run_mu_;
     std::condition_variable cv_, cv_done_;
-    std::function<void(size_t)> fn_;
-    size_t n_ = 0;
-    int want_phys_ = -1;
-    std::atomic<size_t> next_{0}, done_{0};
-    uint64_t gen_ = 0;
+    std::shared_ptr<Job> job_; // the current run (guarded by mu_)
+    std::atomic<uint64_t> gen_{0};
     std::vector<std::thread> threads_;
 };
 
@@ -2620,6 +2669,13 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
     }
     ipcr_genome *g = s->chunk;
     genome_clear(g, true);
+    // Whatever goes wrong between here and the hand-over -- any early return below -- no DMA and no kernel may still read the
+    // caller's bytes or a pinned slab when the call returns: the caller may free the one, the next call rewrites the other.
+    struct Drain {
+        hipStream_t st;
+        bool armed = true;
+        ~Drain() { if (armed) (void)hipStreamSynchronize(st); }
+    } drain{g->stream};
     uint32_t *pinned_flag = pinned_seq(s) + 4; // set when the record holds a byte outside ACGTacgt (by the pack kernel, or by the host's packer)
     *pinned_flag = 0u;
     const int live = p->live_scratches->load(std::memory_order_relaxed);
@@ -2630,7 +2686,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
     // pageable copy pins the caller's pages in place and runs at the link rate, faster than one core packs.
     // IPCR_CHUNK_HOSTPACK=0/1 forces.
     static const int hp_env = getenv("IPCR_CHUNK_HOSTPACK") ? atoi(getenv("IPCR_CHUNK_HOSTPACK")) : -1;
-    const bool hostpack = hp_env >= 0 ? hp_env != 0 : (ipcr::pack_linear_is_simd() && (live > 1 || len >= (16ull << 20)));
+    const bool hostpack = hp_env >= 0 ? hp_env != 0 : (ipcr::pack_linear_is_simd() && (live > 1 || (len >= (1ull << 20) && PackPool::get().size() > 1) || len >= (16ull << 20)));
     if (hostpack) {
         const auto th0 = std::chrono::steady_clock::now();
         const uint64_t cols = record_cols(len), col0 = g->next_col;
@@ -2647,15 +2703,25 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         // in two or four (IPCR_CHUNK_SPLIT: the first part crosses the link while the next is packed) was slower under a
         // pool -- 16 workers: 94 / 72 / 49 Gbases/s for 1 / 2 / 4 parts -- every operation on a stream costs its dispatch latency
         static const uint64_t split_env = getenv("IPCR_CHUNK_SPLIT") ? strtoull(getenv("IPCR_CHUNK_SPLIT"), nullptr, 10) : 1;
-        const uint64_t SLC = pooled ? std::min<uint64_t>(1024, std::max<uint64_t>(128, cols / (2ull * PackPool::get().size())))
+        // A LONE worker (internal/pipeline/pipeline.go:60-125 with Threads = 1; a genome of few large records): a GROUP of
+        // columns is packed by the process's pool, every thread a run of its columns into the group's planes, and sent as
+        // ONE conversion launch that reads the pinned planes over the link itself; the next group is packed under it.  Two
+        // groups for a 4 Mb chunk (pack 0 | pack 1 under transfer 0 | transfer 1, sweep), 8 Mb groups for a chromosome.
+        const uint64_t SLC = pooled ? std::min<uint64_t>(2048, std::max<uint64_t>(128, ((cols + 1) / 2 + 63) / 64 * 64))
                                     : std::min<uint64_t>(1024, std::max<uint64_t>(128, (cols + split_env - 1) / std::max<uint64_t>(split_env, 1)));
         const uint64_t nsl = (cols + SLC - 1) / SLC;
         std::vector<uint32_t> sflags((size_t)nsl, 0);
-        auto pack_slice = [&](uint64_t i, uint8_t *slab) { // planes of slice i: [lo | hi | inv | rst], nc x 128 words each
-            const uint64_t c0 = i * SLC, nc = std::min<uint64_t>(SLC, cols - c0), b0 = c0 * IPCR_COLUMN_BASES, W = nc * 128u;
+        // columns [c0, c0 + nc) of slice i (whose first column is i * SLC and which holds snc columns) into the slice's planes
+        // at `slab`: [lo | hi | inv | rst], snc x 128 words each
+        auto pack_cols = [&](uint64_t i, uint8_t *slab, uint64_t c0, uint64_t nc) -> uint32_t {
+            const uint64_t s0 = i * SLC, snc = std::min<uint64_t>(SLC, cols - s0), W = snc * 128u, b0 = c0 * IPCR_COLUMN_BASES;
             const uint64_t nb = b0 < len ? std::min<uint64_t>(len - b0, nc * IPCR_COLUMN_BASES) : 0;
-            uint32_t *w = reinterpret_cast<uint32_t *>(slab);
-            sflags[(size_t)i] = ipcr::pack_linear(seq + (nb ? b0 : 0), nb, nc * IPCR_COLUMN_BASES, w, w + W, w + 2 * W, w + 3 * W);
+            uint32_t *w = reinterpret_cast<uint32_t *>(slab) + (c0 - s0) * 128u;
+            return ipcr::pack_linear(seq + (nb ? b0 : 0), nb, nc * IPCR_COLUMN_BASES, w, w + W, w + 2 * W, w + 3 * W);
+        };
+        auto pack_slice = [&](uint64_t i, uint8_t *slab) { // planes of slice i: [lo | hi | inv | rst], nc x 128 words each
+            const uint64_t c0 = i * SLC, nc = std::min<uint64_t>(SLC, cols - c0);
+            sflags[(size_t)i] = pack_cols(i, slab, c0, nc);
         };
         auto send_slice = [&](uint64_t i, const uint8_t *slab) -> ipcr_status { // the rst plane crosses the link only if the slice holds lower case
             const uint64_t c0 = i * SLC, nc = std::min<uint64_t>(SLC, cols - c0), W = nc * 128u;
@@ -2685,24 +2751,30 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
                 if (i >= 2) HIPCHK(hipEventSynchronize(s->ev_stage[h])); // the DMA that read this slab has finished
                 pack_slice(i, s->h_stage[h]);
                 st = send_slice(i, s->h_stage[h]);
-                if (st != IPCR_OK) { (void)hipStreamSynchronize(g->stream); return st; } // no DMA may still read a slab the next call rewrites
+                if (st != IPCR_OK) return st;
                 if (i + 2 < nsl) HIPCHK(hipEventRecord(s->ev_stage[h], g->stream));
             }
-        } else { // one worker, a large record: the pool packs a group of slices while the group before crosses the link
+        } else { // one worker: the pool packs group i + 1 while group i crosses the link
             if (dev_bytes > s->h_planes_cap) {
                 if (s->h_planes) (void)hipHostFree(s->h_planes);
                 s->h_planes = nullptr;
                 s->h_planes_cap = dev_bytes + (dev_bytes >> 3);
                 HIPCHK(hipHostMalloc((void **)&s->h_planes, s->h_planes_cap, hipHostMallocDefault));
             }
-            const uint64_t group = std::max<uint64_t>(PackPool::get().size(), (nsl + 3) / 4);
-            for (uint64_t g0 = 0; g0 < nsl; g0 += group) {
-                const uint64_t g1 = std::min(nsl, g0 + group);
-                PackPool::get().run((size_t)(g1 - g0), [&](size_t k) { pack_slice(g0 + k, s->h_planes + (g0 + k) * SLC * 2048ull); }, slot_phys(g->device));
-                for (uint64_t i = g0; i < g1; ++i) {
-                    st = send_slice(i, s->h_planes + i * SLC * 2048ull);
-                    if (st != IPCR_OK) { (void)hipStreamSynchronize(g->stream); return st; }
-                }
+            const uint64_t nthreads = PackPool::get().size();
+            for (uint64_t i = 0; i < nsl; ++i) {
+                const uint64_t c0 = i * SLC, nc = std::min<uint64_t>(SLC, cols - c0);
+                const uint64_t per = std::max<uint64_t>(32, ((nc + nthreads - 1) / nthreads + 7) / 8 * 8); // columns per item: 128 KB of bases at least
+                const uint64_t items = (nc + per - 1) / per;
+                std::vector<uint32_t> iflags((size_t)items, 0);
+                uint8_t *slab = s->h_planes + c0 * 2048ull;
+                PackPool::get().run((size_t)items, [&](size_t k) {
+                    const uint64_t a = c0 + (uint64_t)k * per;
+                    iflags[k] = pack_cols(i, slab, a, std::min<uint64_t>(per, c0 + nc - a));
+                }, slot_phys(g->device));
+                for (uint32_t f : iflags) sflags[(size_t)i] |= f;
+                st = send_slice(i, slab);
+                if (st != IPCR_OK) return st;
             }
         }
         uint32_t fl = 0;
@@ -2753,12 +2825,13 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         }
     }
     st = genome_add_device(g, pack_src, len, false, pinned_flag);
-    if (st != IPCR_OK) { (void)hipStreamSynchronize(g->stream); return st; } // (staged copies may still be reading the pinned slices)
+    if (st != IPCR_OK) return st;
     }
     const double hostpack_keep = s->stats.hostpack_ms; // (scan_enqueue starts the statistics afresh)
     st = scan_enqueue(p, s, g, true);
     if (st == IPCR_OK) st = scan_collect(p, s, g);
-    if (st != IPCR_OK) { (void)hipStreamSynchronize(g->stream); return st; } // nothing of this call may still read the pinned slices
+    if (st != IPCR_OK) return st;
+    drain.armed = false; // the scan has been collected: the stream has passed everything this call queued
     s->stats.hostpack_ms = hostpack_keep;
     {
         float ms = 0; // the pack kernel's events lie in front of the sweep on the same stream
@@ -2930,8 +3003,28 @@ ipcr_status ipcr_probe_products_end(ipcr_scratch *s, ipcr_probe_hit *out, int64_
     if (n == 0) return IPCR_OK;
     if (s->probe_res_off == 0) { memset(out, 0, (size_t)n * sizeof *out); return IPCR_OK; } // empty probe: nothing found (oligo.go:21-23)
     DeviceGuard dg(s->device);
-    HIPCHK(hipStreamSynchronize(s->probe_stream));
-    memcpy(out, s->h_probe + s->probe_res_off, (size_t)n * sizeof(ipcr_probe_hit)); // (ipcr_probe_rec is layout-identical)
+    // every record is ONE tagged 16-byte store into pinned memory: spin on the tags (a handful of products per chunk)
+    const volatile int32_t *res = reinterpret_cast<const volatile int32_t *>(s->h_probe + s->probe_res_off);
+    const uint32_t tag = s->probe_tag;
+    for (int64_t i = 0; i < n; ++i) {
+        for (uint64_t spin = 1; ((uint32_t)__atomic_load_n(res + 4 * i, __ATOMIC_ACQUIRE) >> 1) != tag; ++spin) {
+            if (spin < 0x4000u) __builtin_ia32_pause();
+            else std::this_thread::yield();
+            if ((spin & 0x3FFFu) == 0) {
+                const hipError_t q = hipStreamQuery(s->probe_on);
+                if (q == hipErrorNotReady) continue;
+                if (((uint32_t)__atomic_load_n(res + 4 * i, __ATOMIC_ACQUIRE) >> 1) == tag) break; // the stream has drained
+                return fail(IPCR_ERR_DEVICE, "probe rescan: %s", q == hipSuccess ? "its results did not reach pinned memory" : hipGetErrorString(q));
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (int64_t i = 0; i < n; ++i) { // (ipcr_probe_rec is layout-identical; the tag rides above bit 0 of `found`)
+        out[i].found = res[4 * i] & 1;
+        out[i].strand = res[4 * i + 1];
+        out[i].pos = res[4 * i + 2];
+        out[i].mm = res[4 * i + 3];
+    }
     return IPCR_OK;
 }
 
@@ -2977,18 +3070,31 @@ static ipcr_status probe_begin(ipcr_scratch *s, const ipcr_genome *g, const char
         segs[i] = sg;
     }
     const uint64_t amp_bytes = offs[n] + 16;
-    if (amp_bytes > s->amps_cap) {
-        // (grows to the largest batch seen and stays: hipFree waits for the device, so a steady state must not come here)
-        if (s->d_amps) (void)hipFree(s->d_amps);
-        s->d_amps = nullptr;
-        s->amps_cap = std::max<uint64_t>(amp_bytes + (amp_bytes >> 1), 1u << 20);
-        HIPCHK(hipMalloc((void **)&s->d_amps, s->amps_cap));
-    }
+    uint64_t longest = 0;
+    for (size_t i = 0; i < n; ++i) longest = std::max(longest, offs[i + 1] - offs[i]);
     const uint32_t fast = probe_masks(prb, max_mm, s->h_probe);
     ipcr_probe_rec *res = reinterpret_cast<ipcr_probe_rec *>(s->h_probe + res_off);
-    HIPCHK(ipcr::launch_gather(s->probe_stream, g->planes, g->rst, segs, (uint32_t)n, s->d_amps));
-    HIPCHK(ipcr::launch_probe(s->probe_stream, s->d_amps, offs, (uint32_t)n, s->h_probe, s->h_probe + 128, (uint32_t)prb.size(),
-                              (uint32_t)(max_mm < 0 ? 0 : max_mm), fast, res));
+    s->probe_tag = (s->probe_tag % 0x3FFFFFFFu) + 1u; // never 0, never what the result slots still hold
+    // A chunk's products (the scratch's own tiles): the scratch's stream is idle -- its scan has been collected -- and a
+    // second stream per worker only thins out the hardware queues a pool shares.  A resident genome: the lane of its own.
+    const hipStream_t pst = g == s->chunk ? s->stream : s->probe_stream;
+    s->probe_on = pst;
+    if (longest <= ipcr::launch_probe_tiles_max()) {
+        // ONE launch: every workgroup reads its amplicon straight from the tiles into LDS and rescans it there
+        HIPCHK(ipcr::launch_probe_tiles(pst, g->planes, g->rst, segs, (uint32_t)n, s->h_probe, s->h_probe + 128, (uint32_t)prb.size(),
+                                        (uint32_t)(max_mm < 0 ? 0 : max_mm), fast, res, s->probe_tag));
+    } else { // an amplicon beyond the kernel's LDS stage (--max-length above 16 384): gathered to device memory first
+        if (amp_bytes > s->amps_cap) {
+            // (grows to the largest batch seen and stays: hipFree waits for the device, so a steady state must not come here)
+            if (s->d_amps) (void)hipFree(s->d_amps);
+            s->d_amps = nullptr;
+            s->amps_cap = std::max<uint64_t>(amp_bytes + (amp_bytes >> 1), 1u << 20);
+            HIPCHK(hipMalloc((void **)&s->d_amps, s->amps_cap));
+        }
+        HIPCHK(ipcr::launch_gather(pst, g->planes, g->rst, segs, (uint32_t)n, s->d_amps));
+        HIPCHK(ipcr::launch_probe(pst, s->d_amps, offs, (uint32_t)n, s->h_probe, s->h_probe + 128, (uint32_t)prb.size(),
+                                  (uint32_t)(max_mm < 0 ? 0 : max_mm), fast, res, s->probe_tag));
+    }
     s->probe_res_off = res_off;
     s->probe_pending = (int64_t)n; // (set last: a begin that failed leaves nothing to end)
     return IPCR_OK;

@@ -34,6 +34,8 @@
 #include <mutex>
 #include <sstream>
 #include <thread>
+#include <dirent.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -1023,6 +1025,35 @@ std::string jit_cache_dir() {
     return dir;
 }
 
+// The directory is bounded: after a new file has been written, the least recently used code objects (mtime: a hit touches
+// its file) are removed until the ipcr_*.jit files take at most IPCR_JIT_CACHE_MAX_MB (default 256; a C2-sized kernel is
+// ~0.2 MB, a 1024-row index kernel ~0.1 MB) -- a library must not grow a user's home directory without limit.
+void prune_cache_dir(const std::string &dir) {
+    if (dir.empty()) return;
+    const unsigned long long limit = (unsigned long long)env_int("IPCR_JIT_CACHE_MAX_MB", 256, 1, 1 << 20) << 20;
+    DIR *d = opendir(dir.c_str());
+    if (!d) return;
+    struct Ent { std::string path; unsigned long long size; long long mtime_ns; };
+    std::vector<Ent> ents;
+    unsigned long long total = 0;
+    while (const dirent *de = readdir(d)) {
+        const std::string nm = de->d_name;
+        if (nm.size() < 10 || nm.compare(0, 5, "ipcr_") != 0 || nm.compare(nm.size() - 4, 4, ".jit") != 0) continue;
+        struct stat sb;
+        const std::string path = dir + "/" + nm;
+        if (stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) continue;
+        ents.push_back({path, (unsigned long long)sb.st_size, (long long)sb.st_mtim.tv_sec * 1000000000ll + sb.st_mtim.tv_nsec});
+        total += (unsigned long long)sb.st_size;
+    }
+    closedir(d);
+    if (total <= limit) return;
+    std::sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.mtime_ns < b.mtime_ns; });
+    for (const Ent &e : ents) {
+        if (total <= limit) break;
+        if (remove(e.path.c_str()) == 0) total -= e.size; // (another process may have removed it already: nothing lost)
+    }
+}
+
 // hiprtc -> code object for one group (no device needed except for the arch name)
 bool compile_group(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &err) {
     const std::string key = arch + "\n" + src;
@@ -1042,9 +1073,13 @@ bool compile_group(const std::string &src, const std::string &arch, std::vector<
         const std::string cache_dir = jit_cache_dir();
         const char *dir = cache_dir.c_str();
         if (*dir) {
-            int vmaj = 0, vmin = 0;
+            // the whole version: hiprtc's major.minor, the HIP runtime's number (patch level included) and the headers
+            // this library was built against -- a code object of another ROCm build is compiled afresh, never loaded
+            int vmaj = 0, vmin = 0, vrt = 0;
             (void)hiprtcVersion(&vmaj, &vmin);
-            fullkey = "hiprtc " + std::to_string(vmaj) + "." + std::to_string(vmin) + "\n" + key;
+            (void)hipRuntimeGetVersion(&vrt);
+            fullkey = "hiprtc " + std::to_string(vmaj) + "." + std::to_string(vmin) + " runtime " + std::to_string(vrt) + " built " +
+                      std::to_string(HIP_VERSION) + "\n" + key;
             unsigned long long h = 1469598103934665603ull;
             for (const unsigned char ch : fullkey) { h ^= ch; h *= 1099511628211ull; }
             char name[64];
@@ -1060,8 +1095,10 @@ bool compile_group(const std::string &src, const std::string &arch, std::vector<
                 unsigned long long klen = 0;
                 if (buf.size() > 16 && memcmp(buf.data(), "IPCRJIT1", 8) == 0) memcpy(&klen, buf.data() + 8, 8);
                 if (klen == fullkey.size() && buf.size() > 16 + klen + 64 && memcmp(buf.data() + 16, fullkey.data(), klen) == 0 &&
-                    memcmp(buf.data() + 16 + klen, "\177ELF", 4) == 0)
+                    memcmp(buf.data() + 16 + klen, "\177ELF", 4) == 0) {
                     code.assign(buf.begin() + 16 + (long)klen, buf.end());
+                    (void)utimensat(AT_FDCWD, disk.c_str(), nullptr, 0); // used now: the pruning below removes the least recently used first
+                }
             }
         }
     }
@@ -1076,6 +1113,7 @@ bool compile_group(const std::string &src, const std::string &arch, std::vector<
                           fwrite(code.data(), 1, code.size(), fh) == code.size();
                 ok = (fclose(fh) == 0) && ok;
                 if (!ok || rename(tmpname.c_str(), disk.c_str()) != 0) (void)remove(tmpname.c_str());
+                else prune_cache_dir(jit_cache_dir());
             }
         }
     }

@@ -508,42 +508,15 @@ __device__ __forceinline__ uint32_t probe_onehot(uint32_t b) {
     b &= 0xDFu;
     return (b == 'A') ? 1u : (b == 'C') ? 2u : (b == 'G') ? 4u : (b == 'T') ? 8u : 0u;
 }
-__global__ __launch_bounds__(64) void probe_kernel(const uint8_t *__restrict__ amps,
-                                                   const uint64_t *__restrict__ amp_off, // n+1 offsets
-                                                   const uint8_t *__restrict__ pmask,    // probe IUPAC masks
-                                                   const uint8_t *__restrict__ rmask,    // rc(probe) masks
-                                                   uint32_t plen, uint32_t max_mm, uint32_t fastpath, uint32_t tag,
-                                                   ipcr_probe_rec *__restrict__ out) {
-    __shared__ uint8_t s_mask[256];
-    __shared__ uint32_t s_amp[IPCR_PROBE_LDS_BYTES / 4u];
-    const uint64_t a0 = amp_off[blockIdx.x], a1 = amp_off[blockIdx.x + 1];
-    const uint64_t n = a1 - a0;
-    const uint32_t lane = threadIdx.x;
-    if (plen > 128u) plen = 128u; // (the host refuses longer probes)
-    for (uint32_t i = lane; i < 256u; i += 64u) s_mask[i] = (i < 128u) ? (i < plen ? pmask[i] : 0) : (i - 128u < plen ? rmask[i - 128u] : 0);
-    const bool staged = n <= IPCR_PROBE_LDS_BYTES;
-    if (staged && n > 0) {
-        // dwords of the buffer that cover [a0, a1): the first may begin up to 3 bytes in front of the amplicon, the last
-        // end up to 3 behind it (inside the buffer: every amplicon buffer carries 16 spare bytes)
-        const uintptr_t p0 = reinterpret_cast<uintptr_t>(amps + a0);
-        const uint32_t head = (uint32_t)(p0 & 3u);
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(p0 - head);
-        const uint32_t nw = (uint32_t)((n + head + 3u) / 4u);
-        uint8_t *sb = reinterpret_cast<uint8_t *>(s_amp);
-        for (uint32_t i = lane; i < nw; i += 64u) {
-            const uint32_t v = w[i];
-#pragma unroll
-            for (uint32_t b = 0; b < 4u; ++b) {
-                const int64_t idx = (int64_t)(4u * i + b) - (int64_t)head;
-                if (idx >= 0 && (uint64_t)idx < n) sb[idx] = (uint8_t)probe_onehot((v >> (8u * b)) & 0xFFu);
-            }
-        }
-    }
-    __syncthreads();
+// scan of one amplicon (n one-hot codes in LDS at sb, or bytes in global memory when not staged) by the THREADS threads
+// of a workgroup -> the record; the masks are in s_mask.  Shared by the two kernels below.
+template <uint32_t THREADS>
+__device__ __forceinline__ void probe_scan(const uint8_t *sb, const uint8_t *gamp, bool staged, uint64_t n, const uint8_t *s_mask,
+                                           unsigned long long *s_best, uint32_t plen, uint32_t max_mm, uint32_t fastpath, uint32_t tag,
+                                           ipcr_probe_rec *__restrict__ out) {
     unsigned long long best[2] = {~0ull, ~0ull}; // key = mm<<40 | pos
     if (plen > 0 && n >= plen) {
-        const uint8_t *sb = reinterpret_cast<const uint8_t *>(s_amp);
-        for (uint64_t pos = lane; pos + plen <= n; pos += 64u) {
+        for (uint64_t pos = threadIdx.x; pos + plen <= n; pos += THREADS) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const uint8_t *mk = s_mask + (s ? 128 : 0);
@@ -553,7 +526,7 @@ __global__ __launch_bounds__(64) void probe_kernel(const uint8_t *__restrict__ a
                         if ((mk[j] & sb[pos + j]) == 0u && ++mm > max_mm) break;
                 } else {
                     for (uint32_t j = 0; j < plen; ++j)
-                        if ((mk[j] & probe_onehot(amps[a0 + pos + j])) == 0u && ++mm > max_mm) break;
+                        if ((mk[j] & probe_onehot(gamp[pos + j])) == 0u && ++mm > max_mm) break;
                 }
                 if (mm <= max_mm) {
                     const unsigned long long key = ((unsigned long long)mm << 40) | pos;
@@ -568,7 +541,13 @@ __global__ __launch_bounds__(64) void probe_kernel(const uint8_t *__restrict__ a
             const unsigned long long o = __shfl_xor(best[s], off);
             if (o < best[s]) best[s] = o;
         }
-    if (lane == 0) {
+    if (THREADS > 64u) { // the waves of the workgroup meet in LDS
+        if ((threadIdx.x & 63u) == 0u) { atomicMin(&s_best[0], best[0]); atomicMin(&s_best[1], best[1]); }
+        __syncthreads();
+        best[0] = s_best[0];
+        best[1] = s_best[1];
+    }
+    if (threadIdx.x == 0) {
         ipcr_probe_rec r = {0, 0, 0, 0};
         const bool hp = best[0] != ~0ull, hm = best[1] != ~0ull;
         int pick = -1;
@@ -585,6 +564,71 @@ __global__ __launch_bounds__(64) void probe_kernel(const uint8_t *__restrict__ a
         // ONE 16-byte store: a host that spins on the tag never sees half a record
         *reinterpret_cast<int4 *>(out + blockIdx.x) = make_int4(r.found, r.strand, r.pos, r.mm);
     }
+}
+
+template <uint32_t THREADS>
+__global__ __launch_bounds__(THREADS) void probe_kernel(const uint8_t *__restrict__ amps,
+                                                        const uint64_t *__restrict__ amp_off, // n+1 offsets
+                                                        const uint8_t *__restrict__ pmask,    // probe IUPAC masks
+                                                        const uint8_t *__restrict__ rmask,    // rc(probe) masks
+                                                        uint32_t plen, uint32_t max_mm, uint32_t fastpath, uint32_t tag,
+                                                        ipcr_probe_rec *__restrict__ out) {
+    __shared__ uint8_t s_mask[256];
+    __shared__ uint32_t s_amp[IPCR_PROBE_LDS_BYTES / 4u];
+    __shared__ unsigned long long s_best[2];
+    const uint64_t a0 = amp_off[blockIdx.x], a1 = amp_off[blockIdx.x + 1];
+    const uint64_t n = a1 - a0;
+    if (plen > 128u) plen = 128u; // (the host refuses longer probes)
+    if (threadIdx.x < 2u) s_best[threadIdx.x] = ~0ull;
+    for (uint32_t i = threadIdx.x; i < 256u; i += THREADS) s_mask[i] = (i < 128u) ? (i < plen ? pmask[i] : 0) : (i - 128u < plen ? rmask[i - 128u] : 0);
+    const bool staged = n <= IPCR_PROBE_LDS_BYTES;
+    if (staged && n > 0) {
+        // dwords of the buffer that cover [a0, a1): the first may begin up to 3 bytes in front of the amplicon, the last
+        // end up to 3 behind it (inside the buffer: every amplicon buffer carries 16 spare bytes)
+        const uintptr_t p0 = reinterpret_cast<uintptr_t>(amps + a0);
+        const uint32_t head = (uint32_t)(p0 & 3u);
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(p0 - head);
+        const uint32_t nw = (uint32_t)((n + head + 3u) / 4u);
+        uint8_t *sb = reinterpret_cast<uint8_t *>(s_amp);
+        for (uint32_t i = threadIdx.x; i < nw; i += THREADS) {
+            const uint32_t v = w[i];
+#pragma unroll
+            for (uint32_t b = 0; b < 4u; ++b) {
+                const int64_t idx = (int64_t)(4u * i + b) - (int64_t)head;
+                if (idx >= 0 && (uint64_t)idx < n) sb[idx] = (uint8_t)probe_onehot((v >> (8u * b)) & 0xFFu);
+            }
+        }
+    }
+    __syncthreads();
+    probe_scan<THREADS>(reinterpret_cast<const uint8_t *>(s_amp), amps + a0, staged, n, s_mask, s_best, plen, max_mm, fastpath, tag, out);
+}
+
+// The same with the amplicon read straight from the tiles (gather and rescan in ONE launch): segment seg[blockIdx.x] = the
+// product's bases in padded coordinates, [pa, pa + len_a) ++ [pb, pb + len_b) (a wrap-around product has both).  Every base
+// becomes its one-hot code in LDS: valid -> its base; lower-case acgt (inv, not rst) -> its base too (BestHit upper-cases
+// the amplicon, oligo.go:20); anything else 0.  Amplicons beyond the LDS stage are left to the two-kernel form (host.cpp).
+template <uint32_t THREADS>
+__global__ __launch_bounds__(THREADS) void probe_tiles_kernel(const uint32_t *__restrict__ planes, const uint32_t *__restrict__ rst,
+                                                              const ipcr_amp_seg *__restrict__ segs,
+                                                              const uint8_t *__restrict__ pmask, const uint8_t *__restrict__ rmask,
+                                                              uint32_t plen, uint32_t max_mm, uint32_t fastpath, uint32_t tag,
+                                                              ipcr_probe_rec *__restrict__ out) {
+    __shared__ uint8_t s_mask[256];
+    __shared__ uint32_t s_amp[IPCR_PROBE_LDS_BYTES / 4u];
+    __shared__ unsigned long long s_best[2];
+    const ipcr_amp_seg sg = segs[blockIdx.x];
+    const uint64_t n = sg.len_a + sg.len_b; // <= IPCR_PROBE_LDS_BYTES (the host checks)
+    if (plen > 128u) plen = 128u;
+    if (threadIdx.x < 2u) s_best[threadIdx.x] = ~0ull;
+    for (uint32_t i = threadIdx.x; i < 256u; i += THREADS) s_mask[i] = (i < 128u) ? (i < plen ? pmask[i] : 0) : (i - 128u < plen ? rmask[i - 128u] : 0);
+    uint8_t *sb = reinterpret_cast<uint8_t *>(s_amp);
+    for (uint64_t i = threadIdx.x; i < n; i += THREADS) {
+        const uint64_t P = (i < sg.len_a) ? sg.pa + i : sg.pb + (i - sg.len_a);
+        const uint32_t g = base_bits(planes, P);
+        sb[i] = (uint8_t)((!(g & 4u) || !rst_bit(rst, P)) ? (1u << (g & 3u)) : 0u);
+    }
+    __syncthreads();
+    probe_scan<THREADS>(sb, nullptr, true, n, s_mask, s_best, plen, max_mm, fastpath, tag, out);
 }
 
 // ---------------------------------------------------------------------------- launchers
@@ -687,7 +731,18 @@ hipError_t launch_probe(hipStream_t st, const uint8_t *amps, const uint64_t *amp
                         const uint8_t *pmask, const uint8_t *rmask, uint32_t plen, uint32_t max_mm,
                         uint32_t fastpath, ipcr_probe_rec *out, uint32_t tag) {
     if (namp == 0) return hipSuccess;
-    probe_kernel<<<dim3(namp), dim3(64), 0, st>>>(amps, amp_off, pmask, rmask, plen, max_mm, fastpath, tag, out);
+    // few amplicons (a chunk's products, one amplicon of a collector): four waves share each; a large batch has waves enough
+    if (namp <= 256u) probe_kernel<256><<<dim3(namp), dim3(256), 0, st>>>(amps, amp_off, pmask, rmask, plen, max_mm, fastpath, tag, out);
+    else probe_kernel<64><<<dim3(namp), dim3(64), 0, st>>>(amps, amp_off, pmask, rmask, plen, max_mm, fastpath, tag, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_probe_tiles(hipStream_t st, const uint32_t *planes, const uint32_t *rst, const ipcr_amp_seg *segs, uint32_t namp,
+                              const uint8_t *pmask, const uint8_t *rmask, uint32_t plen, uint32_t max_mm, uint32_t fastpath,
+                              ipcr_probe_rec *out, uint32_t tag) {
+    if (namp == 0) return hipSuccess;
+    if (namp <= 256u) probe_tiles_kernel<256><<<dim3(namp), dim3(256), 0, st>>>(planes, rst, segs, pmask, rmask, plen, max_mm, fastpath, tag, out);
+    else probe_tiles_kernel<64><<<dim3(namp), dim3(64), 0, st>>>(planes, rst, segs, pmask, rmask, plen, max_mm, fastpath, tag, out);
     return hipGetLastError();
 }
 

@@ -40,7 +40,12 @@ hipError_t launch_gather(hipStream_t st, const uint32_t *planes, const uint32_t 
 hipError_t launch_probe(hipStream_t st, const uint8_t *amps, const uint64_t *amp_off, uint32_t namp,
                         const uint8_t *pmask, const uint8_t *rmask, uint32_t plen, uint32_t max_mm,
                         uint32_t fastpath, ipcr_probe_rec *out,
-                        uint32_t tag = 0); // tag != 0: out[i].found = found | tag << 1 (ipcr_probe_best_hit spins on it in pinned memory)
+                        uint32_t tag = 0); // tag != 0: out[i].found = found | tag << 1 (the host spins on it in pinned memory)
+// gather + rescan in one launch: every amplicon (<= launch_probe_tiles_max() bases) read straight from the tiles
+hipError_t launch_probe_tiles(hipStream_t st, const uint32_t *planes, const uint32_t *rst, const ipcr_amp_seg *segs, uint32_t namp,
+                              const uint8_t *pmask, const uint8_t *rmask, uint32_t plen, uint32_t max_mm, uint32_t fastpath,
+                              ipcr_probe_rec *out, uint32_t tag);
+inline uint64_t launch_probe_tiles_max() { return 16384u; } // IPCR_PROBE_LDS_BYTES (kernels.hip)
 // header lines ('>' at a line start .. its line end) of a raw FASTA slab, unordered; *count may exceed cap
 hipError_t launch_fasta_find_headers(hipStream_t st, const uint8_t *raw, uint64_t n, uint32_t at_line_start, ipcr_fasta_range *list,
                                      uint32_t cap, uint32_t *count);

@@ -70,6 +70,29 @@ def test_no_final_newline_header_last_and_empty_file(tmp_path):
     assert load_and_compare(str(w), 64) == [("z", b"AC")]
 
 
+def test_header_line_longer_than_the_slab_is_refused(tmp_path):
+    """A header line that does not end inside its slab: the device-side search would clamp it to the slab -- a truncated
+    ID, the rest of the line decoded as sequence.  The loader refuses the file (IPCR_ERR_UNSUPPORTED); a header at the very
+    end of the file (no line end at all) is still an empty record, and the same file loads with a slab that holds the line."""
+    from ipcr_amd import _lib, engine
+    p = tmp_path / "longhdr.fa"
+    hdr = b">id " + b"x" * 300
+    p.write_bytes(b">a\nACGT\n" + hdr + b"\nGGGG\n")
+    os.environ["IPCR_FASTA_SLAB"] = "128"
+    try:
+        g = engine.Genome(1 << 16, max_records=8)
+        with pytest.raises(_lib.IpcrError) as ei:
+            g.add_fasta(str(p))
+        assert ei.value.status == _lib.ERR_UNSUPPORTED and "header line longer" in ei.value.message
+        g.close()
+    finally:
+        os.environ.pop("IPCR_FASTA_SLAB", None)
+    assert load_and_compare(str(p), 1024) == [("a", b"ACGT"), ("id", b"GGGG")]
+    q = tmp_path / "hdr_at_eof.fa"
+    q.write_bytes(b">a\nACGT\n" + hdr)                 # the last line is a long header without a line end
+    assert load_and_compare(str(q), 4096) == [("a", b"ACGT"), ("id", b"")]
+
+
 def test_long_lines_span_slabs(tmp_path):
     """one sequence line much longer than the slab, with blanks inside and at both ends"""
     rng = random.Random(5)

@@ -301,3 +301,75 @@ def test_config_c5_full_size_probe_rescan():
             assert (bool(out[i].found), chr(out[i].strand) if out[i].found else "", out[i].pos, out[i].mm) == \
                 (w.found, w.strand, w.pos if w.found else 0, w.mm if w.found else 0)
     genome.close()
+
+
+def test_resident_genome_beyond_2_to_32_bases():
+    """More than 2^32 bases resident at once: 36 records x 125 Mb = 4.5 Gb (2.25 GB of tiles + rst) -- padded coordinates,
+    tile word indices and the hit records' positions are 64-bit, grid sizes and counters must not wrap on the way.
+    Amplicons planted in every record, the last ones beyond base 4.3e9; every plant comes back with its mismatch
+    positions, hit lists are sorted and unique and lie inside their records, the scan is idempotent, and the LAST record
+    agrees product for product with the CPU oracle."""
+    torch = pytest.importorskip("torch")
+    from ipcr_amd import engine, primer, workloads
+
+    nrec, reclen = 36, 125_000_000
+    assert nrec * reclen > (1 << 32)
+    pairs = workloads.c2_pairs()
+    fwd, rc_rev = pairs[0].Forward, primer.RevComp(pairs[0].Reverse).decode()
+    genome = engine.Genome(nrec * reclen, nrec)
+    buf = torch.empty(reclen, dtype=torch.uint8, device="cuda:0")
+    plants, host_last = {}, None
+    for r in range(nrec):
+        engine.lcg_fill_device(buf.data_ptr(), reclen, 0x5eed7000 + r)       # (one LCG stream per record: its period is 2^32)
+        for t in range(6):
+            start = 3_000_000 + t * 24_000_000 + 17 * r
+            nm = (r + t) % 3
+            site = list(fwd)
+            if nm >= 1:
+                site[10] = workloads.different_base(site[10])
+            if nm >= 2:
+                site[3] = workloads.different_base(site[3])
+            buf[start:start + 20] = torch.tensor(list("".join(site).encode()), dtype=torch.uint8)
+            buf[start + 160:start + 180] = torch.tensor(list(rc_rev.encode()), dtype=torch.uint8)
+            plants[(r, start)] = nm
+        buf[reclen - 180:reclen - 160] = torch.tensor(list(fwd.encode()), dtype=torch.uint8)     # flush with the record's end
+        buf[reclen - 20:reclen] = torch.tensor(list(rc_rev.encode()), dtype=torch.uint8)
+        plants[(r, reclen - 180)] = 0
+        torch.cuda.synchronize()
+        if r == nrec - 1:
+            host_last = buf.cpu().numpy().copy()
+        genome.add_record_device("chr%d" % (r + 1), buf.data_ptr(), reclen)
+    del buf
+    assert genome.total_bases == nrec * reclen > (1 << 32)
+    cfg = engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12)
+    eng = engine.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    sc = eng.NewSimulationScratch(cp)
+    prods = eng.ScanGenome(genome, cp, sc)
+    st = sc.stats()
+    assert st.kernel_kind == 1 and st.bases == nrec * reclen
+    found = {(p.Record, p.Start): p for p in prods if p.ExperimentID == "bench_000" and p.Type == "forward" and p.Length == 180}
+    for (r, start), nm in plants.items():
+        p = found[(r, start)]
+        assert (p.FwdMM, p.FwdMismatchIdx, p.RevMM) == (nm, () if nm == 0 else ((10,) if nm == 1 else (3, 10)), 0), (r, start)
+    hits = sc.hits()
+    keys = [(h.Record, h.Pattern, h.Pos) for h in hits]
+    assert keys == sorted(keys) and len(set(keys)) == len(keys)
+    assert all(0 <= h.Record < nrec and h.Pos + 20 <= reclen and h.Mismatches <= 2 for h in hits)
+    assert {h.Record for h in hits} == set(range(nrec))
+    assert [p.sig() for p in eng.ScanGenome(genome, cp, sc)] == [p.sig() for p in prods]
+    op = O.Panel(O.Config(max_mm=2, terminal_window=5, max_len=2000, hit_cap=10000, seed_len=12),
+                 [O.Pair(p.ID, p.Forward, p.Reverse, p.MinProduct, p.MaxProduct) for p in pairs])
+    want = op.scan_ptr(host_last.ctypes.data, int(host_last.shape[0]))
+    assert [p.sig() for p in prods if p.Record == nrec - 1] == [w.sig() for w in want] and len(want) >= 7
+    assert genome.read(nrec - 1, reclen - 180, 180) == bytes(host_last[reclen - 180:])        # tiles of the last record decode back
+    # the seed-index kernel walks the same coordinates (column pairs beyond 2^19, positions beyond 2^32)
+    rows = workloads.c4_pairs(128)
+    cp4 = engine.New(engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)).CompilePanel(rows)
+    sc4 = eng.NewSimulationScratch(cp4)
+    prods4 = engine.New(engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=2000, HitCap=10000, SeedLen=12)).ScanGenome(genome, cp4, sc4)
+    assert sc4.stats().kernel_kind == 3
+    found4 = {(p.Record, p.Start) for p in prods4 if p.ExperimentID == "bench_000" and p.Type == "forward" and p.Length == 180}
+    assert all(key in found4 for key, nm in plants.items())          # (window 3: every planted site passes here too)
+    op.close(); sc4.close(); cp4.close(); sc.close(); cp.close()
+    genome.close()

@@ -1681,6 +1681,45 @@ def test_hit_cap_bounds_device_memory(hip, monkeypatch, k, tw, cap):
     g.close(); sc.close(); cp.close()
 
 
+def test_disk_cache_of_code_objects_is_bounded(hip, tmp_path, monkeypatch):
+    """The code objects persist on disk by default; the directory must not grow without limit: after a new file is written
+    the least recently used ones go until the files fit IPCR_JIT_CACHE_MAX_MB (here 1 MB: two C2-sized kernels do not fit),
+    a hit touches its file, and every file's stored key names the HIP runtime version (a code object of another ROCm build
+    is never loaded)."""
+    import glob, os, time
+    from ipcr_amd import workloads
+    d = tmp_path / "cache"
+    d.mkdir()
+    monkeypatch.setenv("IPCR_JIT_CACHE_DIR", str(d))
+    monkeypatch.setenv("IPCR_JIT_CACHE_MAX_MB", "1")
+    monkeypatch.setenv("IPCR_JIT_NO_MEMCACHE", "1")
+    seq = O.bench_dna(200_000, 5)
+    cfg = hip.engine.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12)
+    sizes = []
+    first = None
+    for i in range(4):
+        pairs = hip.primer.AddSelfPairs([workloads.bench_pair(40 + i)])
+        hip.engine.New(cfg).SimulateBatch("s", seq, pairs)
+        files = sorted(glob.glob(str(d / "ipcr_*.jit")), key=os.path.getmtime)
+        assert files, "no code object was written"
+        total = sum(os.path.getsize(f) for f in files)
+        sizes.append((len(files), total))
+        if first is None:
+            first = files[0]
+            blob = open(first, "rb").read(400)
+            assert blob[:8] == b"IPCRJIT1" and b"hiprtc " in blob and b" runtime " in blob and b"gfx950" in blob
+        assert total <= (1 << 20) or len(files) == 1, sizes
+        time.sleep(0.05)
+    assert not os.path.exists(first)                      # the oldest went
+    assert not glob.glob(str(d / "*.tmp*"))
+    # a hit touches its file: scanning the newest panel again makes it the most recently used
+    newest = sorted(glob.glob(str(d / "ipcr_*.jit")), key=os.path.getmtime)[-1]
+    before = os.path.getmtime(newest)
+    time.sleep(0.05)
+    hip.engine.New(cfg).SimulateBatch("s", seq, hip.primer.AddSelfPairs([workloads.bench_pair(43)]))
+    assert os.path.getmtime(newest) > before
+
+
 def test_small_panel_scans_before_its_kernels_are_built(tmp_path):
     """IPCR_JIT_ASYNC (the default outside the tests): hiprtc builds a small panel's kernels on a thread of its own; a scan
     that comes before they are ready takes the table-driven kernel, later ones the specialised one; same products."""

@@ -648,3 +648,16 @@ def test_host_packer_matches_the_pack_kernel_semantics(scalar, avx512):
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
     with pytest.raises(_lib.IpcrError):
         _lib.check(_lib.lib().ipcr_pack_ascii(b"ACGT", 4, 33, None, None, None, None, None))
+
+
+def test_profiles_readme_is_generated():
+    """profiles/README.md is written by tools/collect_profiles.py from the CSV / JSON files beside it: every figure in it is
+    a value of the file its row names.  Regenerated here and compared -- prose cannot drift from the evidence."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("collect_profiles", os.path.join(root, "tools", "collect_profiles.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = mod.readme_text()
+    have = open(os.path.join(root, "profiles", "README.md")).read()
+    assert have == want, "profiles/README.md is stale: run `python tools/collect_profiles.py readme`"

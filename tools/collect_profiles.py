@@ -13,7 +13,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = {"c2": "ipcr_filter", "c3": "ipcr_filter", "c4": "ipcr_index_filter"}
+KERNEL = {"c2": "ipcr_filter", "c2n": "ipcr_filter", "c3": "ipcr_filter", "c4": "ipcr_index_filter"}
+ALG_BYTES = 1_125_000_000   # 3.0e9 bases x 0.375 B: what one sweep of the benchmark genome reads
 
 
 def newest(pattern):
@@ -45,7 +46,7 @@ def main():
     if os.path.exists(serial):
         with open(os.path.join(dst, f"{tag}_bench_serial.json"), "w") as fh:
             fh.write(open(serial).read().strip().splitlines()[-1] + "\n")
-    for w in ("c3", "c4"):   # the other workloads as the main line (their own cpu_baseline)
+    for w in ("c2n", "c3", "c4"):   # the other workloads as the main line (their own cpu_baseline)
         f = os.path.join(src, f"bench_{w}.json")
         if os.path.exists(f):
             with open(os.path.join(dst, f"{tag}_bench_{w}.json"), "w") as fh:
@@ -76,7 +77,7 @@ def main():
             wr = int(out["WRITE_SIZE"]["avg"] * 1024)
             out.update(hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
                        algorithmic_bytes_per_launch=alg)
-        if w in ("c2", "c3") and alg and "SQ_INSTS_VALU" in out and "GRBM_GUI_ACTIVE" in out:
+        if w in ("c2", "c2n", "c3") and alg and "SQ_INSTS_VALU" in out and "GRBM_GUI_ACTIVE" in out:
             # the specialised filter: one wave per block of 64 columns x 32 strands x 128 bases, 128 + 19 row steps each
             blocks = -(-int(alg / 0.375) // 262144)
             cu_cycles = 256.0 * out["GRBM_GUI_ACTIVE"]["avg"] / 8.0
@@ -119,5 +120,104 @@ def main():
               {k: round(v["avg"]) for k, v in out.items() if isinstance(v, dict) and k.startswith("SQ_")})
 
 
+# ------------------------------------------------------------------------------------------------ profiles/README.md
+def _num(x, nd=4):
+    return ("%." + str(nd) + "g") % x
+
+
+def kernel_stats_row(path):
+    """(kernel, calls, average us) of the dominant ipcr kernel in a rocprofv3 --stats CSV"""
+    best = None
+    with open(path, newline="") as fh:
+        for row in csv.DictReader(fh):
+            name = row.get("Name", "")
+            if "ipcr_filter" in name or "ipcr_index_filter" in name:
+                tot = float(row.get("TotalDurationNs", 0) or 0)
+                if best is None or tot > best[3]:
+                    best = (name.split("(")[0], int(row["Calls"]), float(row["AverageNs"]) / 1e3, tot)
+    return best[:3] if best else None
+
+
+def readme_text():
+    """profiles/README.md, every number read from the file its row describes (tests/test_host_logic.py checks that the
+    committed README equals this text: the prose cannot drift from the evidence)"""
+    d = os.path.join(ROOT, "profiles")
+    files = sorted(os.listdir(d))
+    tags = sorted({f.split("_")[0] for f in files if f[:1] == "r" and f[1:3].isdigit()}, reverse=True)
+    out = ["# profiles/", "",
+           "All from `gpurun` on one MI355X: `tools/profile_round.sh <tag> bench|prof` on the GPU box, then",
+           "`python tools/collect_profiles.py <tag>` here; **this file is written by `python tools/collect_profiles.py readme`**,",
+           "every figure below is read from the file named in its row (`tests/test_host_logic.py::test_profiles_readme_is_generated`",
+           "fails when the two differ).  Fractions are of the 8 TB/s HBM3E spec; one sweep of the benchmark genome reads",
+           "1.125 GB (3.0e9 bases x 0.375 B).  What the numbers mean and how they came about: DESIGN.md sections 4 and 5.", ""]
+    for tag in tags:
+        out += ["## " + tag, "", "| file | what it holds |", "|---|---|"]
+        for f in [x for x in files if x.startswith(tag + "_")]:
+            path = os.path.join(d, f)
+            row = None
+            if f.endswith("kernel_stats.csv"):
+                ks = kernel_stats_row(path)
+                if ks:
+                    gbs = ALG_BYTES / (ks[2] * 1e-6) / 1e9
+                    row = "`rocprofv3 --kernel-trace --stats`: `%s` %d calls, average %s us -> %s GB/s = %s of 8 TB/s" % (
+                        ks[0], ks[1], _num(ks[2]), _num(gbs), _num(gbs / 8000.0, 3))
+            elif f.endswith("_pmc.json"):
+                j = json.load(open(path))
+                parts = ["`rocprofv3 --pmc` passes, averages per launch of `%s`" % j.get("kernel", "?")]
+                if j.get("hbm_bytes_per_launch") and j.get("algorithmic_bytes_per_launch"):
+                    parts.append("HBM traffic %d B = %s x the algorithmic %d B" % (
+                        j["hbm_bytes_per_launch"], _num(j["hbm_bytes_per_launch"] / j["algorithmic_bytes_per_launch"]), j["algorithmic_bytes_per_launch"]))
+                dv = j.get("derived") or {}
+                for k, label in (("valu_instructions_per_row_step", "VALU instructions per row step"),
+                                 ("valu_instructions_per_base_step", "VALU instructions per 64-base step"),
+                                 ("lds_instructions_per_base_step", "LDS instructions per step"),
+                                 ("lds_busy_frac", "LDS busy fraction of the sweep"),
+                                 ("lds_bank_conflict_frac_of_busy", "bank conflicts' share of the LDS time"),
+                                 ("valu_issue_busy_frac_upper_bound", "VALU issue (upper bound)")):
+                    if dv.get(k) is not None:
+                        parts.append("%s %s" % (label, _num(dv[k])))
+                row = "; ".join(parts)
+            elif f.endswith(".json") and "_bench" in f:
+                try:
+                    j = json.loads(open(path).read().strip().splitlines()[-1])
+                except Exception:  # noqa: BLE001
+                    j = None
+                if j and "roofline" in j:
+                    r = j["roofline"]
+                    parts = ["`bench.py` line: %s %s %s, %s ms per step; `%s` %s ms per launch = **%s** of 8 TB/s" % (
+                        _num(j["value"], 5), j.get("unit", ""), "(" + j["config"]["workload"].split(":")[0] + ")" if "config" in j and "workload" in j["config"] else "",
+                        _num(j["ms_per_step"]), r.get("kernel", "?"), _num(r.get("avg_launch_ms", 0)), _num(r.get("frac", 0)))]
+                    if r.get("traffic_over_algorithmic"):
+                        parts.append("traffic measured in the run %s x algorithmic" % _num(r["traffic_over_algorithmic"]))
+                    ow = (j.get("config") or {}).get("other_workloads") or {}
+                    for k in ("c2n", "c3", "c4", "c5"):
+                        if k in ow and "sweep_ms" in ow[k]:
+                            parts.append("%s sweep %s ms = %s, step %s ms" % (k, _num(ow[k]["sweep_ms"]), _num(ow[k]["roofline_frac"], 3), _num(ow[k]["ms_per_step"])))
+                    sc = ow.get("scan_chunk") or {}
+                    if sc:
+                        parts.append("scan_chunk " + " / ".join("%s %s" % (k.replace("gbases_per_s_", "").replace("_", " "), _num(v)) for k, v in sc.items() if k.startswith("gbases_per_s")) + " Gbases/s")
+                    c5 = ow.get("c5_chunk") or {}
+                    if c5:
+                        parts.append("c5_chunk " + "; ".join("%s %s" % (k, _num(v)) for k, v in c5.items() if k.startswith("gbases_per_s") or k.startswith("probe_best_hit_us") or k.startswith("probe_rescan_ms")))
+                    ft = ow.get("fasta_to_tsv") or {}
+                    if ft:
+                        parts.append("FASTA -> TSV %s Gbases/s" % _num(ft["gbases_per_s"]))
+                    cb = j.get("cpu_baseline")
+                    if cb:
+                        parts.append("cpu_baseline %s Gbases/s on %d threads (%s)" % (_num(cb["value"]), cb["cores"], cb["kind"]))
+                    row = "; ".join(parts)
+            if row is None:
+                row = "(see the file)"
+            out.append("| `%s` | %s |" % (f, row))
+        out.append("")
+    return "\n".join(out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "readme":
+        with open(os.path.join(ROOT, "profiles", "README.md"), "w") as fh:
+            fh.write(readme_text())
+        sys.exit(0)
     main()
+    with open(os.path.join(ROOT, "profiles", "README.md"), "w") as fh:
+        fh.write(readme_text())

@@ -1,6 +1,6 @@
 // fasta_load.cpp -- ipcr_genome_add_fasta timed from a native process (the system's HIP runtime, no interpreter):
 //   fasta_load <file.fa> [repeats]
-// (development tool: tells a loader limit from a limit of the process it runs in; build: see tools/gpu_round3_m.sh)
+// (development tool: tells a loader limit from a limit of the process it runs in; build: tools/ubench/build.sh)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
