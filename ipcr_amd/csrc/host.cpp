@@ -427,8 +427,12 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
     uint8_t next_group = 0;
     // LDS the bitmaps may take (8 B per 64 keys + 2 B of rank prefix): the 16 waves of a CU keep >= 192 queue entries each
     const size_t lds_budget = 160u * 1024u - 16u * 192u * 16u - 256u;
-    size_t lds_used = 0;
+    size_t lds_used = 0, lds_reserved = 0, lds_upgrades = 0;
     auto shape_bytes = [](unsigned key_bits) { return (size_t)(key_bits <= 10 ? 16u : (1u << (key_bits - 6))) * 10u; };
+    // blocks that may take the 17th key bit, panel-wide (IPCR_INDEX_HALF_MAX; every one doubles a 10 KB bitmap and the waves'
+    // hit queues shrink by as much: with the eight shapes of a split panel four of them cost more than they save, 6.84 ms
+    // per 3 Gb against 6.29 with none)
+    int half_left = env_flag("IPCR_INDEX_HALF_BASES", true) ? (getenv("IPCR_INDEX_HALF_MAX") ? atoi(getenv("IPCR_INDEX_HALF_MAX")) : -1) : 0;
     // Two steps per lookup (jit.cpp): possible when EVERY group keys on "3 protected bases + 5 block bases" -- the panel's
     // tables are then 2^12 32-bit words per shape (18 KiB with the rank prefixes), one ds_read_b32 serves two base steps.
     bool paired = !groups.empty();
@@ -444,6 +448,19 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         }
         if (ns_all > IPCR_INDEX_MAX_SHAPES || ns_all * (2048u * 9u) > lds_budget) paired = false;
         if (paired) paired = ipcr::jit_index_pairable(ns_all, lmax - 1);
+    }
+    {   // what the groups' bitmaps take before any block is given a 17th bit: an upgrade of an early group must not eat the
+        // queue room that a later group's plain bitmaps need
+        size_t base_all = 0;
+        for (const Group &g : groups) {
+            const int t = std::min(g.t, g.lmin);
+            const int bf = (t >= g.lmin) ? 0 : (g.lmin - t) / g.nblk;
+            const bool tri = !g.noprot && k >= 1 && t >= 3 && bf >= 1;
+            const int tu = g.noprot ? 0 : (tri ? 3 : std::min(t, 8));
+            const int b = tri ? std::min(5, bf) : ((tu >= 8) ? 0 : std::min(8 - tu, bf));
+            base_all += (size_t)(b > 0 ? g.nblk : 1) * shape_bytes((unsigned)(2 * tu + 2 * b));
+        }
+        lds_reserved = base_all;
     }
     for (Group &g : groups) {
         const int t = std::min(g.t, g.lmin);
@@ -577,7 +594,7 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
             // for three 10-bit blocks) and a third fewer hits reach the drain.  The larger bitmaps leave the waves smaller
             // hit queues (round 2, two steps per entry: 1 % slower); with one queue entry per four steps the queues fill
             // half as fast and the layout wins: 5.13 -> 4.97 ms.  IPCR_INDEX_HALF_BASES=0 turns it off.
-            const bool half_bases = env_flag("IPCR_INDEX_HALF_BASES", true);
+            const bool half_bases = half_left != 0;
             const int spare = A - b * ns;
             double best = -1;
             unsigned best_mask = 0;
@@ -586,7 +603,8 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
             const uint8_t group_keep = next_group;
             for (unsigned mask = 0; mask < (half_bases ? (1u << ns) : 1u); ++mask) {
                 if (__builtin_popcount(mask) > spare) continue;
-                if (lds_used + (size_t)__builtin_popcount(mask) * (shape_bytes(17) - shape_bytes(16)) > lds_budget) continue;
+                if (half_left >= 0 && __builtin_popcount(mask) > half_left) continue;
+                if (std::max(lds_used, lds_reserved + lds_upgrades) + (size_t)__builtin_popcount(mask) * (shape_bytes(17) - shape_bytes(16)) > lds_budget) continue;
                 std::vector<int> cb(bits), cp(pos);
                 for (int j = 0; j < ns; ++j) {
                     if (mask & (1u << j)) cb[(size_t)j] = 11;
@@ -603,7 +621,7 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
                 next_group = group_keep;
             }
             for (int j = 0; j < ns; ++j) {
-                if (best_mask & (1u << j)) { bits[(size_t)j] = 11; lds_used += shape_bytes(17) - shape_bytes(16); }
+                if (best_mask & (1u << j)) { bits[(size_t)j] = 11; lds_used += shape_bytes(17) - shape_bytes(16); lds_upgrades += shape_bytes(17) - shape_bytes(16); if (half_left > 0) --half_left; }
                 if (j) pos[(size_t)j] = pos[(size_t)j - 1] + ((best_mask & (1u << (j - 1))) ? b + 1 : b);
             }
         }
@@ -1549,7 +1567,9 @@ public:
     // fn(i) for i in [0, n), on the pool's threads and the caller's; returns when all are done
     // phys >= 0: what the items write is pinned memory read by that device next -- the pool's own threads move onto its CPUs
     // (device_cpus; the caller's thread stays where its owner put it)
-    template <class F> void run(size_t n, F fn, int phys = -1) {
+    // on_idle (optional): called again and again by the CALLER's thread while the pool works -- the caller then takes no
+    // items itself (ipcr_scan_chunk sends a group of columns to the device the moment the pool has packed it)
+    template <class F> void run(size_t n, F fn, int phys = -1, const std::function<void()> *on_idle = nullptr) {
         if (n == 0) return;
         std::unique_lock<std::mutex> big(run_mu_); // one record at a time
         // Every run is an object of its own: a pool thread that wakes late still holds the run it woke for -- whose
@@ -1564,6 +1584,10 @@ public:
             gen_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
+        if (on_idle && !threads_.empty()) {
+            while (job->done.load(std::memory_order_acquire) < n) { (*on_idle)(); __builtin_ia32_pause(); }
+            return;
+        }
         work(*job);
         // (an item that has been taken is finished before `done` reaches n: fn is not called once this returns)
         for (unsigned spin = 0; job->done.load(std::memory_order_acquire) < n; ++spin) {
@@ -2761,21 +2785,41 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
                 s->h_planes_cap = dev_bytes + (dev_bytes >> 3);
                 HIPCHK(hipHostMalloc((void **)&s->h_planes, s->h_planes_cap, hipHostMallocDefault));
             }
-            const uint64_t nthreads = PackPool::get().size();
+            // ONE pool run over the items of all groups, group by group; the caller's thread does not pack: it sends group i
+            // (one conversion launch that reads the pinned planes over the link) the moment the group's last item is done, while
+            // the pool is already packing group i + 1
+            const uint64_t nthreads = std::max<uint64_t>(1, PackPool::get().size() - 1);
+            struct Item { uint64_t group, c0, nc; };
+            std::vector<Item> items;
+            std::vector<uint32_t> group_items((size_t)nsl, 0);
             for (uint64_t i = 0; i < nsl; ++i) {
                 const uint64_t c0 = i * SLC, nc = std::min<uint64_t>(SLC, cols - c0);
                 const uint64_t per = std::max<uint64_t>(32, ((nc + nthreads - 1) / nthreads + 7) / 8 * 8); // columns per item: 128 KB of bases at least
-                const uint64_t items = (nc + per - 1) / per;
-                std::vector<uint32_t> iflags((size_t)items, 0);
-                uint8_t *slab = s->h_planes + c0 * 2048ull;
-                PackPool::get().run((size_t)items, [&](size_t k) {
-                    const uint64_t a = c0 + (uint64_t)k * per;
-                    iflags[k] = pack_cols(i, slab, a, std::min<uint64_t>(per, c0 + nc - a));
-                }, slot_phys(g->device));
-                for (uint32_t f : iflags) sflags[(size_t)i] |= f;
-                st = send_slice(i, slab);
-                if (st != IPCR_OK) return st;
+                for (uint64_t a = c0; a < c0 + nc; a += per) { items.push_back({i, a, std::min<uint64_t>(per, c0 + nc - a)}); ++group_items[(size_t)i]; }
             }
+            std::vector<uint32_t> iflags(items.size(), 0);
+            std::unique_ptr<std::atomic<uint32_t>[]> group_done(new std::atomic<uint32_t>[(size_t)nsl]);
+            for (uint64_t i = 0; i < nsl; ++i) group_done[(size_t)i].store(0);
+            uint64_t sent = 0;
+            ipcr_status send_st = IPCR_OK;
+            auto send_ready = [&]() {
+                while (sent < nsl && send_st == IPCR_OK && group_done[(size_t)sent].load(std::memory_order_acquire) == group_items[(size_t)sent]) {
+                    for (size_t k = 0; k < items.size(); ++k)
+                        if (items[k].group == sent) sflags[(size_t)sent] |= iflags[k];
+                    trace("group packed", s);
+                    send_st = send_slice(sent, s->h_planes + sent * SLC * 2048ull);
+                    ++sent;
+                }
+            };
+            const std::function<void()> idle = send_ready;
+            trace("pack>", s);
+            PackPool::get().run(items.size(), [&](size_t k) {
+                const Item &it = items[k];
+                iflags[k] = pack_cols(it.group, s->h_planes + it.group * SLC * 2048ull, it.c0, it.nc);
+                group_done[(size_t)it.group].fetch_add(1, std::memory_order_release);
+            }, slot_phys(g->device), &idle);
+            send_ready();
+            if (send_st != IPCR_OK) return send_st;
         }
         uint32_t fl = 0;
         for (uint32_t f : sflags) fl |= f;

@@ -457,6 +457,59 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
         }
         return o.str();
     };
+    // The rare branch of a row (some strand of some pattern passed the block test): per pattern the exact count, where the
+    // plan has one -- that code names the window's registers, so it exists per (row slot, pattern) -- and then ONE push
+    // site for all patterns: a lane walks the patterns it still has bits for (IPCR_JIT_ONE_PUSH=0: a push per pattern, the
+    // form until round 4 -- three quarters of the generated instructions were those 196 inlined pushes: hiprtc's time is
+    // proportional to the instruction count, 16 300 -> 11 800 for C2).
+    const bool one_push = env_int("IPCR_JIT_ONE_PUSH", 1, 0, 1) != 0;
+    auto rare_code = [&](int sr0, const std::string &cs) {
+        std::ostringstream b;
+        for (size_t q = 0; q < pats.size(); ++q) {
+            const Plan &pl = plans[q];
+            size_t U = 0;
+            for (const auto &blk : pl.blocks) U += blk.size();
+            const bool exact_already = !pl.counted || pl.blocks.size() == U;
+            const bool refine = !exact_already && exact_stage;
+            if (one_push && !refine) { b << "            const u32 w" << q << " = ~f" << q << cs << ";\n"; continue; }
+            b << "            u32 w" << q << " = 0u;\n";
+            b << "            if (f" << q << cs << " != 0xFFFFFFFFu) {\n";
+            b << "              u32 f = f" << q << cs << ";\n";
+            if (refine) {
+                b << "              {\n";
+                int e = 0;
+                for (const auto &blk : pl.blocks)
+                    for (int j : blk) b << "            const u32 e" << e++ << " = " << plane_expr(pats[q].mask[j], (sr0 + j) % W, uses_n) << ";\n";
+                b << count_code((int)U, k);
+                b << "              }\n";
+            }
+            if (one_push) b << "              w" << q << " = ~f;\n";
+            else if (offs[q] == 0)
+                b << "              if (f != 0xFFFFFFFFu) push(" << pid(q) << "ull, pos, ~f, lcnt, lkey, lbits, queue, qcap, qcount, counts);\n";
+            else // the window starts offs[q] rows before the filtered part: in the previous strand (= the previous bit) when that crosses row 0
+                b << "              if (f != 0xFFFFFFFFu) { u64 wp = pos; u32 wm = ~f; if (wp >= " << offs[q] << "ull) wp -= " << offs[q]
+                  << "ull; else { wp += " << 128 - offs[q] << "ull; wm >>= 1; } if (wm) push(" << pid(q)
+                  << "ull, wp, wm, lcnt, lkey, lbits, queue, qcap, qcount, counts); }\n";
+            b << "            }\n";
+        }
+        if (one_push) {
+            b << "            u32 pm = 0u";
+            for (size_t q = 0; q < pats.size(); ++q) b << " | (w" << q << " ? " << (1u << q) << "u : 0u)";
+            b << ";\n";
+            b << "            while (pm) { // (lane-divergent: a lane walks the patterns it has surviving strands for)\n"
+                 "              const u32 q = (u32)__builtin_ctz(pm); pm &= pm - 1u;\n"
+                 "              u32 wm = w0;\n";
+            for (size_t q = 1; q < pats.size(); ++q) b << "              if (q == " << q << "u) wm = w" << q << ";\n";
+            b << "              const u32 info = PUSHTAB[q]; // pattern id | rows dropped at the window's start << 16\n"
+                 "              const u32 off = info >> 16;\n"
+                 "              u64 wp = pos;\n"
+                 "              // the window starts `off` rows before the filtered part: in the previous strand (= the previous bit) when that crosses row 0\n"
+                 "              if (off) { if (wp >= (u64)off) wp -= (u64)off; else { wp += (u64)(128u - off); wm >>= 1; } }\n"
+                 "              if (wm) push((u64)(info & 0xFFFFu), wp, wm, lcnt, lkey, lbits, queue, qcap, qcount, counts);\n"
+                 "            }\n";
+        }
+        return b.str();
+    };
     // one row step: expand the row into mismatch planes at `slot`, then (if a window ends
     // here) evaluate all patterns for the window starting LM1 rows earlier
     auto row_code = [&](int slot, char comp, const std::string &xexpr, const std::string &guard) {
@@ -482,29 +535,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
         b << "          if (__builtin_expect(all != 0xFFFFFFFFu, 0)) {\n";
         b << "            const u64 pos = posbase + (u64)(" << xexpr << " - " << LM1 << "u);\n";
         const int sr0 = ((slot - LM1) % W + W) % W;
-        for (size_t q = 0; q < pats.size(); ++q) {
-            const Plan &pl = plans[q];
-            size_t U = 0;
-            for (const auto &blk : pl.blocks) U += blk.size();
-            const bool exact_already = !pl.counted || pl.blocks.size() == U;
-            b << "            if (f" << q << " != 0xFFFFFFFFu) {\n";
-            b << "              u32 f = f" << q << ";\n";
-            if (!exact_already && exact_stage) {
-                b << "              {\n";
-                int e = 0;
-                for (const auto &blk : pl.blocks)
-                    for (int j : blk) b << "            const u32 e" << e++ << " = " << plane_expr(pats[q].mask[j], (sr0 + j) % W, uses_n) << ";\n";
-                b << count_code((int)U, k);
-                b << "              }\n";
-            }
-            if (offs[q] == 0)
-                b << "              if (f != 0xFFFFFFFFu) push(" << pid(q) << "ull, pos, ~f, lcnt, lkey, lbits, queue, qcap, qcount, counts);\n";
-            else // the window starts offs[q] rows before the filtered part: in the previous strand (= the previous bit) when that crosses row 0
-                b << "              if (f != 0xFFFFFFFFu) { u64 wp = pos; u32 wm = ~f; if (wp >= " << offs[q] << "ull) wp -= " << offs[q]
-                  << "ull; else { wp += " << 128 - offs[q] << "ull; wm >>= 1; } if (wm) push(" << pid(q)
-                  << "ull, wp, wm, lcnt, lkey, lbits, queue, qcap, qcount, counts); }\n";
-            b << "            }\n";
-        }
+        b << rare_code(sr0, "");
         b << "          }\n        }\n      }\n";
         return b.str();
     };
@@ -532,29 +563,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
         b << "          if (all" << cs << " != 0xFFFFFFFFu) {\n";
         b << "            const u64 pos = posbase + (u64)(" << xexpr << " - " << LM1 << "u);\n";
         const int sr0 = ((slot - LM1) % W + W) % W;
-        for (size_t q = 0; q < pats.size(); ++q) {
-            const Plan &pl = plans[q];
-            size_t U = 0;
-            for (const auto &blk : pl.blocks) U += blk.size();
-            const bool exact_already = !pl.counted || pl.blocks.size() == U;
-            b << "            if (f" << q << cs << " != 0xFFFFFFFFu) {\n";
-            b << "              u32 f = f" << q << cs << ";\n";
-            if (!exact_already && exact_stage) {
-                b << "              {\n";
-                int e = 0;
-                for (const auto &blk : pl.blocks)
-                    for (int j : blk) b << "            const u32 e" << e++ << " = " << plane_expr(pats[q].mask[j], (sr0 + j) % W, uses_n) << ";\n";
-                b << count_code((int)U, k);
-                b << "              }\n";
-            }
-            if (offs[q] == 0)
-                b << "              if (f != 0xFFFFFFFFu) push(" << pid(q) << "ull, pos, ~f, lcnt, lkey, lbits, queue, qcap, qcount, counts);\n";
-            else
-                b << "              if (f != 0xFFFFFFFFu) { u64 wp = pos; u32 wm = ~f; if (wp >= " << offs[q] << "ull) wp -= " << offs[q]
-                  << "ull; else { wp += " << 128 - offs[q] << "ull; wm >>= 1; } if (wm) push(" << pid(q)
-                  << "ull, wp, wm, lcnt, lkey, lbits, queue, qcap, qcount, counts); }\n";
-            b << "            }\n";
-        }
+        b << rare_code(sr0, cs);
         b << "          }\n";
         return b.str();
     };
@@ -791,6 +800,9 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     s << "};\n__device__ const u32 PINFO[NPAT * 4u] = {"; // len, seed_off, seed_len, global_id
     for (size_t q = 0; q < full_pats.size(); ++q)
         s << (q ? "," : "") << full_pats[q].len << "u," << full_pats[q].seed_off << "u," << full_pats[q].seed_len << "u," << full_pats[q].global_id << "u";
+    s << "};\n";
+    s << "__device__ const u32 PUSHTAB[NPAT] = {"; // the push's view of a pattern: its index in the panel's device table | rows its filter window starts late << 16
+    for (size_t q = 0; q < pats.size(); ++q) s << (q ? "," : "") << (pid(q) | ((unsigned)offs[q] << 16)) << "u";
     s << "};\n";
     s << "#define CAND_CAP " << CAND_CAP << "u\n";
     s << "// IPCR_WAVES_PER_GROUP " << WPG << "\n";
@@ -1131,7 +1143,9 @@ bool compile_group_uncached(const std::string &src, const std::string &arch, std
         return false;
     }
     const std::string archopt = "--offload-arch=" + arch;
-    const char *opts[] = {archopt.c_str(), "-O3", "-fno-slp-vectorize", "-fno-vectorize"}; // nothing to vectorise: 15 % of the compile time
+    // -O2: the generated code is straight-line explicit instructions -- measured on the C2 / C3 sources: the same instruction
+    // count and registers as -O3 (16 328 against 16 338, 203 VGPRs), 7-12 % less compile time; nothing to vectorise: 15 %
+    const char *opts[] = {archopt.c_str(), "-O2", "-fno-slp-vectorize", "-fno-vectorize"};
     const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
@@ -1561,7 +1575,7 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "    const u32* __restrict__ block_rec, u32 nrec, u32 check_rst, hitrec* __restrict__ hits, u64 hcap, u64* __restrict__ counts,\n"
          "    u64* __restrict__ next_counts, u64* __restrict__ next_qcount, u64* __restrict__ pub, hitrec* __restrict__ pub_hits, u32 pre,\n"
          "    u32* __restrict__ pub_seq, u32 seq) {\n"
-         "  __shared__ u32 lds[((LDS_WORDS + 3u) & ~3u) + " << IPCR_INDEX_WAVES << "u * QCAP * 4u]; // static: every LDS address is a compile-time offset\n"
+         "  __shared__ u32 __attribute__((aligned(16))) lds[((LDS_WORDS + 3u) & ~3u) + " << IPCR_INDEX_WAVES << "u * QCAP * 4u]; // static: every LDS address is a compile-time offset\n"
          "  __shared__ u32 wg_cand; // windows this workgroup's exact checks passed (fused form)\n"
          "  if (threadIdx.x == 0u) wg_cand = 0u;\n"
          "  // the counters alternate between two sets; workgroup 0 clears the set the NEXT scan will use\n"
@@ -1571,7 +1585,9 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
          "  }\n"
          "  const fuse fu = {rst, pats, rec_start, rec_len, block_rec, nrec, check_rst, hits, hcap, counts, pub_hits, pre, seq};\n"
          "  u32 ncand = 0u;\n"
-         "  for (u32 i = threadIdx.x; i < TAB_WORD0; i += blockDim.x) lds[i] = lds_image[i];\n"
+         "  // the image into LDS, 16 bytes per lane and load (TAB_WORD0 is a multiple of 4; a chunk's launch is one unit per wave: the\n"
+         "  // staging is a fifth of its life)\n"
+         "  for (u32 i = threadIdx.x; i < TAB_WORD0 / 4u; i += blockDim.x) reinterpret_cast<v4*>(lds)[i] = reinterpret_cast<const v4*>(lds_image)[i];\n"
          "  if (threadIdx.x < 8u) lds[TAB_WORD0 + threadIdx.x] = reinterpret_cast<const u32*>(BITTAB)[threadIdx.x];\n"
          "  __syncthreads();\n"
          "  const u64* T64 = reinterpret_cast<const u64*>(lds);\n"

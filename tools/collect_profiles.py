@@ -13,7 +13,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = {"c2": "ipcr_filter", "c2n": "ipcr_filter", "c3": "ipcr_filter", "c4": "ipcr_index_filter"}
+KERNEL = {"c2": "ipcr_filter", "c2n": "ipcr_filter", "c3": "ipcr_filter", "c4": "ipcr_index_filter", "c4n": "ipcr_index_filter"}
 ALG_BYTES = 1_125_000_000   # 3.0e9 bases x 0.375 B: what one sweep of the benchmark genome reads
 
 
@@ -35,7 +35,7 @@ def counters(dirname, kernel):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     line = open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]
@@ -88,7 +88,7 @@ def main():
                 "valu_issue_busy_frac_upper_bound": round(out["SQ_INSTS_VALU"]["avg"] * 4.0 / (4.0 * cu_cycles), 3),
                 "hbm_bytes_over_algorithmic": round(out["hbm_bytes_per_launch"] / alg, 4) if "hbm_bytes_per_launch" in out else None,
             }
-        if w == "c4" and all(k in out for k in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")):
+        if w in ("c4", "c4n") and all(k in out for k in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")):
             # the index kernel is not HBM-bound: say what binds it, from the counters themselves.  One wave-level base step =
             # 64 bases (lane = strand, no tail rows): the genome of the profiled run / 64 (its size is in the bench line's
             # algorithmic bytes: 0.375 bytes per base)

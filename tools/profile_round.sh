@@ -1,13 +1,13 @@
 #!/bin/bash
 # Collects the evidence profiles/ holds for one round, on the GPU box:
-#   gpurun --timeout 1150 -- 'bash tools/profile_round.sh r03 bench'; gpurun --timeout 1150 -- 'bash tools/profile_round.sh r03 prof'
+#   gpurun --timeout 1150 -- 'bash tools/profile_round.sh r04 bench'; gpurun --timeout 1150 -- 'bash tools/profile_round.sh r04 prof "c2 c2n c3"'; ... prof "c4 c4n"
 # then, back in the container:  python tools/collect_profiles.py r03
 # Separate passes: bench line (all workloads + cpu_baseline), then per workload a rocprofv3 kernel trace + stats and
 # one --pmc pass per counter set (never mixed with other trace domains).
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 stage=${2:-all}   # bench | prof | all (a gpurun call is limited to 20 minutes: two calls for one round)
-wls=${3:-"c2 c3 c4"}   # workloads of the prof stage (a kernel that has not changed keeps its profile)
+wls=${3:-"c2 c2n c3 c4 c4n"}   # workloads of the prof stage (a kernel that has not changed keeps its profile)
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
@@ -23,7 +23,7 @@ fi
 [ $stage = bench ] && { echo done; exit 0; }
 for w in $wls; do
   steps=400; warm=50; psteps=4
-  if [ $w = c4 ]; then steps=20; warm=3; psteps=3; fi
+  case $w in c4*) steps=20; warm=3; psteps=3;; esac
   args="--workload $w --no-cpu-baseline --no-others --no-traffic"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_$w" -- python3 bench.py $args --steps $steps --warmup $warm > "$out/stats_$w.log" 2>&1 || { tail -5 "$out/stats_$w.log"; exit 1; }
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch_$w" -- python3 bench.py $args --steps $psteps --warmup 1 > "$out/pmc_fetch_$w.log" 2>&1 || { tail -5 "$out/pmc_fetch_$w.log"; exit 1; }
