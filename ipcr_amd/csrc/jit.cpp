@@ -500,8 +500,11 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
                  "              const u32 q = (u32)__builtin_ctz(pm); pm &= pm - 1u;\n"
                  "              u32 wm = w0;\n";
             for (size_t q = 1; q < pats.size(); ++q) b << "              if (q == " << q << "u) wm = w" << q << ";\n";
-            b << "              const u32 info = PUSHTAB[q]; // pattern id | rows dropped at the window's start << 16\n"
-                 "              const u32 off = info >> 16;\n"
+            // pattern id | rows dropped at the window's start << 16: constants, NOT a table in memory -- a load inside this loop makes
+            // the compiler lose count of the tile loads in flight where the rare path joins the main one (vmcnt(3) for vmcnt(6))
+            b << "              u32 info = " << (pid(0) | ((unsigned)offs[0] << 16)) << "u;\n";
+            for (size_t q = 1; q < pats.size(); ++q) b << "              if (q == " << q << "u) info = " << (pid(q) | ((unsigned)offs[q] << 16)) << "u;\n";
+            b << "              const u32 off = info >> 16;\n"
                  "              u64 wp = pos;\n"
                  "              // the window starts `off` rows before the filtered part: in the previous strand (= the previous bit) when that crosses row 0\n"
                  "              if (off) { if (wp >= (u64)off) wp -= (u64)off; else { wp += (u64)(128u - off); wm >>= 1; } }\n"
@@ -800,9 +803,6 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     s << "};\n__device__ const u32 PINFO[NPAT * 4u] = {"; // len, seed_off, seed_len, global_id
     for (size_t q = 0; q < full_pats.size(); ++q)
         s << (q ? "," : "") << full_pats[q].len << "u," << full_pats[q].seed_off << "u," << full_pats[q].seed_len << "u," << full_pats[q].global_id << "u";
-    s << "};\n";
-    s << "__device__ const u32 PUSHTAB[NPAT] = {"; // the push's view of a pattern: its index in the panel's device table | rows its filter window starts late << 16
-    for (size_t q = 0; q < pats.size(); ++q) s << (q ? "," : "") << (pid(q) | ((unsigned)offs[q] << 16)) << "u";
     s << "};\n";
     s << "#define CAND_CAP " << CAND_CAP << "u\n";
     s << "// IPCR_WAVES_PER_GROUP " << WPG << "\n";

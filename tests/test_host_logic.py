@@ -218,8 +218,8 @@ def test_filter_source_is_generated_for_the_headline_panels():
     long_p = "ACGT" * 9  # 36 nt: filtered on the 20 positions next to the protected end; survivors go to the stand-alone verifier
     lsrc = engine.New(engine.Config(MaxMM=1, TerminalWindow=3)).CompilePanel([primer.Pair("l", long_p, long_p)]).filter_source(0)
     assert "ipcr_filter" in lsrc and "#define LIST_CAP 0u" in lsrc and "len 20, 3 protected" in lsrc
-    # right-protected pattern: its window starts 16 rows before the filtered part (the push's table says so: pattern id | 16 << 16)
-    assert "PUSHTAB[NPAT] = {%du,%du}" % (0 | (16 << 16), 1) in lsrc and "wp -= (u64)off" in lsrc
+    # right-protected pattern: its window starts 16 rows before the filtered part (the push's constant says so: pattern id | 16 << 16)
+    assert "u32 info = %du;" % (0 | (16 << 16)) in lsrc and "if (q == 1u) info = 1u;" in lsrc and "wp -= (u64)off" in lsrc
     too_long = "ACGT" * 33           # 132 nt: beyond IPCR_MAX_PRIMER_LEN
     with pytest.raises(_lib.IpcrError):
         engine.New(engine.Config(MaxMM=1)).CompilePanel([primer.Pair("l", too_long, too_long)])
