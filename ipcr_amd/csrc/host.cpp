@@ -2331,82 +2331,108 @@ void orientation_matches(const ipcr_panel *p, int pair, int w, bool rec_reset, c
         std::stable_partition(out.begin(), out.end(), [](const MatchRef &m) { return (m.h->pattern >> 31) == 0; });
 }
 
-ipcr_status join_sorted_hits(const ipcr_panel *p, ipcr_scratch *s, const uint64_t *rec_len, const uint8_t *rec_flags,
-                             uint32_t nrec, ipcr_emit_fn emit, void *user) {
-    JoinCtx c{p, &s->products, emit, user};
-    const std::vector<ipcr_hit> &H = s->hits;
+// the products of ONE record: hits [i, j) of H (sorted by pattern, position), all of record `rec`; false when emit aborted
+bool join_one_record(const ipcr_panel *p, const std::vector<ipcr_hit> &H, size_t i, size_t j, uint32_t rec, int64_t seqlen, uint8_t fl, JoinCtx &c) {
     const size_t npairs = p->id.size();
-    std::vector<MatchRef> m[4];
-    std::vector<MatchRef> sorted_right;
-    std::vector<uint32_t> touched;
+    static thread_local std::vector<MatchRef> m[4];
+    static thread_local std::vector<MatchRef> sorted_right;
+    static thread_local std::vector<uint32_t> touched;
     static thread_local std::vector<uint32_t> pat_begin;
     const size_t ndefs = p->defs.size();
-    size_t i = 0;
-    while (i < H.size()) {
+    const bool rec_reset = fl & 1u;
+    const int mode = (!p->modes_equal && (fl & 2u)) ? 1 : 0;
+    // hits of this record are sorted by pattern: where each pattern's run begins (one pass instead of four
+    // binary searches per touched pair -- a 1024-pair panel touches ~1000 pairs per record)
+    pat_begin.resize(ndefs + 1);
+    {
+        size_t q = i;
+        for (size_t gdx = 0; gdx <= ndefs; ++gdx) {
+            while (q < j && (H[q].pattern & 0x7FFFFFFFu) < gdx) ++q;
+            pat_begin[gdx] = (uint32_t)q;
+        }
+    }
+    // only pairs that scan a pattern with hits in this record can yield products
+    touched.clear();
+    for (size_t h = i; h < j;) {
+        const uint32_t gid = H[h].pattern & 0x7FFFFFFFu;
+        if (gid < p->users[mode].size())
+            touched.insert(touched.end(), p->users[mode][gid].begin(), p->users[mode][gid].end());
+        while (h < j && (H[h].pattern & 0x7FFFFFFFu) == gid) ++h;
+    }
+    std::sort(touched.begin(), touched.end());
+    touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+    for (const uint32_t pi32 : touched) {
+        const size_t pi = pi32;
+        if (pi >= npairs) continue;
+        bool any = false;
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t gid = p->slot[pi][(size_t)w][(size_t)mode];
+            const ipcr_hit *b = H.data() + pat_begin[gid], *e = H.data() + pat_begin[gid + 1];
+            orientation_matches(p, (int)pi, w, rec_reset, b, e, m[w]);
+            any |= !m[w].empty();
+        }
+        if (!any) continue;
+        int64_t minL = p->minp[pi], maxL = p->maxp[pi]; // engine.go:113-120
+        if (minL == 0) minL = p->cfg.min_len;
+        if (maxL == 0) maxL = p->cfg.max_len;
+        const int alen = (int)p->fwd[pi].size(), blen = (int)p->rev[pi].size();
+        auto by_pos = [](const MatchRef &a, const MatchRef &b) { return a.pos < b.pos; };
+        // "forward": A x rc(B)   (rc list sorted by position unless it already is, engine.go:70-85,144)
+        const std::vector<MatchRef> *right = &m[3];
+        if (!std::is_sorted(m[3].begin(), m[3].end(), by_pos)) {
+            sorted_right = m[3];
+            std::stable_sort(sorted_right.begin(), sorted_right.end(), by_pos);
+            right = &sorted_right;
+        }
+        if (!m[0].empty() && !right->empty() &&
+            !join_direction(c, (int)pi, rec, seqlen, minL, maxL, m[0], *right, blen, 0)) return false;
+        // "revcomp": B x rc(A)   (engine.go:275)
+        right = &m[2];
+        if (!std::is_sorted(m[2].begin(), m[2].end(), by_pos)) {
+            sorted_right = m[2];
+            std::stable_sort(sorted_right.begin(), sorted_right.end(), by_pos);
+            right = &sorted_right;
+        }
+        if (!m[1].empty() && !right->empty() &&
+            !join_direction(c, (int)pi, rec, seqlen, minL, maxL, m[1], *right, alen, 1)) return false;
+    }
+    return true;
+}
+
+ipcr_status join_sorted_hits(const ipcr_panel *p, ipcr_scratch *s, const uint64_t *rec_len, const uint8_t *rec_flags,
+                             uint32_t nrec, ipcr_emit_fn emit, void *user) {
+    const std::vector<ipcr_hit> &H = s->hits;
+    struct Range { size_t i, j; uint32_t rec; };
+    std::vector<Range> ranges;
+    for (size_t i = 0; i < H.size();) {
         const uint32_t rec = H[i].record;
         size_t j = i;
         while (j < H.size() && H[j].record == rec) ++j;
         if (rec >= nrec) return fail(IPCR_ERR_INVALID, "hit refers to record %u of %u", rec, nrec);
-        const uint8_t fl = rec_flags ? rec_flags[rec] : 0;
-        const bool rec_reset = fl & 1u;
-        const int mode = (!p->modes_equal && (fl & 2u)) ? 1 : 0;
-        // hits of this record are sorted by pattern: where each pattern's run begins (one pass instead of four
-        // binary searches per touched pair -- a 1024-pair panel touches ~1000 pairs per record)
-        pat_begin.resize(ndefs + 1);
-        {
-            size_t q = i;
-            for (size_t gdx = 0; gdx <= ndefs; ++gdx) {
-                while (q < j && (H[q].pattern & 0x7FFFFFFFu) < gdx) ++q;
-                pat_begin[gdx] = (uint32_t)q;
-            }
-        }
-        // only pairs that scan a pattern with hits in this record can yield products
-        touched.clear();
-        for (size_t h = i; h < j;) {
-            const uint32_t gid = H[h].pattern & 0x7FFFFFFFu;
-            if (gid < p->users[mode].size())
-                touched.insert(touched.end(), p->users[mode][gid].begin(), p->users[mode][gid].end());
-            while (h < j && (H[h].pattern & 0x7FFFFFFFu) == gid) ++h;
-        }
-        std::sort(touched.begin(), touched.end());
-        touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
-        for (const uint32_t pi32 : touched) {
-            const size_t pi = pi32;
-            if (pi >= npairs) continue;
-            bool any = false;
-            for (int w = 0; w < 4; ++w) {
-                const uint32_t gid = p->slot[pi][(size_t)w][(size_t)mode];
-                const ipcr_hit *b = H.data() + pat_begin[gid], *e = H.data() + pat_begin[gid + 1];
-                orientation_matches(p, (int)pi, w, rec_reset, b, e, m[w]);
-                any |= !m[w].empty();
-            }
-            if (!any) continue;
-            int64_t minL = p->minp[pi], maxL = p->maxp[pi]; // engine.go:113-120
-            if (minL == 0) minL = p->cfg.min_len;
-            if (maxL == 0) maxL = p->cfg.max_len;
-            const int alen = (int)p->fwd[pi].size(), blen = (int)p->rev[pi].size();
-            const int64_t seqlen = (int64_t)rec_len[rec];
-            auto by_pos = [](const MatchRef &a, const MatchRef &b) { return a.pos < b.pos; };
-            // "forward": A x rc(B)   (rc list sorted by position unless it already is, engine.go:70-85,144)
-            const std::vector<MatchRef> *right = &m[3];
-            if (!std::is_sorted(m[3].begin(), m[3].end(), by_pos)) {
-                sorted_right = m[3];
-                std::stable_sort(sorted_right.begin(), sorted_right.end(), by_pos);
-                right = &sorted_right;
-            }
-            if (!m[0].empty() && !right->empty() &&
-                !join_direction(c, (int)pi, rec, seqlen, minL, maxL, m[0], *right, blen, 0)) return fail(IPCR_ERR_ABORTED, "emit callback aborted the scan");
-            // "revcomp": B x rc(A)   (engine.go:275)
-            right = &m[2];
-            if (!std::is_sorted(m[2].begin(), m[2].end(), by_pos)) {
-                sorted_right = m[2];
-                std::stable_sort(sorted_right.begin(), sorted_right.end(), by_pos);
-                right = &sorted_right;
-            }
-            if (!m[1].empty() && !right->empty() &&
-                !join_direction(c, (int)pi, rec, seqlen, minL, maxL, m[1], *right, alen, 1)) return fail(IPCR_ERR_ABORTED, "emit callback aborted the scan");
-        }
+        ranges.push_back({i, j, rec});
         i = j;
+    }
+    // Records are independent (core/engine/compiled.go:162-267 is called per record), products come out record by record: a
+    // large hit list (a 1024-row panel at k = 3: 365 000 hits, 15 ms of match lists and binary searches on one thread) is joined
+    // by the process's pool, every record into a list of its own, and the lists are handed out in record order.
+    const bool par_env = env_flag("IPCR_JOIN_PARALLEL", true); // (read per call: the tests compare the two forms in one process)
+    if (par_env && ranges.size() > 1 && H.size() >= 32768 && PackPool::get().size() > 1) {
+        std::vector<std::vector<ipcr_product>> outs(ranges.size());
+        PackPool::get().run(ranges.size(), [&](size_t r) {
+            JoinCtx c{p, &outs[r], nullptr, nullptr};
+            const Range &g = ranges[r];
+            (void)join_one_record(p, H, g.i, g.j, g.rec, (int64_t)rec_len[g.rec], rec_flags ? rec_flags[g.rec] : 0, c);
+        });
+        for (const auto &o : outs)
+            for (const ipcr_product &pr : o) {
+                s->products.push_back(pr);
+                if (emit && emit(&s->products.back(), user) != 0) return fail(IPCR_ERR_ABORTED, "emit callback aborted the scan");
+            }
+    } else {
+        JoinCtx c{p, &s->products, emit, user};
+        for (const Range &g : ranges)
+            if (!join_one_record(p, H, g.i, g.j, g.rec, (int64_t)rec_len[g.rec], rec_flags ? rec_flags[g.rec] : 0, c))
+                return fail(IPCR_ERR_ABORTED, "emit callback aborted the scan");
     }
     s->stats.products = s->products.size();
     return IPCR_OK;
@@ -2731,24 +2757,34 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         // columns is packed by the process's pool, every thread a run of its columns into the group's planes, and sent as
         // ONE conversion launch that reads the pinned planes over the link itself; the next group is packed under it.  Two
         // groups for a 4 Mb chunk (pack 0 | pack 1 under transfer 0 | transfer 1, sweep), 8 Mb groups for a chromosome.
-        const uint64_t SLC = pooled ? std::min<uint64_t>(2048, std::max<uint64_t>(128, ((cols + 1) / 2 + 63) / 64 * 64))
-                                    : std::min<uint64_t>(1024, std::max<uint64_t>(128, (cols + split_env - 1) / std::max<uint64_t>(split_env, 1)));
-        const uint64_t nsl = (cols + SLC - 1) / SLC;
+        const uint64_t SLC = pooled ? 2048 : std::min<uint64_t>(1024, std::max<uint64_t>(128, (cols + split_env - 1) / std::max<uint64_t>(split_env, 1)));
+        // first columns of the slices (+ the end).  The lone worker's chunk of up to 8 Mb goes as TWO groups, three quarters and
+        // a quarter: what follows the packing on the device -- the last group's way over the link, its conversion -- is then
+        // short, and the first group's transfer hides under the packing of the second
+        std::vector<uint64_t> gs;
+        if (pooled && cols <= 2048 && cols >= 256) {
+            const uint64_t first = std::min<uint64_t>(cols - 64, (cols * 3 / 4 + 7) / 8 * 8);
+            gs = {0, first, cols};
+        } else {
+            for (uint64_t c = 0; c < cols; c += SLC) gs.push_back(c);
+            gs.push_back(cols);
+        }
+        const uint64_t nsl = gs.size() - 1;
         std::vector<uint32_t> sflags((size_t)nsl, 0);
-        // columns [c0, c0 + nc) of slice i (whose first column is i * SLC and which holds snc columns) into the slice's planes
+        // columns [c0, c0 + nc) of slice i (whose first column is gs[i] and which holds snc columns) into the slice's planes
         // at `slab`: [lo | hi | inv | rst], snc x 128 words each
         auto pack_cols = [&](uint64_t i, uint8_t *slab, uint64_t c0, uint64_t nc) -> uint32_t {
-            const uint64_t s0 = i * SLC, snc = std::min<uint64_t>(SLC, cols - s0), W = snc * 128u, b0 = c0 * IPCR_COLUMN_BASES;
+            const uint64_t s0 = gs[(size_t)i], snc = gs[(size_t)i + 1] - s0, W = snc * 128u, b0 = c0 * IPCR_COLUMN_BASES;
             const uint64_t nb = b0 < len ? std::min<uint64_t>(len - b0, nc * IPCR_COLUMN_BASES) : 0;
             uint32_t *w = reinterpret_cast<uint32_t *>(slab) + (c0 - s0) * 128u;
             return ipcr::pack_linear(seq + (nb ? b0 : 0), nb, nc * IPCR_COLUMN_BASES, w, w + W, w + 2 * W, w + 3 * W);
         };
         auto pack_slice = [&](uint64_t i, uint8_t *slab) { // planes of slice i: [lo | hi | inv | rst], nc x 128 words each
-            const uint64_t c0 = i * SLC, nc = std::min<uint64_t>(SLC, cols - c0);
+            const uint64_t c0 = gs[(size_t)i], nc = gs[(size_t)i + 1] - c0;
             sflags[(size_t)i] = pack_cols(i, slab, c0, nc);
         };
         auto send_slice = [&](uint64_t i, const uint8_t *slab) -> ipcr_status { // the rst plane crosses the link only if the slice holds lower case
-            const uint64_t c0 = i * SLC, nc = std::min<uint64_t>(SLC, cols - c0), W = nc * 128u;
+            const uint64_t c0 = gs[(size_t)i], nc = gs[(size_t)i + 1] - c0, W = nc * 128u;
             const bool lower = (sflags[(size_t)i] & 2u) != 0;
             uint8_t *d = g->staging + c0 * 2048ull;
             // A lone caller: the conversion kernel reads the pinned slab over the link itself, no copy operation in between
@@ -2793,7 +2829,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
             std::vector<Item> items;
             std::vector<uint32_t> group_items((size_t)nsl, 0);
             for (uint64_t i = 0; i < nsl; ++i) {
-                const uint64_t c0 = i * SLC, nc = std::min<uint64_t>(SLC, cols - c0);
+                const uint64_t c0 = gs[(size_t)i], nc = gs[(size_t)i + 1] - c0;
                 const uint64_t per = std::max<uint64_t>(32, ((nc + nthreads - 1) / nthreads + 7) / 8 * 8); // columns per item: 128 KB of bases at least
                 for (uint64_t a = c0; a < c0 + nc; a += per) { items.push_back({i, a, std::min<uint64_t>(per, c0 + nc - a)}); ++group_items[(size_t)i]; }
             }
@@ -2807,7 +2843,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
                     for (size_t k = 0; k < items.size(); ++k)
                         if (items[k].group == sent) sflags[(size_t)sent] |= iflags[k];
                     trace("group packed", s);
-                    send_st = send_slice(sent, s->h_planes + sent * SLC * 2048ull);
+                    send_st = send_slice(sent, s->h_planes + gs[(size_t)sent] * 2048ull);
                     ++sent;
                 }
             };
@@ -2815,7 +2851,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
             trace("pack>", s);
             PackPool::get().run(items.size(), [&](size_t k) {
                 const Item &it = items[k];
-                iflags[k] = pack_cols(it.group, s->h_planes + it.group * SLC * 2048ull, it.c0, it.nc);
+                iflags[k] = pack_cols(it.group, s->h_planes + gs[(size_t)it.group] * 2048ull, it.c0, it.nc);
                 group_done[(size_t)it.group].fetch_add(1, std::memory_order_release);
             }, slot_phys(g->device), &idle);
             send_ready();

@@ -668,6 +668,46 @@ def test_probe_on_the_chunk_path_wrap_product(hip):
     cp.close()
 
 
+def test_probe_amplicons_beyond_the_lds_stage(hip):
+    """--max-length above the probe kernel's LDS stage (16 384 bases): the batched rescan falls back to gather + rescan
+    from device memory (two launches, the same tagged hand-over), on the chunk path and over a resident genome; a batch
+    that mixes a long amplicon with short ones goes the same way as a whole."""
+    P = hip.primer.Pair
+    fwd, rev = "ACGTTGCATGCAAGCTTGCA", "GGCCTTAAGGCCATATCCGG"
+    rc = O.revcomp(rev)
+    n = 120_000
+    s = bytearray(O.bench_dna(n, 0x1ab5))
+    s[1000:1020] = fwd.encode()
+    s[1000 + 30_000 - 20:1000 + 30_000] = rc          # a 30 000-base product
+    s[60_000:60_020] = fwd.encode()
+    s[60_300 - 20:60_300] = rc                         # and a 300-base one
+    seq = bytes(s)
+    pairs = [P("long", fwd, rev, 0, 0)]
+    cfg = hip.engine.Config(MaxMM=1, TerminalWindow=3, MaxLen=40_000, HitCap=10000, SeedLen=12)
+    eng = hip.engine.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    sc = eng.NewSimulationScratch(cp)
+    got = eng.SimulateCompiledWithScratch("r", seq, cp, sc)
+    want = O.simulate_batch(ocfg(cfg), seq, opairs(pairs))
+    assert [g.sig() for g in got] == [w.sig() for w in want]
+    assert any(p.Length == 30_000 for p in got) and any(p.Length == 300 for p in got)
+    deep = seq[1000 + 20_000:1000 + 20_021].decode()   # a probe site 20 000 bases into the long amplicon
+    for prb, k in [(deep, 0), (O.revcomp(deep).decode(), 1), (seq[60_100:60_121].decode(), 0), ("TTTTTTTTTTTTTTTTTTTTTTTT", 0)]:
+        out = sc.probe_products(prb, k)
+        for h, p in zip(out, got):
+            assert _probe_tuple(h) == _want_probe(seq[p.Start:p.End], prb, k), (prb, k, p)
+    g = hip.engine.Genome(n + 8192, 1)
+    g.add_record("r", seq)
+    got_g = eng.ScanGenome(g, cp, sc)
+    assert [p.sig() for p in got_g] == [w.sig() for w in want]
+    out = (hip.lib.ProbeHit * len(got_g))()
+    hip.lib.check(hip.lib.lib().ipcr_probe_products(sc._h, g._h, deep.encode(), 0, out, len(got_g)))
+    for i, p in enumerate(got_g):
+        assert _probe_tuple(out[i]) == _want_probe(seq[p.Start:p.End], deep, 0)
+    g.close()
+    cp.close()
+
+
 def test_probe_best_hit_from_many_threads(hip):
     """ipcr_probe_best_hit is what a collector calls per product next to the workers' sweeps: no allocation, no
     null-stream work, one pinned block and stream per concurrent caller.  Eight threads, amplicons of 5..20 000 bases

@@ -662,3 +662,50 @@ def test_profiles_readme_is_generated():
     want = mod.readme_text()
     have = open(os.path.join(root, "profiles", "README.md")).read()
     assert have == want, "profiles/README.md is stale: run `python tools/collect_profiles.py readme`"
+
+
+def test_large_hit_lists_are_joined_per_record_in_parallel(monkeypatch):
+    """join_sorted_hits hands a hit list of 32 768 records and more to the process's pool, one record per item, and emits
+    the records' product lists in record order: the same products, in the same order, as the one-thread join
+    (IPCR_JOIN_PARALLEL=0), emit callbacks and their abort included."""
+    import ctypes as C
+    from ipcr_amd.dist import HIT_DTYPE
+    rng = np.random.default_rng(12)
+    pairs = [primer.Pair("p%d" % i, "ACGTACGTACGTACGTAC"[: 16 + i % 3], "TTGGCCAATTGGCCAATTGG"[: 17 + i % 4], 0, 0) for i in range(6)]
+    cfg = engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=400, HitCap=50, SeedLen=12)
+    cp = engine.New(cfg).CompilePanel(pairs)
+    nrec, per = 40, 1200
+    hits = np.zeros(nrec * per, dtype=HIT_DTYPE)
+    pats = cp.scanned_patterns(0)
+    hits["record"] = np.repeat(np.arange(nrec, dtype=np.uint32), per)
+    hits["pattern"] = rng.choice(pats, nrec * per).astype(np.uint32)
+    hits["pos"] = rng.integers(0, 20_000, nrec * per)
+    hits["mm0"] = rng.choice([0, 0, 1 << 9, (1 << 5) | (1 << 11)], nrec * per).astype(np.uint64)
+    rng.shuffle(hits)
+    assert len(hits) >= 32768
+    lens, flags = [30_000] * nrec, [0] * nrec
+    sc = engine.SimulationScratch(cp, host_only=True)
+    monkeypatch.setenv("IPCR_JOIN_PARALLEL", "0")
+    want = [(p.SequenceID,) + p.sig() for p in engine.New(cfg).JoinHits(cp, sc, hits, lens, flags)]
+    monkeypatch.setenv("IPCR_JOIN_PARALLEL", "1")
+    got = [(p.SequenceID,) + p.sig() for p in engine.New(cfg).JoinHits(cp, sc, hits, lens, flags)]
+    assert got == want and len(want) > 1000
+    assert [w[0] for w in want] == sorted((w[0] for w in want), key=int)       # record order
+    # emit: called in the same order, and a non-zero return stops the hand-out
+    L = _lib.lib()
+    seen = []
+    stop_at = 137
+
+    @_lib.EMIT_FN
+    def cb(pp, _u):
+        seen.append((pp.contents.record, pp.contents.pair, pp.contents.start, pp.contents.end, pp.contents.type))
+        return 1 if len(seen) == stop_at else 0
+
+    lens_c = (C.c_uint64 * nrec)(*lens)
+    fl_c = (C.c_uint8 * nrec)(*flags)
+    st = L.ipcr_join_hits(cp._h, sc._h, C.c_void_p(hits.ctypes.data), len(hits), lens_c, fl_c, nrec, C.cast(cb, C.c_void_p), None)
+    assert st == _lib.ERR_ABORTED and len(seen) == stop_at
+    first = [(int(w[0]), w[2], w[3]) for w in want[:stop_at]]
+    assert [(r, s, e) for (r, _p, s, e, _t) in seen] == first
+    sc.close()
+    cp.close()

@@ -33,6 +33,21 @@ for w in $wls; do
   rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc_grbm_$w" -- python3 bench.py $args --steps $psteps --warmup 1 > "$out/pmc_grbm_$w.log" 2>&1 || { tail -5 "$out/pmc_grbm_$w.log"; exit 1; }
   echo "profiled $w"
 done
-# keep the merge-back small: the per-dispatch traces are not needed, the summaries are
-find "$out" -name "*kernel_trace.csv" -size +4M -delete
+# keep the merge-back small (gpurun merges at most 64 MiB): of the per-dispatch counter files only the rows of our kernels and
+# the three columns collect_profiles.py reads; the per-dispatch traces are not needed, the summaries are
+python3 - "$out" <<'PY'
+import csv, glob, os, sys
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    rows = []
+    with open(f, newline="") as fh:
+        for row in csv.DictReader(fh):
+            if "ipcr_" in row.get("Kernel_Name", ""):
+                rows.append({k: row[k] for k in ("Kernel_Name", "Counter_Name", "Counter_Value")})
+    with open(f, "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=["Kernel_Name", "Counter_Name", "Counter_Value"])
+        w.writeheader()
+        w.writerows(rows)
+PY
+find "$out" -name "*kernel_trace.csv" -delete
+find "$out" -name "*agent_info.csv" -delete
 echo done
