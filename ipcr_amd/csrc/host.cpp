@@ -1679,10 +1679,60 @@ void dedup_sorted_hits(std::vector<ipcr_hit> &v) {
     v.resize(w);
 }
 
+// order inside one (record, pattern): by position; records of one window (the seed index may report it through several keys)
+// are identical, but the order is total all the same, so that every form of the sort keeps the same one of them
+inline bool hit_pos_less(const ipcr_hit &x, const ipcr_hit &y) {
+    if (x.pos != y.pos) return x.pos < y.pos;
+    if (x.mm_mask[0] != y.mm_mask[0]) return x.mm_mask[0] < y.mm_mask[0];
+    if (x.mm_mask[1] != y.mm_mask[1]) return x.mm_mask[1] < y.mm_mask[1];
+    return x.pattern < y.pattern;
+}
+
+// A large list (a 1024-row panel at k = 3: 365 000 hits, 6 ms on one thread) is sorted by the process's pool: the input is
+// cut into slices, every slice is counted by record, the slices are scattered into the records' ranges (each slice has its
+// own place in every range), and the records are sorted -- (pattern, position) -- side by side.  Same result as sort_hits.
+bool sort_hits_parallel(const std::vector<ipcr_hit> &in, std::vector<ipcr_hit> &out, uint32_t nrec, uint32_t npat) {
+    const size_t n = in.size();
+    const size_t T = std::min<size_t>(PackPool::get().size(), 16);
+    if (T < 2 || nrec < 2 || nrec > 65536) return false;
+    for (const ipcr_hit &h : in)
+        if (h.record >= nrec || (h.pattern & 0x7FFFFFFFu) >= npat) return false; // (the one-thread form handles stray records)
+    std::vector<uint32_t> cnt(T * (size_t)nrec, 0);
+    const size_t per = (n + T - 1) / T;
+    PackPool::get().run(T, [&](size_t t) {
+        uint32_t *c = cnt.data() + t * nrec;
+        for (size_t i = t * per, e = std::min(n, (t + 1) * per); i < e; ++i) ++c[in[i].record];
+    });
+    std::vector<uint64_t> rec_begin((size_t)nrec + 1, 0);
+    std::vector<uint64_t> place(T * (size_t)nrec, 0); // where slice t's hits of record r go
+    uint64_t run = 0;
+    for (uint32_t r = 0; r < nrec; ++r) {
+        rec_begin[r] = run;
+        for (size_t t = 0; t < T; ++t) { place[t * nrec + r] = run; run += cnt[t * nrec + r]; }
+    }
+    rec_begin[nrec] = run;
+    out.resize(n);
+    PackPool::get().run(T, [&](size_t t) {
+        uint64_t *pl = place.data() + t * nrec;
+        for (size_t i = t * per, e = std::min(n, (t + 1) * per); i < e; ++i) out[pl[in[i].record]++] = in[i];
+    });
+    PackPool::get().run(nrec, [&](size_t r) {
+        std::sort(out.begin() + (long)rec_begin[r], out.begin() + (long)rec_begin[r + 1], [](const ipcr_hit &x, const ipcr_hit &y) {
+            const uint32_t px = x.pattern & 0x7FFFFFFFu, py = y.pattern & 0x7FFFFFFFu;
+            return px != py ? px < py : hit_pos_less(x, y);
+        });
+    });
+    return true;
+}
+
 // Hits come back in atomic-append order; the join wants them grouped by (record, pattern) and
 // ascending in position.  Counting sort over the (record, pattern) buckets, then each small
 // bucket by position -- O(n) instead of a comparison sort of 32-byte records.
 void sort_hits(const std::vector<ipcr_hit> &in, std::vector<ipcr_hit> &out, uint32_t nrec, uint32_t npat) {
+    if (in.size() >= 65536 && env_flag("IPCR_JOIN_PARALLEL", true) && sort_hits_parallel(in, out, nrec, npat)) {
+        dedup_sorted_hits(out);
+        return;
+    }
     static thread_local std::vector<uint32_t> cnt, cur;
     const size_t n = in.size();
     out.resize(n);
@@ -1705,7 +1755,7 @@ void sort_hits(const std::vector<ipcr_hit> &in, std::vector<ipcr_hit> &out, uint
     for (const ipcr_hit &h : in) out[cur[(uint64_t)h.record * npat + (h.pattern & 0x7FFFFFFFu)]++] = h;
     for (uint64_t i = 0; i < nb; ++i) {
         const uint32_t b = cnt[i], e = cnt[i + 1];
-        if (e - b > 1) std::sort(out.begin() + b, out.begin() + e, [](const ipcr_hit &x, const ipcr_hit &y) { return x.pos < y.pos; });
+        if (e - b > 1) std::sort(out.begin() + b, out.begin() + e, hit_pos_less);
     }
     dedup_sorted_hits(out);
 }

@@ -674,7 +674,7 @@ def test_large_hit_lists_are_joined_per_record_in_parallel(monkeypatch):
     pairs = [primer.Pair("p%d" % i, "ACGTACGTACGTACGTAC"[: 16 + i % 3], "TTGGCCAATTGGCCAATTGG"[: 17 + i % 4], 0, 0) for i in range(6)]
     cfg = engine.Config(MaxMM=2, TerminalWindow=3, MaxLen=400, HitCap=50, SeedLen=12)
     cp = engine.New(cfg).CompilePanel(pairs)
-    nrec, per = 40, 1200
+    nrec, per = 40, 1800        # 72 000 hits: the parallel sort (>= 65 536) and the parallel join (>= 32 768)
     hits = np.zeros(nrec * per, dtype=HIT_DTYPE)
     pats = cp.scanned_patterns(0)
     hits["record"] = np.repeat(np.arange(nrec, dtype=np.uint32), per)
@@ -682,7 +682,7 @@ def test_large_hit_lists_are_joined_per_record_in_parallel(monkeypatch):
     hits["pos"] = rng.integers(0, 20_000, nrec * per)
     hits["mm0"] = rng.choice([0, 0, 1 << 9, (1 << 5) | (1 << 11)], nrec * per).astype(np.uint64)
     rng.shuffle(hits)
-    assert len(hits) >= 32768
+    assert len(hits) >= 65536
     lens, flags = [30_000] * nrec, [0] * nrec
     sc = engine.SimulationScratch(cp, host_only=True)
     monkeypatch.setenv("IPCR_JOIN_PARALLEL", "0")
