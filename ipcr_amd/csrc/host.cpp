@@ -1716,11 +1716,28 @@ bool sort_hits_parallel(const std::vector<ipcr_hit> &in, std::vector<ipcr_hit> &
         uint64_t *pl = place.data() + t * nrec;
         for (size_t i = t * per, e = std::min(n, (t + 1) * per); i < e; ++i) out[pl[in[i].record]++] = in[i];
     });
-    PackPool::get().run(nrec, [&](size_t r) {
-        std::sort(out.begin() + (long)rec_begin[r], out.begin() + (long)rec_begin[r + 1], [](const ipcr_hit &x, const ipcr_hit &y) {
-            const uint32_t px = x.pattern & 0x7FFFFFFFu, py = y.pattern & 0x7FFFFFFFu;
-            return px != py ? px < py : hit_pos_less(x, y);
-        });
+    PackPool::get().run(nrec, [&](size_t r) { // one record: counting sort by pattern, then every small bucket by position
+        static thread_local std::vector<uint32_t> pc;
+        static thread_local std::vector<ipcr_hit> tmp;
+        ipcr_hit *base = out.data() + rec_begin[r];
+        const size_t m = (size_t)(rec_begin[r + 1] - rec_begin[r]);
+        if (m < 2) return;
+        pc.assign((size_t)npat + 1, 0);
+        for (size_t i = 0; i < m; ++i) ++pc[(base[i].pattern & 0x7FFFFFFFu) + 1];
+        for (uint32_t q = 0; q < npat; ++q) pc[q + 1] += pc[q];
+        tmp.resize(m);
+        {
+            std::vector<uint32_t> &cur = pc; // (consumed as the write cursor; the bucket ends are the next bucket's start afterwards)
+            for (size_t i = 0; i < m; ++i) tmp[cur[base[i].pattern & 0x7FFFFFFFu]++] = base[i];
+        }
+        // pc[q] is now the END of bucket q = the start of bucket q + 1
+        size_t b = 0;
+        for (uint32_t q = 0; q < npat; ++q) {
+            const size_t e = pc[q];
+            if (e - b > 1) std::sort(tmp.begin() + (long)b, tmp.begin() + (long)e, hit_pos_less);
+            b = e;
+        }
+        memcpy(base, tmp.data(), m * sizeof(ipcr_hit));
     });
     return true;
 }

@@ -1984,7 +1984,7 @@ __device__ __forceinline__ u32 check_entry(u32 idx, u64 km, u32 bad, int erow, u
                     const std::string kn = "key" + std::to_string(si) + "_" + K, wn = "w" + std::to_string(si) + "_" + K;
                     pa << "        const u32 " << kn << " = " << key << ";\n";
                     pa << "        const u32 " << wn << " = lds[" << off64[(size_t)si] * 2u << "u + (" << kn << " >> 5)];\n";
-                    q = "((" + wn + " >> (" + kn + " & 31u)) & 1u)";
+                    q = "__builtin_amdgcn_ubfe(" + wn + ", " + kn + ", 1u)"; // v_bfe_u32 takes the low five bits of the offset itself: one instruction for and, shift, and
                 }
                 if (first_pack) pb << "        u32 hm" << K << " = " << q << ";\n";
                 else // (kept apart: the compiler would otherwise pull the shift in front of the mask and spend a second mask on it)

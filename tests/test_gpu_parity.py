@@ -815,6 +815,59 @@ def test_config_c4_large_panel_index(hip, monkeypatch, half_bases, two_step):
     g.close()
 
 
+@pytest.mark.parametrize("k,tw", [(2, 3), (1, 5), (3, 3), (2, 1)])
+def test_index_split_keys_for_orientations_scanned_without_their_window(hip, monkeypatch, k, tw):
+    """Every ipcr_scan_chunk call (and every record of a genome that holds an N) scans the rc orientations WITHOUT their 5'
+    window -- the reference caps them before the window filter (core/engine/compiled.go:249-256) -- and the seed index files
+    such a pattern under two families of keys: window exact + one of k + 1 blocks, or a mismatch in the window + one of k
+    longer blocks (host.cpp: build_index, SPLIT).  A 256-row panel through the chunk path, records with and without N,
+    sites with their mismatches inside and outside the window, against the oracle -- with the split and with the old
+    keys (IPCR_INDEX_SPLIT=0): the same products either way, and the split really is in the generated kernel."""
+    from ipcr_amd import workloads
+    rng = random.Random(1000 * k + tw)
+    pairs = workloads.c4_pairs(256)
+    rows = pairs[:256]
+    cfg = hip.engine.Config(MaxMM=k, TerminalWindow=tw, MaxLen=2000, HitCap=10000, SeedLen=12)
+    seqs = []
+    for with_n in (True, False):
+        s = bytearray(O.bench_dna(300_000, 0x5eed3000 + k + 16 * tw + int(with_n)))
+        for t in range(60):
+            p = rows[rng.randrange(len(rows))]
+            a = 2000 + t * 4800 + rng.randrange(500)
+            f = list(p.Forward)
+            rc = list(O.revcomp(p.Reverse).decode())
+            for _ in range(rng.choice([0, 0, 1, k])):        # mismatches anywhere in the forward site: inside its 3' window too
+                j = rng.randrange(len(f)); f[j] = O.different_base(f[j])
+            for _ in range(rng.choice([0, 1, k])):           # ... and in the rc site: inside its 5' window too (raw matches the host filters)
+                j = rng.randrange(len(rc)); rc[j] = O.different_base(rc[j])
+            s[a:a + len(f)] = "".join(f).encode()
+            s[a + 180 - len(rc):a + 180] = "".join(rc).encode()
+        if with_n:
+            for _ in range(12):
+                q = rng.randrange(len(s) - 50); s[q:q + rng.randint(1, 30)] = b"N" * 30
+        seqs.append(bytes(s[:300_000]))
+    results = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("IPCR_INDEX_SPLIT", split)
+        eng = hip.engine.New(cfg)
+        cp = eng.CompilePanel(pairs)
+        sc = eng.NewSimulationScratch(cp)
+        head = cp.filter_source(3).splitlines()[0]
+        nshapes = int(head.split("),")[1].split("key shapes")[0]) if ")," in head else int(head.split(", ")[1].split(" key shapes")[0])
+        out = []
+        for seq in seqs:
+            got = eng.SimulateCompiledWithScratch("chunk", seq, cp, sc)
+            assert sc.stats().kernel_kind == 3
+            want = O.simulate_batch(ocfg(cfg), seq, opairs(pairs))
+            assert [g.sig() for g in got] == [w.sig() for w in want] and len(want) >= 10, (k, tw, split)
+            out.append([g.sig() for g in got])
+        results[split] = (nshapes, out)
+        sc.close(); cp.close()
+    assert results["1"][1] == results["0"][1]
+    # right group k + 1 shapes; rc group: (k + 1) + k with the split, k + 1 without
+    assert results["1"][0] == 3 * k + 2 and results["0"][0] == 2 * (k + 1), results
+
+
 def test_buffer_regrowth_on_dense_hits(hip):
     """millions of hits: the device hit buffer (1 Mi records) and candidate queue must regrow and the
     scan re-run transparently; HitCap still keeps only the first matches per orientation"""
