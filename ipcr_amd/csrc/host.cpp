@@ -407,7 +407,7 @@ void build_index(const ipcr_panel &p, PatternSet &set) {
         // one of k + 1 blocks", the protected orientation's own 16-17-bit keys -- or it has a mismatch among them -- then
         // <= k - 1 lie behind: one of only k blocks, twice as long (8 bases at k = 2), is exact.  The pattern is filed under
         // both families; the exact check accepts any window with <= k mismatches, so the union is exactly the raw matches.
-        static const bool split_on = env_flag("IPCR_INDEX_SPLIT", true);
+        const bool split_on = env_flag("IPCR_INDEX_SPLIT", true); // (read per panel: the tests compare the two in one process)
         const int twp = std::min(p.tw, L);
         if (split_on && d.left && d.tw_dev == 0 && k >= 1 && twp >= 1 && L - twp >= k + 1) {
             join(std::min(twp, 32), k + 1, false);
