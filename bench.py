@@ -262,8 +262,8 @@ def workload_spec(name, engine, workloads):
                     text="C2 on the +N genome (SURVEY 8d: 0.1 % of positions in runs of 1-1000 N): every record holds reset bytes, "
                          "so with k > 0 and a hit cap the reference takes FindMatches for every orientation "
                          "(core/engine/compiled.go:185-190,238-258) and caps the rc orientations before their 5' window filter -- "
-                         "the device scans those two patterns unprotected and the host filters (the kernel every "
-                         "ipcr_scan_chunk call and every real genome runs)")
+                         "the device scans those two patterns unprotected and the host filters (the kernel every record and "
+                         "every chunk with a non-ACGT byte runs, and every chunk the device packs)")
     if name == "c3":
         return dict(cfg=E.Config(MaxMM=3, TerminalWindow=3, MinLen=0, MaxLen=2000, HitCap=10000, SeedLen=12, Circular=True),
                     pairs=workloads.c3_pairs(), genome="c3", kernel="ipcr_filter",
@@ -570,7 +570,7 @@ def roofline_of(res, traffic_file=None):
 
 
 # ----------------------------------------------------------------------------------------------- other measurements
-def scan_chunk_rates(args, local=0, record_bases=125_000_000, chunk=4_000_000, probe=False):
+def scan_chunk_rates(args, local=0, record_bases=125_000_000, chunk=4_000_000, probe=False, with_n=False, panel_rows=0, workers=None):
     """Drop-in entry point (what the cgo shim binds): ipcr_scan_chunk on host ASCII under the reference's worker model
     (internal/pipeline/pipeline.go:60-125): W threads, one scratch each, one shared panel, rolling chunks of one
     record from a queue.  PCIe-inclusive; reported next to the raw pinned H2D rate; never `value`.  Measured by the
@@ -585,10 +585,16 @@ def scan_chunk_rates(args, local=0, record_bases=125_000_000, chunk=4_000_000, p
     n = min(record_bases, args.record_len)
     # probe: BASELINE C5 over the drop-in call -- every worker annotates its chunk's products (ipcr_probe_scratch_products),
     # a collector thread calls ipcr_probe_best_hit per amplicon beside them (chunk_workers.cpp: --probe)
-    argv = [exe, "--probe", str(n), str(chunk), "16"] if probe else [exe, str(n), str(chunk), "1", "8", "16"]
-    r = subprocess.run(argv, capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local)),
-                                GPU_MAX_HW_QUEUES=os.environ.get("IPCR_CHUNK_HW_QUEUES", "4")))   # see chunk_workers.cpp
+    # with_n: 0.1 % of the record's positions are N (every chunk then holds a reset byte and takes the pattern set without the rc
+    # orientations' window; a clean chunk packed by the host keeps it).  panel_rows: an n-row multiplex panel (k=2, window 3)
+    # instead of C2's -- the seed-index kernel under the worker pool
+    argv = [exe] + (["--probe"] if probe else []) + (["--with-n"] if with_n else []) + [str(n), str(chunk)]
+    argv += [str(w) for w in (workers or ((16,) if probe else (1, 8, 16)))]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local)),
+               GPU_MAX_HW_QUEUES=os.environ.get("IPCR_CHUNK_HW_QUEUES", "4"))   # see chunk_workers.cpp
+    if panel_rows:
+        env["CHUNK_PANEL_ROWS"] = str(panel_rows)
+    r = subprocess.run(argv, capture_output=True, text=True, timeout=600, env=env)
     if r.returncode != 0:
         raise SystemExit("chunk_workers failed (%d): %s" % (r.returncode, r.stderr[-2000:]))
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -822,11 +828,17 @@ def main() -> None:
         import subprocess
         raise SystemExit(subprocess.call(cmd, env=dict(os.environ)))
 
-    chunk_rates, c5_chunk, all_dev_rates, traffic = None, None, None, None
+    chunk_rates, c5_chunk, all_dev_rates, traffic, chunk_panel = None, None, None, None, None
     single = "RANK" not in os.environ and args.gpus <= 1 and not os.environ.get("IPCR_EXCHANGE_SELFTEST")
     if not args.no_others and single:
         chunk_rates = scan_chunk_rates(args)      # child process, before anything here has initialised HIP
         c5_chunk = scan_chunk_rates(args, probe=True)
+        # the drop-in call under C4's panel (1024 rows: seed-index kernel), 16 workers: clean chunks and chunks that hold N
+        chunk_panel = {"panel_rows": 1024, "workers": 16, "chunk_bases": 4_000_000}
+        for key, wn in (("clean", False), ("with_n", True)):
+            cr = scan_chunk_rates(args, with_n=wn, panel_rows=1024, workers=(16,))
+            chunk_panel["gbases_per_s_" + key] = cr["gbases_per_s_16_workers"]
+            chunk_panel["calls_unwindowed_" + key] = cr["calls_unwindowed_16_workers"]
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if not args.no_traffic and not under_profiler and single and args.records == RECORDS and args.record_len == RECORD_LEN:
         traffic = measure_traffic(args.workload, "ipcr_index_filter" if args.workload in ("c4", "c4n") else "ipcr_filter")
@@ -883,6 +895,8 @@ def main() -> None:
                 r["prods"] = None
             if chunk_rates is not None:
                 others["scan_chunk"] = chunk_rates
+            if chunk_panel is not None:
+                others["scan_chunk_c4_panel"] = chunk_panel
             if c5_chunk is not None:    # ipcr-probe over ipcr_scan_chunk + ipcr_probe_scratch_products, 16 workers; ipcr_probe_best_hit latency
                 others["c5_chunk"] = c5_chunk
             others["fasta_to_tsv"] = fasta_to_tsv(ctx)

@@ -124,7 +124,9 @@ typedef struct {
     double hostpack_ms;            /* ipcr_scan_chunk: host time packing the caller's ASCII into bit planes (0: the bases went over the link as ASCII) */
     uint32_t segmented;            /* 1: a capped scan with more raw matches than the hit buffer may take was repeated in position
                                       order, range of blocks by range of blocks, keeping what HitCap can use (host.cpp: scan_segmented) */
-    uint32_t reserved0;
+    uint32_t pattern_set;          /* 1: the rc orientations were scanned without their 5' window and the host applied it after the
+                                      cap (core/engine/compiled.go:249-256: what a record with a non-ACGT byte takes -- and a chunk whose
+                                      bytes the device packs, where that is not known at launch); 0: every orientation kept its window */
 } ipcr_scan_stats;
 
 typedef struct ipcr_panel ipcr_panel;     /* engine.CompiledPanel + device tables */

@@ -68,7 +68,7 @@ class ScanStats(C.Structure):
                 ("wait_ms", C.c_double), ("sort_ms", C.c_double), ("join_ms", C.c_double),
                 ("handover_refetched", C.c_uint64), ("handover_checked", C.c_uint64),
                 ("handover_check_diffs", C.c_uint64), ("leftover_patterns", C.c_uint32), ("leftover_kernels", C.c_uint32),
-                ("hostpack_ms", C.c_double), ("segmented", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("hostpack_ms", C.c_double), ("segmented", C.c_uint32), ("pattern_set", C.c_uint32)]
 
 
 EMIT_FN = C.CFUNCTYPE(C.c_int, C.POINTER(Product), C.c_void_p)

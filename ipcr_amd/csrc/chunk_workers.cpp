@@ -53,17 +53,18 @@ static std::string bench_primer(unsigned idx, int n = 20) { // core/engine/perfo
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static int usage(const char *why) {
-    fprintf(stderr, "chunk_workers: %s\nusage: chunk_workers [--devices d0,d1,...] [--bind] [record_bases] [chunk_bases > 2000] [workers >= 1 ...]\n", why);
+    fprintf(stderr, "chunk_workers: %s\nusage: chunk_workers [--devices d0,d1,...] [--bind] [--probe] [--with-n] [record_bases] [chunk_bases > 2000] [workers >= 1 ...]\n", why);
     return 2;
 }
 
 int main(int argc, char **argv) {
     std::vector<int> devices;
     std::vector<const char *> pos;
-    bool bind = false, probe_on = false;
+    bool bind = false, probe_on = false, with_n = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--bind")) bind = true;
         else if (!strcmp(argv[i], "--probe")) probe_on = true;
+        else if (!strcmp(argv[i], "--with-n")) with_n = true;
         else if (!strcmp(argv[i], "--devices")) {
             if (i + 1 >= argc) return usage("--devices needs a list");
             for (const char *q = argv[++i]; *q;) {
@@ -113,6 +114,21 @@ int main(int argc, char **argv) {
         memcpy(&seq[a], fwd.data(), 20);
         memcpy(&seq[a + 160], rc_rev.data(), 20);
         if (probe_on) memcpy(&seq[a + 60], PROBE, sizeof PROBE - 1);
+    }
+    // --with-n: 0.1 % of the positions become 'N' in runs of 1..1000 (bench.py: n_runs; SURVEY 8d "+N") -- every chunk then
+    // holds a reset byte and takes the pattern set in which the rc orientations are scanned without their window
+    // (core/engine/compiled.go:185-190, 249-256).  Without it a chunk is clean, and the host's packer knows that.
+    uint64_t n_positions = 0;
+    if (with_n) {
+        uint32_t r = 0x2545F491u;
+        auto next = [&r] { r ^= r << 13; r ^= r >> 17; r ^= r << 5; return r; };
+        while (n_positions < n / 1000 && n > 1002) {
+            const uint64_t ln = 1 + next() % 1000, at = next() % (n - ln);
+            const uint64_t rel = at % 1000000; // the planted amplicons lie at 500000 + 1 Mb * i, 180 bases each: keep clear of them
+            if (rel + ln > 499000 && rel < 501000) continue;
+            memset(&seq[at], 'N', ln);
+            n_positions += ln;
+        }
     }
 
     // the link: pinned host -> device, 256 MiB, best of 4
@@ -200,8 +216,8 @@ int main(int argc, char **argv) {
     std::vector<std::vector<uint8_t>> jobs;
     for (uint64_t s : starts) jobs.emplace_back(seq.begin() + (long)s, seq.begin() + (long)std::min(n, s + chunk));
 
-    printf("{\"pinned_h2d_GBps\": %.1f, \"record_bases\": %llu, \"chunk_bases\": %llu, \"chunks\": %zu, \"planted\": %llu, \"devices\": [",
-           h2d, (unsigned long long)n, (unsigned long long)chunk, jobs.size(), (unsigned long long)planted);
+    printf("{\"pinned_h2d_GBps\": %.1f, \"record_bases\": %llu, \"chunk_bases\": %llu, \"chunks\": %zu, \"planted\": %llu, \"n_positions\": %llu, \"devices\": [",
+           h2d, (unsigned long long)n, (unsigned long long)chunk, jobs.size(), (unsigned long long)planted, (unsigned long long)n_positions);
     for (size_t i = 0; i < devices.size(); ++i) printf("%s%d", i ? ", " : "", devices[i]);
     printf("], \"hw_queues\": %d", atoi(getenv("GPU_MAX_HW_QUEUES")));
     int rc = 0;
@@ -219,7 +235,7 @@ int main(int argc, char **argv) {
         // the pool lives as long as the run, as the reference's worker goroutines do: the threads start once
         // and meet at a barrier before every timed pass (best of three: a thread's first HIP call falls into the first)
         std::atomic<size_t> next{0};
-        std::atomic<long long> nprod{0}, nannot{0}, probe_ns{0}, ns[4] = {{0}, {0}, {0}, {0}};
+        std::atomic<long long> nprod{0}, nannot{0}, probe_ns{0}, nset1{0}, ns[4] = {{0}, {0}, {0}, {0}};
         std::atomic<int> failed{0}, at_gate{0}, finished{0}, pass_no{-1};
         std::atomic<int> bound{0};
         auto work = [&](ipcr_scratch *sc) {
@@ -255,6 +271,7 @@ int main(int argc, char **argv) {
                         ns[1].fetch_add((long long)(stt.enqueue_ms * 1e6));
                         ns[2].fetch_add((long long)(stt.wait_ms * 1e6));
                         ns[3].fetch_add((long long)((stt.sort_ms + stt.join_ms) * 1e6));
+                        if (stt.pattern_set) nset1.fetch_add(1);
                     }
                 }
                 finished.fetch_add(1);
@@ -282,7 +299,7 @@ int main(int argc, char **argv) {
         long long products = -1, annotated = 0;
         for (int pass = 0; pass < PASSES; ++pass) {
             while (at_gate.load() < (pass + 1) * W) std::this_thread::yield(); // everyone is at the gate
-            next.store(0); nprod.store(0); nannot.store(0); probe_ns.store(0);
+            next.store(0); nprod.store(0); nannot.store(0); probe_ns.store(0); nset1.store(0);
             for (auto &x : ns) x.store(0);
             const double t0 = now();
             pass_no.store(pass, std::memory_order_release);
@@ -311,6 +328,8 @@ int main(int argc, char **argv) {
         // per call: the rest of `call` is the copy into device memory (through pinned slices under a pool) and the pack enqueue
         printf(", \"call_ms_%d_worker%s\": {\"call\": %.3f, \"enqueue\": %.3f, \"wait\": %.3f, \"sort_join\": %.3f}", W, W == 1 ? "" : "s",
                call_ms[0], call_ms[1], call_ms[2], call_ms[3]);
+        // calls that scanned the rc orientations without their window (a reset byte in the chunk, or the device packed it)
+        printf(", \"calls_unwindowed_%d_worker%s\": %.3f", W, W == 1 ? "" : "s", (double)nset1.load() / (double)total);
         if (probe_on) printf(", \"probe_rescan_ms_per_call_%d_worker%s\": %.4f", W, W == 1 ? "" : "s", probe_call_ms);
         if (probe_on && W == workers.back())
             printf(", \"probe\": \"%s\", \"probe_annotated_per_pass\": %lld, \"probe_best_hit_us_under_%d_workers\": %.2f, \"probe_best_hit_calls\": %lld", PROBE, annotated, W,

@@ -1989,7 +1989,9 @@ ipcr_status scan_launch(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
 }
 
 // first half of a scan: everything up to (and including) the enqueue; returns without waiting
-ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g, bool chunk = false) {
+// chunk_reset (chunk path): 1 = the chunk holds a reset byte, 0 = it holds none (the host's packer has seen every byte),
+// -1 = not known yet (the pack kernel finds out on the device)
+ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g, bool chunk = false, int chunk_reset = -1) {
     ipcr_scratch::Pending &pd = s->pend;
     if (pd.active) return fail(IPCR_ERR_INVALID, "a scan is already in flight on this scratch (ipcr_scan_genome_end not called)");
     pd.t0 = std::chrono::steady_clock::now();
@@ -2001,15 +2003,19 @@ ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g, b
     memset(&s->stats, 0, sizeof s->stats);
     s->stats.pack_ms = pack_ms_keep;
     trace("enqueue>", s);
-    // chunk path: nothing is waited for before the sweep is enqueued.  Whether the record holds a reset byte is
-    // only known afterwards, so it is scanned the way a genome with such records is (rc patterns unprotected,
-    // the host applies the 5' window): right for both kinds of record, as in a resident genome that mixes them
+    // chunk path: nothing is waited for before the sweep is enqueued.  Where the device packs the bases, whether the
+    // record holds a reset byte is only known afterwards, so it is scanned the way a genome with such records is (rc
+    // patterns unprotected, the host applies the 5' window): right for both kinds of record, as in a resident genome that
+    // mixes them.  Where the HOST has packed them it knows, and a chunk without one is scanned like a genome without
+    // one -- the pattern set in which every orientation keeps its window (a 1024-row panel: 4.2 ms per 3 Gb against 6.0)
     ipcr_status st = chunk ? genome_finalize_async(g) : genome_finalize(g);
     if (st != IPCR_OK) return st;
     trace("finalized", s);
     s->last_rec_len = g->rec_len;
     s->last_rec_start = g->rec_start;
-    pd.mode = chunk ? (p->modes_equal ? 0 : 1) : ((!p->modes_equal && genome_any_reset(g)) ? 1 : 0);
+    const bool clean_chunks = !chunk || env_flag("IPCR_CHUNK_CLEAN_MODE", true); // (per call, for the same reason as IPCR_CHUNK_HOSTPACK)
+    const bool any_reset = chunk ? (chunk_reset != 0 || !clean_chunks) : genome_any_reset(g);
+    pd.mode = (!p->modes_equal && any_reset) ? 1 : 0;
     st = panel_upload(p, pd.mode, s->device, &s->sdev[pd.mode]);
     if (st != IPCR_OK) return st;
     const PatternSet &set = p->set[pd.mode];
@@ -2017,7 +2023,8 @@ ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g, b
     pd.nblocks = (g->next_col + 63) / 64;
     pd.block0 = 0;
     pd.segment = false;
-    pd.check_rst = (chunk || genome_any_reset(g)) ? 1u : 0u;
+    pd.check_rst = any_reset ? 1u : 0u;
+    s->stats.pattern_set = (uint32_t)pd.mode;
     s->stats.bases = g->total_bases;
     s->stats.tile_bytes = pd.nblocks * IPCR_BLOCK_PLANE_WORDS * 4ull;
     s->stats.n_patterns = (int32_t)set.ids.size();
@@ -2802,7 +2809,8 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
     // (the process's pack pool shares the slices).  (b) As ASCII: a single worker with a small chunk -- the runtime's
     // pageable copy pins the caller's pages in place and runs at the link rate, faster than one core packs.
     // IPCR_CHUNK_HOSTPACK=0/1 forces.
-    static const int hp_env = getenv("IPCR_CHUNK_HOSTPACK") ? atoi(getenv("IPCR_CHUNK_HOSTPACK")) : -1;
+    const char *hp_str = getenv("IPCR_CHUNK_HOSTPACK"); // (read per call: the tests run both forms in one process)
+    const int hp_env = hp_str ? atoi(hp_str) : -1;
     const bool hostpack = hp_env >= 0 ? hp_env != 0 : (ipcr::pack_linear_is_simd() && (live > 1 || (len >= (1ull << 20) && PackPool::get().size() > 1) || len >= (16ull << 20)));
     if (hostpack) {
         const auto th0 = std::chrono::steady_clock::now();
@@ -2975,7 +2983,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
     if (st != IPCR_OK) return st;
     }
     const double hostpack_keep = s->stats.hostpack_ms; // (scan_enqueue starts the statistics afresh)
-    st = scan_enqueue(p, s, g, true);
+    st = scan_enqueue(p, s, g, true, hostpack ? (int)(*pinned_flag & 1u) : -1);
     if (st == IPCR_OK) st = scan_collect(p, s, g);
     if (st != IPCR_OK) return st;
     drain.armed = false; // the scan has been collected: the stream has passed everything this call queued
@@ -2988,7 +2996,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
     }
     g->flags.assign(1, (uint8_t)(pinned_seq(s)[4] & 1u));
     g->flags_valid = true;
-    const uint8_t fl = (uint8_t)((g->flags[0] & 1u) | (p->modes_equal ? 0u : 2u));
+    const uint8_t fl = (uint8_t)((g->flags[0] & 1u) | (s->pend.mode == 1 ? 2u : 0u));
     st = join_sorted_hits(p, s, g->rec_len.data(), &fl, 1, emit, user);
     s->last_was_chunk = st == IPCR_OK; // the products' amplicons lie in s->chunk until the next scan (ipcr_probe_scratch_products)
     s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -284,6 +284,46 @@ def test_hit_cap_quirks(hip):
                 check(hip, cfg, seq, [P("q", "ACGTTG", "TGCAAC"), P("r", "CGTT", "GCAA")])
 
 
+def test_host_packed_chunks_take_the_pattern_set_their_bytes_ask_for(hip, monkeypatch):
+    """A chunk the HOST packs is scanned knowing whether it holds a reset byte: without one every orientation keeps its
+    window on the device (what the reference's seeded path does, compiled.go:185-258), with one the rc orientations are
+    scanned raw and the host applies the window after the cap (compiled.go:249-256).  A chunk the device packs takes the
+    second form whatever it holds.  The cap quirks, the halo case and random panels under the host's packer, vs the oracle;
+    and which form ran is read back from the statistics."""
+    from ipcr_amd import workloads
+    E = hip.engine
+    monkeypatch.setenv("IPCR_CHUNK_HOSTPACK", "1")
+    test_hit_cap_quirks(hip)
+    test_halo_case(hip)
+    test_random_differential(hip, True, 1)
+    test_random_differential(hip, False, 2)
+    pairs = workloads.c2_pairs()
+    cfg = E.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12)
+    eng = E.New(cfg)
+    cp = eng.CompilePanel(pairs)
+    sc = eng.NewSimulationScratch(cp)
+    rng = random.Random(31)
+    seq = rand_case(rng, 300_000, with_junk=False)
+    for a in (1000, 150_000, 299_000):
+        plant(rng, seq, pairs[0].Forward, a, 1)
+        plant(rng, seq, O.revcomp(pairs[0].Reverse).decode(), a + 160, 1)    # (the pair takes products of 128..212)
+    clean = "".join(seq).encode()
+    dirty = clean[:70_000] + b"N" + clean[70_001:]
+    lower = clean[:70_000] + b"acgt" + clean[70_004:]        # lower case is not a reset byte (hostpack.cpp: flag bit 1)
+    for name, b, env, want_set in (("clean", clean, "1", 0), ("dirty", dirty, "1", 1), ("lower", lower, "1", 0),
+                                   ("device-packed", clean, "0", 1), ("clean", clean, "1", 0)):
+        monkeypatch.setenv("IPCR_CHUNK_HOSTPACK", env)
+        got = [p.sig() for p in eng.SimulateCompiledWithScratch("s", b, cp, sc)]
+        want = [w.sig() for w in O.simulate_batch(ocfg(cfg), b, opairs(pairs))]
+        assert got == want and len(want) >= 3, name
+        assert sc.stats().pattern_set == want_set, name
+    monkeypatch.setenv("IPCR_CHUNK_CLEAN_MODE", "0")           # the knob that puts round 3's behaviour back
+    eng.SimulateCompiledWithScratch("s", clean, cp, sc)
+    assert sc.stats().pattern_set == 1
+    sc.close()
+    cp.close()
+
+
 def test_edge_inputs(hip):
     E, P = hip.engine, hip.primer.Pair
     eng = E.New(E.Config(MaxMM=1, TerminalWindow=2, MaxLen=100))
