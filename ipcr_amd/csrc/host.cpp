@@ -13,6 +13,8 @@
 
 #include <emmintrin.h>
 #include <sched.h>
+#include <sys/prctl.h>
+#include <time.h>
 #include <unistd.h>
 #include <hip/hip_runtime_api.h>
 
@@ -170,6 +172,65 @@ const CpuSet &device_cpus(int phys) {
 bool bind_this_thread(int phys) {
     const CpuSet &c = device_cpus(phys);
     return c.known && sched_setaffinity(0, sizeof c.set, &c.set) == 0;
+}
+
+// The pack pool's threads, one physical core each, dealt round-robin over the L3 domains (CCDs) of the device's CPUs.  Left to
+// the scheduler, ten of fifteen polling threads ended up on ONE CCD (woken next to their waker), and a CCD's path to the I/O
+// die carries only so many write-combined stores: the same 229 KB item took 10-13 us on a thread alone on its CCD and 45-60 us
+// on that one (round 4, IPCR_DEBUG_TIMES).  -> the CPU sets (a core's hardware threads) in dealing order; empty when the
+// topology cannot be read.
+const std::vector<cpu_set_t> &spread_core_sets(int phys) {
+    static std::mutex mu;
+    static std::map<int, std::vector<cpu_set_t>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(phys);
+    if (it != cache.end()) return it->second;
+    std::vector<cpu_set_t> &out = cache[phys];
+    const CpuSet &dc = device_cpus(phys);
+    const cpu_set_t &allowed = dc.known ? dc.set : g_initial_cpus.set;
+    if (!dc.known && !g_initial_cpus.known) return out;
+    auto read_int = [](const char *fmt, int cpu, long &v) {
+        char path[160];
+        snprintf(path, sizeof path, fmt, cpu);
+        FILE *fh = fopen(path, "r");
+        if (!fh) return false;
+        const bool ok = fscanf(fh, "%ld", &v) == 1;
+        fclose(fh);
+        return ok;
+    };
+    std::map<long, std::map<long, cpu_set_t>> l3; // L3 domain -> (package, core) -> its hardware threads
+    for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu) {
+        if (!CPU_ISSET(cpu, &allowed)) continue;
+        long core = 0, pkg = 0, dom = 0;
+        if (!read_int("/sys/devices/system/cpu/cpu%d/topology/core_id", cpu, core)) { out.clear(); return out; }
+        (void)read_int("/sys/devices/system/cpu/cpu%d/topology/physical_package_id", cpu, pkg);
+        if (!read_int("/sys/devices/system/cpu/cpu%d/cache/index3/id", cpu, dom)) dom = pkg;
+        auto &cs = l3[dom];
+        auto f = cs.find(pkg * 100000 + core);
+        if (f == cs.end()) { cpu_set_t z; CPU_ZERO(&z); f = cs.emplace(pkg * 100000 + core, z).first; }
+        CPU_SET(cpu, &f->second);
+    }
+    for (bool any = true; any;) {
+        any = false;
+        for (auto &d : l3)
+            if (!d.second.empty()) {
+                out.push_back(d.second.begin()->second);
+                d.second.erase(d.second.begin());
+                any = true;
+            }
+    }
+    return out;
+}
+// pool thread `index` onto its core; false: the topology is unknown (the caller falls back to the device's whole set)
+bool bind_pool_thread(int phys, unsigned index) {
+    static const bool on = !(getenv("IPCR_POOL_SPREAD") && atoi(getenv("IPCR_POOL_SPREAD")) == 0) &&
+                           !(getenv("IPCR_BIND_THREADS") && *getenv("IPCR_BIND_THREADS") && atoi(getenv("IPCR_BIND_THREADS")) == 0);
+    if (!on) return false;
+    const std::vector<cpu_set_t> &cores = spread_core_sets(phys);
+    if (cores.empty()) return false;
+    // (from the far end of the list: the caller's own thread and the runtime's helpers tend to sit on the first CPUs)
+    const cpu_set_t &c = cores[cores.size() - 1 - index % cores.size()];
+    return sched_setaffinity(0, sizeof c, &c) == 0;
 }
 
 #define HIPCHK(expr)                                                                         \
@@ -820,6 +881,7 @@ ipcr_status ipcr_panel_create(const ipcr_config *cfg, const ipcr_pair *pairs, in
     std::unique_ptr<ipcr_panel> p(new ipcr_panel);
     p->cfg = *cfg;
     p->tw = cfg->terminal_window > 0 ? cfg->terminal_window : 0;
+    p->specialize = env_flag("IPCR_SPECIALIZE", true); // 0: the table-driven kernel for every panel (profiles; ipcr_panel_set_specialize per panel)
     const int k = cfg->max_mm, tw = p->tw;
     std::map<std::string, uint32_t> index; // key: seq | side | tw_dev
     auto intern = [&](const std::string &seq, bool left, int tw_dev, const SeedSpan &sp) -> uint32_t {
@@ -1060,6 +1122,7 @@ struct ipcr_genome {
     uint64_t total_bases = 0;
     uint8_t *staging = nullptr;
     uint64_t staging_cap = 0;
+    bool staging_fine = false; // allocated fine-grained (the host writes it through the BAR: ipcr_scan_chunk)
     hipStream_t stream = nullptr;
     bool shared_stream = false; // stream belongs to a scratch (its private chunk genome): never destroyed here
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1557,6 +1620,22 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode, int slot, SetDev **out)
     return IPCR_OK;
 }
 
+// Large BAR: the whole of the device's memory is mapped into the host's address space, and the CPU's write-combining
+// stores reach it at ~45 GB/s (tools/exp/bar_write.cpp: 80 % of the link's DMA rate, from one thread or sixteen) -- the
+// host's packer then writes its planes where the device reads them and no copy operation is queued at all.
+// IPCR_CHUNK_BAR=0: pinned slabs + DMA (round 3's path; also what runs without a large BAR).
+bool device_memory_is_host_writable(int phys) {
+    static std::mutex mu;
+    static std::map<int, bool> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(phys);
+    if (it != cache.end()) return it->second;
+    int v = 0;
+    const bool ok = hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, phys) == hipSuccess && v != 0;
+    cache[phys] = ok;
+    return ok;
+}
+
 // A few threads that pack slices of ONE large record (a single worker scanning whole chromosomes: a lone core packs
 // ~10 GB/s of ASCII, the link carries 57): created at the first use, they live as long as the process.  A pool of
 // workers never comes here -- every worker packs its own chunk.
@@ -1578,17 +1657,25 @@ public:
         job->fn = [&fn](size_t i) { fn(i); };
         job->n = n;
         job->phys = phys;
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            job_ = job;
-            gen_.fetch_add(1, std::memory_order_release);
+        job->taken.reset(new std::atomic<uint8_t>[n]);
+        for (size_t i = 0; i < n; ++i) job->taken[i].store(0, std::memory_order_relaxed);
+        // Every pool thread has a mailbox of its own (one cache line): the run goes into all of them -- reference counts taken
+        // here, by one thread -- and then the generation moves on.  A polling thread that sees it takes the run out of ITS box and
+        // begins with the item of its own number: no lock, no counter and no reference count shared with the fourteen others on
+        // its way to the first byte (through one mutex they began 25 us apart, through one spin lock + one shared counter 15 us:
+        // cache lines crossing between CCDs; the items themselves take 10-20 us).
+        for (Mailbox &m : boxes_) {
+            SpinGuard sg(m.lock);
+            m.job = job;
         }
+        gen_.fetch_add(1, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(mu_); } // (a thread on its way to sleep has either seen the new generation or is waiting by now)
         cv_.notify_all();
         if (on_idle && !threads_.empty()) {
             while (job->done.load(std::memory_order_acquire) < n) { (*on_idle)(); __builtin_ia32_pause(); }
             return;
         }
-        work(*job);
+        work(*job, ~(size_t)0);
         // (an item that has been taken is finished before `done` reaches n: fn is not called once this returns)
         for (unsigned spin = 0; job->done.load(std::memory_order_acquire) < n; ++spin) {
             if (spin < 2000u) { __builtin_ia32_pause(); continue; }
@@ -1601,49 +1688,74 @@ private:
         std::function<void(size_t)> fn;
         size_t n = 0;
         int phys = -1;
+        std::unique_ptr<std::atomic<uint8_t>[]> taken; // per item: somebody has it
         std::atomic<size_t> next{0}, done{0};
+    };
+    struct alignas(64) Mailbox {
+        std::atomic_flag lock = ATOMIC_FLAG_INIT;
+        std::shared_ptr<Job> job;
+    };
+    struct SpinGuard {
+        std::atomic_flag &f;
+        explicit SpinGuard(std::atomic_flag &x) : f(x) { while (f.test_and_set(std::memory_order_acquire)) __builtin_ia32_pause(); }
+        ~SpinGuard() { f.clear(std::memory_order_release); }
     };
     PackPool() {
         unsigned t = std::min(std::thread::hardware_concurrency(), 16u); // IPCR_PACK_THREADS: up to 64
         if (const char *v = getenv("IPCR_PACK_THREADS")) t = (unsigned)std::max(1, atoi(v));
         t = std::min(std::max(t, 1u), 64u);
-        for (unsigned i = 1; i < t; ++i) threads_.emplace_back([this] { loop(); });
+        boxes_ = std::vector<Mailbox>(t > 1 ? t - 1 : 0);
+        for (unsigned i = 1; i < t; ++i) threads_.emplace_back([this, i] { loop(i - 1); });
         for (auto &th : threads_) th.detach(); // they sleep on the condition variable for the rest of the process's life
     }
-    void work(Job &j) {
+    void one(Job &j, size_t i) {
+        j.fn(i);
+        if (j.done.fetch_add(1, std::memory_order_acq_rel) + 1 >= j.n) { std::lock_guard<std::mutex> lk(mu_); cv_done_.notify_all(); }
+    }
+    // first: the item this thread begins with if nobody has it yet (its own number), then whatever the counter hands out -- the
+    // counter runs over every item, so the item of a thread that sleeps is taken by the others
+    void work(Job &j, size_t first) {
+        if (first < j.n && j.taken[first].exchange(1, std::memory_order_acq_rel) == 0) one(j, first);
         for (;;) {
             const size_t i = j.next.fetch_add(1);
             if (i >= j.n) break;
-            j.fn(i);
-            if (j.done.fetch_add(1, std::memory_order_acq_rel) + 1 >= j.n) { std::lock_guard<std::mutex> lk(mu_); cv_done_.notify_all(); }
+            if (j.taken[i].exchange(1, std::memory_order_acq_rel) == 0) one(j, i);
         }
     }
-    void loop() {
+    void loop(unsigned index) {
         uint64_t seen = 0;
         int bound = -1;
+        Mailbox &box = boxes_[index];
         for (;;) {
             // a lone worker that scans chunk after chunk comes back every ~100 us: poll for that long before sleeping (a
             // wake-up through the condition variable costs 20-50 us of the ~25 us a 4 Mb chunk takes to pack)
             const auto t0 = std::chrono::steady_clock::now();
-            while (gen_.load(std::memory_order_acquire) == seen) {
+            bool changed = false;
+            while (!(changed = gen_.load(std::memory_order_acquire) != seen)) {
                 __builtin_ia32_pause();
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) break;
             }
-            std::shared_ptr<Job> job;
-            {
+            if (!changed) {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
-                seen = gen_.load(std::memory_order_acquire);
-                job = job_;
             }
-            if (!job) continue;
-            if (job->phys >= 0 && job->phys != bound) { (void)bind_this_thread(job->phys); bound = job->phys; }
-            work(*job);
+            seen = gen_.load(std::memory_order_acquire);
+            std::shared_ptr<Job> job;
+            {
+                SpinGuard sg(box.lock); // (uncontended but for the moment the next run is being posted)
+                job = std::move(box.job);
+            }
+            if (!job) continue; // (posted and taken already: this thread saw two generations in one look)
+            if (job->phys >= 0 && job->phys != bound) { // onto a core of its own next to the device (or, failing that, anywhere next to it)
+                if (!bind_pool_thread(job->phys, index)) (void)bind_this_thread(job->phys);
+                bound = job->phys;
+            }
+            work(*job, index);
         }
     }
     std::mutex mu_, run_mu_;
     std::condition_variable cv_, cv_done_;
-    std::shared_ptr<Job> job_; // the current run (guarded by mu_)
+    std::vector<Mailbox> boxes_; // one per pool thread
     std::atomic<uint64_t> gen_{0};
     std::vector<std::thread> threads_;
 };
@@ -1812,8 +1924,21 @@ ipcr_status wait_published(ipcr_scratch *s) {
     const uint32_t want = s->seq;
     const hipStream_t lane = s->lane_used ? s->lane_used->s : s->stream;
     const auto t0 = std::chrono::steady_clock::now();
+    // IPCR_WAIT_SLEEP_US=n: after IPCR_WAIT_SPIN_US of spinning, sleep n us between two looks.  For a pool of MORE workers than
+    // the process has CPUs (a cgroup quota counts spinning as work): 24 / 48 workers on 16 CPUs 78 / 47 -> 122 / 83-95 Gbases/s
+    // with n = 20 (chunks over DMA; 16 workers: 137-144 either way).  Off by default: with as many workers as CPUs it changes nothing
+    static const int sleep_us = getenv("IPCR_WAIT_SLEEP_US") ? atoi(getenv("IPCR_WAIT_SLEEP_US")) : 0;
+    static const int spin_us = getenv("IPCR_WAIT_SPIN_US") ? atoi(getenv("IPCR_WAIT_SPIN_US")) : 30;
+    if (sleep_us > 0) {
+        static thread_local bool slack_set = false;
+        if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; } // (the default slack of 50 us would round every sleep up)
+    }
     for (uint64_t spin = 1;; ++spin) {
         if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == want) return IPCR_OK;
+        if (sleep_us > 0 && (spin & 63u) == 0 && ms_since(t0) * 1000.0 > (double)spin_us) {
+            struct timespec ts = {0, sleep_us * 1000L};
+            (void)nanosleep(&ts, nullptr);
+        }
         if (spin < 0x10000u) __builtin_ia32_pause(); // the first millisecond (a sweep takes 0.2 ms): pure spin
         else std::this_thread::yield();              // long scans (large panels, huge genomes): let other workers run
         if ((spin & 0xFFFFu) == 0) { // a fault on the stream would otherwise spin for ever
@@ -2817,11 +2942,15 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         const uint64_t cols = record_cols(len), col0 = g->next_col;
         if (g->rec_start.size() >= g->max_records || col0 + cols > g->cap_cols) return fail(IPCR_ERR_CAPACITY, "chunk genome capacity exceeded");
         const uint64_t dev_bytes = cols * 2048ull; // four planes x 128 words per column
-        if (dev_bytes > g->staging_cap) {
+        const bool bar = env_flag("IPCR_CHUNK_BAR", true) && device_memory_is_host_writable(slot_phys(g->device));
+        if (dev_bytes > g->staging_cap || (bar && !g->staging_fine)) {
             if (g->staging) (void)hipFree(g->staging);
             g->staging = nullptr;
-            g->staging_cap = dev_bytes + (dev_bytes >> 3);
-            HIPCHK(hipMalloc((void **)&g->staging, g->staging_cap));
+            g->staging_cap = std::max(g->staging_cap, dev_bytes + (dev_bytes >> 3));
+            // fine-grained: the device reads what the host has just written through the BAR past its L2, never a stale line
+            if (bar) HIPCHK(hipExtMallocWithFlags((void **)&g->staging, g->staging_cap, hipDeviceMallocFinegrained));
+            else HIPCHK(hipMalloc((void **)&g->staging, g->staging_cap));
+            g->staging_fine = bar;
         }
         const bool pooled = live <= 1 && PackPool::get().size() > 1 && cols >= 64;
         // columns per slice: up to 1024 = 4 Mbases, i.e. a worker's 4 Mb chunk is ONE copy + ONE conversion launch.  Cutting it
@@ -2837,7 +2966,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         // a quarter: what follows the packing on the device -- the last group's way over the link, its conversion -- is then
         // short, and the first group's transfer hides under the packing of the second
         std::vector<uint64_t> gs;
-        if (pooled && cols <= 2048 && cols >= 256) {
+        if (pooled && cols <= 2048 && cols >= 256) { // (one group instead, now that the packer writes through the BAR: no difference, 47-52 Gbases/s either way)
             const uint64_t first = std::min<uint64_t>(cols - 64, (cols * 3 / 4 + 7) / 8 * 8);
             gs = {0, first, cols};
         } else {
@@ -2848,11 +2977,14 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         std::vector<uint32_t> sflags((size_t)nsl, 0);
         // columns [c0, c0 + nc) of slice i (whose first column is gs[i] and which holds snc columns) into the slice's planes
         // at `slab`: [lo | hi | inv | rst], snc x 128 words each
+        // (bar: the two code planes go straight into the slice's place in device memory, write-only, through the BAR; the
+        // invalid and reset planes stay in the pinned slab and follow by DMA only if the slice holds such a byte)
         auto pack_cols = [&](uint64_t i, uint8_t *slab, uint64_t c0, uint64_t nc) -> uint32_t {
             const uint64_t s0 = gs[(size_t)i], snc = gs[(size_t)i + 1] - s0, W = snc * 128u, b0 = c0 * IPCR_COLUMN_BASES;
             const uint64_t nb = b0 < len ? std::min<uint64_t>(len - b0, nc * IPCR_COLUMN_BASES) : 0;
             uint32_t *w = reinterpret_cast<uint32_t *>(slab) + (c0 - s0) * 128u;
-            return ipcr::pack_linear(seq + (nb ? b0 : 0), nb, nc * IPCR_COLUMN_BASES, w, w + W, w + 2 * W, w + 3 * W);
+            uint32_t *wd = bar ? reinterpret_cast<uint32_t *>(g->staging + s0 * 2048ull) + (c0 - s0) * 128u : w;
+            return ipcr::pack_linear(seq + (nb ? b0 : 0), nb, nc * IPCR_COLUMN_BASES, wd, wd + W, w + 2 * W, w + 3 * W);
         };
         auto pack_slice = [&](uint64_t i, uint8_t *slab) { // planes of slice i: [lo | hi | inv | rst], nc x 128 words each
             const uint64_t c0 = gs[(size_t)i], nc = gs[(size_t)i + 1] - c0;
@@ -2861,16 +2993,21 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         auto send_slice = [&](uint64_t i, const uint8_t *slab) -> ipcr_status { // the rst plane crosses the link only if the slice holds lower case
             const uint64_t c0 = gs[(size_t)i], nc = gs[(size_t)i + 1] - c0, W = nc * 128u;
             const bool lower = (sflags[(size_t)i] & 2u) != 0;
+            // ... and the invalid-bit plane only if it holds a byte outside ACGT at all: the conversion kernel knows where the
+            // record ends and makes the padding's bits itself (0.25 B/base on the link: IPCR_CHUNK_SKIP_INV=0 sends it always)
+            const bool need_inv = lower || (sflags[(size_t)i] & 1u) != 0 || !env_flag("IPCR_CHUNK_SKIP_INV", true);
             uint8_t *d = g->staging + c0 * 2048ull;
             // A lone caller: the conversion kernel reads the pinned slab over the link itself, no copy operation in between
             // (whole 150 Mb record: 60 Gbases/s against 51).  A pool of workers keeps the copy engine: their kernels would
             // otherwise wait on the link with the compute units held (16 workers: 78 Gbases/s against 99).
             // IPCR_CHUNK_ZEROCOPY=0/1 forces.
             static const int zc_env = getenv("IPCR_CHUNK_ZEROCOPY") ? atoi(getenv("IPCR_CHUNK_ZEROCOPY")) : -1;
-            const bool zerocopy = zc_env >= 0 ? zc_env != 0 : live <= 1;
-            if (!zerocopy) HIPCHK(hipMemcpyAsync(d, slab, W * 4u * (lower ? 4u : 3u), hipMemcpyHostToDevice, g->stream));
+            const bool zerocopy = !bar && (zc_env >= 0 ? zc_env != 0 : live <= 1);
+            if (bar) { // the code planes are there already; the other two follow only if the slice needs them
+                if (need_inv) HIPCHK(hipMemcpyAsync(d + W * 8u, slab + W * 8u, W * 4u * (lower ? 2u : 1u), hipMemcpyHostToDevice, g->stream));
+            } else if (!zerocopy) HIPCHK(hipMemcpyAsync(d, slab, W * 4u * (lower ? 4u : need_inv ? 3u : 2u), hipMemcpyHostToDevice, g->stream));
             const uint32_t *dl = zerocopy ? reinterpret_cast<const uint32_t *>(slab) : reinterpret_cast<const uint32_t *>(d);
-            HIPCHK(ipcr::launch_tiles_from_linear(g->stream, dl, dl + W, dl + 2 * W, lower ? dl + 3 * W : nullptr, col0, col0 + c0, nc, len,
+            HIPCHK(ipcr::launch_tiles_from_linear(g->stream, dl, dl + W, need_inv ? dl + 2 * W : nullptr, lower ? dl + 3 * W : nullptr, col0, col0 + c0, nc, len,
                                                   g->planes, g->rst, i == 0 ? g->d_rec_start : nullptr, i == 0 ? g->d_rec_len : nullptr,
                                                   i == 0 ? g->e0 : nullptr, i + 1 == nsl ? g->e1 : nullptr));
             return IPCR_OK;
@@ -2924,12 +3061,22 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
             };
             const std::function<void()> idle = send_ready;
             trace("pack>", s);
+            static const bool item_times = getenv("IPCR_DEBUG_TIMES") != nullptr;
+            std::vector<double> it0(item_times ? items.size() : 0), it1(item_times ? items.size() : 0);
+            std::vector<int> itcpu(item_times ? items.size() : 0);
+            const auto tp0 = std::chrono::steady_clock::now();
             PackPool::get().run(items.size(), [&](size_t k) {
                 const Item &it = items[k];
+                if (item_times) { it0[k] = ms_since(tp0) * 1000.0; itcpu[k] = sched_getcpu(); }
                 iflags[k] = pack_cols(it.group, s->h_planes + gs[(size_t)it.group] * 2048ull, it.c0, it.nc);
+                if (item_times) it1[k] = ms_since(tp0) * 1000.0;
                 group_done[(size_t)it.group].fetch_add(1, std::memory_order_release);
             }, slot_phys(g->device), &idle);
             send_ready();
+            if (item_times)
+                for (size_t k = 0; k < items.size(); ++k)
+                    fprintf(stderr, "    item %2zu group %llu cols %4llu cpu %3d: %6.1f .. %6.1f us\n", k, (unsigned long long)items[k].group,
+                            (unsigned long long)items[k].nc, itcpu[k], it0[k], it1[k]);
             if (send_st != IPCR_OK) return send_st;
         }
         uint32_t fl = 0;

@@ -154,6 +154,7 @@ uint32_t pack_linear(const uint8_t *seq, uint64_t len, uint64_t padded, uint32_t
         ++w;
     }
     for (; w < padded / 32u; ++w) { lo[w] = 0; hi[w] = 0; iv[w] = 0xFFFFFFFFu; rs[w] = 0; }
+    _mm_sfence(); // the planes may be device memory behind the BAR (write-combining): everything is on its way before anyone is told
     return flags;
 }
 

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const uint8_t *__restri
 // j-th words.  One half wave per (column, plane): lane s loads the four words of strand s (one 16-byte load, 512
 // contiguous bytes per half wave), four cross-lane transposes (butterflies over ds_swizzle, as the seed-index kernel's
 // k-mer transposes), lane i stores rows i, 32 + i, 64 + i, 96 + i.  Plane 3 = rst; without a fourth linear plane
-// (no lower-case acgt in the chunk) rst is inv.
+// (no lower-case acgt in the chunk) rst is inv.  Without a third one either (lin_iv null: every byte of the slice is one of
+// ACGT -- most slices of most genomes) the invalid bits are made here: 0.25 bytes per base cross the link instead of 0.375.
 template <int D> __device__ __forceinline__ uint32_t tl_stage(uint32_t x, uint32_t lane) {
     constexpr uint32_t m0 = D == 16 ? 0x0000FFFFu : D == 8 ? 0x00FF00FFu : D == 4 ? 0x0F0F0F0Fu : D == 2 ? 0x33333333u : 0x55555555u;
     const uint32_t p = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, (D << 10) | 0x1F);
@@ -176,7 +177,18 @@ __global__ __launch_bounds__(256) void tiles_from_linear_kernel(const uint4 *__r
     const uint64_t c = live ? item >> 2 : 0u; // column of this launch's range
     const uint32_t plane = (uint32_t)item & 3u;
     const uint4 *src = plane == 0u ? lin_lo : plane == 1u ? lin_hi : (plane == 2u || !lin_rs) ? lin_iv : lin_rs;
-    const uint4 v = src[c * 32u + lane];
+    uint4 v;
+    if (src) v = src[c * 32u + lane];
+    else { // no invalid-bit plane came over the link: the slice holds ACGT only, what is invalid is what lies behind the record's end
+        const uint64_t b0 = ((col0 - rec_col0 + c) * 32u + lane) * 128u; // first base of this lane's strand
+        uint32_t w[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint64_t b = b0 + 32u * j;
+            w[j] = b >= len ? 0xFFFFFFFFu : (b + 32u <= len ? 0u : ~((1u << (uint32_t)(len - b)) - 1u));
+        }
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
     const uint32_t t0 = tl_transpose(v.x, lane), t1 = tl_transpose(v.y, lane), t2 = tl_transpose(v.z, lane), t3 = tl_transpose(v.w, lane);
     if (!live) return;
     const uint64_t col = col0 + c, block = col >> 6;
@@ -251,7 +263,11 @@ __device__ __forceinline__ uint32_t fetch_row(const uint32_t *__restrict__ plane
 // (32 strands) of one row; pattern position j compares row r+j.  Mismatches outside the
 // protected window feed a thermometer counter u[t] = "count >= t"; a mismatch inside it, or
 // count > k, kills the position.  Survivors go to the candidate queue.
-template <int KMAX>
+// PB patterns share one walk down the rows (round 4): a row's three words are loaded once and decoded into its four
+// one-hot base masks once, then every pattern of the pass takes its step -- a quarter of the loads of one pattern per
+// walk, and four independent counters between two loads where one pattern's was a chain that waited for every load
+// (profiles/r04_c2g_pmc.json, before: 82 % of the wave cycles waiting, 4.2 x the algorithmic bytes from HBM).
+template <int KMAX, int PB>
 __global__ __launch_bounds__(256) void filter_generic_kernel(const uint32_t *__restrict__ planes,
                                                              uint64_t block0, uint64_t nblocks, // blocks [block0, block0 + nblocks)
                                                              const ipcr_dev_pattern *__restrict__ pats,
@@ -265,61 +281,82 @@ __global__ __launch_bounds__(256) void filter_generic_kernel(const uint32_t *__r
     const uint64_t block = block0 + (tile >> 7);
     const uint32_t row = (uint32_t)(tile & 127u);
 
-    for (uint32_t qi = 0; qi < npat; ++qi) {
-        const uint32_t q = sel ? sel[qi] : qi;
-        const ipcr_dev_pattern *pp = pats + q;
-        const uint32_t L = pp->len;
-        uint32_t u[KMAX + 1];
+    for (uint32_t qi0 = 0; qi0 < npat; qi0 += PB) {
+        uint32_t q[PB], L[PB], dead[PB], u[PB][KMAX + 1];
+        const ipcr_dev_pattern *pp[PB];
+        uint32_t Lmax = 0;
 #pragma unroll
-        for (int t = 0; t <= KMAX; ++t) u[t] = 0u;
-        uint32_t dead = 0u;
-        for (uint32_t j = 0; j < L; ++j) {
-            const uint32_t m = pp->mask[j]; // wave-uniform
+        for (int b = 0; b < PB; ++b) {
+            const bool on = qi0 + (uint32_t)b < npat; // wave-uniform
+            q[b] = on ? (sel ? sel[qi0 + (uint32_t)b] : qi0 + (uint32_t)b) : 0u;
+            pp[b] = pats + q[b];
+            L[b] = on ? pp[b]->len : 0u;
+            dead[b] = on ? 0u : 0xFFFFFFFFu;
+            Lmax = L[b] > Lmax ? L[b] : Lmax;
+#pragma unroll
+            for (int t = 0; t <= KMAX; ++t) u[b][t] = 0u;
+        }
+        for (uint32_t j = 0; j < Lmax; ++j) {
             const uint32_t lo = fetch_row(planes, block, row + j, 0, lane);
             const uint32_t hi = fetch_row(planes, block, row + j, 1, lane);
             const uint32_t inv = fetch_row(planes, block, row + j, 2, lane);
-            const uint32_t sA = (m & 1u) ? 0xFFFFFFFFu : 0u, sC = (m & 2u) ? 0xFFFFFFFFu : 0u;
-            const uint32_t sG = (m & 4u) ? 0xFFFFFFFFu : 0u, sT = (m & 8u) ? 0xFFFFFFFFu : 0u;
-            const uint32_t match = ((~lo & ~hi) & sA) | ((lo & ~hi) & sC) | ((~lo & hi) & sG) | ((lo & hi) & sT);
-            const uint32_t mm = ~match | inv;
-            if (m & 16u) {
-                dead |= mm;
-            } else {
+            const uint32_t isA = ~lo & ~hi, isC = lo & ~hi, isG = ~lo & hi, isT = lo & hi;
+            uint32_t gone = 0xFFFFFFFFu; // positions no pattern of the pass can still match
 #pragma unroll
-                for (int t = KMAX; t >= 1; --t)
-                    if ((uint32_t)t <= max_mm + 1u) u[t] |= ((t == 1) ? 0xFFFFFFFFu : u[t - 1]) & mm;
+            for (int b = 0; b < PB; ++b) {
+                if (j < L[b]) { // wave-uniform
+                    const uint32_t m = pp[b]->mask[j];
+                    const uint32_t match = (isA & ((m & 1u) ? 0xFFFFFFFFu : 0u)) | (isC & ((m & 2u) ? 0xFFFFFFFFu : 0u)) |
+                                           (isG & ((m & 4u) ? 0xFFFFFFFFu : 0u)) | (isT & ((m & 8u) ? 0xFFFFFFFFu : 0u));
+                    const uint32_t mm = ~match | inv;
+                    if (m & 16u) {
+                        dead[b] |= mm;
+                    } else {
+#pragma unroll
+                        for (int t = KMAX; t >= 1; --t)
+                            if ((uint32_t)t <= max_mm + 1u) u[b][t] |= ((t == 1) ? 0xFFFFFFFFu : u[b][t - 1]) & mm;
+                    }
+                }
+                uint32_t over = 0u;
+#pragma unroll
+                for (int t = 1; t <= KMAX; ++t)
+                    if ((uint32_t)t == max_mm + 1u) over = u[b][t];
+                gone &= dead[b] | over;
             }
+            if (__ballot(gone != 0xFFFFFFFFu) == 0ull) { // every position of these 64 words is out for every pattern of the pass
+#pragma unroll
+                for (int b = 0; b < PB; ++b) dead[b] = 0xFFFFFFFFu;
+                break;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
             uint32_t over = 0u;
 #pragma unroll
             for (int t = 1; t <= KMAX; ++t)
-                if ((uint32_t)t == max_mm + 1u) over = u[t];
-            if (__ballot((dead | over) != 0xFFFFFFFFu) == 0ull) { dead = 0xFFFFFFFFu; break; }
-        }
-        uint32_t over = 0u;
-#pragma unroll
-        for (int t = 1; t <= KMAX; ++t)
-            if ((uint32_t)t == max_mm + 1u) over = u[t];
-        const uint32_t alive = ~(dead | over);
-        if (alive) { // one queue entry per surviving word: 32 strands of this row
-            const uint32_t shard = (uint32_t)block & (IPCR_QUEUE_SHARDS - 1u);
-            const unsigned long long idx = atomicAdd(qcount + shard * IPCR_QUEUE_COUNTER_STRIDE, 1ull);
-            if (idx < qcap) { // qcap = capacity of one shard's segment
-                ipcr_queue_entry e;
-                e.key = ((uint64_t)q << 48) | ipcr_join_pos(block * 64u + lane, 0, row);
-                e.bits = alive;
-                e.pad = 0;
-                queue[(uint64_t)shard * qcap + idx] = e;
+                if ((uint32_t)t == max_mm + 1u) over = u[b][t];
+            const uint32_t alive = ~(dead[b] | over);
+            if (alive) { // one queue entry per surviving word: 32 strands of this row
+                const uint32_t shard = (uint32_t)block & (IPCR_QUEUE_SHARDS - 1u);
+                const unsigned long long idx = atomicAdd(qcount + shard * IPCR_QUEUE_COUNTER_STRIDE, 1ull);
+                if (idx < qcap) { // qcap = capacity of one shard's segment
+                    ipcr_queue_entry e;
+                    e.key = ((uint64_t)q[b] << 48) | ipcr_join_pos(block * 64u + lane, 0, row);
+                    e.bits = alive;
+                    e.pad = 0;
+                    queue[(uint64_t)shard * qcap + idx] = e;
+                }
             }
         }
     }
 }
 
-template __global__ void filter_generic_kernel<4>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t,
-                                                  uint32_t, const uint32_t *, ipcr_queue_entry *, uint64_t,
-                                                  unsigned long long *);
-template __global__ void filter_generic_kernel<17>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t,
-                                                   uint32_t, const uint32_t *, ipcr_queue_entry *, uint64_t,
-                                                   unsigned long long *);
+template __global__ void filter_generic_kernel<4, 4>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t,
+                                                     uint32_t, const uint32_t *, ipcr_queue_entry *, uint64_t,
+                                                     unsigned long long *);
+template __global__ void filter_generic_kernel<17, 2>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t,
+                                                      uint32_t, const uint32_t *, ipcr_queue_entry *, uint64_t,
+                                                      unsigned long long *);
 
 // ------------------------------------------------------------------------------ verify
 // verifyAt (core/engine/ac.go:186-213) / the inner loop of FindMatches
@@ -692,10 +729,10 @@ hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_
     const uint64_t tiles = nblocks * 128u; // one wave per (block, row)
     const dim3 grid((uint32_t)((tiles + 3u) / 4u));
     if (max_mm <= 3u)
-        hipExtLaunchKernelGGL(filter_generic_kernel<4>, grid, dim3(256), 0, st, start, stop, 0, planes, block0, nblocks, pats,
+        hipExtLaunchKernelGGL((filter_generic_kernel<4, 4>), grid, dim3(256), 0, st, start, stop, 0, planes, block0, nblocks, pats,
                               npat, max_mm, sel, queue, qcap, qcount);
     else
-        hipExtLaunchKernelGGL(filter_generic_kernel<17>, grid, dim3(256), 0, st, start, stop, 0, planes, block0, nblocks, pats,
+        hipExtLaunchKernelGGL((filter_generic_kernel<17, 2>), grid, dim3(256), 0, st, start, stop, 0, planes, block0, nblocks, pats,
                               npat, max_mm, sel, queue, qcap, qcount);
     return hipGetLastError();
 }

@@ -310,13 +310,29 @@ def test_host_packed_chunks_take_the_pattern_set_their_bytes_ask_for(hip, monkey
     clean = "".join(seq).encode()
     dirty = clean[:70_000] + b"N" + clean[70_001:]
     lower = clean[:70_000] + b"acgt" + clean[70_004:]        # lower case is not a reset byte (hostpack.cpp: flag bit 1)
-    for name, b, env, want_set in (("clean", clean, "1", 0), ("dirty", dirty, "1", 1), ("lower", lower, "1", 0),
-                                   ("device-packed", clean, "0", 1), ("clean", clean, "1", 0)):
-        monkeypatch.setenv("IPCR_CHUNK_HOSTPACK", env)
-        got = [p.sig() for p in eng.SimulateCompiledWithScratch("s", b, cp, sc)]
-        want = [w.sig() for w in O.simulate_batch(ocfg(cfg), b, opairs(pairs))]
-        assert got == want and len(want) >= 3, name
-        assert sc.stats().pattern_set == want_set, name
+    # IPCR_CHUNK_BAR: the packer writes the code planes into device memory through the PCIe BAR (default where the BAR is
+    # large) / into pinned slabs that a copy operation takes over (IPCR_CHUNK_BAR=0, and every host without a large BAR);
+    # IPCR_CHUNK_SKIP_INV=0: the invalid-bit plane crosses the link even for a slice of ACGT only
+    for bar, skip in (("1", "1"), ("0", "1"), ("0", "0"), ("1", "1")):
+        monkeypatch.setenv("IPCR_CHUNK_BAR", bar)
+        monkeypatch.setenv("IPCR_CHUNK_SKIP_INV", skip)
+        for name, b, env, want_set in (("clean", clean, "1", 0), ("dirty", dirty, "1", 1), ("lower", lower, "1", 0),
+                                       ("device-packed", clean, "0", 1), ("clean", clean, "1", 0), ("dirty", dirty, "1", 1)):
+            monkeypatch.setenv("IPCR_CHUNK_HOSTPACK", env)
+            got = [p.sig() for p in eng.SimulateCompiledWithScratch("s", b, cp, sc)]
+            want = [w.sig() for w in O.simulate_batch(ocfg(cfg), b, opairs(pairs))]
+            assert got == want and len(want) >= 3, (name, bar, skip)
+            assert sc.stats().pattern_set == want_set, (name, bar, skip)
+        # lengths around the word, strand and column ends, the amplicon at the very end: the invalid bits behind the record's
+        # end are made on the device when the plane does not cross the link
+        for n in (160, 4095, 4096, 4097, 12_289, 131_071):
+            tail = bytearray(clean[:n])
+            tail[n - 180:n - 160] = pairs[0].Forward.encode()
+            tail[n - 20:n] = O.revcomp(pairs[0].Reverse)
+            tail = bytes(tail) if n >= 180 else clean[:n]
+            got = [p.sig() for p in eng.SimulateCompiledWithScratch("s", tail, cp, sc)]
+            want = [w.sig() for w in O.simulate_batch(ocfg(cfg), tail, opairs(pairs))]
+            assert got == want and (n < 180 or len(want) >= 1), (n, bar, skip)
     monkeypatch.setenv("IPCR_CHUNK_CLEAN_MODE", "0")           # the knob that puts round 3's behaviour back
     eng.SimulateCompiledWithScratch("s", clean, cp, sc)
     assert sc.stats().pattern_set == 1

@@ -13,7 +13,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = {"c2": "ipcr_filter", "c2n": "ipcr_filter", "c3": "ipcr_filter", "c4": "ipcr_index_filter", "c4n": "ipcr_index_filter"}
+KERNEL = {"c2": "ipcr_filter", "c2n": "ipcr_filter", "c3": "ipcr_filter", "c4": "ipcr_index_filter", "c4n": "ipcr_index_filter",
+          "c2g": "filter_generic_kernel"}   # c2g: C2 through the table-driven kernel (IPCR_SPECIALIZE=0)
 ALG_BYTES = 1_125_000_000   # 3.0e9 bases x 0.375 B: what one sweep of the benchmark genome reads
 
 
@@ -131,7 +132,7 @@ def kernel_stats_row(path):
     with open(path, newline="") as fh:
         for row in csv.DictReader(fh):
             name = row.get("Name", "")
-            if "ipcr_filter" in name or "ipcr_index_filter" in name:
+            if "ipcr_filter" in name or "ipcr_index_filter" in name or ("_c2g_" in path and "filter_generic_kernel" in name):
                 tot = float(row.get("TotalDurationNs", 0) or 0)
                 if best is None or tot > best[3]:
                     best = (name.split("(")[0], int(row["Calls"]), float(row["AverageNs"]) / 1e3, tot)
@@ -196,6 +197,10 @@ def readme_text():
                     sc = ow.get("scan_chunk") or {}
                     if sc:
                         parts.append("scan_chunk " + " / ".join("%s %s" % (k.replace("gbases_per_s_", "").replace("_", " "), _num(v)) for k, v in sc.items() if k.startswith("gbases_per_s")) + " Gbases/s")
+                    cp = ow.get("scan_chunk_c4_panel") or {}
+                    if cp:
+                        parts.append("scan_chunk under the 1024-row panel, 16 workers: clean chunks %s, chunks with N %s Gbases/s" % (
+                            _num(cp["gbases_per_s_clean"]), _num(cp["gbases_per_s_with_n"])))
                     c5 = ow.get("c5_chunk") or {}
                     if c5:
                         parts.append("c5_chunk " + "; ".join("%s %s" % (k, _num(v)) for k, v in c5.items() if k.startswith("gbases_per_s") or k.startswith("probe_best_hit_us") or k.startswith("probe_rescan_ms")))

@@ -24,7 +24,11 @@ fi
 for w in $wls; do
   steps=400; warm=50; psteps=4
   case $w in c4*) steps=20; warm=3; psteps=3;; esac
-  args="--workload $w --no-cpu-baseline --no-others --no-traffic"
+  bw=$w
+  unset IPCR_SPECIALIZE
+  # c2g: C2 through the table-driven kernel (what runs while hiprtc builds a small panel's kernels, and for panels beyond every limit)
+  case $w in c2g) bw=c2; steps=12; warm=2; psteps=2; export IPCR_SPECIALIZE=0;; esac
+  args="--workload $bw --no-cpu-baseline --no-others --no-traffic"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_$w" -- python3 bench.py $args --steps $steps --warmup $warm > "$out/stats_$w.log" 2>&1 || { tail -5 "$out/stats_$w.log"; exit 1; }
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch_$w" -- python3 bench.py $args --steps $psteps --warmup 1 > "$out/pmc_fetch_$w.log" 2>&1 || { tail -5 "$out/pmc_fetch_$w.log"; exit 1; }
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write_$w" -- python3 bench.py $args --steps $psteps --warmup 1 > "$out/pmc_write_$w.log" 2>&1 || { tail -5 "$out/pmc_write_$w.log"; exit 1; }
@@ -41,7 +45,7 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
     rows = []
     with open(f, newline="") as fh:
         for row in csv.DictReader(fh):
-            if "ipcr_" in row.get("Kernel_Name", ""):
+            if "ipcr_" in row.get("Kernel_Name", "") or "filter_generic" in row.get("Kernel_Name", ""):
                 rows.append({k: row[k] for k in ("Kernel_Name", "Counter_Name", "Counter_Value")})
     with open(f, "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=["Kernel_Name", "Counter_Name", "Counter_Value"])
@@ -50,4 +54,5 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
 PY
 find "$out" -name "*kernel_trace.csv" -delete
 find "$out" -name "*agent_info.csv" -delete
+unset IPCR_SPECIALIZE
 echo done

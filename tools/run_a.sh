@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "host_packed_chunks or hit_cap or concurrent_workers or probe_on_the_chunk" > gpurun_out/t.log 2>&1
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/t_full.log 2>&1
 rc=$?
-tail -40 gpurun_out/t.log
+tail -6 gpurun_out/t_full.log
 exit $rc
