@@ -295,7 +295,6 @@ def test_host_packed_chunks_take_the_pattern_set_their_bytes_ask_for(hip, monkey
     monkeypatch.setenv("IPCR_CHUNK_HOSTPACK", "1")
     test_hit_cap_quirks(hip)
     test_halo_case(hip)
-    test_random_differential(hip, True, 1)
     test_random_differential(hip, False, 2)
     pairs = workloads.c2_pairs()
     cfg = E.Config(MaxMM=2, TerminalWindow=5, MaxLen=2000, HitCap=10000, SeedLen=12)
