@@ -1624,16 +1624,20 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode, int slot, SetDev **out)
 // stores reach it at ~45 GB/s (tools/exp/bar_write.cpp: 80 % of the link's DMA rate, from one thread or sixteen) -- the
 // host's packer then writes its planes where the device reads them and no copy operation is queued at all.
 // IPCR_CHUNK_BAR=0: pinned slabs + DMA (round 3's path; also what runs without a large BAR).
+std::mutex g_bar_mu;
+std::map<int, bool> g_bar_cache;
 bool device_memory_is_host_writable(int phys) {
-    static std::mutex mu;
-    static std::map<int, bool> cache;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(phys);
-    if (it != cache.end()) return it->second;
+    std::lock_guard<std::mutex> lk(g_bar_mu);
+    auto it = g_bar_cache.find(phys);
+    if (it != g_bar_cache.end()) return it->second;
     int v = 0;
     const bool ok = hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, phys) == hipSuccess && v != 0;
-    cache[phys] = ok;
+    g_bar_cache[phys] = ok;
     return ok;
+}
+void host_writable_off(int phys) {
+    std::lock_guard<std::mutex> lk(g_bar_mu);
+    g_bar_cache[phys] = false;
 }
 
 // A few threads that pack slices of ONE large record (a single worker scanning whole chromosomes: a lone core packs
@@ -1761,6 +1765,35 @@ private:
 };
 
 } // namespace
+
+// tests/test_host_logic.py: runs of every size in quick succession, from two callers at once, with and without an idle
+// callback; every item of every run must have been called exactly once when its run returns.  -> the number of violations
+extern "C" int32_t ipcr_internal_pool_selftest(uint32_t rounds, uint32_t max_items) {
+    std::atomic<int32_t> bad{0};
+    auto caller = [&](uint32_t seed) {
+        uint32_t x = seed;
+        for (uint32_t r = 0; r < rounds; ++r) {
+            x = x * 1664525u + 1013904223u;
+            const size_t n = 1u + (x >> 8) % std::max(1u, max_items);
+            std::unique_ptr<std::atomic<uint32_t>[]> calls(new std::atomic<uint32_t>[n]);
+            for (size_t i = 0; i < n; ++i) calls[i].store(0);
+            std::atomic<uint64_t> idle_calls{0};
+            const std::function<void()> idle = [&] { idle_calls.fetch_add(1, std::memory_order_relaxed); };
+            const bool with_idle = (x >> 4) & 1u;
+            PackPool::get().run(n, [&](size_t i) {
+                volatile uint32_t sink = 0;
+                for (uint32_t k = 0; k < ((uint32_t)i * 2654435761u >> 24); ++k) sink = sink + k; // items of uneven length
+                calls[i].fetch_add(1, std::memory_order_relaxed);
+            }, -1, with_idle ? &idle : nullptr);
+            for (size_t i = 0; i < n; ++i)
+                if (calls[i].load() != 1u) bad.fetch_add(1);
+        }
+    };
+    std::thread other(caller, 0x1234567u);
+    caller(0x7654321u);
+    other.join();
+    return bad.load();
+}
 
 // fasta.cpp: its file reads run on the same threads (threads started per slab slowed the slab copies, see there)
 void ipcr_internal_pool_run(size_t n, const std::function<void(size_t)> &fn, int phys) { PackPool::get().run(n, [&](size_t i) { fn(i); }, phys); }
@@ -2942,16 +2975,21 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         const uint64_t cols = record_cols(len), col0 = g->next_col;
         if (g->rec_start.size() >= g->max_records || col0 + cols > g->cap_cols) return fail(IPCR_ERR_CAPACITY, "chunk genome capacity exceeded");
         const uint64_t dev_bytes = cols * 2048ull; // four planes x 128 words per column
-        const bool bar = env_flag("IPCR_CHUNK_BAR", true) && device_memory_is_host_writable(slot_phys(g->device));
+        bool bar = env_flag("IPCR_CHUNK_BAR", true) && device_memory_is_host_writable(slot_phys(g->device));
         if (dev_bytes > g->staging_cap || (bar && !g->staging_fine)) {
             if (g->staging) (void)hipFree(g->staging);
             g->staging = nullptr;
+            g->staging_fine = false;
             g->staging_cap = std::max(g->staging_cap, dev_bytes + (dev_bytes >> 3));
             // fine-grained: the device reads what the host has just written through the BAR past its L2, never a stale line
-            if (bar) HIPCHK(hipExtMallocWithFlags((void **)&g->staging, g->staging_cap, hipDeviceMallocFinegrained));
-            else HIPCHK(hipMalloc((void **)&g->staging, g->staging_cap));
-            g->staging_fine = bar;
+            if (bar && hipExtMallocWithFlags((void **)&g->staging, g->staging_cap, hipDeviceMallocFinegrained) == hipSuccess) g->staging_fine = true;
+            else {
+                if (bar) { (void)hipGetLastError(); host_writable_off(slot_phys(g->device)); } // no such memory here: pinned slabs + DMA from now on
+                g->staging = nullptr;
+                HIPCHK(hipMalloc((void **)&g->staging, g->staging_cap));
+            }
         }
+        bar = bar && g->staging_fine;
         const bool pooled = live <= 1 && PackPool::get().size() > 1 && cols >= 64;
         // columns per slice: up to 1024 = 4 Mbases, i.e. a worker's 4 Mb chunk is ONE copy + ONE conversion launch.  Cutting it
         // in two or four (IPCR_CHUNK_SPLIT: the first part crosses the link while the next is packed) was slower under a

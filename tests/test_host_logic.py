@@ -709,3 +709,16 @@ def test_large_hit_lists_are_joined_per_record_in_parallel(monkeypatch):
     assert [(r, s, e) for (r, _p, s, e, _t) in seen] == first
     sc.close()
     cp.close()
+
+
+def test_pack_pool_runs_every_item_exactly_once():
+    """the process's pool of pack threads (host.cpp: PackPool -- per-thread mailboxes, a first item by thread number, a shared
+    counter for the rest): thousands of runs of 1..200 items from two callers at once, with and without the idle callback of the
+    lone-worker chunk path; no item may be skipped or run twice, whichever threads were polling, asleep or late"""
+    import ctypes
+    from ipcr_amd import _lib
+    fn = _lib.lib().ipcr_internal_pool_selftest
+    fn.restype = ctypes.c_int32
+    fn.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    assert fn(3000, 200) == 0
+    assert fn(300, 3) == 0        # fewer items than threads
