@@ -52,6 +52,8 @@ static std::string bench_primer(unsigned idx, int n = 20) { // core/engine/perfo
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+extern "C" int32_t ipcr_internal_device_bar(int32_t slot); // host.cpp: how the packer's planes reach the device
+
 static int usage(const char *why) {
     fprintf(stderr, "chunk_workers: %s\nusage: chunk_workers [--devices d0,d1,...] [--bind] [--probe] [--with-n] [record_bases] [chunk_bases > 2000] [workers >= 1 ...]\n", why);
     return 2;
@@ -219,7 +221,8 @@ int main(int argc, char **argv) {
     printf("{\"pinned_h2d_GBps\": %.1f, \"record_bases\": %llu, \"chunk_bases\": %llu, \"chunks\": %zu, \"planted\": %llu, \"n_positions\": %llu, \"devices\": [",
            h2d, (unsigned long long)n, (unsigned long long)chunk, jobs.size(), (unsigned long long)planted, (unsigned long long)n_positions);
     for (size_t i = 0; i < devices.size(); ++i) printf("%s%d", i ? ", " : "", devices[i]);
-    printf("], \"hw_queues\": %d", atoi(getenv("GPU_MAX_HW_QUEUES")));
+    printf("], \"hw_queues\": %d, \"packer_path\": \"%s\"", atoi(getenv("GPU_MAX_HW_QUEUES")),
+           ipcr_internal_device_bar(devices[0]) == 2 ? "PCIe BAR + HDP flush" : ipcr_internal_device_bar(devices[0]) == 1 ? "PCIe BAR" : "pinned slabs + DMA");
     int rc = 0;
     for (int W : workers) {
         std::vector<ipcr_scratch *> scs((size_t)W, nullptr);

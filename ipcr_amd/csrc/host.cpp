@@ -16,7 +16,10 @@
 #include <sys/prctl.h>
 #include <time.h>
 #include <unistd.h>
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 
 #include <algorithm>
 #include <array>
@@ -1624,20 +1627,66 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode, int slot, SetDev **out)
 // stores reach it at ~45 GB/s (tools/exp/bar_write.cpp: 80 % of the link's DMA rate, from one thread or sixteen) -- the
 // host's packer then writes its planes where the device reads them and no copy operation is queued at all.
 // IPCR_CHUNK_BAR=0: pinned slabs + DMA (round 3's path; also what runs without a large BAR).
+// What the CPU writes through the BAR passes the device's HDP block (host data path), which may hold it back: the runtime
+// publishes the register that flushes it (HSA_AMD_AGENT_INFO_HDP_FLUSH) and uses it itself for the kernel arguments it keeps in
+// device memory.  The library writes that register -- and reads it back, so that the write has arrived -- after the packer's
+// stores and before the launch that reads them; a device whose register cannot be found does not take the BAR path.
+// (The HSA runtime is the one the process has loaded already -- HIP sits on it -- found by dlopen(RTLD_NOLOAD): no link dependency.)
+volatile uint32_t *find_hdp_flush_register(int phys) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, phys) != hipSuccess) return nullptr;
+    unsigned dom = 0, b = 0, d = 0, f = 0;
+    if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) != 4) return nullptr;
+    void *h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_NOLOAD);
+    auto sym = [&](const char *n) { void *p = h ? dlsym(h, n) : nullptr; return p ? p : dlsym(RTLD_DEFAULT, n); };
+    using iterate_t = hsa_status_t (*)(hsa_status_t (*)(hsa_agent_t, void *), void *);
+    using info_t = hsa_status_t (*)(hsa_agent_t, hsa_agent_info_t, void *);
+    struct Ctx { info_t info; uint32_t dom, bdf; volatile uint32_t *reg; } c{reinterpret_cast<info_t>(sym("hsa_agent_get_info")), dom, (b << 8) | (d << 3) | f, nullptr};
+    const iterate_t iterate = reinterpret_cast<iterate_t>(sym("hsa_iterate_agents"));
+    if (!iterate || !c.info) return nullptr;
+    (void)iterate([](hsa_agent_t a, void *vp) -> hsa_status_t {
+        Ctx &c = *static_cast<Ctx *>(vp);
+        hsa_device_type_t type;
+        uint32_t bdf = 0, dom = 0;
+        if (c.info(a, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS || type != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+        if (c.info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+        if (c.info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom) != HSA_STATUS_SUCCESS) dom = c.dom;
+        if ((bdf & 0xFFFFu) != c.bdf || dom != c.dom) return HSA_STATUS_SUCCESS;
+        hsa_amd_hdp_flush_t hdp{nullptr, nullptr};
+        if (c.info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_HDP_FLUSH, &hdp) == HSA_STATUS_SUCCESS) c.reg = hdp.HDP_MEM_FLUSH_CNTL;
+        return HSA_STATUS_INFO_BREAK;
+    }, &c);
+    return c.reg;
+}
+
+struct BarInfo { bool writable = false; volatile uint32_t *hdp_flush = nullptr; };
 std::mutex g_bar_mu;
-std::map<int, bool> g_bar_cache;
-bool device_memory_is_host_writable(int phys) {
+std::map<int, BarInfo> g_bar_cache;
+BarInfo device_bar(int phys) {
     std::lock_guard<std::mutex> lk(g_bar_mu);
     auto it = g_bar_cache.find(phys);
     if (it != g_bar_cache.end()) return it->second;
+    BarInfo bi;
     int v = 0;
-    const bool ok = hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, phys) == hipSuccess && v != 0;
-    g_bar_cache[phys] = ok;
-    return ok;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, phys) == hipSuccess && v != 0) {
+        bi.hdp_flush = find_hdp_flush_register(phys);
+        // IPCR_CHUNK_BAR=2: take the BAR path even where the flush register is not known (the runtime's own flush in front of every
+        // dispatch then stands in for it: measurements only)
+        bi.writable = bi.hdp_flush != nullptr || (getenv("IPCR_CHUNK_BAR") && atoi(getenv("IPCR_CHUNK_BAR")) == 2);
+    }
+    g_bar_cache[phys] = bi;
+    return bi;
+}
+// everything the packer's threads have stored through the BAR (each of them has fenced) is in device memory when this returns
+inline void bar_flush(const BarInfo &bi) {
+    if (!bi.hdp_flush) return;
+    _mm_sfence();
+    *bi.hdp_flush = 1u;
+    (void)*bi.hdp_flush; // a read does not pass the writes in front of it: the flush has been taken
 }
 void host_writable_off(int phys) {
     std::lock_guard<std::mutex> lk(g_bar_mu);
-    g_bar_cache[phys] = false;
+    g_bar_cache[phys].writable = false;
 }
 
 // A few threads that pack slices of ONE large record (a single worker scanning whole chromosomes: a lone core packs
@@ -1765,6 +1814,14 @@ private:
 };
 
 } // namespace
+
+// tests, chunk_workers: how ipcr_scan_chunk's packer reaches device slot `slot` -- 0: pinned slabs + DMA; 1: through the BAR,
+// flush register unknown (IPCR_CHUNK_BAR=2 only); 2: through the BAR, with the HDP flush in front of every launch
+extern "C" int32_t ipcr_internal_device_bar(int32_t slot) {
+    if (slot < 0 || slot >= slot_count()) return 0;
+    const BarInfo bi = device_bar(slot_phys(slot));
+    return !bi.writable || !env_flag("IPCR_CHUNK_BAR", true) ? 0 : (bi.hdp_flush ? 2 : 1);
+}
 
 // tests/test_host_logic.py: runs of every size in quick succession, from two callers at once, with and without an idle
 // callback; every item of every run must have been called exactly once when its run returns.  -> the number of violations
@@ -2975,7 +3032,8 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         const uint64_t cols = record_cols(len), col0 = g->next_col;
         if (g->rec_start.size() >= g->max_records || col0 + cols > g->cap_cols) return fail(IPCR_ERR_CAPACITY, "chunk genome capacity exceeded");
         const uint64_t dev_bytes = cols * 2048ull; // four planes x 128 words per column
-        bool bar = env_flag("IPCR_CHUNK_BAR", true) && device_memory_is_host_writable(slot_phys(g->device));
+        const BarInfo bar_info = device_bar(slot_phys(g->device));
+        bool bar = env_flag("IPCR_CHUNK_BAR", true) && bar_info.writable;
         if (dev_bytes > g->staging_cap || (bar && !g->staging_fine)) {
             if (g->staging) (void)hipFree(g->staging);
             g->staging = nullptr;
@@ -3042,6 +3100,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
             static const int zc_env = getenv("IPCR_CHUNK_ZEROCOPY") ? atoi(getenv("IPCR_CHUNK_ZEROCOPY")) : -1;
             const bool zerocopy = !bar && (zc_env >= 0 ? zc_env != 0 : live <= 1);
             if (bar) { // the code planes are there already; the other two follow only if the slice needs them
+                bar_flush(bar_info);
                 if (need_inv) HIPCHK(hipMemcpyAsync(d + W * 8u, slab + W * 8u, W * 4u * (lower ? 2u : 1u), hipMemcpyHostToDevice, g->stream));
             } else if (!zerocopy) HIPCHK(hipMemcpyAsync(d, slab, W * 4u * (lower ? 4u : need_inv ? 3u : 2u), hipMemcpyHostToDevice, g->stream));
             const uint32_t *dl = zerocopy ? reinterpret_cast<const uint32_t *>(slab) : reinterpret_cast<const uint32_t *>(d);

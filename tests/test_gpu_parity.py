@@ -312,6 +312,12 @@ def test_host_packed_chunks_take_the_pattern_set_their_bytes_ask_for(hip, monkey
     # IPCR_CHUNK_BAR: the packer writes the code planes into device memory through the PCIe BAR (default where the BAR is
     # large) / into pinned slabs that a copy operation takes over (IPCR_CHUNK_BAR=0, and every host without a large BAR);
     # IPCR_CHUNK_SKIP_INV=0: the invalid-bit plane crosses the link even for a slice of ACGT only
+    import ctypes
+    how = hip.lib.lib().ipcr_internal_device_bar
+    how.restype, how.argtypes = ctypes.c_int32, [ctypes.c_int32]
+    # 2: the whole of device memory is mapped (large BAR) and the runtime's HDP flush register was found; 0: no large BAR.  Never
+    # 1 by default: without the flush register the library does not write through the BAR
+    assert how(0) in (0, 2)
     for bar, skip in (("1", "1"), ("0", "1"), ("0", "0"), ("1", "1")):
         monkeypatch.setenv("IPCR_CHUNK_BAR", bar)
         monkeypatch.setenv("IPCR_CHUNK_SKIP_INV", skip)
