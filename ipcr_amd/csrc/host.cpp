@@ -1038,6 +1038,10 @@ int32_t ipcr_panel_slot_pattern(const ipcr_panel *p, int32_t pair, char which, i
 }
 
 ipcr_status ipcr_panel_filter_source(const ipcr_panel *p, int32_t mode, char *out, size_t cap, size_t *needed) {
+    // mode 0 / 1: the specialised filter of that pattern set; 2 / 3: the seed-index filter's; 4 / 5: the specialised filter in
+    // its form for small launches (a block shared by four waves)
+    int segs = 1;
+    if (mode == 4 || mode == 5) { segs = 4; mode -= 4; }
     if (!p || mode < 0 || mode > 3) return fail(IPCR_ERR_INVALID, "ipcr_panel_filter_source: bad argument");
     if (mode >= 2) { // the seed-index filter's source for mode - 2
         ipcr_panel *mp = const_cast<ipcr_panel *>(p);
@@ -1055,7 +1059,7 @@ ipcr_status ipcr_panel_filter_source(const ipcr_panel *p, int32_t mode, char *ou
     }
     const std::vector<ipcr_dev_pattern> &all = p->set[mode].host;
     const size_t G = ipcr::jit_group_size(all, p->cfg.max_mm); // source of the first pattern group
-    const std::string src = G ? ipcr::jit_source(std::vector<ipcr_dev_pattern>(all.begin(), all.begin() + (long)std::min(G, all.size())), p->cfg.max_mm) : std::string();
+    const std::string src = G ? ipcr::jit_source(std::vector<ipcr_dev_pattern>(all.begin(), all.begin() + (long)std::min(G, all.size())), p->cfg.max_mm, 0, nullptr, false, segs) : std::string();
     if (needed) *needed = src.size() + 1;
     if (out && cap) {
         const size_t n = std::min(cap - 1, src.size());
@@ -1814,6 +1818,9 @@ private:
 };
 
 } // namespace
+
+// tests: launches of the specialised filter that took its form for small launches, so far in this process
+extern "C" uint64_t ipcr_internal_small_launches(void) { return ipcr::jit_small_launches(); }
 
 // tests, chunk_workers: how ipcr_scan_chunk's packer reaches device slot `slot` -- 0: pinned slabs + DMA; 1: through the BAR,
 // flush register unknown (IPCR_CHUNK_BAR=2 only); 2: through the BAR, with the HDP flush in front of every launch

@@ -45,6 +45,18 @@ struct JitFilter {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
     unsigned waves_per_group = 4;
+    // what the kernel was generated from: the form for small launches (a block shared by several waves) is built from it
+    // when the first small launch comes -- on a thread of its own; launches until then take the kernel above
+    std::vector<ipcr_dev_pattern> pats;
+    std::vector<uint32_t> ids;
+    bool has_ids = false, spill_only = false;
+    int max_mm = 0;
+    unsigned qbase = 0;
+    std::string arch;
+    unsigned segments = 1;            // of THIS kernel (1: one wave per block)
+    JitFilter *small = nullptr;       // the segmented form, once built
+    std::atomic<int> small_state{0};  // 0 not asked for, 1 being built, 2 ready, 3 cannot be built
+    std::thread small_thread;
 };
 
 std::string count_code(int B, int k, int *cost = nullptr);
@@ -342,8 +354,16 @@ std::string count_code(int B, int k, int *cost) {
 }
 
 std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, unsigned qbase,
-                       const std::vector<uint32_t> *ids, bool spill_only) {
+                       const std::vector<uint32_t> *ids, bool spill_only, int segments) {
     if (full_pats.empty() || full_pats.size() > 48 || (ids && ids->size() != full_pats.size())) return "";
+    // segments > 1: the form for SMALL launches (a 4 Mb chunk is 16 blocks: 16 waves on a device with room for thousands, each
+    // streaming its block's 37 row quads one behind the other -- ~25 us whatever the launch size).  A block is then shared by
+    // `segments` waves: wave s tests the windows that END in iterations [e0, e1) of the rolled loop and runs the iteration in
+    // front of them only to fill its register window.  Every wave loads the head quads of its block into the stash itself
+    // (only the wave that walks iteration 0 has streamed them).  The rolled loop's 10 % in the sweep do not matter here -- a
+    // small launch is latency, not bandwidth -- and it builds in two thirds of the time.
+    const int SEG = segments < 1 ? 1 : segments;
+    const bool seg = SEG > 1;
     auto pid = [&](size_t q) { return ids ? (unsigned)(*ids)[q] : qbase + (unsigned)q; }; // index in the panel's device table
     // The register window is the kernel's budget (W rows x 4 planes), and the filter only has to be SOUND: a window
     // with <= k mismatches has <= k mismatches at any subset of its positions.  So a pattern longer than LF is
@@ -377,7 +397,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     // two waves per SIMD) buys 15 fewer v_cmp + s_cbranch_vccz pairs per 20 rows.  Needs the peeled loop (no row guards).
     // MEASURED (3 Gb): C3 0.1958 / 0.1994 ms against 0.1970 / 0.2002 without, C2 0.1806 / 0.1876 against 0.1830 / 0.1815 --
     // inside the run-to-run spread, for 15 % more generated source (a 24-row loop body): off by default, parity-tested.
-    const bool roll = env_int("IPCR_JIT_ROLL", 0, 0, 1) != 0;
+    const bool roll = seg || env_int("IPCR_JIT_ROLL", 0, 0, 1) != 0;
     const bool want_merge = !roll && env_int("IPCR_JIT_PEEL", 1, 0, 1) != 0 && env_int("IPCR_JIT_MERGE", 0, 0, 1) != 0 && Lmax <= 20;
     const int W = (Lmax + 3 + (want_merge ? 3 : 0)) / 4 * 4; // window rows, multiple of the row-quad (merge: at least three spare)
     // tuning knobs; defaults = best of the sweeps on MI355X (tools/sweep_jit.py): windows up to
@@ -641,6 +661,11 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     // that is built once per panel and swept for as long as the run lasts keeps the fast loop; the build is off the
     // critical path anyway (the first scans take the table-driven kernel).  Parity-tested (test_random_differential).
     const int NIT = roll ? (QTOTAL + QPI - 1) / QPI : NFULL;
+    if (seg) { // every wave's first prefetch must lie inside the strand (quads < 32), and every wave must have an iteration to test
+        if (NIT < SEG) return "";
+        const int f0_last = ((SEG - 1) * NIT) / SEG - 1;
+        if (f0_last * QPI + D > 32) return "";
+    }
     auto load_wrap_dyn = [&](const std::string &kq) { // load_wrap for a quad number known at run time (wave-uniform)
         std::ostringstream b;
         b << "{ const u32 kq = " << kq << ";\n";
@@ -691,7 +716,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
             body << "      else if (qi + " << D << "u < " << QTOTAL << "u) " << load_wrap_dyn("qi + " + std::to_string(D) + "u - 32u") << "\n";
         } else
             body << "      " << load_normal("qi + " + std::to_string(D) + "u") << "\n";
-        if (u4 < QW && !peel)
+        if (u4 < QW && !peel && !seg)
             body << "      if (it == 0u) { st[" << u4 * 3 << "][lane] = clo; st[" << u4 * 3 + 1 << "][lane] = chi; st[" << u4 * 3 + 2
                  << "][lane] = civ; }\n";
         if (merge) {
@@ -703,6 +728,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
         for (int c = 0; c < 4; ++c) {
             const int step = u4 * 4 + c;
             std::string guard = step < LM1 && !peel ? "it > 0u" : "";
+            if (seg) guard += std::string(guard.empty() ? "" : " && ") + "it >= seg_e0"; // (the iteration in front of a wave's own only fills the window)
             if (roll) { // row x = it * W + step ends a window of this strand iff LM1 <= x < 128 + LM1
                 const int it_max = (128 + LM1 - 1 - step) / W;
                 if (it_max < 0) guard = "never";
@@ -817,13 +843,19 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     s << "  const u32 lane = threadIdx.x & 63u;\n";
     s << "  const u32 wv = threadIdx.x >> 6;\n";
     s << "  const u64 bidx = (u64)blockIdx.x * " << WPG << "u + wv; // this launch sweeps blocks [block0, block0 + nblocks)\n";
-    s << "  const u64 block = block0 + bidx;\n";
+    s << "  const u64 nwv = nblocks * " << SEG << "ull; // waves that work in this launch\n";
+    if (seg) {
+        s << "  const u64 block = block0 + bidx / " << SEG << "ull;\n";
+        s << "  const u32 sg = (u32)(bidx % " << SEG << "ull); // this wave's share of the block: windows that end in iterations [e0, e1)\n";
+        s << "  const u32 seg_e0 = sg * " << NIT << "u / " << SEG << "u, seg_e1 = (sg + 1u) * " << NIT << "u / " << SEG << "u, seg_f0 = seg_e0 ? seg_e0 - 1u : 0u;\n";
+    } else
+        s << "  const u64 block = block0 + bidx;\n";
     // the counters alternate between two sets; workgroup 0 clears the set the NEXT scan will use
     s << "  if (blockIdx.x == 0u && next_counts) {\n"
          "    if (threadIdx.x < 4u) next_counts[threadIdx.x] = 0ull;\n"
          "    for (u32 t = threadIdx.x; t < 256u; t += " << WPG * 64 << "u) next_qcount[t * 16u] = 0ull;\n"
          "  }\n";
-    s << "  if (bidx >= nblocks) return;\n";
+    s << "  if (bidx >= nwv) return;\n";
     s << "  __shared__ u64 lkey_all[" << WPG << "][LIST_CAP + 1u];\n";
     s << "  __shared__ u32 lbits_all[" << WPG << "][LIST_CAP + 1u];\n";
     s << "  __shared__ u32 lcnt_all[" << WPG << "];\n";
@@ -850,16 +882,26 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
     const int SC = nb_lds ? 65 : 64; // stash columns: the wave's 64 + column 0 of the next block
     s << "  __shared__ v4 stash[" << WPG << "][" << QW * 3 << "][" << SC << "]; // head quads of each wave's block, for the wrap rows\n";
     s << "  v4 (*st)[" << SC << "] = stash[wv];\n";
-    for (int i = 1; i <= D; ++i)
-        s << "  v4 p" << i << "lo = own[" << (i - 1) * 192 << "], p" << i << "hi = own[" << (i - 1) * 192 + 64 << "], p" << i
-          << "iv = own[" << (i - 1) * 192 + 128 << "];\n";
+    for (int i = 1; i <= D; ++i) {
+        const std::string at = seg ? "(seg_f0 * " + std::to_string(QPI) + "u + " + std::to_string(i - 1) + "u) * 192u" : std::to_string((i - 1) * 192);
+        s << "  v4 p" << i << "lo = own[" << at << "], p" << i << "hi = own[" << at << " + 64u], p" << i << "iv = own[" << at << " + 128u];\n";
+    }
     if (nb_lds)
         s << "  v4 nbv = {0u, 0u, 0u, 0u}; // word (lane / 3, lane % 3) of the next block's column 0\n"
              "  if (lane < " << QW * 3 << "u) nbv = nblk[(lane / 3u) * 192u + (lane % 3u) * 64u];\n";
+    if (seg) { // the head quads for the wrap rows: loaded by every wave whose walk reaches them (they are in the L2: the block's first wave streams them)
+        s << "  if (seg_e1 * " << QPI << "u + " << D << "u > 32u) {\n";
+        for (int q = 0; q < QW; ++q)
+            s << "    st[" << q * 3 << "][lane] = own[" << q * 192 << "]; st[" << q * 3 + 1 << "][lane] = own[" << q * 192 + 64 << "]; st["
+              << q * 3 + 2 << "][lane] = own[" << q * 192 + 128 << "];\n";
+        if (nb_lds) s << "    if (lane < " << QW * 3 << "u) st[lane][64] = nbv;\n";
+        s << "  }\n";
+    }
     s << pro.str();
     if (nb_lds && peel) s << "  if (lane < " << QW * 3 << "u) st[lane][64] = nbv; // (loaded before iteration 0: it has long arrived)\n";
-    s << "  for (u32 it = " << (peel ? 1 : 0) << "u; it < " << NIT << "u; ++it) {\n";
-    if (nb_lds && !peel) s << "    if (it == 1u && lane < " << QW * 3 << "u) st[lane][64] = nbv;\n";
+    if (seg) s << "  for (u32 it = seg_f0; it < seg_e1; ++it) {\n";
+    else s << "  for (u32 it = " << (peel ? 1 : 0) << "u; it < " << NIT << "u; ++it) {\n";
+    if (nb_lds && !peel && !seg) s << "    if (it == 1u && lane < " << QW * 3 << "u) st[lane][64] = nbv;\n";
     s << body.str() << "  }\n";
     s << epi.str();
     // ---- exact verification of this wave's survivors (verifyAt, core/engine/ac.go:186-213 / the
@@ -973,7 +1015,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
          "    // (thousands of waves issuing one cost half the kernel time again)\n"
          "    if (wrote || ncand) asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
          "    const u32 sh = (u32)bidx & 63u;\n"
-         "    const u32 expect = (u32)((nblocks - sh + 63ull) >> 6); // waves of this ticket shard\n"
+         "    const u32 expect = (u32)((nwv - sh + 63ull) >> 6); // waves of this ticket shard\n"
          "    u32 t = 0u;\n"
          "    if (lane == 0u) t = atomicAdd(tickets + sh * 32u, 1u);\n"
          "    t = (u32)__builtin_amdgcn_readfirstlane(t);\n"
@@ -981,7 +1023,7 @@ std::string jit_source(const std::vector<ipcr_dev_pattern> &full_pats, int k, un
          "      u32 t2 = 0u;\n"
          "      if (lane == 0u) { tickets[sh * 32u] = 0u; t2 = atomicAdd(tickets + 2048u, 1u); }\n"
          "      t2 = (u32)__builtin_amdgcn_readfirstlane(t2);\n"
-         "      const u32 nsh = nblocks < 64ull ? (u32)nblocks : 64u;\n"
+         "      const u32 nsh = nwv < 64ull ? (u32)nwv : 64u;\n"
          "      if (t2 + 1u == nsh) { // every other wave of the scan has finished\n"
          "        __threadfence();\n"
          "        u32 cs = __hip_atomic_load(tickets + lane * 32u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // candidate windows, 64 partial counts\n"
@@ -1236,6 +1278,16 @@ std::vector<JitFilter *> jit_build(const std::vector<ipcr_dev_pattern> &all_pats
         if (!ok[g]) { err = errs[g]; return out; }
     for (size_t g = 0; g < ngroups; ++g) {
         JitFilter *f = new JitFilter;
+        {
+            const size_t q0 = g * G, q1 = std::min(pats.size(), q0 + G);
+            f->pats.assign(pats.begin() + (long)q0, pats.begin() + (long)q1);
+            f->has_ids = subset != nullptr;
+            if (subset) f->ids.assign(subset->begin() + (long)q0, subset->begin() + (long)q1);
+            f->spill_only = subset != nullptr;
+            f->max_mm = max_mm;
+            f->qbase = subset ? 0u : (unsigned)q0;
+            f->arch = arch;
+        }
         const size_t at = srcs[g].find("// IPCR_WAVES_PER_GROUP ");
         if (at != std::string::npos) f->waves_per_group = (unsigned)atoi(srcs[g].c_str() + at + 24);
         if (hipModuleLoadData(&f->module, codes[g].data()) != hipSuccess ||
@@ -2133,6 +2185,50 @@ hipError_t jit_launch_index(JitFilter *f, hipStream_t st, const uint32_t *planes
     return e;
 }
 
+namespace {
+std::atomic<uint64_t> g_small_launches{0};
+
+// builds f's form for small launches (f->small); false when it cannot be had
+bool build_small(JitFilter *f, int segs) {
+    const std::string src = jit_source(f->pats, f->max_mm, f->qbase, f->has_ids ? &f->ids : nullptr, f->spill_only, segs);
+    if (src.empty()) return false;
+    std::vector<char> code;
+    std::string err;
+    if (!compile_group(src, f->arch, code, err)) return false;
+    JitFilter *sm = new JitFilter;
+    sm->segments = (unsigned)segs;
+    const size_t at = src.find("// IPCR_WAVES_PER_GROUP ");
+    if (at != std::string::npos) sm->waves_per_group = (unsigned)atoi(src.c_str() + at + 24);
+    if (hipModuleLoadData(&sm->module, code.data()) != hipSuccess || hipModuleGetFunction(&sm->fn, sm->module, "ipcr_filter") != hipSuccess) {
+        jit_destroy(sm);
+        return false;
+    }
+    f->small = sm;
+    return true;
+}
+
+// the segmented form of f if it is there; the first caller to ask starts its build (in the background unless IPCR_JIT_ASYNC=0)
+JitFilter *small_form(JitFilter *f, int segs) {
+    int st = f->small_state.load(std::memory_order_acquire);
+    if (st == 2) return f->small;
+    if (st != 0) return nullptr;
+    int expected = 0;
+    if (!f->small_state.compare_exchange_strong(expected, 1)) return f->small_state.load(std::memory_order_acquire) == 2 ? f->small : nullptr;
+    static const bool async_on = !(getenv("IPCR_JIT_ASYNC") && atoi(getenv("IPCR_JIT_ASYNC")) == 0);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!async_on) {
+        f->small_state.store(build_small(f, segs) ? 2 : 3, std::memory_order_release);
+        return f->small_state.load() == 2 ? f->small : nullptr;
+    }
+    f->small_thread = std::thread([f, segs, dev] {
+        (void)hipSetDevice(dev); // the code object is loaded onto the device of the launch that asked
+        f->small_state.store(build_small(f, segs) ? 2 : 3, std::memory_order_release);
+    });
+    return nullptr;
+}
+} // namespace
+
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t block0, uint64_t nblocks, void *queue,
                       uint64_t qcap, unsigned long long *qcount, const JitVerify &v, hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0) return hipSuccess;
@@ -2142,14 +2238,25 @@ hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint
                     (void *)&a.max_mm, (void *)&a.check_rst, (void *)&a.hits, (void *)&a.hcap, (void *)&a.counts,
                     (void *)&a.next_counts, (void *)&a.next_qcount, (void *)&a.tickets, (void *)&a.pub,
                     (void *)&a.pub_hits, (void *)&a.pre, (void *)&a.pub_seq, (void *)&a.seq, (void *)&a.withhold};
+    // A small launch -- a chunk of the drop-in path, a bacterial genome -- takes the form in which a block is shared by several
+    // waves, as soon as that has been built (IPCR_JIT_SEGMENTS=1: never; IPCR_JIT_SEG_BLOCKS: what "small" is)
+    const int seg_n = env_int("IPCR_JIT_SEGMENTS", 4, 1, 8); // (read per launch: the tests run both forms in one process)
+    const int seg_blocks = env_int("IPCR_JIT_SEG_BLOCKS", 512, 0, 1 << 20);
+    if (seg_n > 1 && nblocks <= (uint64_t)seg_blocks && f->segments == 1)
+        if (JitFilter *sm = small_form(f, seg_n)) { f = sm; g_small_launches.fetch_add(1, std::memory_order_relaxed); }
     const unsigned wpg = f->waves_per_group, threads = wpg * 64u;
-    const unsigned grid = (unsigned)((nblocks + wpg - 1) / wpg);
+    const uint64_t waves = nblocks * f->segments;
+    const unsigned grid = (unsigned)((waves + wpg - 1) / wpg);
     // start/stop are attached to this dispatch itself (its begin/end timestamps)
     return hipExtModuleLaunchKernel(f->fn, grid * threads, 1, 1, threads, 1, 1, 0, st, args, nullptr, start, stop, 0);
 }
 
+uint64_t jit_small_launches() { return g_small_launches.load(std::memory_order_relaxed); }
+
 void jit_destroy(JitFilter *f) {
     if (!f) return;
+    if (f->small_thread.joinable()) f->small_thread.join();
+    if (f->small) jit_destroy(f->small);
     if (f->module) (void)hipModuleUnload(f->module);
     delete f;
 }

@@ -17,8 +17,9 @@ struct JitFilter;
 // check); queue entries carry pattern index qbase + position in `pats`
 // ids: the patterns' indices in the panel's device table when they are not qbase, qbase + 1, ... (a subset of a panel);
 // spill_only: every survivor goes to the candidate queue (the stand-alone verifier follows), nothing is verified in the kernel
+// segments > 1: the form for small launches -- a block is shared by that many waves (jit.cpp); "" when the panel's loop cannot be cut so
 std::string jit_source(const std::vector<ipcr_dev_pattern> &pats, int max_mm, unsigned qbase = 0,
-                       const std::vector<uint32_t> *ids = nullptr, bool spill_only = false);
+                       const std::vector<uint32_t> *ids = nullptr, bool spill_only = false, int segments = 1);
 // patterns per kernel for this panel; 0 = not specialisable (table-driven filter)
 size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats, int max_mm);
 // one kernel per pattern group, compiled in parallel; empty (and `err` set) when the panel
@@ -59,6 +60,8 @@ struct JitVerify {
 // blocks [block0, block0 + nblocks) of the tiles
 hipError_t jit_launch(JitFilter *f, hipStream_t st, const uint32_t *planes, uint64_t block0, uint64_t nblocks, void *queue,
                       uint64_t qcap, unsigned long long *qcount, const JitVerify &v, hipEvent_t start, hipEvent_t stop);
+// launches that took the form for small launches (a block shared by several waves) so far, in this process: tests
+uint64_t jit_small_launches();
 // seed-index filter for large panels, with the panel's key shapes baked in (host.cpp: build_index)
 struct IndexGeom {
     int tail_rows = 0;     // bases of history a window can reach behind the newest base (longest pattern - 1)

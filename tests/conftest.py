@@ -22,4 +22,7 @@ def _private_jit_cache(tmp_path_factory):
     # a small panel's kernels are built in the background and its first scans take the table-driven kernel: the tests
     # say which kernel they mean to exercise (ipcr_scan_stats.kernel_kind), so every build is synchronous here
     os.environ.setdefault("IPCR_JIT_ASYNC", "0")
+    # small launches keep the one-wave-per-block kernel in the tests (the kernel of the headline numbers, and what the suite
+    # has always covered); test_small_launches_share_a_block_between_waves turns the segmented form on for its cases
+    os.environ.setdefault("IPCR_JIT_SEGMENTS", "1")
     yield

@@ -345,6 +345,39 @@ def test_host_packed_chunks_take_the_pattern_set_their_bytes_ask_for(hip, monkey
     cp.close()
 
 
+def test_small_launches_share_a_block_between_waves(hip, monkeypatch):
+    """A launch of up to IPCR_JIT_SEG_BLOCKS blocks takes the specialised filter's form in which FOUR waves share a block
+    (jit.cpp: jit_source(..., segments): wave s tests the windows that end in its iterations of the rolled loop, runs the
+    iteration in front of them only to fill its register window, loads the head quads for the wrap rows itself; the last
+    wave's tickets count four waves per block).  The suite's own parity cases on it -- windows across strand and block ends,
+    random panels, the cap quirks, long primers (their survivors spill), C2 / C3 / the +N genome, hundreds of tiny records in
+    one block, workers sharing a panel -- and the counter says that it is the form that ran."""
+    import ctypes
+    n_small = hip.lib.lib().ipcr_internal_small_launches
+    n_small.restype = ctypes.c_uint64
+    monkeypatch.setenv("IPCR_JIT_SEGMENTS", "4")
+    before = n_small()
+    test_windows_across_strand_and_block_ends(hip, monkeypatch, 0)
+    assert n_small() >= before + 3
+    mid = n_small()
+    for seed in (0, 3):
+        test_random_differential(hip, True, seed)
+    test_hit_cap_quirks(hip)
+    test_halo_case(hip)
+    test_long_primers_take_the_specialised_filter(hip, 1)
+    test_config_c2_single_pair_k2_tw5(hip)
+    test_config_c2_with_reference_n(hip)
+    test_config_c3_iupac_k3_circular(hip)
+    test_many_tiny_records_in_one_block(hip)
+    test_concurrent_workers_share_one_panel(hip)
+    assert n_small() > mid + 20
+    # launches of more blocks than "small" keep one wave per block
+    monkeypatch.setenv("IPCR_JIT_SEG_BLOCKS", "0")
+    mid = n_small()
+    test_config_c2_single_pair_k2_tw5(hip)
+    assert n_small() == mid
+
+
 def test_edge_inputs(hip):
     E, P = hip.engine, hip.primer.Pair
     eng = E.New(E.Config(MaxMM=1, TerminalWindow=2, MaxLen=100))

@@ -220,6 +220,14 @@ def test_filter_source_is_generated_for_the_headline_panels():
     assert "ipcr_filter" in lsrc and "#define LIST_CAP 0u" in lsrc and "len 20, 3 protected" in lsrc
     # right-protected pattern: its window starts 16 rows before the filtered part (the push's constant says so: pattern id | 16 << 16)
     assert "u32 info = %du;" % (0 | (16 << 16)) in lsrc and "if (q == 1u) info = 1u;" in lsrc and "wp -= (u64)off" in lsrc
+    # the form for small launches (mode 4 = set 0, a block shared by four waves): the rolled loop between a wave's own bounds, every
+    # window test behind "it >= seg_e0", the head quads loaded by the wave itself, four waves per block in the ticket arithmetic
+    seg = cp.filter_source(4)
+    assert "const u64 nwv = nblocks * 4ull;" in seg and "for (u32 it = seg_f0; it < seg_e1; ++it)" in seg
+    assert "const u32 seg_e0 = sg * 8u / 4u, seg_e1 = (sg + 1u) * 8u / 4u" in seg       # 37 quads in iterations of five: 8 iterations
+    assert seg.count("it >= seg_e0") == 20 and "if (it == 0u) { st[" not in seg            # one guard per row of the 20-row loop body
+    assert "if (seg_e1 * 5u + 2u > 32u) {" in seg and "st[0][lane] = own[0];" in seg
+    assert "const u64 nwv = nblocks * 1ull;" in src and "seg_e0" not in src
     too_long = "ACGT" * 33           # 132 nt: beyond IPCR_MAX_PRIMER_LEN
     with pytest.raises(_lib.IpcrError):
         engine.New(engine.Config(MaxMM=1)).CompilePanel([primer.Pair("l", too_long, too_long)])
