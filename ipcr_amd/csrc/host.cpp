@@ -1564,7 +1564,7 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode, int slot, SetDev **out)
     const bool force_index = getenv("IPCR_FORCE_INDEX") && atoi(getenv("IPCR_FORCE_INDEX")) != 0;
     if (p->specialize && !d.jit_tried && !s.host.empty()) {
         d.jit_tried = true;
-        // hiprtc takes ~0.8 s for a C2-sized panel; the table-driven kernel scans such a panel at ~4 ms per pattern and 3 Gb.
+        // hiprtc takes ~0.8 s for a C2-sized panel; the table-driven kernel scans such a panel at ~1.6 ms per pattern and 3 Gb (four patterns per walk).
         // So a SMALL panel's first scans do not wait: the kernels are built on a thread of their own, the scans that come
         // before they are ready take the table-driven kernel (same results: both are parity-tested against the oracle), and
         // the first panel_upload after the build publishes them.  A cold `ipcr` run on a 3 Gb genome has its products after
@@ -1613,7 +1613,7 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode, int slot, SetDev **out)
             HIPCHK(hipMemcpy(d.d_table, ix.table.data(), ix.table.size() * sizeof(ipcr_index_entry), hipMemcpyHostToDevice));
             if (!ix.leftover.empty()) {
                 // What the index cannot key (primers > 32 nt, too many IUPAC expansions in a key): a handful of patterns
-                // in practice.  The table-driven kernel costs ~4 ms per pattern and 3 Gb; specialised spill-only filters
+                // in practice.  The table-driven kernel costs ~1.6 ms per pattern and 3 Gb; specialised spill-only filters
                 // (their survivors join the index's in the candidate queue) cost one ~0.25 ms sweep per 12 patterns.
                 std::string lerr;
                 d.leftover_jit = ipcr::jit_build(s.host, p->cfg.max_mm, lerr, &ix.leftover);

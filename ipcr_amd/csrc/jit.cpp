@@ -1219,7 +1219,7 @@ size_t jit_group_size(const std::vector<ipcr_dev_pattern> &pats, int max_mm) {
     // every group is a separate hiprtc compile (seconds each) and a sweep of its own: beyond 8 groups the
     // seed-index kernel serves (one compile, one sweep of ~8 ms per 3 Gb whatever the panel) -- but it takes panels
     // of k <= 3 only (host.cpp: panel_upload).  With more mismatches the alternative is the table-driven filter,
-    // ~4 ms per pattern and 3 Gb: there 32 groups (384 patterns; ~10 s of compiles, 32 sweeps of ~0.25 ms) are the
+    // ~1.6 ms per pattern and 3 Gb: there 32 groups (384 patterns; ~10 s of compiles, 32 sweeps of ~0.25 ms) are the
     // better trade
     if (ngroups > (size_t)env_int("IPCR_JIT_MAX_GROUPS", max_mm > 3 ? 32 : 8, 1, 4096)) return 0;
     return (pats.size() + ngroups - 1) / ngroups; // balanced
