@@ -338,6 +338,25 @@ def test_host_packed_chunks_take_the_pattern_set_their_bytes_ask_for(hip, monkey
             got = [p.sig() for p in eng.SimulateCompiledWithScratch("s", tail, cp, sc)]
             want = [w.sig() for w in O.simulate_batch(ocfg(cfg), tail, opairs(pairs))]
             assert got == want and (n < 180 or len(want) >= 1), (n, bar, skip)
+    # a lone worker's 20 Mb record: the pack pool fills three groups of columns (2048 columns = 8 388 608 bases each), the first
+    # clean, the second with a run of N (its invalid-bit plane follows by DMA), the third with lower case (invalid + reset planes);
+    # amplicons across both group boundaries
+    for bar in ("1", "0"):
+        monkeypatch.setenv("IPCR_CHUNK_BAR", bar)
+        monkeypatch.setenv("IPCR_CHUNK_SKIP_INV", "1")
+        monkeypatch.delenv("IPCR_CHUNK_HOSTPACK", raising=False)
+        big = bytearray(O.bench_dna(20_000_000, 77))
+        big[9_000_000:9_000_300] = b"N" * 300
+        big[17_500_000:17_500_004] = b"acgt"
+        for a in (5_000, 8_388_608 - 90, 16_777_216 - 100, 19_999_800):
+            big[a:a + 20] = pairs[0].Forward.encode()
+            big[a + 160:a + 180] = O.revcomp(pairs[0].Reverse)
+        big = bytes(big)
+        got = [p.sig() for p in eng.SimulateCompiledWithScratch("big", big, cp, sc)]
+        want = [w.sig() for w in O.simulate_batch(ocfg(cfg), big, opairs(pairs))]
+        assert got == want and len(want) >= 4, bar
+        assert sc.stats().pattern_set == 1 and sc.stats().hostpack_ms > 0
+    monkeypatch.setenv("IPCR_CHUNK_BAR", "1")
     monkeypatch.setenv("IPCR_CHUNK_CLEAN_MODE", "0")           # the knob that puts round 3's behaviour back
     eng.SimulateCompiledWithScratch("s", clean, cp, sc)
     assert sc.stats().pattern_set == 1
@@ -370,6 +389,7 @@ def test_small_launches_share_a_block_between_waves(hip, monkeypatch):
     test_config_c3_iupac_k3_circular(hip)
     test_many_tiny_records_in_one_block(hip)
     test_concurrent_workers_share_one_panel(hip)
+    test_hit_cap_bounds_device_memory(hip, monkeypatch, 1, 3, 7)      # capped scans repeated over ranges of blocks (block0 > 0)
     assert n_small() > mid + 20
     # launches of more blocks than "small" keep one wave per block
     monkeypatch.setenv("IPCR_JIT_SEG_BLOCKS", "0")
