@@ -38,10 +38,14 @@
 #include <thread>
 #include <vector>
 
+#include "cpu_pool.h"
 #include "device_types.h"
 #include "jit.h"
 #include "launch.h"
 #include "tile_layout.h"
+
+using ipcr::PackPool;          // cpu_pool.h: the process's pool of pack threads
+using ipcr::bind_this_thread;  // ... and the CPUs next to a device
 
 static_assert(sizeof(ipcr_hit) == sizeof(ipcr_hit_rec), "hit layouts must agree");
 static_assert(sizeof(ipcr_probe_hit) == sizeof(ipcr_probe_rec), "probe layouts must agree");
@@ -114,127 +118,6 @@ struct DeviceGuard {
     DeviceGuard(const DeviceGuard &) = delete;
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
-
-// ------------------------------------------------------------ the CPUs next to a device
-// A slab of pinned memory that cores of the OTHER socket have just written crosses the link at 31 GB/s instead of 54: the
-// DMA engine's reads find the lines dirty in caches two hops away (measured round 3 -- the FASTA
-// loader's threads bound to the far socket: 40 ms per GB, to the device's own: 26 ms; unbound it was the scheduler's luck).
-// So the threads of this library that fill pinned memory run on the CPUs the kernel lists as local to the device
-// (/sys/bus/pci/devices/<bus id>/local_cpulist), as far as the process is allowed on them.  IPCR_BIND_THREADS=0: never.
-struct CpuSet {
-    cpu_set_t set;
-    bool known = false;
-};
-// What the process may run on, captured ONCE when the library is loaded: sched_getaffinity later would return the mask of
-// whichever thread asks -- after ipcr_bind_thread_to_device has narrowed the main thread to one device's CPUs, every other
-// device's set (allowed AND local) would come out empty and stay cached so.
-const CpuSet g_initial_cpus = [] {
-    CpuSet c;
-    CPU_ZERO(&c.set);
-    c.known = sched_getaffinity(0, sizeof c.set, &c.set) == 0;
-    return c;
-}();
-
-const CpuSet &device_cpus(int phys) {
-    static std::mutex mu;
-    static std::map<int, CpuSet> cache;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(phys);
-    if (it != cache.end()) return it->second;
-    CpuSet &c = cache[phys];
-    CPU_ZERO(&c.set);
-    if (const char *v = getenv("IPCR_BIND_THREADS")) if (*v && atoi(v) == 0) return c;
-    char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, phys) != hipSuccess) return c;
-    for (char *q = bus; *q; ++q) *q = (char)tolower((unsigned char)*q);
-    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
-    FILE *fh = fopen(path.c_str(), "r");
-    if (!fh) return c;
-    char line[4096] = {0};
-    const bool got = fgets(line, sizeof line, fh) != nullptr;
-    fclose(fh);
-    if (!got) return c;
-    cpu_set_t allowed = g_initial_cpus.set, local; // the process's mask as it was when the library was loaded, before anybody was bound
-    CPU_ZERO(&local);
-    if (!g_initial_cpus.known) return c;
-    for (const char *q = line; *q;) { // "0-63,128-191"
-        char *e = nullptr;
-        const long a = strtol(q, &e, 10);
-        if (e == q) break;
-        long b = a;
-        if (*e == '-') { q = e + 1; b = strtol(q, &e, 10); }
-        for (long k = a; k <= b && k < CPU_SETSIZE; ++k) if (k >= 0) CPU_SET((int)k, &local);
-        q = (*e == ',') ? e + 1 : e;
-        if (*e != ',') break;
-    }
-    CPU_AND(&c.set, &allowed, &local);
-    c.known = CPU_COUNT(&c.set) > 0 && CPU_COUNT(&c.set) < CPU_COUNT(&allowed); // nothing to choose on a one-socket host
-    return c;
-}
-// the calling thread onto the device's CPUs; false when they are not known (or binding is off)
-bool bind_this_thread(int phys) {
-    const CpuSet &c = device_cpus(phys);
-    return c.known && sched_setaffinity(0, sizeof c.set, &c.set) == 0;
-}
-
-// The pack pool's threads, one physical core each, dealt round-robin over the L3 domains (CCDs) of the device's CPUs.  Left to
-// the scheduler, ten of fifteen polling threads ended up on ONE CCD (woken next to their waker), and a CCD's path to the I/O
-// die carries only so many write-combined stores: the same 229 KB item took 10-13 us on a thread alone on its CCD and 45-60 us
-// on that one (round 4, IPCR_DEBUG_TIMES).  -> the CPU sets (a core's hardware threads) in dealing order; empty when the
-// topology cannot be read.
-const std::vector<cpu_set_t> &spread_core_sets(int phys) {
-    static std::mutex mu;
-    static std::map<int, std::vector<cpu_set_t>> cache;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(phys);
-    if (it != cache.end()) return it->second;
-    std::vector<cpu_set_t> &out = cache[phys];
-    const CpuSet &dc = device_cpus(phys);
-    const cpu_set_t &allowed = dc.known ? dc.set : g_initial_cpus.set;
-    if (!dc.known && !g_initial_cpus.known) return out;
-    auto read_int = [](const char *fmt, int cpu, long &v) {
-        char path[160];
-        snprintf(path, sizeof path, fmt, cpu);
-        FILE *fh = fopen(path, "r");
-        if (!fh) return false;
-        const bool ok = fscanf(fh, "%ld", &v) == 1;
-        fclose(fh);
-        return ok;
-    };
-    std::map<long, std::map<long, cpu_set_t>> l3; // L3 domain -> (package, core) -> its hardware threads
-    for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu) {
-        if (!CPU_ISSET(cpu, &allowed)) continue;
-        long core = 0, pkg = 0, dom = 0;
-        if (!read_int("/sys/devices/system/cpu/cpu%d/topology/core_id", cpu, core)) { out.clear(); return out; }
-        (void)read_int("/sys/devices/system/cpu/cpu%d/topology/physical_package_id", cpu, pkg);
-        if (!read_int("/sys/devices/system/cpu/cpu%d/cache/index3/id", cpu, dom)) dom = pkg;
-        auto &cs = l3[dom];
-        auto f = cs.find(pkg * 100000 + core);
-        if (f == cs.end()) { cpu_set_t z; CPU_ZERO(&z); f = cs.emplace(pkg * 100000 + core, z).first; }
-        CPU_SET(cpu, &f->second);
-    }
-    for (bool any = true; any;) {
-        any = false;
-        for (auto &d : l3)
-            if (!d.second.empty()) {
-                out.push_back(d.second.begin()->second);
-                d.second.erase(d.second.begin());
-                any = true;
-            }
-    }
-    return out;
-}
-// pool thread `index` onto its core; false: the topology is unknown (the caller falls back to the device's whole set)
-bool bind_pool_thread(int phys, unsigned index) {
-    static const bool on = !(getenv("IPCR_POOL_SPREAD") && atoi(getenv("IPCR_POOL_SPREAD")) == 0) &&
-                           !(getenv("IPCR_BIND_THREADS") && *getenv("IPCR_BIND_THREADS") && atoi(getenv("IPCR_BIND_THREADS")) == 0);
-    if (!on) return false;
-    const std::vector<cpu_set_t> &cores = spread_core_sets(phys);
-    if (cores.empty()) return false;
-    // (from the far end of the list: the caller's own thread and the runtime's helpers tend to sit on the first CPUs)
-    const cpu_set_t &c = cores[cores.size() - 1 - index % cores.size()];
-    return sched_setaffinity(0, sizeof c, &c) == 0;
-}
 
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
@@ -1693,130 +1576,6 @@ void host_writable_off(int phys) {
     g_bar_cache[phys].writable = false;
 }
 
-// A few threads that pack slices of ONE large record (a single worker scanning whole chromosomes: a lone core packs
-// ~10 GB/s of ASCII, the link carries 57): created at the first use, they live as long as the process.  A pool of
-// workers never comes here -- every worker packs its own chunk.
-class PackPool {
-public:
-    static PackPool &get() { static PackPool *p = new PackPool; return *p; } // never destroyed: its threads sleep on the condition variable until the process ends
-    unsigned size() const { return (unsigned)threads_.size() + 1u; }
-    // fn(i) for i in [0, n), on the pool's threads and the caller's; returns when all are done
-    // phys >= 0: what the items write is pinned memory read by that device next -- the pool's own threads move onto its CPUs
-    // (device_cpus; the caller's thread stays where its owner put it)
-    // on_idle (optional): called again and again by the CALLER's thread while the pool works -- the caller then takes no
-    // items itself (ipcr_scan_chunk sends a group of columns to the device the moment the pool has packed it)
-    template <class F> void run(size_t n, F fn, int phys = -1, const std::function<void()> *on_idle = nullptr) {
-        if (n == 0) return;
-        std::unique_lock<std::mutex> big(run_mu_); // one record at a time
-        // Every run is an object of its own: a pool thread that wakes late still holds the run it woke for -- whose
-        // items are all taken, so it does nothing -- and never reads the fields of the run that has begun since.
-        auto job = std::make_shared<Job>();
-        job->fn = [&fn](size_t i) { fn(i); };
-        job->n = n;
-        job->phys = phys;
-        job->taken.reset(new std::atomic<uint8_t>[n]);
-        for (size_t i = 0; i < n; ++i) job->taken[i].store(0, std::memory_order_relaxed);
-        // Every pool thread has a mailbox of its own (one cache line): the run goes into all of them -- reference counts taken
-        // here, by one thread -- and then the generation moves on.  A polling thread that sees it takes the run out of ITS box and
-        // begins with the item of its own number: no lock, no counter and no reference count shared with the fourteen others on
-        // its way to the first byte (through one mutex they began 25 us apart, through one spin lock + one shared counter 15 us:
-        // cache lines crossing between CCDs; the items themselves take 10-20 us).
-        for (Mailbox &m : boxes_) {
-            SpinGuard sg(m.lock);
-            m.job = job;
-        }
-        gen_.fetch_add(1, std::memory_order_release);
-        { std::lock_guard<std::mutex> lk(mu_); } // (a thread on its way to sleep has either seen the new generation or is waiting by now)
-        cv_.notify_all();
-        if (on_idle && !threads_.empty()) {
-            while (job->done.load(std::memory_order_acquire) < n) { (*on_idle)(); __builtin_ia32_pause(); }
-            return;
-        }
-        work(*job, ~(size_t)0);
-        // (an item that has been taken is finished before `done` reaches n: fn is not called once this returns)
-        for (unsigned spin = 0; job->done.load(std::memory_order_acquire) < n; ++spin) {
-            if (spin < 2000u) { __builtin_ia32_pause(); continue; }
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_done_.wait_for(lk, std::chrono::microseconds(200), [&] { return job->done.load(std::memory_order_acquire) >= n; });
-        }
-    }
-private:
-    struct Job {
-        std::function<void(size_t)> fn;
-        size_t n = 0;
-        int phys = -1;
-        std::unique_ptr<std::atomic<uint8_t>[]> taken; // per item: somebody has it
-        std::atomic<size_t> next{0}, done{0};
-    };
-    struct alignas(64) Mailbox {
-        std::atomic_flag lock = ATOMIC_FLAG_INIT;
-        std::shared_ptr<Job> job;
-    };
-    struct SpinGuard {
-        std::atomic_flag &f;
-        explicit SpinGuard(std::atomic_flag &x) : f(x) { while (f.test_and_set(std::memory_order_acquire)) __builtin_ia32_pause(); }
-        ~SpinGuard() { f.clear(std::memory_order_release); }
-    };
-    PackPool() {
-        unsigned t = std::min(std::thread::hardware_concurrency(), 16u); // IPCR_PACK_THREADS: up to 64
-        if (const char *v = getenv("IPCR_PACK_THREADS")) t = (unsigned)std::max(1, atoi(v));
-        t = std::min(std::max(t, 1u), 64u);
-        boxes_ = std::vector<Mailbox>(t > 1 ? t - 1 : 0);
-        for (unsigned i = 1; i < t; ++i) threads_.emplace_back([this, i] { loop(i - 1); });
-        for (auto &th : threads_) th.detach(); // they sleep on the condition variable for the rest of the process's life
-    }
-    void one(Job &j, size_t i) {
-        j.fn(i);
-        if (j.done.fetch_add(1, std::memory_order_acq_rel) + 1 >= j.n) { std::lock_guard<std::mutex> lk(mu_); cv_done_.notify_all(); }
-    }
-    // first: the item this thread begins with if nobody has it yet (its own number), then whatever the counter hands out -- the
-    // counter runs over every item, so the item of a thread that sleeps is taken by the others
-    void work(Job &j, size_t first) {
-        if (first < j.n && j.taken[first].exchange(1, std::memory_order_acq_rel) == 0) one(j, first);
-        for (;;) {
-            const size_t i = j.next.fetch_add(1);
-            if (i >= j.n) break;
-            if (j.taken[i].exchange(1, std::memory_order_acq_rel) == 0) one(j, i);
-        }
-    }
-    void loop(unsigned index) {
-        uint64_t seen = 0;
-        int bound = -1;
-        Mailbox &box = boxes_[index];
-        for (;;) {
-            // a lone worker that scans chunk after chunk comes back every ~100 us: poll for that long before sleeping (a
-            // wake-up through the condition variable costs 20-50 us of the ~25 us a 4 Mb chunk takes to pack)
-            const auto t0 = std::chrono::steady_clock::now();
-            bool changed = false;
-            while (!(changed = gen_.load(std::memory_order_acquire) != seen)) {
-                __builtin_ia32_pause();
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) break;
-            }
-            if (!changed) {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
-            }
-            seen = gen_.load(std::memory_order_acquire);
-            std::shared_ptr<Job> job;
-            {
-                SpinGuard sg(box.lock); // (uncontended but for the moment the next run is being posted)
-                job = std::move(box.job);
-            }
-            if (!job) continue; // (posted and taken already: this thread saw two generations in one look)
-            if (job->phys >= 0 && job->phys != bound) { // onto a core of its own next to the device (or, failing that, anywhere next to it)
-                if (!bind_pool_thread(job->phys, index)) (void)bind_this_thread(job->phys);
-                bound = job->phys;
-            }
-            work(*job, index);
-        }
-    }
-    std::mutex mu_, run_mu_;
-    std::condition_variable cv_, cv_done_;
-    std::vector<Mailbox> boxes_; // one per pool thread
-    std::atomic<uint64_t> gen_{0};
-    std::vector<std::thread> threads_;
-};
-
 } // namespace
 
 // tests: launches of the specialised filter that took its form for small launches, so far in this process
@@ -1828,35 +1587,6 @@ extern "C" int32_t ipcr_internal_device_bar(int32_t slot) {
     if (slot < 0 || slot >= slot_count()) return 0;
     const BarInfo bi = device_bar(slot_phys(slot));
     return !bi.writable || !env_flag("IPCR_CHUNK_BAR", true) ? 0 : (bi.hdp_flush ? 2 : 1);
-}
-
-// tests/test_host_logic.py: runs of every size in quick succession, from two callers at once, with and without an idle
-// callback; every item of every run must have been called exactly once when its run returns.  -> the number of violations
-extern "C" int32_t ipcr_internal_pool_selftest(uint32_t rounds, uint32_t max_items) {
-    std::atomic<int32_t> bad{0};
-    auto caller = [&](uint32_t seed) {
-        uint32_t x = seed;
-        for (uint32_t r = 0; r < rounds; ++r) {
-            x = x * 1664525u + 1013904223u;
-            const size_t n = 1u + (x >> 8) % std::max(1u, max_items);
-            std::unique_ptr<std::atomic<uint32_t>[]> calls(new std::atomic<uint32_t>[n]);
-            for (size_t i = 0; i < n; ++i) calls[i].store(0);
-            std::atomic<uint64_t> idle_calls{0};
-            const std::function<void()> idle = [&] { idle_calls.fetch_add(1, std::memory_order_relaxed); };
-            const bool with_idle = (x >> 4) & 1u;
-            PackPool::get().run(n, [&](size_t i) {
-                volatile uint32_t sink = 0;
-                for (uint32_t k = 0; k < ((uint32_t)i * 2654435761u >> 24); ++k) sink = sink + k; // items of uneven length
-                calls[i].fetch_add(1, std::memory_order_relaxed);
-            }, -1, with_idle ? &idle : nullptr);
-            for (size_t i = 0; i < n; ++i)
-                if (calls[i].load() != 1u) bad.fetch_add(1);
-        }
-    };
-    std::thread other(caller, 0x1234567u);
-    caller(0x7654321u);
-    other.join();
-    return bad.load();
 }
 
 // fasta.cpp: its file reads run on the same threads (threads started per slab slowed the slab copies, see there)
