@@ -10,6 +10,7 @@
 // Two consumers: the streaming reader (ipcr_fasta_next: host parse, what a worker of the drop-in
 // pipeline or the CLI's chunked mode pulls from) and the resident-genome loader
 // (ipcr_genome_add_fasta: raw slabs to the device, normalisation in fasta_kernels.hip).
+#include <errno.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <hip/hip_runtime_api.h>
@@ -36,7 +37,8 @@
 #include "launch.h"
 
 struct ipcr_fasta {
-    gzFile fh = nullptr;
+    gzFile fh = nullptr; // gzip input, or stdin
+    int fd = -1;         // a plain file is read with read(2): zlib's transparent mode copies every byte through a buffer of its own
     std::vector<uint8_t> buf; // raw read buffer
     size_t bpos = 0, blen = 0;
     bool eof = false;
@@ -98,7 +100,9 @@ bool read_line(ipcr_fasta *f, std::string &line) {
     for (;;) {
         if (f->bpos == f->blen) {
             if (f->eof) return !line.empty();
-            const int n = gzread(f->fh, f->buf.data(), (unsigned)f->buf.size());
+            long n;
+            if (f->fd >= 0) { do n = (long)::read(f->fd, f->buf.data(), f->buf.size()); while (n < 0 && errno == EINTR); }
+            else n = gzread(f->fh, f->buf.data(), (unsigned)f->buf.size());
             if (n <= 0) { f->eof = true; f->bpos = f->blen = 0; return !line.empty(); }
             f->bpos = 0;
             f->blen = (size_t)n;
@@ -117,6 +121,24 @@ bool read_line(ipcr_fasta *f, std::string &line) {
     }
 }
 
+// one line including its '\n' (if any) as a view: into the read buffer where the whole line lies inside it (no copy: all but
+// one line per 4 MiB), assembled in f->line where it crosses a refill.  The view is good until the next call.
+bool next_line(ipcr_fasta *f, const uint8_t *&lp, size_t &ln) {
+    if (f->bpos < f->blen) {
+        const uint8_t *p = f->buf.data() + f->bpos;
+        if (const void *nl = memchr(p, '\n', f->blen - f->bpos)) {
+            ln = (size_t)((const uint8_t *)nl - p) + 1;
+            lp = p;
+            f->bpos += ln;
+            return true;
+        }
+    }
+    if (!read_line(f, f->line)) return false;
+    lp = (const uint8_t *)f->line.data();
+    ln = f->line.size();
+    return true;
+}
+
 void emit_chunk(ipcr_fasta *f, uint64_t start, uint64_t end, const uint8_t *seq, size_t n) { // path_ctx.go:109-124
     char tmp[64];
     snprintf(tmp, sizeof tmp, ":%llu-%llu", (unsigned long long)start, (unsigned long long)end);
@@ -132,7 +154,8 @@ bool flush_record(ipcr_fasta *f) {
     f->have_id = false;
     if (!f->emitted_chunk) {
         f->out_id = f->id;
-        f->out_seq = f->window;
+        f->out_seq.swap(f->window); // (the whole record: handed over, not copied -- start_record clears the window)
+        f->window.clear();
         return true;
     }
     if (f->last_emitted_end < f->total_len) {
@@ -642,8 +665,14 @@ ipcr_status ipcr_fasta_open(const char *path, int64_t chunk_size, int64_t overla
     gzFile fh = strcmp(path, "-") == 0 ? gzdopen(0, "rb") : gzopen(path, "rb"); // gz or plain, transparently
     if (!fh) return ipcr_internal_fail(IPCR_ERR_INVALID, "cannot open %s", path);
     gzbuffer(fh, 1 << 20);
+    int fd = -1;
+    if (strcmp(path, "-") != 0 && gzdirect(fh)) { // not gzip: read the file itself
+        fd = ::open(path, O_RDONLY);
+        if (fd >= 0) { gzclose(fh); fh = nullptr; }
+    }
     ipcr_fasta *f = new ipcr_fasta;
     f->fh = fh;
+    f->fd = fd;
     f->buf.resize(1 << 22);
     f->chunk_size = chunk_size;
     f->overlap = overlap;
@@ -656,6 +685,7 @@ ipcr_status ipcr_fasta_open(const char *path, int64_t chunk_size, int64_t overla
 void ipcr_fasta_close(ipcr_fasta *f) {
     if (!f) return;
     if (f->fh) gzclose(f->fh);
+    if (f->fd >= 0) ::close(f->fd);
     delete f;
 }
 
@@ -684,30 +714,31 @@ ipcr_status ipcr_fasta_next(ipcr_fasta *f, const char **id, const uint8_t **seq,
             f->window_start += (uint64_t)f->step;
             return deliver();
         }
-        if (!read_line(f, f->line)) { // EOF
+        const uint8_t *lp = nullptr;
+        size_t ln = 0;
+        if (!next_line(f, lp, ln)) { // EOF
             f->finished = true;
             if (flush_record(f)) return deliver();
             return IPCR_OK;
         }
-        if (f->line[0] == '>') { // scan.go:27 ('>' counts only at line start; read_line returns whole lines)
-            f->pending_header = f->line.substr(1);
+        if (lp[0] == '>') { // scan.go:27 ('>' counts only at line start; next_line returns whole lines)
+            f->pending_header.assign((const char *)lp + 1, ln - 1);
             f->header_pending = true;
             if (flush_record(f)) return deliver();
             continue;
         }
         if (!f->have_id) continue; // sequence before the first header (path_ctx.go:142-144)
-        size_t a, b;
-        trim(f->line, a, b); // normalize.go:5-14
-        const size_t before = f->window.size();
-        f->window.resize(before + (b - a));
+        size_t a = 0, b = ln; // normalize.go:5-14: TrimSpace, then a-z -> A-Z
+        while (a < b && is_space(lp[a])) ++a;
+        while (b > a && is_space(lp[b - 1])) --b;
+        const size_t before = f->window.size(), n = b - a;
+        f->window.insert(f->window.end(), lp + a, lp + b);
         uint8_t *dst = f->window.data() + before;
-        const uint8_t *src = (const uint8_t *)f->line.data() + a;
-        for (size_t i = 0; i < b - a; ++i) {
-            uint8_t c = src[i];
-            if (c >= 'a' && c <= 'z') c = (uint8_t)(c - ('a' - 'A'));
-            dst[i] = c;
+        for (size_t i = 0; i < n; ++i) { // (branch-free: the compiler makes vector code of it)
+            const uint8_t c = dst[i];
+            dst[i] = (uint8_t)(c - (((uint8_t)(c - 'a') < 26u) ? 32u : 0u));
         }
-        f->total_len += b - a;
+        f->total_len += n;
     }
 }
 
