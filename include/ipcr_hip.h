@@ -294,6 +294,33 @@ ipcr_status ipcr_scan_genome(const ipcr_panel *p, ipcr_scratch *s, const ipcr_ge
  * scratch's stream and returns at once; end() waits, rebuilds the match lists and joins.  The
  * scratch must not be used in between; other scratches may scan (and be joined) meanwhile. */
 ipcr_status ipcr_scan_genome_begin(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g);
+
+/* ---- a resident genome scanned the way the pipeline scans it under --chunk-size ----
+ * The reference cuts every record into rolling windows (core/fasta/path_ctx.go:83-179: windows of chunk_size bases, step
+ * chunk_size - overlap; a record that never fills a window goes whole, under its own ID) and every window is ONE
+ * Engine.ForEachCompiledProduct call: HitCap, the reset-byte rules (core/engine/compiled.go:185-190) and the join apply per
+ * window, coordinates are window-local (internal/pipeline/pipeline.go:60-161 puts them back).  Here the tiles are swept ONCE;
+ * the hits of every window are then taken out of the record's list (a window's hits lie wholly inside it), the windows of a
+ * record with a reset byte are asked on the device whether they hold one, and every window is joined as its own call.
+ * Products: `record` = index into the window list (ipcr_scratch_chunk_windows), start / end window-local.
+ * IPCR_ERR_INVALID for a circular panel (internal/runutil/runutil.go:46-49 disables chunking there); IPCR_ERR_UNSUPPORTED when a
+ * capped scan had to run in segments (ipcr_scan_stats.segmented: the device kept per RECORD what HitCap can use -- the caller
+ * streams the chunks through ipcr_scan_chunk instead). */
+typedef struct {
+    uint32_t record;   /* record of the genome */
+    uint32_t plain;    /* 1: the whole record under its own ID (no window was ever emitted); 0: ID "id:start-end" */
+    uint64_t start, end; /* [start, end) in the record */
+    uint32_t reset;    /* the window holds a byte outside ACGTacgt */
+    uint32_t reserved0;
+} ipcr_chunk_window;
+ipcr_status ipcr_scan_genome_chunked(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g, int64_t chunk_size, int64_t overlap,
+                                     ipcr_emit_fn emit, void *user);
+/* the windows of the last ipcr_scan_genome_chunked on this scratch, in order; valid until its next scan */
+ipcr_status ipcr_scratch_chunk_windows(const ipcr_scratch *s, const ipcr_chunk_window **out, int64_t *n);
+/* the windows of ONE record of `len` bases (record, reset left 0): what the streaming reader (ipcr_fasta_next) emits for it;
+ * *n = how many there are (out may be null or shorter: the first `cap` are written) */
+ipcr_status ipcr_chunk_windows(uint64_t len, int64_t chunk_size, int64_t overlap, ipcr_chunk_window *out, int64_t cap, int64_t *n);
+
 /* order two pipelined scans on the device: the next scan begun on `s` runs its filter sweep
  * directly after the filter sweep of the scan most recently begun on `prev` (the two sweeps share
  * one in-order stream, so they never compete for HBM); prev's verify kernel, read-back and

@@ -50,6 +50,12 @@ class ProbeHit(C.Structure):
     _fields_ = [("found", C.c_int32), ("strand", C.c_int32), ("pos", C.c_int32), ("mm", C.c_int32)]
 
 
+class ChunkWindow(C.Structure):
+    """ipcr_chunk_window: one rolling window of a record (ipcr_scan_genome_chunked)"""
+    _fields_ = [("record", C.c_uint32), ("plain", C.c_uint32), ("start", C.c_uint64), ("end", C.c_uint64),
+                ("reset", C.c_uint32), ("reserved0", C.c_uint32)]
+
+
 class Window(C.Structure):
     _fields_ = [("start", C.c_int64), ("end", C.c_int64), ("record", C.c_int32), ("reserved", C.c_int32)]
 
@@ -131,6 +137,9 @@ SYMBOLS = {
     "ipcr_genome_add_fasta": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ipcr_scan_genome": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipcr_scan_genome_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ipcr_scan_genome_chunked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ipcr_scratch_chunk_windows": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(ChunkWindow)), C.POINTER(C.c_int64)]),
+    "ipcr_chunk_windows": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.POINTER(ChunkWindow), C.c_int64, C.POINTER(C.c_int64)]),
     "ipcr_scan_genome_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipcr_scratch_chain_after": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ipcr_scan_genome_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

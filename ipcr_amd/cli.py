@@ -228,6 +228,25 @@ def run(argv: Optional[Sequence[str]] = None, stdout=None, stderr=None) -> int:
         print(f"warning: {w}", file=stderr)
     collector = Collector(o.dedup_cap)
     for path in seq_files:
+        if chunk and not o.probe and not os.environ.get("IPCR_CLI_STREAM_CHUNKS"):
+            # --chunk-size from a resident genome: the file goes through the device loader, the tiles are swept ONCE, and
+            # every rolling window is joined as its own ForEachCompiledProduct call (ipcr_scan_genome_chunked) -- the same
+            # products, IDs and window-local coordinates as the stream below, which one thread parses at ~1 Gbases/s
+            size = os.path.getsize(path) if path != "-" and os.path.exists(path) else (1 << 28)
+            g = engine.Genome(max(size * (8 if path.endswith(".gz") else 1), 1 << 20), max_records=1 << 16)
+            try:
+                g.add_fasta(path)
+                for p in eng.ScanGenomeChunked(g, cp, sc, chunk, overlap):
+                    p = collector.add(path, p)
+                    if p is not None:
+                        rows.append((path, p, None))
+                g.close()
+                continue
+            except _lib.IpcrError as e:
+                g.close()
+                if e.status != _lib.ERR_UNSUPPORTED:                  # (a capped scan that ran in segments: stream the chunks)
+                    print(f"error: {e}", file=stderr)
+                    continue
         if chunk:
             # the reference's data path: every rolling chunk goes through the engine on its own
             # (ForEachCompiledProduct = ipcr_scan_chunk), the collector restores record coordinates

@@ -1392,6 +1392,7 @@ struct ipcr_scratch {
     std::vector<uint64_t> last_rec_len; // of the last scanned genome (for probe)
     std::vector<uint64_t> last_rec_start;
     ipcr_scan_stats stats{};
+    std::vector<ipcr_chunk_window> windows; // of the last ipcr_scan_genome_chunked
     ipcr_genome *chunk = nullptr; // private genome of ipcr_scan_chunk
     bool dev_hits_stale = false;  // the device hit buffer does NOT hold the last scan's hits (scan_segmented: only its last range): hits_raw does
     bool last_was_chunk = false;  // the products in `products` are those of an ipcr_scan_chunk: their amplicons lie in `chunk`
@@ -2644,6 +2645,123 @@ ipcr_status ipcr_scan_genome(const ipcr_panel *p, ipcr_scratch *s, const ipcr_ge
     s->stats.join_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj).count();
     s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return st;
+}
+
+// The rolling windows of one record, as the streaming reader emits them (fasta.cpp: ipcr_fasta_next; core/fasta/path_ctx.go:
+// 148-160 a window leaves as soon as more than chunk_size bases are waiting, the reader then moves on by `step`; :126-138 at
+// the record's end what is left goes out -- the whole record under its own ID if no window ever left).
+static void record_windows(uint32_t rec, uint64_t len, int64_t chunk, int64_t step, std::vector<ipcr_chunk_window> &out) {
+    uint64_t ws = 0, last_end = 0;
+    bool emitted = false;
+    if (step > 0)
+        while (len - ws > (uint64_t)chunk) {
+            out.push_back({rec, 0u, ws, ws + (uint64_t)chunk, 0u, 0u});
+            last_end = ws + (uint64_t)chunk;
+            emitted = true;
+            ws += (uint64_t)step;
+        }
+    if (!emitted) out.push_back({rec, 1u, 0, len, 0u, 0u});
+    else if (last_end < len) out.push_back({rec, 0u, ws, len, 0u, 0u});
+}
+
+ipcr_status ipcr_chunk_windows(uint64_t len, int64_t chunk_size, int64_t overlap, ipcr_chunk_window *out, int64_t cap, int64_t *n) {
+    if (!n) return fail(IPCR_ERR_INVALID, "ipcr_chunk_windows: null argument");
+    int64_t step = chunk_size - overlap;
+    if (chunk_size <= 0 || step <= 0) step = 0; // whole records (path_ctx.go:87-90)
+    std::vector<ipcr_chunk_window> w;
+    record_windows(0, len, chunk_size, step, w);
+    *n = (int64_t)w.size();
+    for (int64_t i = 0; out && i < cap && i < *n; ++i) out[i] = w[(size_t)i];
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_scratch_chunk_windows(const ipcr_scratch *s, const ipcr_chunk_window **out, int64_t *n) {
+    if (!s || !out || !n) return fail(IPCR_ERR_INVALID, "ipcr_scratch_chunk_windows: null argument");
+    *out = s->windows.data();
+    *n = (int64_t)s->windows.size();
+    return IPCR_OK;
+}
+
+ipcr_status ipcr_scan_genome_chunked(const ipcr_panel *p, ipcr_scratch *s, const ipcr_genome *g, int64_t chunk_size, int64_t overlap,
+                                     ipcr_emit_fn emit, void *user) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (p && p->cfg.circular) return fail(IPCR_ERR_INVALID, "ipcr_scan_genome_chunked: chunking is disabled for circular templates (runutil.go:46-49)");
+    ipcr_status st = ipcr_scan_genome_hits(p, s, g); // ONE sweep of the tiles: every window's hits are in the record's list
+    if (st != IPCR_OK) return st;
+    if (s->stats.segmented)
+        return fail(IPCR_ERR_UNSUPPORTED, "ipcr_scan_genome_chunked: the capped scan ran in segments (the device kept per record what HitCap can use, not per window)");
+    DeviceGuard dg(s->device);
+    int64_t step = chunk_size - overlap;
+    if (chunk_size <= 0 || step <= 0) step = 0;
+    const uint32_t nrec = (uint32_t)g->rec_start.size();
+    s->windows.clear();
+    std::vector<size_t> first_window(nrec + 1, 0);
+    for (uint32_t r = 0; r < nrec; ++r) {
+        first_window[r] = s->windows.size();
+        record_windows(r, g->rec_len[r], chunk_size, step, s->windows);
+    }
+    first_window[nrec] = s->windows.size();
+    // which windows hold a reset byte: asked on the device for the windows of records that hold one at all
+    {
+        std::vector<uint64_t> ab;
+        std::vector<size_t> which;
+        for (size_t w = 0; w < s->windows.size(); ++w) {
+            const ipcr_chunk_window &cw = s->windows[w];
+            if (!(g->flags[cw.record] & 1u) || cw.end <= cw.start) continue;
+            ab.push_back(g->rec_start[cw.record] + cw.start);
+            ab.push_back(g->rec_start[cw.record] + cw.end);
+            which.push_back(w);
+        }
+        if (!which.empty()) {
+            uint64_t *d_ab = nullptr;
+            uint32_t *d_fl = nullptr;
+            std::vector<uint32_t> fl(which.size(), 0);
+            HIPCHK(hipMalloc((void **)&d_ab, ab.size() * 8u + which.size() * 4u));
+            d_fl = reinterpret_cast<uint32_t *>(d_ab + ab.size());
+            hipError_t e = hipMemcpyAsync(d_ab, ab.data(), ab.size() * 8u, hipMemcpyHostToDevice, s->stream);
+            if (e == hipSuccess) e = ipcr::launch_window_reset(s->stream, g->rst, d_ab, (uint32_t)which.size(), d_fl);
+            if (e == hipSuccess) e = hipMemcpyAsync(fl.data(), d_fl, which.size() * 4u, hipMemcpyDeviceToHost, s->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+            (void)hipFree(d_ab);
+            if (e != hipSuccess) return fail(IPCR_ERR_DEVICE, "HIP: %s (window reset flags)", hipGetErrorString(e));
+            for (size_t i = 0; i < which.size(); ++i) s->windows[which[i]].reset = fl[i] ? 1u : 0u;
+        }
+    }
+    // every window is one ForEachCompiledProduct call over its own hits (those that lie wholly inside it), window-local
+    const auto tj = std::chrono::steady_clock::now();
+    const bool mode1 = s->pend.mode == 1;
+    const std::vector<ipcr_hit> &H = s->hits; // sorted by (record, pattern, position)
+    std::vector<ipcr_hit> wh;
+    JoinCtx c{p, &s->products, emit, user};
+    size_t i = 0;
+    for (uint32_t r = 0; r < nrec && !c.aborted; ++r) {
+        while (i < H.size() && H[i].record < r) ++i;
+        size_t j = i;
+        while (j < H.size() && H[j].record == r) ++j;
+        for (size_t w = first_window[r]; w < first_window[r + 1] && !c.aborted; ++w) {
+            const ipcr_chunk_window &cw = s->windows[w];
+            wh.clear();
+            for (size_t h = i; h < j; ++h) {
+                const uint32_t gid = H[h].pattern & 0x7FFFFFFFu;
+                const uint64_t L = gid < p->defs.size() ? p->defs[gid].seq.size() : 0;
+                if (H[h].pos < cw.start || H[h].pos + L > cw.end) continue;
+                wh.push_back(H[h]);
+                wh.back().pos -= cw.start;
+                wh.back().record = (uint32_t)w;
+            }
+            if (wh.empty()) continue;
+            // a hit's "seed span touched a reset byte" bit was taken in the record: it lies inside the hit's window, so it holds in
+            // every window that holds the hit
+            const uint8_t fl = (uint8_t)((cw.reset ? 1u : 0u) | (mode1 ? 2u : 0u));
+            (void)join_one_record(p, wh, 0, wh.size(), (uint32_t)w, (int64_t)(cw.end - cw.start), fl, c);
+        }
+        i = j;
+    }
+    s->stats.products = s->products.size();
+    s->stats.join_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj).count();
+    s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (c.aborted) return fail(IPCR_ERR_ABORTED, "emit callback aborted the scan");
+    return IPCR_OK;
 }
 
 ipcr_status ipcr_scratch_chain_after(ipcr_scratch *s, const ipcr_scratch *prev) {

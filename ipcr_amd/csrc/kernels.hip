@@ -220,6 +220,50 @@ __global__ void fill_pad_kernel(uint32_t *__restrict__ planes, uint32_t *__restr
     rst[ipcr_rst_word(block, row, ln)] = 0u;
 }
 
+// -------------------------------------------------------------------------- reset bytes per window
+// Does the run of bases [a, b) (padded genome coordinates) hold a reset byte?  One workgroup per window.  The strands that lie
+// wholly inside the window are tested a tile word at a time -- a word holds one row of 32 strands: the bits of the strands
+// inside, every row -- and the window's first and last strand bit by bit over their rows inside.
+// (ipcr_scan_genome_chunked: the reference's forceFallback rule is per ForEachCompiledProduct call, i.e. per window.)
+__global__ __launch_bounds__(256) void window_reset_kernel(const uint32_t *__restrict__ rst, const uint64_t *__restrict__ win, // [2 i] = a, [2 i + 1] = b
+                                                          uint32_t nwin, uint32_t *__restrict__ flags) {
+    const uint32_t w = blockIdx.x;
+    if (w >= nwin) return;
+    const uint64_t a = win[2u * w], b = win[2u * w + 1u];
+    uint32_t any = 0u;
+    if (b > a) {
+        const uint64_t sa = a >> IPCR_TILE_LOG_N, sb = (b - 1u) >> IPCR_TILE_LOG_N; // first and last strand (inclusive)
+        const uint32_t ra = (uint32_t)(a & (IPCR_TILE_N - 1u)), rb = (uint32_t)((b - 1u) & (IPCR_TILE_N - 1u));
+        // the boundary strands, row by row
+        for (uint32_t t = threadIdx.x; t < 2u * IPCR_TILE_N; t += 256u) {
+            const bool last = t >= IPCR_TILE_N;
+            const uint32_t r = t & (IPCR_TILE_N - 1u);
+            const uint64_t s = last ? sb : sa;
+            if (last && sb == sa) continue; // one strand: the first pass takes it
+            const uint32_t lo = (s == sa) ? ra : 0u, hi = (s == sb) ? rb : IPCR_TILE_N - 1u;
+            if (r < lo || r > hi) continue;
+            const uint64_t col = s >> 5;
+            any |= (rst[ipcr_rst_word(col >> 6, r, (uint32_t)(col & 63u))] >> (uint32_t)(s & 31u)) & 1u;
+        }
+        // the strands between them, a word (32 strands of one row) at a time
+        if (sb > sa + 1u) {
+            const uint64_t s0 = sa + 1u, s1 = sb - 1u; // inclusive
+            const uint64_t c0 = s0 >> 5, c1 = s1 >> 5;
+            const uint64_t nwords = (c1 - c0 + 1u) * IPCR_TILE_N;
+            for (uint64_t i = threadIdx.x; i < nwords; i += 256u) {
+                const uint64_t col = c0 + (i >> IPCR_TILE_LOG_N);
+                const uint32_t r = (uint32_t)(i & (IPCR_TILE_N - 1u));
+                uint32_t m = 0xFFFFFFFFu;
+                if (col == c0) m &= 0xFFFFFFFFu << (uint32_t)(s0 & 31u);
+                if (col == c1) m &= 0xFFFFFFFFu >> (31u - (uint32_t)(s1 & 31u));
+                any |= (rst[ipcr_rst_word(col >> 6, r, (uint32_t)(col & 63u))] & m) ? 1u : 0u;
+            }
+        }
+    }
+    any = __syncthreads_or((int)any) ? 1u : 0u;
+    if (threadIdx.x == 0u) flags[w] = any;
+}
+
 // -------------------------------------------------------------------------- LCG genome
 // benchDNA (core/engine/performance_benchmark_test.go:67-76): x = x*1664525 + 1013904223,
 // base = "ACGT"[(x>>30)&3].  Each thread jumps ahead to its 64-base run by composing the
@@ -704,6 +748,12 @@ hipError_t launch_pack_batch(hipStream_t st, const uint8_t *base, const ipcr_pac
     const uint64_t grid = (total_pairs + 3u) / 4u;
     if (grid == 0 || nrec == 0) return hipSuccess;
     pack_batch_kernel<<<dim3((uint32_t)grid), dim3(256), 0, st>>>(base, recs, pair_prefix, nrec, planes, rst, rec_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_window_reset(hipStream_t st, const uint32_t *rst, const uint64_t *win, uint32_t nwin, uint32_t *flags) {
+    if (nwin == 0) return hipSuccess;
+    window_reset_kernel<<<dim3(nwin), dim3(256), 0, st>>>(rst, win, nwin, flags);
     return hipGetLastError();
 }
 

@@ -21,6 +21,8 @@ bool pack_linear_is_simd();
 hipError_t launch_pack_batch(hipStream_t st, const uint8_t *base, const ipcr_pack_rec *recs, const uint32_t *pair_prefix,
                              uint32_t nrec, uint64_t total_pairs, uint32_t *planes, uint32_t *rst, uint32_t *rec_flags);
 hipError_t launch_fill_pad(hipStream_t st, uint32_t *planes, uint32_t *rst, uint64_t col_begin, uint64_t col_end);
+// flags[i] = does [win[2 i], win[2 i + 1]) (padded genome coordinates) hold a reset byte (win, flags: device memory)
+hipError_t launch_window_reset(hipStream_t st, const uint32_t *rst, const uint64_t *win, uint32_t nwin, uint32_t *flags);
 hipError_t launch_lcg(hipStream_t st, uint8_t *out, uint64_t n, uint32_t seed, uint64_t offset);
 hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_t block0, uint64_t nblocks,
                                  const ipcr_dev_pattern *pats, uint32_t npat, uint32_t max_mm, const uint32_t *sel,

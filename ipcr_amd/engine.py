@@ -458,6 +458,19 @@ class Engine:
         _lib.check(_lib.lib().ipcr_scan_genome(cp._h, scratch._h, genome._h, None, None))
         return scratch.products(genome.ids)
 
+    def ScanGenomeChunked(self, genome: Genome, cp: CompiledPanel, scratch: SimulationScratch, chunkSize: int,
+                          overlap: int) -> List[Product]:
+        """The resident genome scanned as the pipeline scans it under --chunk-size (core/fasta/path_ctx.go:83-179 windows,
+        one Engine.ForEachCompiledProduct call per window: internal/pipeline/pipeline.go:60-125) -- from ONE sweep of the
+        tiles.  Products carry window-local coordinates and the window's ID ('id:start-end', or the record's own ID when
+        it never filled a window), exactly what fasta.StreamChunks + SimulateCompiledWithScratch give chunk by chunk."""
+        _lib.check(_lib.lib().ipcr_scan_genome_chunked(cp._h, scratch._h, genome._h, chunkSize, overlap, None, None))
+        w, n = C.POINTER(_lib.ChunkWindow)(), C.c_int64()
+        _lib.check(_lib.lib().ipcr_scratch_chunk_windows(scratch._h, C.byref(w), C.byref(n)))
+        ids = genome.ids
+        names = [ids[w[i].record] if w[i].plain else "%s:%d-%d" % (ids[w[i].record], w[i].start, w[i].end) for i in range(n.value)]
+        return scratch.products(names)
+
     def ScanGenomeCount(self, genome: Genome, cp: CompiledPanel, scratch: SimulationScratch) -> int:
         """Same scan + join, products left in the scratch (no Python object per product)."""
         _lib.check(_lib.lib().ipcr_scan_genome(cp._h, scratch._h, genome._h, None, None))

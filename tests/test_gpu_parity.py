@@ -398,6 +398,59 @@ def test_small_launches_share_a_block_between_waves(hip, monkeypatch):
     assert n_small() == mid
 
 
+def test_resident_genome_scanned_in_rolling_windows(hip, tmp_path):
+    """ipcr_scan_genome_chunked: a resident genome scanned the way the pipeline scans it under --chunk-size -- ONE sweep, then
+    every rolling window (core/fasta/path_ctx.go:83-179) joined as its own ForEachCompiledProduct call (HitCap, the reset-byte
+    rules and the cap-before-window quirk per window; window-local coordinates) -- against the streaming form: the same file
+    through fasta.StreamChunks and one ipcr_scan_chunk per chunk, itself checked against the oracle chunk by chunk.  Records
+    with runs of N (some windows hold one, some do not), lower case, records shorter than a chunk, an empty record, a header
+    without an ID, amplicons inside overlaps and across window starts, dense low-complexity hits under a small cap."""
+    from ipcr_amd import fasta
+    E, P = hip.engine, hip.primer.Pair
+    rng = random.Random(909)
+    pairs = hip.primer.AddSelfPairs([P("p", "ACGTTGCATGCAAGCTTA", "GGCCTTAAGGCCATATCG", 0, 0), P("q", "ACGTTG", "TGCAAC", 0, 0)])
+    recs = []
+    for r, n in enumerate((70_000, 1_500, 0, 33_333, 120_001)):
+        s = rand_case(rng, n, with_junk=False) if n else []
+        if r in (0, 4):                                     # N runs in some windows only, lower case in others
+            for a in (5_000, 41_000):
+                if a + 30 < n:
+                    s[a:a + 30] = "N" * 30
+            s[20_000:20_004] = list("acgt")
+        if r == 3:
+            s[1000:1400] = list("ACGTTGCA" * 50)            # dense hits for the short pair: the cap bites per window
+        for a in range(300, max(n - 400, 0), 3_700):
+            plant(rng, s, pairs[0].Forward, a, rng.choice([0, 1]))
+            plant(rng, s, O.revcomp(pairs[0].Reverse).decode(), a + rng.randint(60, 250), 0)
+        recs.append("".join(s))
+    path = tmp_path / "g.fa"
+    with open(path, "w") as fh:
+        for r, s in enumerate(recs):
+            fh.write(">rec%d some text\n" % r)
+            for i in range(0, len(s), 61):
+                fh.write(s[i:i + 61] + "\n")
+            if r == 1:
+                fh.write(">\nACGTACGTACGT\n")               # a header without an ID drops its record
+    for k, tw, cap, chunk, overlap in ((1, 3, 10000, 9_000, 700), (2, 3, 5, 20_000, 1_000), (1, 0, 0, 9_000, 700), (0, 3, 3, 4_096, 512),
+                                       (1, 3, 10000, 0, 0), (1, 3, 10000, 1_000_000, 500)):
+        cfg = E.Config(MaxMM=k, TerminalWindow=tw, MinLen=0, MaxLen=400, HitCap=cap, SeedLen=12)
+        eng = E.New(cfg)
+        cp = eng.CompilePanel(pairs)
+        sc = eng.NewSimulationScratch(cp)
+        want = []
+        for rec in fasta.StreamChunks(str(path), chunk, overlap):
+            got_chunk = [(rec.ID,) + p.sig() for p in eng.SimulateCompiledWithScratch(rec.ID, rec.Seq, cp, sc)]
+            assert got_chunk == [(rec.ID,) + w.sig() for w in O.simulate_batch(ocfg(cfg), rec.Seq, opairs(pairs))]
+            want += got_chunk
+        g = E.Genome(sum(len(s) for s in recs) + (1 << 16), max_records=16)
+        g.add_fasta(str(path))
+        got = [(p.SequenceID,) + p.sig() for p in eng.ScanGenomeChunked(g, cp, sc, chunk, overlap)]
+        assert got == want and len(want) >= 20, (k, tw, cap, chunk, overlap)
+        g.close()
+        sc.close()
+        cp.close()
+
+
 def test_edge_inputs(hip):
     E, P = hip.engine, hip.primer.Pair
     eng = E.New(E.Config(MaxMM=1, TerminalWindow=2, MaxLen=100))

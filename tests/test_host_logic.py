@@ -730,3 +730,27 @@ def test_pack_pool_runs_every_item_exactly_once():
     fn.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     assert fn(3000, 200) == 0
     assert fn(300, 3) == 0        # fewer items than threads
+
+
+def test_chunk_windows_are_the_streaming_readers(tmp_path):
+    """ipcr_chunk_windows (what ipcr_scan_genome_chunked cuts a resident record into) against the streaming reader's rolling
+    chunks (ipcr_fasta_next, itself pinned by the reference's chunk literals in tests/test_fasta_cli.py): record lengths around
+    the chunk size, the step and their multiples, overlaps from 0 to chunk - 1, chunking off"""
+    import ctypes as C
+    import random
+    from ipcr_amd import fasta
+    rng = random.Random(5)
+    cases = [(n, c, o) for c, o in ((10, 3), (10, 0), (7, 6), (16, 5), (100, 20)) for n in (0, 1, c - 1, c, c + 1, 2 * c - o, 2 * c - o + 1, 3 * c, 57)]
+    cases += [(rng.randrange(0, 400), c, rng.randrange(0, c)) for c in (5, 11, 64) for _ in range(12)]
+    cases += [(25, 0, 0), (25, 10, 10), (25, 10, 12)]        # chunking off: no size, or no step
+    for n, chunk, overlap in cases:
+        path = tmp_path / "w.fa"
+        seq = "".join(rng.choice("ACGT") for _ in range(n))
+        path.write_text(">r one\n" + "\n".join(seq[i:i + 13] for i in range(0, n, 13)) + "\n")
+        want = [r.ID for r in fasta.StreamChunks(str(path), chunk, overlap)]
+        cnt = C.c_int64()
+        _lib.check(_lib.lib().ipcr_chunk_windows(n, chunk, overlap, None, 0, C.byref(cnt)))
+        w = (_lib.ChunkWindow * max(cnt.value, 1))()
+        _lib.check(_lib.lib().ipcr_chunk_windows(n, chunk, overlap, w, cnt.value, C.byref(cnt)))
+        got = ["r" if w[i].plain else "r:%d-%d" % (w[i].start, w[i].end) for i in range(cnt.value)]
+        assert got == want, (n, chunk, overlap)
