@@ -228,7 +228,7 @@ def run(argv: Optional[Sequence[str]] = None, stdout=None, stderr=None) -> int:
         print(f"warning: {w}", file=stderr)
     collector = Collector(o.dedup_cap)
     for path in seq_files:
-        if chunk and not o.probe and not os.environ.get("IPCR_CLI_STREAM_CHUNKS"):
+        if chunk and not os.environ.get("IPCR_CLI_STREAM_CHUNKS"):
             # --chunk-size from a resident genome: the file goes through the device loader, the tiles are swept ONCE, and
             # every rolling window is joined as its own ForEachCompiledProduct call (ipcr_scan_genome_chunked) -- the same
             # products, IDs and window-local coordinates as the stream below, which one thread parses at ~1 Gbases/s
@@ -236,10 +236,30 @@ def run(argv: Optional[Sequence[str]] = None, stdout=None, stderr=None) -> int:
             g = engine.Genome(max(size * (8 if path.endswith(".gz") else 1), 1 << 20), max_records=1 << 16)
             try:
                 g.add_fasta(path)
-                for p in eng.ScanGenomeChunked(g, cp, sc, chunk, overlap):
+                prods = eng.ScanGenomeChunked(g, cp, sc, chunk, overlap)
+                probe_hits = [None] * len(prods)
+                if o.probe and prods:
+                    # ipcr-probe keeps --chunk-size (internal/probeapp/app.go:108): every product is annotated from its own
+                    # amplicon (the rescan reads it from the resident tiles: window-local coordinates are put back by the library)
+                    out = (_lib.ProbeHit * len(prods))()
+                    _lib.check(_lib.lib().ipcr_probe_products(sc._h, g._h, o.probe.encode(), o.probe_max_mm, out, len(prods)))
+                    probe_hits = [out[i] for i in range(len(prods))]
+                w, nw = C.POINTER(_lib.ChunkWindow)(), C.c_int64()
+                _lib.check(_lib.lib().ipcr_scratch_chunk_windows(sc._h, C.byref(w), C.byref(nw)))
+                for p, h in zip(prods, probe_hits):
+                    ph = None
+                    if h is not None:
+                        if o.require_probe and not h.found:                 # internal/visitors/probe.go:20-22
+                            continue
+                        site = ""
+                        if h.found:
+                            cw = w[p.Record]
+                            amp = g.read(cw.record, cw.start + p.Start, p.End - p.Start)
+                            site = amp.upper()[h.pos:h.pos + len(primer.Normalize(o.probe))].decode()
+                        ph = (h, site)
                     p = collector.add(path, p)
                     if p is not None:
-                        rows.append((path, p, None))
+                        rows.append((path, p, ph))
                 g.close()
                 continue
             except _lib.IpcrError as e:

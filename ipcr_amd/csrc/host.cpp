@@ -1393,6 +1393,7 @@ struct ipcr_scratch {
     std::vector<uint64_t> last_rec_start;
     ipcr_scan_stats stats{};
     std::vector<ipcr_chunk_window> windows; // of the last ipcr_scan_genome_chunked
+    bool products_in_windows = false;       // ... whose products are the current ones: `record` = window, coordinates window-local
     ipcr_genome *chunk = nullptr; // private genome of ipcr_scan_chunk
     bool dev_hits_stale = false;  // the device hit buffer does NOT hold the last scan's hits (scan_segmented: only its last range): hits_raw does
     bool last_was_chunk = false;  // the products in `products` are those of an ipcr_scan_chunk: their amplicons lie in `chunk`
@@ -1950,6 +1951,7 @@ ipcr_status scan_enqueue(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g, b
     pd.t0 = std::chrono::steady_clock::now();
     s->hits.clear();
     s->products.clear();
+    s->products_in_windows = false;
     s->last_was_chunk = false;
     s->dev_hits_stale = false;
     const double pack_ms_keep = s->stats.pack_ms;
@@ -2758,6 +2760,7 @@ ipcr_status ipcr_scan_genome_chunked(const ipcr_panel *p, ipcr_scratch *s, const
         i = j;
     }
     s->stats.products = s->products.size();
+    s->products_in_windows = true;
     s->stats.join_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj).count();
     s->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (c.aborted) return fail(IPCR_ERR_ABORTED, "emit callback aborted the scan");
@@ -2810,6 +2813,7 @@ ipcr_status ipcr_join_hits(const ipcr_panel *p, ipcr_scratch *s, const ipcr_hit 
     s->hits_raw.assign(hits, hits + n_hits);
     sort_hits(s->hits_raw, s->hits, n_records, (uint32_t)p->defs.size());
     s->products.clear();
+    s->products_in_windows = false;
     s->last_was_chunk = false;
     return join_sorted_hits(p, s, record_len, record_flags, n_records, emit, user);
 }
@@ -2844,6 +2848,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
     if (!seq && len) return fail(IPCR_ERR_INVALID, "null sequence");
     s->hits.clear();
     s->products.clear();
+    s->products_in_windows = false;
     memset(&s->stats, 0, sizeof s->stats);
     s->last_was_chunk = p->id.empty();
     if (p->id.empty()) return IPCR_OK; // compiled.go:163-165
@@ -3312,7 +3317,14 @@ static ipcr_status probe_begin(ipcr_scratch *s, const ipcr_genome *g, const char
     uint64_t *offs = reinterpret_cast<uint64_t *>(s->h_probe + off_off);
     offs[0] = 0;
     for (size_t i = 0; i < n; ++i) {
-        const ipcr_product &pr = s->products[i];
+        ipcr_product pr = s->products[i];
+        if (s->products_in_windows && g != s->chunk) { // products of ipcr_scan_genome_chunked: `record` is a window, coordinates are window-local
+            if (pr.record < 0 || (size_t)pr.record >= s->windows.size()) return fail(IPCR_ERR_INVALID, "product window outside the window list");
+            const ipcr_chunk_window &cw = s->windows[(size_t)pr.record];
+            pr.record = (int32_t)cw.record;
+            pr.start += (int64_t)cw.start;
+            pr.end += (int64_t)cw.start;
+        }
         if ((size_t)pr.record >= g->rec_start.size()) return fail(IPCR_ERR_INVALID, "product record outside genome");
         const uint64_t rs = g->rec_start[(size_t)pr.record], rl = g->rec_len[(size_t)pr.record];
         if (pr.start < 0 || pr.end < 0 || (uint64_t)pr.start > rl || (uint64_t)pr.end > rl) return fail(IPCR_ERR_INVALID, "product outside its record");

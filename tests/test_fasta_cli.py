@@ -113,7 +113,7 @@ def test_config_c1_demo_fa_header_only():
 
 
 @pytest.mark.gpu
-def test_cli_end_to_end_matches_oracle(tmp_path):
+def test_cli_end_to_end_matches_oracle(tmp_path, monkeypatch):
     import random
     rng = random.Random(8)
     recs = []
@@ -156,10 +156,15 @@ def test_cli_end_to_end_matches_oracle(tmp_path):
         prb = probe if not extra or extra[0] != "--probe-max-mm" else probe[:8] + ("A" if probe[8] != "A" else "C") + probe[9:]
         base = ["-f", fwd, "-r", rev, "-m", "1", "--sort", "--probe", prb] + extra
         assert cli.run(base + [str(fa)], stdout=a) == 0
-        err = io.StringIO()
-        assert cli.run(base + ["--chunk-size", "3000", str(fa)], stdout=b, stderr=err) == 0
-        assert "chunking disabled" not in err.getvalue()
-        assert a.getvalue() == b.getvalue() and len(a.getvalue().splitlines()) >= 2
+        # both chunked forms: the resident genome scanned in rolling windows (ipcr_scan_genome_chunked: one sweep; the default), and
+        # the windows streamed through ipcr_scan_chunk one by one as a worker of the Go pipeline sends them
+        for stream in ("", "1"):
+            monkeypatch.setenv("IPCR_CLI_STREAM_CHUNKS", stream)
+            b, err = io.StringIO(), io.StringIO()
+            assert cli.run(base + ["--chunk-size", "3000", str(fa)], stdout=b, stderr=err) == 0
+            assert "chunking disabled" not in err.getvalue()
+            assert a.getvalue() == b.getvalue() and len(a.getvalue().splitlines()) >= 2, stream
+        monkeypatch.delenv("IPCR_CLI_STREAM_CHUNKS")
         rows = [l.split("\t") for l in a.getvalue().splitlines()[1:]]
         for r in rows:                                                   # and both equal oligo.BestHit on the amplicon
             rec = dict(recs)[r[1]]

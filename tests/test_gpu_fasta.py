@@ -150,9 +150,12 @@ def _cli(args):
     return out.getvalue(), err.getvalue()
 
 
-def test_chunking_keeps_boundary_hits(tmp_path):  # internal/integration/integration_test.go:125-225
-    """--chunk-size output == unchunked output: rolling chunks through ipcr_scan_chunk, collector rebasing and
-    de-duplication (internal/pipeline/pipeline.go:127-161) against the resident whole-record scan"""
+@pytest.mark.parametrize("stream", ["", "1"])
+def test_chunking_keeps_boundary_hits(tmp_path, monkeypatch, stream):  # internal/integration/integration_test.go:125-225
+    """--chunk-size output == unchunked output: rolling chunks (the resident genome scanned in windows, or every window through
+    ipcr_scan_chunk), collector rebasing and de-duplication (internal/pipeline/pipeline.go:127-161) against the resident
+    whole-record scan"""
+    monkeypatch.setenv("IPCR_CLI_STREAM_CHUNKS", stream)
     fa = tmp_path / "chunk.fa"
     fa.write_text(">s\nACGTACGTACGTACGTACGTACGTACGT\n")
     base = ["--forward", "ACGTAC", "--reverse", "ACGTAC", "--sort", "--max-length", "8"]
@@ -164,8 +167,10 @@ def test_chunking_keeps_boundary_hits(tmp_path):  # internal/integration/integra
     assert same == whole and "disabling chunking" in warn
 
 
-def test_chunked_equals_unchunked_on_planted_records(tmp_path):
+@pytest.mark.parametrize("stream", ["", "1"])   # "": the resident genome scanned in rolling windows (one sweep); "1": every window through ipcr_scan_chunk
+def test_chunked_equals_unchunked_on_planted_records(tmp_path, monkeypatch, stream):
     import ipcr_oracle as O
+    monkeypatch.setenv("IPCR_CLI_STREAM_CHUNKS", stream)
     rng = random.Random(91)
     fwd, rev = "ACGTTGCATGCAAGCTTA", "GGCCTTAAGGCCATATCG"
     rc = O.revcomp(rev).decode()
