@@ -1935,6 +1935,11 @@ def test_hit_cap_bounds_device_memory(hip, monkeypatch, k, tw, cap):
         for w in O.simulate_batch(ocfg(cfg), s, opairs(pairs)):
             want.append((r,) + w.sig())
     assert [(p.Record,) + p.sig() for p in got] == want and len(want) >= 10
+    # a scan in rolling windows cannot be cut out of that list -- the device kept per RECORD what HitCap can use, every window has
+    # a cap of its own: the library says so and the caller streams the windows through ipcr_scan_chunk (ipcr_amd/cli.py does)
+    with pytest.raises(hip.lib.IpcrError) as e:
+        eng.ScanGenomeChunked(g, cp, sc, 100_000, 100)
+    assert e.value.status == hip.lib.ERR_UNSUPPORTED
     # the chunk path goes the same way (one record may fit the buffer as it is)
     got1 = eng.SimulateCompiledWithScratch("r1", recs[1], cp, sc)
     assert [p.sig() for p in got1] == [w.sig() for w in O.simulate_batch(ocfg(cfg), recs[1], opairs(pairs))]
