@@ -136,9 +136,9 @@ def test_go_shim_uses_only_what_the_header_declares():
             elif name.startswith("IPCR_"):
                 assert name in consts, f"{path}: C.{name} is not defined in include/ipcr_hip.h"
             else:
-                assert name in {"CString", "GoString", "free", "int32_t", "int64_t", "uint64_t", "uint8_t", "int"}, f"{path}: unexpected C.{name}"
+                assert name in {"CString", "GoString", "free", "int32_t", "int64_t", "uint32_t", "uint64_t", "uint8_t", "int"}, f"{path}: unexpected C.{name}"
         # field accesses on values of the C structs (variable -> struct, as the sources name them)
-        for var, struct in (("cpr", "ipcr_product"), ("cfg", "ipcr_config"), ("h", "ipcr_probe_hit")):
+        for var, struct in (("cpr", "ipcr_product"), ("cfg", "ipcr_config"), ("ccfg", "ipcr_config"), ("h", "ipcr_probe_hit"), ("cw", "ipcr_chunk_window")):
             if not re.search(r"\b%s\b" % var, code):
                 continue
             for fld in re.findall(r"(?<![\w.])%s\.(\w+)" % var, code):
