@@ -2734,24 +2734,33 @@ ipcr_status ipcr_scan_genome_chunked(const ipcr_panel *p, ipcr_scratch *s, const
     const bool mode1 = s->pend.mode == 1;
     const std::vector<ipcr_hit> &H = s->hits; // sorted by (record, pattern, position)
     std::vector<ipcr_hit> wh;
+    std::vector<uint32_t> by_pos; // the record's hits in position order: the windows move along it (a record of hundreds of windows
+                                  // and hundreds of thousands of hits is then cut in one pass, not searched once per window)
     JoinCtx c{p, &s->products, emit, user};
     size_t i = 0;
     for (uint32_t r = 0; r < nrec && !c.aborted; ++r) {
         while (i < H.size() && H[i].record < r) ++i;
         size_t j = i;
         while (j < H.size() && H[j].record == r) ++j;
+        by_pos.resize(j - i);
+        for (size_t h = i; h < j; ++h) by_pos[h - i] = (uint32_t)(h - i);
+        std::sort(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return H[i + a].pos != H[i + b].pos ? H[i + a].pos < H[i + b].pos : a < b; });
+        size_t lo = 0; // first hit (in position order) at or behind the window's start: window starts only grow
         for (size_t w = first_window[r]; w < first_window[r + 1] && !c.aborted; ++w) {
             const ipcr_chunk_window &cw = s->windows[w];
             wh.clear();
-            for (size_t h = i; h < j; ++h) {
-                const uint32_t gid = H[h].pattern & 0x7FFFFFFFu;
+            while (lo < by_pos.size() && H[i + by_pos[lo]].pos < cw.start) ++lo;
+            for (size_t q = lo; q < by_pos.size() && H[i + by_pos[q]].pos < cw.end; ++q) {
+                const ipcr_hit &hh = H[i + by_pos[q]];
+                const uint32_t gid = hh.pattern & 0x7FFFFFFFu;
                 const uint64_t L = gid < p->defs.size() ? p->defs[gid].seq.size() : 0;
-                if (H[h].pos < cw.start || H[h].pos + L > cw.end) continue;
-                wh.push_back(H[h]);
+                if (hh.pos + L > cw.end) continue; // the window must hold the whole site (ac.go:188-190)
+                wh.push_back(hh);
                 wh.back().pos -= cw.start;
                 wh.back().record = (uint32_t)w;
             }
             if (wh.empty()) continue;
+            std::sort(wh.begin(), wh.end(), HitLess()); // back into (pattern, position) order: what the join reads
             // a hit's "seed span touched a reset byte" bit was taken in the record: it lies inside the hit's window, so it holds in
             // every window that holds the hit
             const uint8_t fl = (uint8_t)((cw.reset ? 1u : 0u) | (mode1 ? 2u : 0u));
