@@ -100,6 +100,21 @@ def test_config_c2_reference_n_full_size():
         op = O.Panel(O.Config(max_mm=2, terminal_window=5, max_len=2000, hit_cap=cap, seed_len=12), opairs)
         want = op.scan_ptr(host0.ctypes.data, int(host0.shape[0]))
         assert [p.sig() for p in prods if p.Record == 0] == [w.sig() for w in want] and len(want) >= 40
+        # the same genome under --chunk-size 4 Mb (ipcr_scan_genome_chunked: one sweep, 24 x 32 rolling windows, each joined as
+        # its own call with its own reset flag -- asked on the device: with N in runs of up to 1000 most windows hold one, not
+        # all): after the collector's rebasing and de-duplication the products are the whole-record ones (no cap bites here)
+        import ctypes as C
+        from ipcr_amd import _lib, cli
+        chunked = eng.ScanGenomeChunked(genome, cp, sc, 4_000_000, 2020)
+        w, nw = C.POINTER(_lib.ChunkWindow)(), C.c_int64()
+        _lib.check(_lib.lib().ipcr_scratch_chunk_windows(sc._h, C.byref(w), C.byref(nw)))
+        assert nw.value == 24 * 32 and all(w[i].end - w[i].start <= 4_000_000 for i in range(nw.value))
+        dirty = sum(w[i].reset for i in range(nw.value))
+        assert 0.5 * nw.value <= dirty <= nw.value
+        coll = cli.Collector(1 << 20)
+        kept = [q for q in (coll.add("g", p) for p in chunked) if q is not None]
+        key = lambda p: (p.SequenceID, p.Start, p.End, p.ExperimentID, p.Type, p.FwdMM, p.RevMM, tuple(p.FwdMismatchIdx), tuple(p.RevMismatchIdx))
+        assert sorted(map(key, kept)) == sorted(map(key, prods)) and len(chunked) >= len(kept)
         op.close()
         sc.close()
         cp.close()
