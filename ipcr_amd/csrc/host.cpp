@@ -125,6 +125,76 @@ struct DeviceGuard {
         if (e_ != hipSuccess) return fail(IPCR_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+bool env_flag(const char *name, bool dflt);
+
+// ------------------------------------------------------------ the host's way into device memory
+// Large BAR: the whole of the device's memory is mapped into the host's address space, and the CPU's write-combining
+// stores reach it at ~45 GB/s (tools/exp/bar_write.cpp: 80 % of the link's DMA rate, from one thread or sixteen) -- the
+// host's packer then writes its planes where the device reads them and no copy operation is queued at all.
+// IPCR_CHUNK_BAR=0: pinned slabs + DMA (round 3's path; also what runs without a large BAR).
+// What the CPU writes through the BAR passes the device's HDP block (host data path), which may hold it back: the runtime
+// publishes the register that flushes it (HSA_AMD_AGENT_INFO_HDP_FLUSH) and uses it itself for the kernel arguments it keeps in
+// device memory.  The library writes that register -- and reads it back, so that the write has arrived -- after the packer's
+// stores and before the launch that reads them; a device whose register cannot be found does not take the BAR path.
+// (The HSA runtime is the one the process has loaded already -- HIP sits on it -- found by dlopen(RTLD_NOLOAD): no link dependency.)
+volatile uint32_t *find_hdp_flush_register(int phys) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, phys) != hipSuccess) return nullptr;
+    unsigned dom = 0, b = 0, d = 0, f = 0;
+    if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) != 4) return nullptr;
+    void *h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_NOLOAD);
+    auto sym = [&](const char *n) { void *p = h ? dlsym(h, n) : nullptr; return p ? p : dlsym(RTLD_DEFAULT, n); };
+    using iterate_t = hsa_status_t (*)(hsa_status_t (*)(hsa_agent_t, void *), void *);
+    using info_t = hsa_status_t (*)(hsa_agent_t, hsa_agent_info_t, void *);
+    struct Ctx { info_t info; uint32_t dom, bdf; volatile uint32_t *reg; } c{reinterpret_cast<info_t>(sym("hsa_agent_get_info")), dom, (b << 8) | (d << 3) | f, nullptr};
+    const iterate_t iterate = reinterpret_cast<iterate_t>(sym("hsa_iterate_agents"));
+    if (!iterate || !c.info) return nullptr;
+    (void)iterate([](hsa_agent_t a, void *vp) -> hsa_status_t {
+        Ctx &c = *static_cast<Ctx *>(vp);
+        hsa_device_type_t type;
+        uint32_t bdf = 0, dom = 0;
+        if (c.info(a, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS || type != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+        if (c.info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+        if (c.info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom) != HSA_STATUS_SUCCESS) dom = c.dom;
+        if ((bdf & 0xFFFFu) != c.bdf || dom != c.dom) return HSA_STATUS_SUCCESS;
+        hsa_amd_hdp_flush_t hdp{nullptr, nullptr};
+        if (c.info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_HDP_FLUSH, &hdp) == HSA_STATUS_SUCCESS) c.reg = hdp.HDP_MEM_FLUSH_CNTL;
+        return HSA_STATUS_INFO_BREAK;
+    }, &c);
+    return c.reg;
+}
+
+struct BarInfo { bool writable = false; volatile uint32_t *hdp_flush = nullptr; };
+std::mutex g_bar_mu;
+std::map<int, BarInfo> g_bar_cache;
+BarInfo device_bar(int phys) {
+    std::lock_guard<std::mutex> lk(g_bar_mu);
+    auto it = g_bar_cache.find(phys);
+    if (it != g_bar_cache.end()) return it->second;
+    BarInfo bi;
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, phys) == hipSuccess && v != 0) {
+        bi.hdp_flush = find_hdp_flush_register(phys);
+        // IPCR_CHUNK_BAR=2: take the BAR path even where the flush register is not known (the runtime's own flush in front of every
+        // dispatch then stands in for it: measurements only)
+        bi.writable = bi.hdp_flush != nullptr || (getenv("IPCR_CHUNK_BAR") && atoi(getenv("IPCR_CHUNK_BAR")) == 2);
+    }
+    g_bar_cache[phys] = bi;
+    return bi;
+}
+// everything the packer's threads have stored through the BAR (each of them has fenced) is in device memory when this returns
+inline void bar_flush(const BarInfo &bi) {
+    if (!bi.hdp_flush) return;
+    _mm_sfence();
+    *bi.hdp_flush = 1u;
+    (void)*bi.hdp_flush; // a read does not pass the writes in front of it: the flush has been taken
+}
+void host_writable_off(int phys) {
+    std::lock_guard<std::mutex> lk(g_bar_mu);
+    g_bar_cache[phys].writable = false;
+}
+
+
 // ------------------------------------------------------------ core/primer tables
 struct Tables {
     uint8_t mask[256];
@@ -1013,6 +1083,7 @@ struct ipcr_genome {
     uint8_t *staging = nullptr;
     uint64_t staging_cap = 0;
     bool staging_fine = false; // allocated fine-grained (the host writes it through the BAR: ipcr_scan_chunk)
+    uint8_t *h_planes = nullptr; // pinned: the invalid / reset planes of one group of columns (ipcr_genome_add_record through the BAR)
     hipStream_t stream = nullptr;
     bool shared_stream = false; // stream belongs to a scratch (its private chunk genome): never destroyed here
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1237,15 +1308,87 @@ void ipcr_genome_destroy(ipcr_genome *g) {
     DeviceGuard dg(g->device);
     genome_free_buffers(g);
     if (g->staging) (void)hipFree(g->staging);
+    if (g->h_planes) (void)hipHostFree(g->h_planes);
     if (g->e0) (void)hipEventDestroy(g->e0);
     if (g->e1) (void)hipEventDestroy(g->e1);
     if (g->stream && !g->shared_stream) (void)hipStreamDestroy(g->stream);
     delete g;
 }
 
+// A record of host bytes into a resident genome, packed by the process's pool straight into device memory through the BAR
+// (the resident form of what ipcr_scan_chunk does for a chunk: DESIGN 5): the code planes are written where the conversion
+// kernel reads them, the invalid / reset planes of a group of columns follow by DMA only if the group holds such a byte.
+// false: not here (no large BAR, no SIMD packer, a record too small to be worth it) -- the caller sends ASCII.
+static bool genome_add_host_packed(ipcr_genome *g, const uint8_t *seq, uint64_t len, ipcr_status *st) {
+    *st = IPCR_OK;
+    const BarInfo bi = device_bar(slot_phys(g->device));
+    if (!bi.writable || !env_flag("IPCR_CHUNK_BAR", true) || !ipcr::pack_linear_is_simd() || len < 4096) return false;
+    const uint64_t cols = record_cols(len), col0 = g->next_col;
+    if (g->rec_start.size() >= g->max_records) { *st = fail(IPCR_ERR_CAPACITY, "genome holds its maximum of %u records", g->max_records); return true; }
+    if (col0 + cols > g->cap_cols) {
+        *st = fail(IPCR_ERR_CAPACITY, "genome capacity exceeded (%llu + %llu columns > %llu)", (unsigned long long)col0, (unsigned long long)cols, (unsigned long long)g->cap_cols);
+        return true;
+    }
+    auto hip = [&](hipError_t e, const char *what) { if (e != hipSuccess && *st == IPCR_OK) *st = fail(IPCR_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e)); return e == hipSuccess; };
+    constexpr uint64_t GROUP = 2048; // columns per group: 8 Mb
+    const uint64_t gcols = std::min(cols, GROUP), dev_bytes = gcols * 2048ull;
+    if (dev_bytes > g->staging_cap || !g->staging_fine) {
+        if (g->staging) (void)hipFree(g->staging);
+        g->staging = nullptr;
+        g->staging_fine = false;
+        g->staging_cap = std::max(g->staging_cap, dev_bytes);
+        if (hipExtMallocWithFlags((void **)&g->staging, g->staging_cap, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            g->staging = nullptr;
+            g->staging_cap = 0;
+            return false;
+        }
+        g->staging_fine = true;
+    }
+    if (!g->h_planes) { // the invalid / reset planes of one group (pinned: a dirty group's DMA reads them)
+        if (!hip(hipHostMalloc((void **)&g->h_planes, GROUP * 1024ull, hipHostMallocDefault), "hipHostMalloc")) return true;
+    }
+    const uint64_t nthreads = std::max<uint64_t>(1, PackPool::get().size());
+    uint32_t flags_all = 0;
+    for (uint64_t c0 = 0; c0 < cols && *st == IPCR_OK; c0 += GROUP) {
+        const uint64_t nc = std::min(GROUP, cols - c0), W = nc * 128u;
+        const uint64_t per = std::max<uint64_t>(8, ((nc + nthreads - 1) / nthreads + 7) / 8 * 8);
+        const size_t nitems = (size_t)((nc + per - 1) / per);
+        std::vector<uint32_t> iflags(nitems, 0);
+        uint32_t *dlo = reinterpret_cast<uint32_t *>(g->staging), *hiv = reinterpret_cast<uint32_t *>(g->h_planes);
+        // (the previous group's kernel has read the staging buffer and its DMA the pinned planes: in order on the stream, waited for below)
+        PackPool::get().run(nitems, [&](size_t k) {
+            const uint64_t a = (uint64_t)k * per, n = std::min(per, nc - a), b0 = (c0 + a) * IPCR_COLUMN_BASES;
+            const uint64_t nb = b0 < len ? std::min<uint64_t>(len - b0, n * IPCR_COLUMN_BASES) : 0;
+            iflags[k] = ipcr::pack_linear(seq + (nb ? b0 : 0), nb, n * IPCR_COLUMN_BASES, dlo + a * 128u, dlo + W + a * 128u, hiv + a * 128u, hiv + W + a * 128u);
+        }, slot_phys(g->device));
+        uint32_t fl = 0;
+        for (uint32_t f : iflags) fl |= f;
+        flags_all |= fl;
+        bar_flush(bi);
+        const bool lower = (fl & 2u) != 0, need_inv = lower || (fl & 1u) != 0;
+        if (need_inv && !hip(hipMemcpyAsync(g->staging + W * 8u, g->h_planes, W * 4u * (lower ? 2u : 1u), hipMemcpyHostToDevice, g->stream), "hipMemcpyAsync")) break;
+        if (!hip(ipcr::launch_tiles_from_linear(g->stream, dlo, dlo + W, need_inv ? dlo + 2 * W : nullptr, lower ? dlo + 3 * W : nullptr, col0, col0 + c0, nc, len,
+                                                g->planes, g->rst, nullptr, nullptr, c0 == 0 ? g->e0 : nullptr, c0 + nc >= cols ? g->e1 : nullptr), "tiles_from_linear")) break;
+        if (c0 + nc < cols && !hip(hipStreamSynchronize(g->stream), "hipStreamSynchronize")) break; // the next group reuses both buffers
+    }
+    if (*st != IPCR_OK) { (void)hipStreamSynchronize(g->stream); return true; }
+    const uint32_t rec = (uint32_t)g->rec_start.size();
+    if (!hip(hipMemsetD32Async((hipDeviceptr_t)(g->d_flags + rec), (int)(flags_all & 1u), 1, g->stream), "hipMemsetD32Async")) return true;
+    genome_account_record(g, len, cols);
+    if (!hip(hipStreamSynchronize(g->stream), "hipStreamSynchronize")) return true; // the caller may free its bytes; the pinned planes are free again
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, g->e0, g->e1) == hipSuccess) g->pack_ms += ms;
+    return true;
+}
+
 ipcr_status ipcr_genome_add_record(ipcr_genome *g, const uint8_t *seq, uint64_t len) {
     if (!g || (!seq && len)) return fail(IPCR_ERR_INVALID, "ipcr_genome_add_record: null argument");
     DeviceGuard dg(g->device);
+    {
+        ipcr_status hst = IPCR_OK;
+        if (genome_add_host_packed(g, seq, len, &hst)) return hst;
+    }
     if (len + 16 > g->staging_cap) {
         if (g->staging) (void)hipFree(g->staging);
         g->staging = nullptr;
@@ -1510,72 +1653,6 @@ ipcr_status panel_upload(const ipcr_panel *cp, int mode, int slot, SetDev **out)
         }
     }
     return IPCR_OK;
-}
-
-// Large BAR: the whole of the device's memory is mapped into the host's address space, and the CPU's write-combining
-// stores reach it at ~45 GB/s (tools/exp/bar_write.cpp: 80 % of the link's DMA rate, from one thread or sixteen) -- the
-// host's packer then writes its planes where the device reads them and no copy operation is queued at all.
-// IPCR_CHUNK_BAR=0: pinned slabs + DMA (round 3's path; also what runs without a large BAR).
-// What the CPU writes through the BAR passes the device's HDP block (host data path), which may hold it back: the runtime
-// publishes the register that flushes it (HSA_AMD_AGENT_INFO_HDP_FLUSH) and uses it itself for the kernel arguments it keeps in
-// device memory.  The library writes that register -- and reads it back, so that the write has arrived -- after the packer's
-// stores and before the launch that reads them; a device whose register cannot be found does not take the BAR path.
-// (The HSA runtime is the one the process has loaded already -- HIP sits on it -- found by dlopen(RTLD_NOLOAD): no link dependency.)
-volatile uint32_t *find_hdp_flush_register(int phys) {
-    char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, phys) != hipSuccess) return nullptr;
-    unsigned dom = 0, b = 0, d = 0, f = 0;
-    if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) != 4) return nullptr;
-    void *h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_NOLOAD);
-    auto sym = [&](const char *n) { void *p = h ? dlsym(h, n) : nullptr; return p ? p : dlsym(RTLD_DEFAULT, n); };
-    using iterate_t = hsa_status_t (*)(hsa_status_t (*)(hsa_agent_t, void *), void *);
-    using info_t = hsa_status_t (*)(hsa_agent_t, hsa_agent_info_t, void *);
-    struct Ctx { info_t info; uint32_t dom, bdf; volatile uint32_t *reg; } c{reinterpret_cast<info_t>(sym("hsa_agent_get_info")), dom, (b << 8) | (d << 3) | f, nullptr};
-    const iterate_t iterate = reinterpret_cast<iterate_t>(sym("hsa_iterate_agents"));
-    if (!iterate || !c.info) return nullptr;
-    (void)iterate([](hsa_agent_t a, void *vp) -> hsa_status_t {
-        Ctx &c = *static_cast<Ctx *>(vp);
-        hsa_device_type_t type;
-        uint32_t bdf = 0, dom = 0;
-        if (c.info(a, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS || type != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
-        if (c.info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
-        if (c.info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom) != HSA_STATUS_SUCCESS) dom = c.dom;
-        if ((bdf & 0xFFFFu) != c.bdf || dom != c.dom) return HSA_STATUS_SUCCESS;
-        hsa_amd_hdp_flush_t hdp{nullptr, nullptr};
-        if (c.info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_HDP_FLUSH, &hdp) == HSA_STATUS_SUCCESS) c.reg = hdp.HDP_MEM_FLUSH_CNTL;
-        return HSA_STATUS_INFO_BREAK;
-    }, &c);
-    return c.reg;
-}
-
-struct BarInfo { bool writable = false; volatile uint32_t *hdp_flush = nullptr; };
-std::mutex g_bar_mu;
-std::map<int, BarInfo> g_bar_cache;
-BarInfo device_bar(int phys) {
-    std::lock_guard<std::mutex> lk(g_bar_mu);
-    auto it = g_bar_cache.find(phys);
-    if (it != g_bar_cache.end()) return it->second;
-    BarInfo bi;
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, phys) == hipSuccess && v != 0) {
-        bi.hdp_flush = find_hdp_flush_register(phys);
-        // IPCR_CHUNK_BAR=2: take the BAR path even where the flush register is not known (the runtime's own flush in front of every
-        // dispatch then stands in for it: measurements only)
-        bi.writable = bi.hdp_flush != nullptr || (getenv("IPCR_CHUNK_BAR") && atoi(getenv("IPCR_CHUNK_BAR")) == 2);
-    }
-    g_bar_cache[phys] = bi;
-    return bi;
-}
-// everything the packer's threads have stored through the BAR (each of them has fenced) is in device memory when this returns
-inline void bar_flush(const BarInfo &bi) {
-    if (!bi.hdp_flush) return;
-    _mm_sfence();
-    *bi.hdp_flush = 1u;
-    (void)*bi.hdp_flush; // a read does not pass the writes in front of it: the flush has been taken
-}
-void host_writable_off(int phys) {
-    std::lock_guard<std::mutex> lk(g_bar_mu);
-    g_bar_cache[phys].writable = false;
 }
 
 } // namespace
