@@ -13,6 +13,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
+#include "hostpack.h"
 #include "ipcr_hip.h"
 
 ipcr_status ipcr_internal_fail(ipcr_status st, const char *fmt, ...);
@@ -159,6 +162,86 @@ uint32_t pack_linear(const uint8_t *seq, uint64_t len, uint64_t padded, uint32_t
 }
 
 bool pack_linear_is_simd() { return have_avx2(); }
+
+// ----------------------------------------------------------------------------------------------------------------------
+// FASTA text -> bit planes on the host (the resident loader's fast way in: host.cpp: genome_add_fasta_hostpacked).
+// A record's sequence region is `full` lines of W base bytes + lt terminator bytes ("\n" or "\r\n") and a shorter last line;
+// this packs the bases of its 64-byte blocks [j0, j1) -- the line ends squeezed out of the classification masks with pext --
+// to bit offset `bases before block j0` of the record's linear planes: bit i of 64-bit word w = base 64 w + i.  Case is
+// folded (core/fasta/normalize.go:5-14), so inv = not one of ACGTacgt and the reset plane equals it.
+// Whole words go to lo / hi (device memory through the BAR: written once, never read) with non-temporal stores and to iv
+// (host memory) with ordinary ones; the partial words at the piece's ends come back in `edge` for the caller to compose.
+// Returns false when the text is not what was assumed -- a line end where a base should be or the other way round, a blank
+// or tab at a line's first or last base (the reference trims those) -- and the caller takes the device loader instead.
+bool fasta_blocks_supported() {
+    return simd_level() == 2 && __builtin_cpu_supports("bmi2");
+}
+
+__attribute__((target("avx512bw,avx512f,bmi2,popcnt")))
+bool pack_fasta_blocks(const uint8_t *region, uint64_t area /* = full * (W + lt) bytes */, uint32_t W, uint32_t lt, const uint64_t *tab /* 4 x stride masks */,
+                       uint64_t j0, uint64_t j1, uint64_t *lo, uint64_t *hi, uint64_t *iv, FastaEdge *edge, uint32_t *any_invalid) {
+    const uint32_t stride = W + lt;
+    const __m512i lut = _mm512_broadcast_i32x4(_mm_setr_epi8(0x01, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 0, 0));
+    const __m512i nib = _mm512_set1_epi8(0x0F), up = _mm512_set1_epi8((char)0xDF), bit1 = _mm512_set1_epi8(2), bit2 = _mm512_set1_epi8(4);
+    const __m512i c_nl = _mm512_set1_epi8('\n'), c_cr = _mm512_set1_epi8('\r'), c_sp = _mm512_set1_epi8(' '), c_tab = _mm512_set1_epi8('\t'),
+                  c_vt = _mm512_set1_epi8('\v'), c_ff = _mm512_set1_epi8('\f');
+    const uint64_t *t_nl = tab, *t_cr = tab + stride, *t_first = tab + 2 * stride, *t_last = tab + 3 * stride;
+    const uint64_t p0 = j0 * 64u;
+    const uint64_t before = (p0 / stride) * W + std::min<uint64_t>(p0 % stride, W); // bases in front of block j0
+    uint64_t w = before >> 6;          // word the accumulators are filling
+    uint32_t fill = (uint32_t)(before & 63u);
+    uint64_t al = 0, ah = 0, av = 0, inv_any = 0;
+    bool first_word = fill != 0;       // the first word this piece completes is shared with the piece in front
+    edge->n = 0;
+    auto emit = [&](uint64_t l, uint64_t h, uint64_t v) {
+        if (first_word) {
+            edge->word[edge->n] = w; edge->val[edge->n][0] = l; edge->val[edge->n][1] = h; edge->val[edge->n][2] = v;
+            ++edge->n;
+            first_word = false;
+        } else {
+            _mm_stream_si64(reinterpret_cast<long long *>(lo + w), (long long)l);
+            _mm_stream_si64(reinterpret_cast<long long *>(hi + w), (long long)h);
+            iv[w] = v;
+        }
+        ++w;
+    };
+    uint32_t s = (uint32_t)(p0 % stride);
+    for (uint64_t j = j0; j < j1; ++j) {
+        const uint64_t off = j * 64u;
+        const uint64_t live = area - off >= 64u ? ~0ull : ((1ull << (area - off)) - 1ull);
+        const __m512i c = _mm512_maskz_loadu_epi8((__mmask64)live, region + off);
+        const uint64_t nl = _mm512_cmpeq_epi8_mask(c, c_nl) & live, cr = _mm512_cmpeq_epi8_mask(c, c_cr) & live;
+        if (nl != (t_nl[s] & live) || cr != (t_cr[s] & live)) return false;
+        const uint64_t ws = (_mm512_cmpeq_epi8_mask(c, c_sp) | _mm512_cmpeq_epi8_mask(c, c_tab) | _mm512_cmpeq_epi8_mask(c, c_vt) | _mm512_cmpeq_epi8_mask(c, c_ff)) & live;
+        if (ws & (t_first[s] | t_last[s])) return false;
+        const uint64_t valid = live & ~(nl | cr);
+        const __m512i want = _mm512_shuffle_epi8(lut, _mm512_and_si512(c, nib));
+        const uint64_t m_acgt = _mm512_cmpeq_epi8_mask(want, _mm512_and_si512(c, up));
+        const uint64_t b2 = _mm512_test_epi8_mask(c, bit2), b1 = _mm512_test_epi8_mask(c, bit1);
+        const uint64_t l = _pext_u64((b1 ^ b2) & m_acgt, valid), h = _pext_u64(b2 & m_acgt, valid), v = _pext_u64(~m_acgt, valid);
+        const uint32_t k = (uint32_t)_mm_popcnt_u64(valid);
+        inv_any |= v;
+        if (k) {
+            al |= l << fill; ah |= h << fill; av |= v << fill;
+            if (fill + k >= 64u) {
+                emit(al, ah, av);
+                const uint32_t used = 64u - fill; // bits of this block that went into the word just finished (1..64)
+                al = used < 64u ? l >> used : 0; ah = used < 64u ? h >> used : 0; av = used < 64u ? v >> used : 0;
+                fill = fill + k - 64u;
+            } else
+                fill += k;
+        }
+        s = (uint32_t)((s + 64u) % stride);
+    }
+    // the unfinished word at the piece's end (it is also the piece's first when the piece never finished one)
+    if (first_word ? fill > (uint32_t)(before & 63u) : fill > 0u) {
+        edge->word[edge->n] = w; edge->val[edge->n][0] = al; edge->val[edge->n][1] = ah; edge->val[edge->n][2] = av;
+        ++edge->n;
+    }
+    *any_invalid = inv_any ? 1u : 0u;
+    _mm_sfence();
+    return true;
+}
 
 } // namespace ipcr
 

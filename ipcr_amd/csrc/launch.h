@@ -1,5 +1,6 @@
 // launch.h -- host-callable launchers of the kernels in kernels.hip
 #pragma once
+#include "hostpack.h"
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
@@ -18,6 +19,7 @@ hipError_t launch_tiles_from_linear(hipStream_t st, const uint32_t *lin_lo, cons
 // ASCII -> linear planes on the host (returns bit 0: a byte outside ACGTacgt, bit 1: a lower-case acgt)
 uint32_t pack_linear(const uint8_t *seq, uint64_t len, uint64_t padded, uint32_t *lo, uint32_t *hi, uint32_t *iv, uint32_t *rs);
 bool pack_linear_is_simd();
+
 hipError_t launch_pack_batch(hipStream_t st, const uint8_t *base, const ipcr_pack_rec *recs, const uint32_t *pair_prefix,
                              uint32_t nrec, uint64_t total_pairs, uint32_t *planes, uint32_t *rst, uint32_t *rec_flags);
 hipError_t launch_fill_pad(hipStream_t st, uint32_t *planes, uint32_t *rst, uint64_t col_begin, uint64_t col_end);

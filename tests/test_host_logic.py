@@ -754,3 +754,66 @@ def test_chunk_windows_are_the_streaming_readers(tmp_path):
         _lib.check(_lib.lib().ipcr_chunk_windows(n, chunk, overlap, w, cnt.value, C.byref(cnt)))
         got = ["r" if w[i].plain else "r:%d-%d" % (w[i].start, w[i].end) for i in range(cnt.value)]
         assert got == want, (n, chunk, overlap)
+
+
+def test_fasta_host_packer_equals_the_streaming_reader(tmp_path):
+    """FASTA text packed on the host (csrc/fasta_hostpack.cpp: line ends squeezed out of the classification masks with pext, 2 bits
+    per base, 64-bit words; the resident loader's fast way in, written through the PCIe BAR on the GPU box) against the streaming
+    reader's records packed by pack_linear: IDs, lengths and every word of every plane -- line widths around the word and block
+    sizes, "\\n" and "\\r\\n", a last line of any length with or without its end, empty records, headers without an ID, text in
+    front of the first header, N runs and lower case.  Files that are not that regular (a short or long line in the middle, a
+    blank line, a blank or tab at a line's end or start, a lone CR) must be REFUSED (the device loader takes them), never packed."""
+    import ctypes
+    import random
+    fn = _lib.lib().ipcr_internal_fasta_hostpack_check
+    fn.restype = ctypes.c_int32
+    fn.argtypes = [ctypes.c_char_p]
+    probe = tmp_path / "p.fa"
+    probe.write_text(">a\nACGT\n")
+    if fn(str(probe).encode()) == -1:
+        pytest.skip("no AVX-512BW + BMI2 on this host: the loader takes the device path")
+    rng = random.Random(3)
+    path = str(tmp_path / "fhp.fa")
+
+    def seq(n, junk=0.0, lower=0.0):
+        s = [rng.choice("ACGT") for _ in range(n)]
+        for i in range(n):
+            x = rng.random()
+            if x < junk: s[i] = rng.choice("NRYKMnx-")
+            elif x < junk + lower: s[i] = s[i].lower()
+        return "".join(s)
+    def write(path, recs, W, nl="\n", final_nl=True, lead=""):
+        with open(path, "w", newline="") as fh:
+            fh.write(lead)
+            for k, (hdr, s) in enumerate(recs):
+                fh.write(">" + hdr + nl)
+                lines = [s[i:i + W] for i in range(0, len(s), W)]
+                last = k == len(recs) - 1
+                fh.write(nl.join(lines) + (nl if lines and (final_nl or not last) else ""))
+    for case in range(150):
+        W = rng.choice([1, 7, 31, 32, 60, 61, 63, 64, 65, 70, 80, 100, 127, 128, 129, 1000])
+        nl = rng.choice(["\n", "\n", "\r\n"])
+        nrec = rng.randint(1, 5)
+        recs = []
+        for r in range(nrec):
+            n = rng.choice([0, 1, W - 1 if W > 1 else 1, W, W + 1, 2 * W, 3 * W + 5, rng.randint(0, 5000), rng.randint(60000, 300000)])
+            recs.append(("r%d desc text > more" % r, seq(n, junk=rng.choice([0, 0, 0.001, 0.05]), lower=rng.choice([0, 0.01, 0.3]))))
+        if rng.random() < 0.2: recs.insert(rng.randrange(len(recs) + 1), ("", seq(100)))      # header without an ID: dropped
+        write(path, recs, W, nl, final_nl=rng.random() < 0.7, lead=rng.choice(["", "", "ACGT" + nl, nl]))
+        rc = fn(path.encode())
+        assert rc == 0, (case, W, nl, [len(s) for _, s in recs], rc)
+    # irregular files must be refused (-1 / -2), never packed wrongly
+    for case in range(60):
+        W = rng.choice([60, 80])
+        s = seq(rng.randint(500, 20000))
+        lines = [s[i:i + W] for i in range(0, len(s), W)]
+        kind = case % 6
+        if kind == 0 and len(lines) > 3: lines[2] = lines[2][:-5]                  # a short line in the middle
+        elif kind == 1: lines[1] = lines[1] + " "                                   # trailing blank
+        elif kind == 2: lines.insert(2, "")                                         # blank line
+        elif kind == 3: lines[1] = "\t" + lines[1][1:]                              # leading tab
+        elif kind == 4 and len(lines) > 3: lines[2] = lines[2] + "ACGT"             # a long line
+        elif kind == 5: lines[0] = lines[0][:10] + "\r" + lines[0][11:]             # a lone CR inside a line
+        open(path, "w", newline="").write(">x\n" + "\n".join(lines) + "\n")
+        rc = fn(path.encode())
+        assert rc < 0, (case, kind, rc)
