@@ -72,6 +72,8 @@ extern size_t ipcr_internal_batch_table_bytes(size_t n);
 extern void ipcr_internal_pool_run(size_t n, const std::function<void(size_t)> &fn, int phys); // phys >= 0: on that device's CPUs
 extern bool ipcr_internal_bind_thread(int phys);
 extern unsigned ipcr_internal_pool_size();
+// host.cpp: the file loaded with its text packed on the host and written through the PCIe BAR (*taken = 1), or not a file for that
+extern "C" ipcr_status ipcr_internal_genome_add_fasta_hostpacked(ipcr_genome *g, const char *path, uint32_t *n_added, std::string *ids, int *taken);
 
 namespace {
 
@@ -761,6 +763,25 @@ ipcr_status ipcr_genome_add_fasta(ipcr_genome *g, const char *path, uint32_t *n_
         ~OnDevice() { if (prev != want) (void)hipSetDevice(prev); }
     } on_device(ipcr_internal_genome_phys_device(g));
     if (n_added) *n_added = 0;
+    // the fast way in first: the text packed on the host and written through the PCIe BAR (host.cpp, fasta_hostpack.cpp) -- for
+    // the files and hosts that allow it; every other file goes through the loader below, as before
+    {
+        uint32_t added = 0;
+        std::string fast_ids;
+        int taken = 0;
+        const ipcr_status fst = ipcr_internal_genome_add_fasta_hostpacked(g, path, &added, &fast_ids, &taken);
+        if (fst != IPCR_OK) return fst;
+        if (taken) {
+            if (n_added) *n_added = added;
+            if (ids_needed) *ids_needed = fast_ids.size() + 1;
+            if (ids_out && cap) {
+                const size_t m = fast_ids.size() < cap - 1 ? fast_ids.size() : cap - 1;
+                memcpy(ids_out, fast_ids.data(), m);
+                ids_out[m] = 0;
+            }
+            return IPCR_OK;
+        }
+    }
     FastaLoader L;
     ipcr_status st = L.open(g, path);
     if (st == IPCR_OK) st = L.run();

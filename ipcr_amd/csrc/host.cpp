@@ -40,6 +40,7 @@
 
 #include "cpu_pool.h"
 #include "device_types.h"
+#include "fasta_hostpack.h"
 #include "jit.h"
 #include "launch.h"
 #include "tile_layout.h"
@@ -1381,6 +1382,130 @@ static bool genome_add_host_packed(ipcr_genome *g, const uint8_t *seq, uint64_t 
     if (hipEventElapsedTime(&ms, g->e0, g->e1) == hipSuccess) g->pack_ms += ms;
     return true;
 }
+
+// A FASTA file into a resident genome with the text packed on the host (fasta_hostpack.cpp) and the code planes written straight
+// into device memory through the BAR: 0.25 bytes per base on the link instead of the device loader's 1.0125.  *taken = 0: not a
+// file for this way in (no large BAR, no AVX-512 + BMI2, gzip / stdin, lines of several widths, blanks at line ends, thousands of
+// records ...): nothing has been changed and the caller takes the device loader.
+namespace {
+struct FastaStage { // kept for the process's next load (allocating and mapping them is a few milliseconds)
+    int phys = -1;
+    uint64_t words = 0; // 64-bit words per plane
+    uint64_t *d_lo = nullptr, *d_hi = nullptr, *d_iv = nullptr, *h_iv = nullptr;
+};
+std::mutex g_fasta_stage_mu;
+FastaStage g_fasta_stage;
+std::atomic<uint64_t> g_fasta_hostpacked_loads{0};
+} // namespace
+
+ipcr_status ipcr_internal_genome_add_fasta_hostpacked(ipcr_genome *g, const char *path, uint32_t *n_added, std::string *ids, int *taken) {
+    *taken = 0;
+    if (!env_flag("IPCR_FASTA_HOSTPACK", true) || !env_flag("IPCR_CHUNK_BAR", true) || !ipcr::fasta_blocks_supported()) return IPCR_OK;
+    if (getenv("IPCR_FASTA_SLAB")) return IPCR_OK; // (somebody is tuning or testing the device loader's slabs: that loader it is)
+    const int phys = slot_phys(g->device);
+    const BarInfo bi = device_bar(phys);
+    if (!bi.writable) return IPCR_OK;
+    const bool times = getenv("IPCR_DEBUG_TIMES") != nullptr;
+    const auto tt0 = std::chrono::steady_clock::now();
+    auto since0 = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count(); };
+    ipcr::FastaText t;
+    if (!t.open(path) || t.records.empty() || t.records.size() > 2048) return IPCR_OK;
+    const double ms_open = since0();
+    if (g->rec_start.size() + t.records.size() > g->max_records) return IPCR_OK; // (the device loader reports it)
+    constexpr uint64_t GROUP = 2048; // columns per group: whether a group's invalid-bit plane reaches the device
+    std::vector<uint64_t> word0(t.records.size() + 1, 0), cols(t.records.size()), group0(t.records.size() + 1, 0);
+    uint64_t total_cols = 0;
+    for (size_t r = 0; r < t.records.size(); ++r) {
+        cols[r] = record_cols(t.records[r].len);
+        word0[r + 1] = word0[r] + cols[r] * 64u;
+        group0[r + 1] = group0[r] + (cols[r] + GROUP - 1) / GROUP;
+        total_cols += cols[r];
+    }
+    if (g->next_col + total_cols > g->cap_cols) return IPCR_OK;
+    DeviceGuard dg(g->device);
+    std::lock_guard<std::mutex> stage_lock(g_fasta_stage_mu);
+    FastaStage &fs = g_fasta_stage;
+    const uint64_t words = word0.back();
+    if (fs.phys != phys || fs.words < words) {
+        if (fs.d_lo) (void)hipFree(fs.d_lo);
+        if (fs.h_iv) free(fs.h_iv);
+        fs = FastaStage();
+        const uint64_t want = words + (words >> 3);
+        uint8_t *base = nullptr;
+        if (hipExtMallocWithFlags((void **)&base, want * 24u, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return IPCR_OK; }
+        fs.d_lo = reinterpret_cast<uint64_t *>(base);
+        fs.d_hi = fs.d_lo + want;
+        fs.d_iv = fs.d_hi + want;
+        fs.h_iv = static_cast<uint64_t *>(malloc(want * 8u));
+        if (!fs.h_iv) { (void)hipFree(base); fs = FastaStage(); return IPCR_OK; }
+        fs.phys = phys;
+        fs.words = want;
+    }
+    const double ms_stage = since0();
+    // ---- every record's text into its planes (the pool shares a record's pieces); nothing is registered before all of them are in
+    std::vector<uint8_t> dirty((size_t)group0.back(), 0);
+    for (size_t r = 0; r < t.records.size(); ++r)
+        if (!t.pack(t.records[r], fs.d_lo + word0[r], fs.d_hi + word0[r], fs.h_iv + word0[r], cols[r] * 64u, dirty.data() + group0[r], GROUP))
+            return IPCR_OK; // irregular text after all: the device loader takes the file
+    const double ms_pack = since0();
+    // ---- the invalid-bit planes of the groups that hold an invalid base follow (host memory -> device, through the BAR as well)
+    {
+        struct Span { uint64_t w0, n; };
+        std::vector<Span> spans;
+        for (size_t r = 0; r < t.records.size(); ++r)
+            for (uint64_t q = group0[r]; q < group0[r + 1]; ++q)
+                if (dirty[(size_t)q]) {
+                    const uint64_t c0 = (q - group0[r]) * GROUP, nc = std::min(GROUP, cols[r] - c0);
+                    spans.push_back({word0[r] + c0 * 64u, nc * 64u});
+                }
+        if (!spans.empty())
+            PackPool::get().run(spans.size(), [&](size_t i) {
+                const uint64_t *src = fs.h_iv + spans[i].w0;
+                uint64_t *dst = fs.d_iv + spans[i].w0;
+                for (uint64_t w = 0; w < spans[i].n; ++w) _mm_stream_si64(reinterpret_cast<long long *>(dst + w), (long long)src[w]);
+                _mm_sfence();
+            }, phys);
+    }
+    bar_flush(bi);
+    // ---- tiles, record by record: one launch per run of groups that agree on whether they bring an invalid-bit plane
+    for (size_t r = 0; r < t.records.size(); ++r) {
+        const ipcr::FastaRecord &fr = t.records[r];
+        const uint64_t col0 = g->next_col;
+        const uint32_t *lo32 = reinterpret_cast<const uint32_t *>(fs.d_lo + word0[r]), *hi32 = reinterpret_cast<const uint32_t *>(fs.d_hi + word0[r]),
+                       *iv32 = reinterpret_cast<const uint32_t *>(fs.d_iv + word0[r]);
+        uint32_t any = 0;
+        for (uint64_t q = group0[r]; q < group0[r + 1];) {
+            uint64_t e = q + 1;
+            while (e < group0[r + 1] && dirty[(size_t)e] == dirty[(size_t)q]) ++e;
+            const uint64_t c0 = (q - group0[r]) * GROUP, nc = std::min(cols[r], (e - group0[r]) * GROUP) - c0;
+            const bool d = dirty[(size_t)q] != 0;
+            any |= d ? 1u : 0u;
+            HIPCHK(ipcr::launch_tiles_from_linear(g->stream, lo32 + c0 * 128u, hi32 + c0 * 128u, d ? iv32 + c0 * 128u : nullptr, nullptr, col0, col0 + c0, nc, fr.len,
+                                                  g->planes, g->rst, nullptr, nullptr, nullptr, nullptr));
+            q = e;
+        }
+        const uint32_t rec = (uint32_t)g->rec_start.size();
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(g->d_flags + rec), (int)any, 1, g->stream));
+        genome_account_record(g, fr.len, cols[r]);
+        g->ids.back() = fr.id;
+        if (n_added) ++*n_added;
+        if (ids) { if (r) ids->push_back('\n'); *ids += fr.id; }
+    }
+    HIPCHK(hipStreamSynchronize(g->stream)); // the staging planes are free for the next load
+    if (!env_flag("IPCR_FASTA_CACHE", true)) { // (kept for the process's next load otherwise: 0.5 bytes per base, a quarter of them host memory)
+        (void)hipFree(fs.d_lo);
+        free(fs.h_iv);
+        fs = FastaStage();
+    }
+    if (times)
+        fprintf(stderr, "fasta host packer: map + headers + plan %.2f ms, staging %.2f, pack %.2f, invalid planes + tiles %.2f (total %.2f ms, %zu records)\n",
+                ms_open, ms_stage - ms_open, ms_pack - ms_stage, since0() - ms_pack, since0(), t.records.size());
+    *taken = 1;
+    g_fasta_hostpacked_loads.fetch_add(1, std::memory_order_relaxed);
+    return IPCR_OK;
+}
+// tests: files loaded that way so far, in this process
+uint64_t ipcr_internal_fasta_hostpacked_loads(void) { return g_fasta_hostpacked_loads.load(std::memory_order_relaxed); }
 
 ipcr_status ipcr_genome_add_record(ipcr_genome *g, const uint8_t *seq, uint64_t len) {
     if (!g || (!seq && len)) return fail(IPCR_ERR_INVALID, "ipcr_genome_add_record: null argument");

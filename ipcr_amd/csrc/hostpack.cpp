@@ -183,8 +183,7 @@ bool pack_fasta_blocks(const uint8_t *region, uint64_t area /* = full * (W + lt)
     const uint32_t stride = W + lt;
     const __m512i lut = _mm512_broadcast_i32x4(_mm_setr_epi8(0x01, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 0, 0));
     const __m512i nib = _mm512_set1_epi8(0x0F), up = _mm512_set1_epi8((char)0xDF), bit1 = _mm512_set1_epi8(2), bit2 = _mm512_set1_epi8(4);
-    const __m512i c_nl = _mm512_set1_epi8('\n'), c_cr = _mm512_set1_epi8('\r'), c_sp = _mm512_set1_epi8(' '), c_tab = _mm512_set1_epi8('\t'),
-                  c_vt = _mm512_set1_epi8('\v'), c_ff = _mm512_set1_epi8('\f');
+    const __m512i c_nl = _mm512_set1_epi8('\n'), c_cr = _mm512_set1_epi8('\r'), c_sp = _mm512_set1_epi8(' ');
     const uint64_t *t_nl = tab, *t_cr = tab + stride, *t_first = tab + 2 * stride, *t_last = tab + 3 * stride;
     const uint64_t p0 = j0 * 64u;
     const uint64_t before = (p0 / stride) * W + std::min<uint64_t>(p0 % stride, W); // bases in front of block j0
@@ -206,14 +205,16 @@ bool pack_fasta_blocks(const uint8_t *region, uint64_t area /* = full * (W + lt)
         ++w;
     };
     uint32_t s = (uint32_t)(p0 % stride);
+    const uint64_t jfull = std::min(j1, area / 64u); // blocks that lie wholly inside the text: plain loads
     for (uint64_t j = j0; j < j1; ++j) {
         const uint64_t off = j * 64u;
-        const uint64_t live = area - off >= 64u ? ~0ull : ((1ull << (area - off)) - 1ull);
-        const __m512i c = _mm512_maskz_loadu_epi8((__mmask64)live, region + off);
+        const uint64_t live = j < jfull ? ~0ull : ((1ull << (area - off)) - 1ull);
+        const __m512i c = j < jfull ? _mm512_loadu_si512(region + off) : _mm512_maskz_loadu_epi8((__mmask64)live, region + off);
         const uint64_t nl = _mm512_cmpeq_epi8_mask(c, c_nl) & live, cr = _mm512_cmpeq_epi8_mask(c, c_cr) & live;
-        if (nl != (t_nl[s] & live) || cr != (t_cr[s] & live)) return false;
-        const uint64_t ws = (_mm512_cmpeq_epi8_mask(c, c_sp) | _mm512_cmpeq_epi8_mask(c, c_tab) | _mm512_cmpeq_epi8_mask(c, c_vt) | _mm512_cmpeq_epi8_mask(c, c_ff)) & live;
-        if (ws & (t_first[s] | t_last[s])) return false;
+        // blanks, tabs and every other control byte at a line's first or last base (the reference trims white space there): one
+        // unsigned compare, line ends taken out
+        const uint64_t ctl = _mm512_cmple_epu8_mask(c, c_sp) & live & ~(nl | cr);
+        if (((nl ^ t_nl[s]) | (cr ^ t_cr[s])) & live || (ctl & (t_first[s] | t_last[s]))) return false;
         const uint64_t valid = live & ~(nl | cr);
         const __m512i want = _mm512_shuffle_epi8(lut, _mm512_and_si512(c, nib));
         const uint64_t m_acgt = _mm512_cmpeq_epi8_mask(want, _mm512_and_si512(c, up));
@@ -231,7 +232,8 @@ bool pack_fasta_blocks(const uint8_t *region, uint64_t area /* = full * (W + lt)
             } else
                 fill += k;
         }
-        s = (uint32_t)((s + 64u) % stride);
+        s += 64u;
+        while (s >= stride) s -= stride; // (no division in the loop: a line is rarely shorter than a block)
     }
     // the unfinished word at the piece's end (it is also the piece's first when the piece never finished one)
     if (first_word ? fill > (uint32_t)(before & 63u) : fill > 0u) {

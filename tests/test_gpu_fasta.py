@@ -210,3 +210,73 @@ def test_thousands_of_tiny_records_batched(tmp_path):
     p.write_bytes(b"".join(parts))
     for slab in (None, 65536, 4096):
         load_and_compare(str(p), slab)
+
+
+def test_regular_files_are_packed_on_the_host_and_written_through_the_bar(tmp_path):
+    """ipcr_genome_add_fasta's fast way in (csrc/fasta_hostpack.cpp + host.cpp: the text packed on the host, line ends squeezed out
+    with pext, the code planes written straight into device memory through the PCIe BAR, the invalid-bit plane only for groups of
+    columns that hold an invalid base): regular files of several shapes against the streaming reader -- IDs, lengths, every base
+    read back from the tiles, the reset flags -- and the counter says that this loader took them; an irregular file, a gzip file
+    and a file under IPCR_FASTA_SLAB take the device loader and give the same records."""
+    import ctypes
+    from ipcr_amd import _lib, engine, fasta
+    loads = _lib.lib().ipcr_internal_fasta_hostpacked_loads
+    loads.restype = ctypes.c_uint64
+    how = _lib.lib().ipcr_internal_device_bar
+    how.restype, how.argtypes = ctypes.c_int32, [ctypes.c_int32]
+    rng = random.Random(77)
+
+    def seq(n, junk, lower):
+        s = [rng.choice("ACGT") for _ in range(n)]
+        for i in range(n):
+            x = rng.random()
+            if x < junk:
+                s[i] = rng.choice("NRYKMnx-")
+            elif x < junk + lower:
+                s[i] = s[i].lower()
+        return "".join(s)
+
+    to_n = bytes(c if c in b"ACGT" else ord("N") for c in range(256))       # what is not a base reads back as one invalid code
+
+    def check(path, expect_fast):
+        before = loads()
+        g = engine.Genome(40_000_000, max_records=64)
+        g.add_fasta(str(path))
+        want = list(fasta.StreamChunks(str(path), 0, 0))
+        assert g.ids == [r.ID for r in want]
+        for i, r in enumerate(want):
+            assert g.record_len(i) == len(r.Seq)
+            # the tiles keep the case-folded text: every base is read back (N and other codes come back as 'N'? no: as what was packed)
+            got = g.read(i, 0, len(r.Seq)) if len(r.Seq) else b""
+            assert got.translate(to_n) == r.Seq.translate(to_n), (str(path), i)
+            assert (g.record_flags(i) & 1) == (1 if r.Seq.translate(None, b"ACGTacgt") else 0)
+        g.close()
+        if expect_fast is not None and how(0) == 2:
+            assert (loads() - before == 1) == expect_fast, (str(path), expect_fast)
+
+    for k, (W, nl, final_nl) in enumerate(((60, "\n", True), (80, "\r\n", True), (61, "\n", False), (1000, "\n", True), (7, "\n", True))):
+        p = tmp_path / ("reg%d.fa" % k)
+        with open(p, "w", newline="") as fh:
+            fh.write("text in front of the first header" + nl)
+            for r, n in enumerate((9_000_001, 0, W, 3 * W, 123_457, 5)):
+                s = seq(n if W > 7 else min(n, 50_000), rng.choice([0, 0.001]), rng.choice([0, 0.2]))
+                if r == 0 and W == 60:
+                    s = s[:4_000_000] + "N" * 5000 + s[4_005_000:]     # a run of N in ONE group of columns: only its plane follows
+                fh.write(">rec%d description > text%s" % (r, nl))
+                if r == 3:
+                    fh.write(">%sACGT%s" % (nl, nl))                     # a header without an ID drops its record
+                lines = [s[i:i + W] for i in range(0, len(s), W)]
+                fh.write(nl.join(lines) + (nl if lines and (final_nl or r < 5) else ""))
+        check(p, True)
+    irr = tmp_path / "irregular.fa"
+    irr.write_text(">a\nACGTACGT\nACG\nACGTACGT\n>b\nACGT \nAC\n")
+    check(irr, False)
+    gz = tmp_path / "reg.fa.gz"
+    with gzip.open(gz, "wt") as fh:
+        fh.write(">z\n" + "\n".join(["ACGTACGTAC"] * 50) + "\n")
+    check(gz, False)
+    os.environ["IPCR_FASTA_SLAB"] = "4096"
+    try:
+        check(tmp_path / "reg0.fa", False)
+    finally:
+        del os.environ["IPCR_FASTA_SLAB"]
