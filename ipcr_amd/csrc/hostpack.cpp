@@ -232,8 +232,8 @@ bool pack_fasta_blocks(const uint8_t *region, uint64_t area /* = full * (W + lt)
             } else
                 fill += k;
         }
-        s += 64u;
-        while (s >= stride) s -= stride; // (no division in the loop: a line is rarely shorter than a block)
+        s += 64u; // (no division in the loop unless a line is shorter than a block)
+        if (s >= stride) s = stride >= 64u ? s - stride : s % stride;
     }
     // the unfinished word at the piece's end (it is also the piece's first when the piece never finished one)
     if (first_word ? fill > (uint32_t)(before & 63u) : fill > 0u) {
