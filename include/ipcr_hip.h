@@ -279,9 +279,12 @@ ipcr_status ipcr_fasta_open(const char *path, int64_t chunk_size, int64_t overla
 void ipcr_fasta_close(ipcr_fasta *f);
 /* next record/chunk; *got = 0 at end of input; *id and *seq stay valid until the next call */
 ipcr_status ipcr_fasta_next(ipcr_fasta *f, const char **id, const uint8_t **seq, uint64_t *len, int32_t *got);
-/* pack every record of a FASTA file (plain or gzip, "-" = stdin) into a resident genome: raw
- * slabs go to the device, which strips line ends / white space and folds case itself (same record
- * semantics as the stream above); record IDs come back '\n'-joined and via ipcr_genome_record_id */
+/* pack every record of a FASTA file (plain or gzip, "-" = stdin) into a resident genome (same record semantics as the
+ * stream above); record IDs come back '\n'-joined and via ipcr_genome_record_id.  Two loaders behind it: a plain file whose
+ * records are lines of one width is mapped, packed on the host (2 bits per base) and written straight into device memory through
+ * the PCIe BAR where the host has a large one (IPCR_FASTA_HOSTPACK=0: never); every other file, and every host without, sends
+ * raw slabs to the device, which strips line ends / white space and folds case itself.  The mapped file must not be truncated
+ * while it is loaded. */
 ipcr_status ipcr_genome_add_fasta(ipcr_genome *g, const char *path, uint32_t *n_added, char *ids_out, size_t cap,
                                   size_t *ids_needed);
 
