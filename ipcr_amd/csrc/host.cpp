@@ -12,6 +12,7 @@
 #include "ipcr_hip.h"
 
 #include <emmintrin.h>
+#include <immintrin.h>
 #include <sched.h>
 #include <sys/prctl.h>
 #include <time.h>
@@ -182,6 +183,18 @@ BarInfo device_bar(int phys) {
     }
     g_bar_cache[phys] = bi;
     return bi;
+}
+// host memory -> device memory through the BAR, in the widest non-temporal stores the CPU has (64-byte write-combining bursts reach
+// ~45 GB/s from one thread, 8-byte ones 13: tools/exp/bar_write.cpp); both 64-byte aligned, bytes a multiple of 64
+__attribute__((target("avx512f"))) static void bar_copy_512(uint8_t *dst, const uint8_t *src, uint64_t bytes) {
+    for (uint64_t i = 0; i < bytes; i += 64) _mm512_stream_si512(reinterpret_cast<__m512i *>(dst + i), _mm512_load_si512(reinterpret_cast<const void *>(src + i)));
+    _mm_sfence();
+}
+static void bar_copy(uint8_t *dst, const uint8_t *src, uint64_t bytes) {
+    static const bool wide = __builtin_cpu_supports("avx512f");
+    if (wide && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | bytes) & 63u) == 0) { bar_copy_512(dst, src, bytes); return; }
+    for (uint64_t i = 0; i + 16 <= bytes; i += 16) _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i), _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i)));
+    _mm_sfence();
 }
 // everything the packer's threads have stored through the BAR (each of them has fenced) is in device memory when this returns
 inline void bar_flush(const BarInfo &bi) {
@@ -1368,7 +1381,8 @@ static bool genome_add_host_packed(ipcr_genome *g, const uint8_t *seq, uint64_t 
         flags_all |= fl;
         bar_flush(bi);
         const bool lower = (fl & 2u) != 0, need_inv = lower || (fl & 1u) != 0;
-        if (need_inv && !hip(hipMemcpyAsync(g->staging + W * 8u, g->h_planes, W * 4u * (lower ? 2u : 1u), hipMemcpyHostToDevice, g->stream), "hipMemcpyAsync")) break;
+        if (need_inv) bar_copy(g->staging + W * 8u, g->h_planes, W * 4u * (lower ? 2u : 1u)); // (through the BAR as well: no copy operation)
+        bar_flush(bi);
         if (!hip(ipcr::launch_tiles_from_linear(g->stream, dlo, dlo + W, need_inv ? dlo + 2 * W : nullptr, lower ? dlo + 3 * W : nullptr, col0, col0 + c0, nc, len,
                                                 g->planes, g->rst, nullptr, nullptr, c0 == 0 ? g->e0 : nullptr, c0 + nc >= cols ? g->e1 : nullptr), "tiles_from_linear")) break;
         if (c0 + nc < cols && !hip(hipStreamSynchronize(g->stream), "hipStreamSynchronize")) break; // the next group reuses both buffers
@@ -3164,6 +3178,7 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
         auto send_slice = [&](uint64_t i, const uint8_t *slab) -> ipcr_status { // the rst plane crosses the link only if the slice holds lower case
             const uint64_t c0 = gs[(size_t)i], nc = gs[(size_t)i + 1] - c0, W = nc * 128u;
             const bool lower = (sflags[(size_t)i] & 2u) != 0;
+            const uint32_t *iv_cols = nullptr; // (device) one bit per column: its invalid plane has crossed the link
             // ... and the invalid-bit plane only if it holds a byte outside ACGT at all: the conversion kernel knows where the
             // record ends and makes the padding's bits itself (0.25 B/base on the link: IPCR_CHUNK_SKIP_INV=0 sends it always)
             const bool need_inv = lower || (sflags[(size_t)i] & 1u) != 0 || !env_flag("IPCR_CHUNK_SKIP_INV", true);
@@ -3174,14 +3189,37 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
             // IPCR_CHUNK_ZEROCOPY=0/1 forces.
             static const int zc_env = getenv("IPCR_CHUNK_ZEROCOPY") ? atoi(getenv("IPCR_CHUNK_ZEROCOPY")) : -1;
             const bool zerocopy = !bar && (zc_env >= 0 ? zc_env != 0 : live <= 1);
-            if (bar) { // the code planes are there already; the other two follow only if the slice needs them
+            if (bar) { // the code planes are there already; the other two follow only if the slice needs them -- through the BAR as well
+                // (a copy operation per dirty chunk cost a stream of chunks with N a third of its rate: 16 workers 108 Gbases/s against 157)
+                if (need_inv) {
+                    static const bool inv_dma = env_flag("IPCR_CHUNK_INV_DMA", false);
+                    static const bool inv_cols = env_flag("IPCR_CHUNK_INV_COLUMNS", true);
+                    if (inv_dma) HIPCHK(hipMemcpyAsync(d + W * 8u, slab + W * 8u, W * 4u * (lower ? 2u : 1u), hipMemcpyHostToDevice, g->stream));
+                    else if (lower || !inv_cols || nc > 2048) bar_copy(d + W * 8u, slab + W * 8u, W * 4u * (lower ? 2u : 1u));
+                    else {
+                        // Runs of N are short and far between (a genome's 0.1 %: one column of 4096 bases in a hundred holds one): only the
+                        // columns whose invalid plane holds a bit cross the link, 512 bytes each, and a bitmap in the (unused) reset
+                        // plane's place tells the conversion kernel which -- it makes the others' bits itself, as for a clean slice
+                        alignas(64) uint32_t bits[64] = {0};
+                        const uint32_t *hiv = reinterpret_cast<const uint32_t *>(slab) + 2 * W;
+                        for (uint64_t c = 0; c < nc; ++c) {
+                            uint32_t any = 0;
+                            for (uint32_t k = 0; k < 128u; ++k) any |= hiv[c * 128u + k];
+                            if (any) {
+                                bits[c >> 5] |= 1u << (c & 31u);
+                                bar_copy(d + W * 8u + c * 512u, slab + W * 8u + c * 512u, 512u);
+                            }
+                        }
+                        bar_copy(d + W * 12u, reinterpret_cast<const uint8_t *>(bits), sizeof bits);
+                        iv_cols = reinterpret_cast<const uint32_t *>(d + W * 12u);
+                    }
+                }
                 bar_flush(bar_info);
-                if (need_inv) HIPCHK(hipMemcpyAsync(d + W * 8u, slab + W * 8u, W * 4u * (lower ? 2u : 1u), hipMemcpyHostToDevice, g->stream));
             } else if (!zerocopy) HIPCHK(hipMemcpyAsync(d, slab, W * 4u * (lower ? 4u : need_inv ? 3u : 2u), hipMemcpyHostToDevice, g->stream));
             const uint32_t *dl = zerocopy ? reinterpret_cast<const uint32_t *>(slab) : reinterpret_cast<const uint32_t *>(d);
             HIPCHK(ipcr::launch_tiles_from_linear(g->stream, dl, dl + W, need_inv ? dl + 2 * W : nullptr, lower ? dl + 3 * W : nullptr, col0, col0 + c0, nc, len,
                                                   g->planes, g->rst, i == 0 ? g->d_rec_start : nullptr, i == 0 ? g->d_rec_len : nullptr,
-                                                  i == 0 ? g->e0 : nullptr, i + 1 == nsl ? g->e1 : nullptr));
+                                                  i == 0 ? g->e0 : nullptr, i + 1 == nsl ? g->e1 : nullptr, iv_cols));
             return IPCR_OK;
         };
         if (!pooled) { // this worker's own two pinned slices: slice i + 1 is packed while slice i crosses the link

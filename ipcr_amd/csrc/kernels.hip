@@ -164,6 +164,7 @@ __device__ __forceinline__ uint32_t tl_transpose(uint32_t x, uint32_t lane) {
 }
 __global__ __launch_bounds__(256) void tiles_from_linear_kernel(const uint4 *__restrict__ lin_lo, const uint4 *__restrict__ lin_hi,
                                                                const uint4 *__restrict__ lin_iv, const uint4 *__restrict__ lin_rs,
+                                                               const uint32_t *__restrict__ iv_cols, // null, or one bit per column of the launch: its invalid bits are in lin_iv (else: made here)
                                                                uint64_t rec_col0, uint64_t col0, uint64_t ncol, uint64_t len,
                                                                uint32_t *__restrict__ planes, uint32_t *__restrict__ rst,
                                                                uint64_t *__restrict__ rec_start_out, uint64_t *__restrict__ rec_len_out) {
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256) void tiles_from_linear_kernel(const uint4 *__r
     const uint64_t c = live ? item >> 2 : 0u; // column of this launch's range
     const uint32_t plane = (uint32_t)item & 3u;
     const uint4 *src = plane == 0u ? lin_lo : plane == 1u ? lin_hi : (plane == 2u || !lin_rs) ? lin_iv : lin_rs;
+    if (plane >= 2u && src == lin_iv && iv_cols && live && !((iv_cols[c >> 5] >> (uint32_t)(c & 31u)) & 1u)) src = nullptr; // a column of ACGT only
     uint4 v;
     if (src) v = src[c * 32u + lane];
     else { // no invalid-bit plane came over the link: the slice holds ACGT only, what is invalid is what lies behind the record's end
@@ -733,12 +735,12 @@ hipError_t launch_pack(hipStream_t st, const uint8_t *seq, uint64_t len, uint64_
 hipError_t launch_tiles_from_linear(hipStream_t st, const uint32_t *lin_lo, const uint32_t *lin_hi, const uint32_t *lin_iv,
                                     const uint32_t *lin_rs, uint64_t rec_col0, uint64_t col0, uint64_t ncol, uint64_t len,
                                     uint32_t *planes, uint32_t *rst, uint64_t *rec_start_out, uint64_t *rec_len_out,
-                                    hipEvent_t start, hipEvent_t stop) {
+                                    hipEvent_t start, hipEvent_t stop, const uint32_t *iv_cols) {
     const uint64_t grid = (ncol * 4u + 7u) / 8u; // 8 half waves per workgroup
     if (grid == 0) return hipSuccess;
     hipExtLaunchKernelGGL(tiles_from_linear_kernel, dim3((uint32_t)grid), dim3(256), 0, st, start, stop, 0,
                           reinterpret_cast<const uint4 *>(lin_lo), reinterpret_cast<const uint4 *>(lin_hi),
-                          reinterpret_cast<const uint4 *>(lin_iv), reinterpret_cast<const uint4 *>(lin_rs), rec_col0, col0, ncol, len,
+                          reinterpret_cast<const uint4 *>(lin_iv), reinterpret_cast<const uint4 *>(lin_rs), iv_cols, rec_col0, col0, ncol, len,
                           planes, rst, rec_start_out, rec_len_out);
     return hipGetLastError();
 }

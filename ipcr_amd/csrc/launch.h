@@ -15,7 +15,7 @@ hipError_t launch_pack(hipStream_t st, const uint8_t *seq, uint64_t len, uint64_
 hipError_t launch_tiles_from_linear(hipStream_t st, const uint32_t *lin_lo, const uint32_t *lin_hi, const uint32_t *lin_iv,
                                     const uint32_t *lin_rs, uint64_t rec_col0, uint64_t col0, uint64_t ncol, uint64_t len,
                                     uint32_t *planes, uint32_t *rst, uint64_t *rec_start_out, uint64_t *rec_len_out,
-                                    hipEvent_t start, hipEvent_t stop);
+                                    hipEvent_t start, hipEvent_t stop, const uint32_t *iv_cols = nullptr);
 // ASCII -> linear planes on the host (returns bit 0: a byte outside ACGTacgt, bit 1: a lower-case acgt)
 uint32_t pack_linear(const uint8_t *seq, uint64_t len, uint64_t padded, uint32_t *lo, uint32_t *hi, uint32_t *iv, uint32_t *rs);
 bool pack_linear_is_simd();
