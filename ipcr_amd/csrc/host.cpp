@@ -3175,6 +3175,27 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
             const uint64_t c0 = gs[(size_t)i], nc = gs[(size_t)i + 1] - c0;
             sflags[(size_t)i] = pack_cols(i, slab, c0, nc);
         };
+        // Runs of N are short and far between (a genome's 0.1 %: one column of 4096 bases in a hundred holds one): of a slice that
+        // holds an invalid base only the columns whose invalid plane holds a bit cross the link -- 512 bytes each, through the BAR --
+        // and a bitmap in the (unused) reset plane's place tells the conversion kernel which; it makes the others' bits itself.
+        // Whoever packed the columns looks them over (the pool's threads for a lone worker's groups), the sender writes the bitmap.
+        static const bool inv_cols = env_flag("IPCR_CHUNK_INV_COLUMNS", true);
+        std::vector<uint32_t> colbits((size_t)nsl * 64u, 0);
+        auto mark_columns = [&](uint64_t i, const uint8_t *slab, uint64_t c0, uint64_t nc) { // columns [c0, c0 + nc) of slice i
+            const uint64_t s0 = gs[(size_t)i], snc = gs[(size_t)i + 1] - s0, W = snc * 128u;
+            if (snc > 2048) return;
+            uint8_t *d = g->staging + s0 * 2048ull;
+            const uint32_t *hiv = reinterpret_cast<const uint32_t *>(slab) + 2 * W;
+            for (uint64_t c = c0 - s0; c < c0 - s0 + nc; ++c) {
+                uint32_t any = 0;
+                for (uint32_t k = 0; k < 128u; ++k) any |= hiv[c * 128u + k];
+                if (any) {
+                    __atomic_fetch_or(&colbits[(size_t)i * 64u + (size_t)(c >> 5)], 1u << (c & 31u), __ATOMIC_RELAXED);
+                    bar_copy(d + W * 8u + c * 512u, slab + W * 8u + c * 512u, 512u);
+                }
+            }
+        };
+        std::vector<uint8_t> marked((size_t)nsl, 0); // the slice's columns have been looked over by its packers
         auto send_slice = [&](uint64_t i, const uint8_t *slab) -> ipcr_status { // the rst plane crosses the link only if the slice holds lower case
             const uint64_t c0 = gs[(size_t)i], nc = gs[(size_t)i + 1] - c0, W = nc * 128u;
             const bool lower = (sflags[(size_t)i] & 2u) != 0;
@@ -3193,23 +3214,12 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
                 // (a copy operation per dirty chunk cost a stream of chunks with N a third of its rate: 16 workers 108 Gbases/s against 157)
                 if (need_inv) {
                     static const bool inv_dma = env_flag("IPCR_CHUNK_INV_DMA", false);
-                    static const bool inv_cols = env_flag("IPCR_CHUNK_INV_COLUMNS", true);
                     if (inv_dma) HIPCHK(hipMemcpyAsync(d + W * 8u, slab + W * 8u, W * 4u * (lower ? 2u : 1u), hipMemcpyHostToDevice, g->stream));
                     else if (lower || !inv_cols || nc > 2048) bar_copy(d + W * 8u, slab + W * 8u, W * 4u * (lower ? 2u : 1u));
                     else {
-                        // Runs of N are short and far between (a genome's 0.1 %: one column of 4096 bases in a hundred holds one): only the
-                        // columns whose invalid plane holds a bit cross the link, 512 bytes each, and a bitmap in the (unused) reset
-                        // plane's place tells the conversion kernel which -- it makes the others' bits itself, as for a clean slice
-                        alignas(64) uint32_t bits[64] = {0};
-                        const uint32_t *hiv = reinterpret_cast<const uint32_t *>(slab) + 2 * W;
-                        for (uint64_t c = 0; c < nc; ++c) {
-                            uint32_t any = 0;
-                            for (uint32_t k = 0; k < 128u; ++k) any |= hiv[c * 128u + k];
-                            if (any) {
-                                bits[c >> 5] |= 1u << (c & 31u);
-                                bar_copy(d + W * 8u + c * 512u, slab + W * 8u + c * 512u, 512u);
-                            }
-                        }
+                        if (!marked[(size_t)i]) mark_columns(i, slab, c0, nc); // (a worker's own slice: nobody has looked yet)
+                        alignas(64) uint32_t bits[64];
+                        memcpy(bits, &colbits[(size_t)i * 64u], sizeof bits);
                         bar_copy(d + W * 12u, reinterpret_cast<const uint8_t *>(bits), sizeof bits);
                         iv_cols = reinterpret_cast<const uint32_t *>(d + W * 12u);
                     }
@@ -3274,11 +3284,13 @@ ipcr_status ipcr_scan_chunk(const ipcr_panel *p, ipcr_scratch *s, const uint8_t 
             static const bool item_times = getenv("IPCR_DEBUG_TIMES") != nullptr;
             std::vector<double> it0(item_times ? items.size() : 0), it1(item_times ? items.size() : 0);
             std::vector<int> itcpu(item_times ? items.size() : 0);
+            if (bar && inv_cols) std::fill(marked.begin(), marked.end(), (uint8_t)1); // (every item looks its own columns over)
             const auto tp0 = std::chrono::steady_clock::now();
             PackPool::get().run(items.size(), [&](size_t k) {
                 const Item &it = items[k];
                 if (item_times) { it0[k] = ms_since(tp0) * 1000.0; itcpu[k] = sched_getcpu(); }
                 iflags[k] = pack_cols(it.group, s->h_planes + gs[(size_t)it.group] * 2048ull, it.c0, it.nc);
+                if (bar && inv_cols && (iflags[k] & 1u)) mark_columns(it.group, s->h_planes + gs[(size_t)it.group] * 2048ull, it.c0, it.nc);
                 if (item_times) it1[k] = ms_since(tp0) * 1000.0;
                 group_done[(size_t)it.group].fetch_add(1, std::memory_order_release);
             }, slot_phys(g->device), &idle);
