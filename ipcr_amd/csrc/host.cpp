@@ -1406,6 +1406,7 @@ struct FastaStage { // kept for the process's next load (allocating and mapping 
     int phys = -1;
     uint64_t words = 0; // 64-bit words per plane
     uint64_t *d_lo = nullptr, *d_hi = nullptr, *d_iv = nullptr, *h_iv = nullptr;
+    uint32_t *d_bits = nullptr; // one bit per column: its invalid plane has crossed the link (behind the three planes)
 };
 std::mutex g_fasta_stage_mu;
 FastaStage g_fasta_stage;
@@ -1426,7 +1427,7 @@ ipcr_status ipcr_internal_genome_add_fasta_hostpacked(ipcr_genome *g, const char
     if (!t.open(path) || t.records.empty() || t.records.size() > 2048) return IPCR_OK;
     const double ms_open = since0();
     if (g->rec_start.size() + t.records.size() > g->max_records) return IPCR_OK; // (the device loader reports it)
-    constexpr uint64_t GROUP = 2048; // columns per group: whether a group's invalid-bit plane reaches the device
+    constexpr uint64_t GROUP = 256; // columns per group (1 Mb): the groups that hold an invalid base are looked over column by column
     std::vector<uint64_t> word0(t.records.size() + 1, 0), cols(t.records.size()), group0(t.records.size() + 1, 0);
     uint64_t total_cols = 0;
     for (size_t r = 0; r < t.records.size(); ++r) {
@@ -1446,10 +1447,12 @@ ipcr_status ipcr_internal_genome_add_fasta_hostpacked(ipcr_genome *g, const char
         fs = FastaStage();
         const uint64_t want = words + (words >> 3);
         uint8_t *base = nullptr;
-        if (hipExtMallocWithFlags((void **)&base, want * 24u, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return IPCR_OK; }
+        // (+ the column bitmaps: a column is 64 words, a record's bitmap is padded to 64 bytes)
+        if (hipExtMallocWithFlags((void **)&base, want * 24u + want / 8u + 2048u * 64u + 64u, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return IPCR_OK; }
         fs.d_lo = reinterpret_cast<uint64_t *>(base);
         fs.d_hi = fs.d_lo + want;
         fs.d_iv = fs.d_hi + want;
+        fs.d_bits = reinterpret_cast<uint32_t *>(fs.d_iv + want);
         fs.h_iv = static_cast<uint64_t *>(malloc(want * 8u));
         if (!fs.h_iv) { (void)hipFree(base); fs = FastaStage(); return IPCR_OK; }
         fs.phys = phys;
@@ -1462,42 +1465,51 @@ ipcr_status ipcr_internal_genome_add_fasta_hostpacked(ipcr_genome *g, const char
         if (!t.pack(t.records[r], fs.d_lo + word0[r], fs.d_hi + word0[r], fs.h_iv + word0[r], cols[r] * 64u, dirty.data() + group0[r], GROUP))
             return IPCR_OK; // irregular text after all: the device loader takes the file
     const double ms_pack = since0();
-    // ---- the invalid-bit planes of the groups that hold an invalid base follow (host memory -> device, through the BAR as well)
+    // ---- invalid bases: runs of N are short and far between, so of the groups that hold one only the COLUMNS whose invalid plane holds
+    // a bit bring it along (512 bytes each, host memory -> device through the BAR as well); a bitmap per record tells the
+    // conversion kernel which columns did -- it makes the others' bits itself
+    std::vector<uint64_t> bit0(t.records.size() + 1, 0); // 32-bit words of the records' bitmaps, each padded to 64 bytes
+    for (size_t r = 0; r < t.records.size(); ++r) bit0[r + 1] = bit0[r] + ((cols[r] + 31) / 32 + 15) / 16 * 16;
+    std::vector<uint32_t> bits((size_t)bit0.back(), 0);
+    std::vector<uint8_t> rec_dirty(t.records.size(), 0);
     {
-        struct Span { uint64_t w0, n; };
+        struct Span { size_t r; uint64_t c0, nc; };
         std::vector<Span> spans;
         for (size_t r = 0; r < t.records.size(); ++r)
             for (uint64_t q = group0[r]; q < group0[r + 1]; ++q)
                 if (dirty[(size_t)q]) {
-                    const uint64_t c0 = (q - group0[r]) * GROUP, nc = std::min(GROUP, cols[r] - c0);
-                    spans.push_back({word0[r] + c0 * 64u, nc * 64u});
+                    const uint64_t c0 = (q - group0[r]) * GROUP;
+                    spans.push_back({r, c0, std::min(GROUP, cols[r] - c0)});
+                    rec_dirty[r] = 1;
                 }
         if (!spans.empty())
             PackPool::get().run(spans.size(), [&](size_t i) {
-                const uint64_t *src = fs.h_iv + spans[i].w0;
-                uint64_t *dst = fs.d_iv + spans[i].w0;
-                for (uint64_t w = 0; w < spans[i].n; ++w) _mm_stream_si64(reinterpret_cast<long long *>(dst + w), (long long)src[w]);
-                _mm_sfence();
+                const Span &sp = spans[i];
+                const uint64_t *src = fs.h_iv + word0[sp.r];
+                uint64_t *dst = fs.d_iv + word0[sp.r];
+                for (uint64_t c = sp.c0; c < sp.c0 + sp.nc; ++c) { // (a group is 256 columns = 8 whole bitmap words: no word is shared)
+                    uint64_t any = 0;
+                    for (uint32_t k = 0; k < 64u; ++k) any |= src[c * 64u + k];
+                    if (any) {
+                        bits[(size_t)bit0[sp.r] + (size_t)(c >> 5)] |= 1u << (c & 31u);
+                        bar_copy(reinterpret_cast<uint8_t *>(dst + c * 64u), reinterpret_cast<const uint8_t *>(src + c * 64u), 512u);
+                    }
+                }
             }, phys);
+        for (size_t r = 0; r < t.records.size(); ++r)
+            if (rec_dirty[r])
+                bar_copy(reinterpret_cast<uint8_t *>(fs.d_bits + bit0[r]), reinterpret_cast<const uint8_t *>(bits.data() + bit0[r]), (bit0[r + 1] - bit0[r]) * 4u);
     }
     bar_flush(bi);
-    // ---- tiles, record by record: one launch per run of groups that agree on whether they bring an invalid-bit plane
+    // ---- tiles: one launch per record
     for (size_t r = 0; r < t.records.size(); ++r) {
         const ipcr::FastaRecord &fr = t.records[r];
         const uint64_t col0 = g->next_col;
         const uint32_t *lo32 = reinterpret_cast<const uint32_t *>(fs.d_lo + word0[r]), *hi32 = reinterpret_cast<const uint32_t *>(fs.d_hi + word0[r]),
                        *iv32 = reinterpret_cast<const uint32_t *>(fs.d_iv + word0[r]);
-        uint32_t any = 0;
-        for (uint64_t q = group0[r]; q < group0[r + 1];) {
-            uint64_t e = q + 1;
-            while (e < group0[r + 1] && dirty[(size_t)e] == dirty[(size_t)q]) ++e;
-            const uint64_t c0 = (q - group0[r]) * GROUP, nc = std::min(cols[r], (e - group0[r]) * GROUP) - c0;
-            const bool d = dirty[(size_t)q] != 0;
-            any |= d ? 1u : 0u;
-            HIPCHK(ipcr::launch_tiles_from_linear(g->stream, lo32 + c0 * 128u, hi32 + c0 * 128u, d ? iv32 + c0 * 128u : nullptr, nullptr, col0, col0 + c0, nc, fr.len,
-                                                  g->planes, g->rst, nullptr, nullptr, nullptr, nullptr));
-            q = e;
-        }
+        const uint32_t any = rec_dirty[r];
+        HIPCHK(ipcr::launch_tiles_from_linear(g->stream, lo32, hi32, any ? iv32 : nullptr, nullptr, col0, col0, cols[r], fr.len,
+                                              g->planes, g->rst, nullptr, nullptr, nullptr, nullptr, any ? fs.d_bits + bit0[r] : nullptr));
         const uint32_t rec = (uint32_t)g->rec_start.size();
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(g->d_flags + rec), (int)any, 1, g->stream));
         genome_account_record(g, fr.len, cols[r]);
