@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "device_types.h"
 #include "tile_layout.h"
@@ -404,6 +405,136 @@ template __global__ void filter_generic_kernel<17, 2>(const uint32_t *, uint64_t
                                                       uint32_t, const uint32_t *, ipcr_queue_entry *, uint64_t,
                                                       unsigned long long *);
 
+// ------------------------------------------------------- table-driven filter, a row quad per wave
+// The same count as filter_generic_kernel for max_mm <= 3, re-cut for the tile layout: a wave owns the FOUR start rows of one
+// row quad and walks down quad by quad -- one 16-byte load per plane and lane brings four rows (the layout's unit; the
+// row-at-a-time form used 4 of every 16 bytes its loads touched and issued sixteen times the loads for the same steps), every
+// row is decoded once and then steps 4 starts x PB patterns = 16 independent counters.  K1 = max_mm + 1 is a compile-time
+// constant (no branch per counter level); a protected position's mismatch goes straight into the top level (count >= K1: out),
+// so there is no separate dead mask.  Workgroups are dealt to the XCDs round-robin by the dispatcher: the index is turned
+// so that every XCD walks a contiguous eighth of the blocks and the rows a wave shares with the waves below it (it reads
+// ~4 quads past its own) come out of that XCD's L2 instead of crossing from HBM once per XCD.
+__device__ __forceinline__ uint4 fetch_quad(const uint4 *__restrict__ planes4, uint64_t block, uint32_t quad, uint32_t plane, uint32_t lane) {
+    if (quad < 32u) return planes4[((block * 32u + quad) * 3u + plane) * 64u + lane];
+    const uint32_t q2 = quad - 32u; // the next strand: the same words one bit down, the next column's bit 0 on top
+    const uint4 own = planes4[((block * 32u + q2) * 3u + plane) * 64u + lane];
+    const uint4 nxt = (lane < 63u) ? planes4[((block * 32u + q2) * 3u + plane) * 64u + lane + 1u]
+                                   : planes4[(((block + 1u) * 32u + q2) * 3u + plane) * 64u];
+    return make_uint4((own.x >> 1) | (nxt.x << 31), (own.y >> 1) | (nxt.y << 31), (own.z >> 1) | (nxt.z << 31), (own.w >> 1) | (nxt.w << 31));
+}
+
+template <int K1, int PB>
+__global__ __launch_bounds__(256) void filter_generic_quad_kernel(const uint32_t *__restrict__ planes,
+                                                                  uint64_t block0, uint64_t nblocks, // blocks [block0, block0 + nblocks)
+                                                                  const ipcr_dev_pattern *__restrict__ pats, uint32_t npat,
+                                                                  const uint32_t *__restrict__ sel, // pattern subset or null
+                                                                  ipcr_queue_entry *__restrict__ queue, uint64_t qcap,
+                                                                  unsigned long long *__restrict__ qcount) {
+    const uint4 *__restrict__ planes4 = reinterpret_cast<const uint4 *>(planes);
+    const uint32_t lane = threadIdx.x & 63u;
+    // the grid is 8 * nblocks workgroups (8 per block: 32 row quads / 4 waves); workgroup w runs on XCD w % 8
+    const uint64_t wg = (uint64_t)(blockIdx.x & 7u) * nblocks + (blockIdx.x >> 3);
+    const uint64_t tile = wg * 4u + (threadIdx.x >> 6); // (block, row quad)
+    if ((tile >> 5) >= nblocks) return;
+    const uint64_t block = block0 + (tile >> 5);
+    const uint32_t rq = (uint32_t)(tile & 31u);
+
+    for (uint32_t qi0 = 0; qi0 < npat; qi0 += PB) {
+        uint32_t u[4][PB][K1]; // [start row of the quad][pattern][t]: count >= t + 1
+        uint32_t qid[PB], L[PB], prevw[PB], curw[PB]; // (wave-uniform: the masks of the pattern positions 4 q - 4 ... 4 q + 3, a byte each)
+        const uint32_t *mw[PB];
+        uint32_t Lmax = 0;
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            const bool on = qi0 + (uint32_t)b < npat; // wave-uniform
+            qid[b] = on ? (sel ? sel[qi0 + (uint32_t)b] : qi0 + (uint32_t)b) : 0u;
+            mw[b] = reinterpret_cast<const uint32_t *>(pats[qid[b]].mask);
+            L[b] = on ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pats[qid[b]].len) : 0u;
+            prevw[b] = 0u;
+            Lmax = L[b] > Lmax ? L[b] : Lmax;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int t = 0; t < K1; ++t) u[s][b][t] = 0u;
+                if (!on) u[s][b][K1 - 1] = 0xFFFFFFFFu;
+            }
+        }
+        const uint32_t nq = (Lmax + 2u) / 4u + 1u; // start row 3 ends at row Lmax + 2 of the walk
+        for (uint32_t q = 0; q < nq; ++q) {
+            const uint4 lo4 = fetch_quad(planes4, block, rq + q, 0, lane);
+            const uint4 hi4 = fetch_quad(planes4, block, rq + q, 1, lane);
+            const uint4 iv4 = fetch_quad(planes4, block, rq + q, 2, lane);
+            const uint32_t los[4] = {lo4.x, lo4.y, lo4.z, lo4.w}, his[4] = {hi4.x, hi4.y, hi4.z, hi4.w}, ivs[4] = {iv4.x, iv4.y, iv4.z, iv4.w};
+#pragma unroll
+            for (int b = 0; b < PB; ++b) // (scalar registers: every mask test below is scalar work, the lanes only AND and OR)
+                curw[b] = q * 4u < L[b] ? ~(uint32_t)__builtin_amdgcn_readfirstlane((int)mw[b][q]) : 0u; // complemented: bit set = base NOT allowed / not protected
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t lo = los[i], hi = his[i], inv = ivs[i];
+                const uint32_t isA = ~lo & ~hi, isC = lo & ~hi, isG = ~lo & hi, isT = lo & hi;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int jj = (int)(q * 4u) + i - s; // the pattern position this row is for start row s (wave-uniform)
+                    if (i < s && jj < 0) continue;        // (rows above the start row: the first quad only)
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) {
+                        if ((uint32_t)jj < L[b]) { // wave-uniform
+                            const int sh = 8 * ((i - s) & 3); // position 4 q + (i - s): this quad's word, or the one before
+                            const uint32_t w = i >= s ? curw[b] : prevw[b];
+                            const uint32_t nA = (uint32_t)((int32_t)(w << (31 - sh)) >> 31), nC = (uint32_t)((int32_t)(w << (30 - sh)) >> 31),
+                                           nG = (uint32_t)((int32_t)(w << (29 - sh)) >> 31), nT = (uint32_t)((int32_t)(w << (28 - sh)) >> 31);
+                            const uint32_t mm = inv | (isA & nA) | (isC & nC) | (isG & nG) | (isT & nT);
+                            // a mismatch at a protected position goes into the top level whatever the count below it (the lower levels take
+                            // it too: the position is out either way) -- no branch, K1 + 1 operations
+                            const uint32_t prot = ~(uint32_t)((int32_t)(w << (27 - sh)) >> 31);
+                            if (K1 > 1) {
+                                u[s][b][K1 - 1] |= (u[s][b][K1 > 1 ? K1 - 2 : 0] | prot) & mm;
+#pragma unroll
+                                for (int t = K1 - 2; t >= 1; --t) u[s][b][t] |= u[s][b][t - 1] & mm;
+                            }
+                            u[s][b][0] |= mm;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < PB; ++b) prevw[b] = curw[b];
+            uint32_t gone = 0xFFFFFFFFu; // positions no start row and no pattern of the pass can still match
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int b = 0; b < PB; ++b) gone &= u[s][b][K1 - 1];
+            if (__ballot(gone != 0xFFFFFFFFu) == 0ull) break;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                const uint32_t alive = ~u[s][b][K1 - 1];
+                if (alive) { // one queue entry per surviving word: 32 strands of this row
+                    const uint32_t shard = (uint32_t)block & (IPCR_QUEUE_SHARDS - 1u);
+                    const unsigned long long idx = atomicAdd(qcount + shard * IPCR_QUEUE_COUNTER_STRIDE, 1ull);
+                    if (idx < qcap) { // qcap = capacity of one shard's segment
+                        ipcr_queue_entry e;
+                        e.key = ((uint64_t)qid[b] << 48) | ipcr_join_pos(block * 64u + lane, 0, rq * 4u + (uint32_t)s);
+                        e.bits = alive;
+                        e.pad = 0;
+                        queue[(uint64_t)shard * qcap + idx] = e;
+                    }
+                }
+            }
+    }
+}
+
+template __global__ void filter_generic_quad_kernel<1, 4>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t, const uint32_t *,
+                                                          ipcr_queue_entry *, uint64_t, unsigned long long *);
+template __global__ void filter_generic_quad_kernel<2, 4>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t, const uint32_t *,
+                                                          ipcr_queue_entry *, uint64_t, unsigned long long *);
+template __global__ void filter_generic_quad_kernel<3, 4>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t, const uint32_t *,
+                                                          ipcr_queue_entry *, uint64_t, unsigned long long *);
+template __global__ void filter_generic_quad_kernel<4, 4>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t, const uint32_t *,
+                                                          ipcr_queue_entry *, uint64_t, unsigned long long *);
+
 // ------------------------------------------------------------------------------ verify
 // verifyAt (core/engine/ac.go:186-213) / the inner loop of FindMatches
 // (core/primer/match.go:67-84) for one candidate per thread, straight from the tiles.
@@ -778,6 +909,21 @@ hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_
                                  ipcr_queue_entry *queue, uint64_t qcap, unsigned long long *qcount,
                                  hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0 || npat == 0) return hipSuccess;
+    // max_mm <= 3: a wave per (block, row quad), IPCR_GENERIC_QUAD=0: the row-at-a-time form (kept for comparison and for k > 3)
+    static const bool quad = [] { const char *e = getenv("IPCR_GENERIC_QUAD"); return !(e && e[0] == '0'); }();
+    if (quad && max_mm <= 3u && nblocks * 8u <= 0x7FFFFFFFull) {
+        const dim3 qgrid((uint32_t)(nblocks * 8u)); // 32 row quads per block, 4 waves per workgroup
+#define IPCR_QUAD_LAUNCH(K1) hipExtLaunchKernelGGL((filter_generic_quad_kernel<K1, 4>), qgrid, dim3(256), 0, st, start, stop, 0, planes, block0, nblocks, \
+                                                   pats, npat, sel, queue, qcap, qcount)
+        switch (max_mm) {
+        case 0: IPCR_QUAD_LAUNCH(1); break;
+        case 1: IPCR_QUAD_LAUNCH(2); break;
+        case 2: IPCR_QUAD_LAUNCH(3); break;
+        default: IPCR_QUAD_LAUNCH(4); break;
+        }
+#undef IPCR_QUAD_LAUNCH
+        return hipGetLastError();
+    }
     const uint64_t tiles = nblocks * 128u; // one wave per (block, row)
     const dim3 grid((uint32_t)((tiles + 3u) / 4u));
     if (max_mm <= 3u)

@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI, via the ipcr_amd mirror of the reference API)
 against the CPU oracle on the same inputs.  Bit-exact, including emission order."""
+import os
 import random
+import sys
 from collections import Counter
 
 import pytest
@@ -227,6 +229,41 @@ def test_windows_across_strand_and_block_ends(hip, monkeypatch, roll):
             plant(rng, seq, rc, a + ln - len(rc), rng.choice([0, 0, 1]) if k else 0)
         cfg = E.Config(MaxMM=k, TerminalWindow=tw, MinLen=0, MaxLen=400, HitCap=0, SeedLen=12)
         check(hip, cfg, "".join(seq).encode(), hip.primer.AddSelfPairs(pairs), specialize=True)
+
+
+@pytest.mark.parametrize("quad", ["1", "0"])
+def test_table_driven_filter_across_strand_column_and_block_ends(hip, quad):
+    """the table-driven filter in both forms -- a wave per row quad (four start rows, 16-byte loads; max_mm <= 3) and, in a
+    child process with IPCR_GENERIC_QUAD=0, a wave per row -- on sites whose windows start in the last rows of a strand
+    (the walk continues in the next strand: the same words one bit down), in the last strand of a column (the next
+    column's bit 0 comes in on top) and of a block (lane 63's neighbour is column 0 of the next block: p near 262144),
+    k = 0..3 with and without a terminal window, IUPAC primers, junk bytes; vs the oracle"""
+    if quad == "0":   # the switch is read once per process
+        import subprocess
+        env = dict(os.environ, IPCR_GENERIC_QUAD="0")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
+                            "test_table_driven_filter_across_strand_column_and_block_ends and 1"], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        return
+    rng = random.Random(777)
+    E, P = hip.engine, hip.primer.Pair
+    n = 270000
+    for k, tw in ((2, 5), (3, 3), (0, 0), (1, 0)):
+        seq = rand_case(rng, n, with_junk=True)
+        pairs = [P("a", "ACGTTGCATGGATCCTAACG", "TTGACCGTAGGCATTCAGGA", 0, 0), P("b", "AGAGTTTGATCMTGGCTCAG", "TACGGYTACCTTGTTAYGACTT", 0, 0)]
+        starts = [s0 + r for s0 in (0, 3 * 4096, 131072, 262144 - 4096) for r in (100, 109, 118, 125, 126, 127, 4096 - 128 + 120, 4095 - 10, 4095)]
+        starts += [262144 - d for d in (1, 5, 10, 19, 20, 21, 40, 127, 128)]
+        for i, a in enumerate(sorted(set(starts))):
+            p = pairs[i % 2]
+            ln = rng.randint(60, 150)
+            if a + ln > n:
+                continue
+            plant(rng, seq, p.Forward, a, rng.choice([0, 1, 2]) if k else 0)
+            rc = O.revcomp(p.Reverse).decode()
+            plant(rng, seq, rc, a + ln - len(rc), rng.choice([0, 0, 1]) if k else 0)
+        cfg = E.Config(MaxMM=k, TerminalWindow=tw, MinLen=0, MaxLen=400, HitCap=0, SeedLen=12)
+        got = check(hip, cfg, "".join(seq).encode(), hip.primer.AddSelfPairs(pairs), specialize=False)
+        assert len(got) >= 10
 
 
 @pytest.mark.parametrize("seed", range(4))
