@@ -2,7 +2,7 @@
 //
 //  pack_kernel            ASCII record -> strand-major bit planes (tile_layout.h)
 //  lcg_fill_kernel        reference benchDNA generator on the device (jump-ahead LCG)
-//  filter_generic_kernel  table-driven bit-sliced k-mismatch scan (any panel)
+//  filter_generic_quad_kernel  table-driven bit-sliced k-mismatch scan (any panel), a wave per row quad
 //  verify_kernel          exact per-candidate verification -> ipcr_hit records
 //  unpack_kernel          tiles -> ASCII (tests, amplicon extraction)
 //  probe_kernel           oligo.BestHit over a batch of amplicons
@@ -12,7 +12,6 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "device_types.h"
 #include "tile_layout.h"
@@ -292,128 +291,23 @@ __global__ void lcg_fill_kernel(uint8_t *__restrict__ out, uint64_t n, uint32_t 
     }
 }
 
-// ------------------------------------------------------------- row fetch with strand wrap
-// Row `row` of my lane's column; rows >= 128 continue in the next strand: same word shifted
-// down one bit, with bit 0 of the next column's word entering at the top.
-__device__ __forceinline__ uint32_t fetch_row(const uint32_t *__restrict__ planes, uint64_t block,
-                                              uint32_t row, uint32_t plane, uint32_t lane) {
-    if (row < IPCR_TILE_N) return planes[ipcr_plane_word(block, row, plane, lane)];
-    const uint32_t r2 = row - IPCR_TILE_N;
-    const uint32_t own = planes[ipcr_plane_word(block, r2, plane, lane)];
-    const uint32_t nxt = (lane < 63u) ? planes[ipcr_plane_word(block, r2, plane, lane + 1u)]
-                                      : planes[ipcr_plane_word(block + 1u, r2, plane, 0u)];
-    return (own >> 1) | (nxt << 31);
-}
-
-// --------------------------------------------------------------- table-driven filter
-// Exact bit-sliced k-mismatch count for every pattern of the panel: each lane owns one word
-// (32 strands) of one row; pattern position j compares row r+j.  Mismatches outside the
-// protected window feed a thermometer counter u[t] = "count >= t"; a mismatch inside it, or
-// count > k, kills the position.  Survivors go to the candidate queue.
-// PB patterns share one walk down the rows (round 4): a row's three words are loaded once and decoded into its four
-// one-hot base masks once, then every pattern of the pass takes its step -- a quarter of the loads of one pattern per
-// walk, and four independent counters between two loads where one pattern's was a chain that waited for every load
-// (profiles/r04_c2g_pmc.json, before: 82 % of the wave cycles waiting, 4.2 x the algorithmic bytes from HBM).
-template <int KMAX, int PB>
-__global__ __launch_bounds__(256) void filter_generic_kernel(const uint32_t *__restrict__ planes,
-                                                             uint64_t block0, uint64_t nblocks, // blocks [block0, block0 + nblocks)
-                                                             const ipcr_dev_pattern *__restrict__ pats,
-                                                             uint32_t npat, uint32_t max_mm,
-                                                             const uint32_t *__restrict__ sel, // pattern subset or null
-                                                             ipcr_queue_entry *__restrict__ queue, uint64_t qcap,
-                                                             unsigned long long *__restrict__ qcount) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t tile = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); // (block, row)
-    if ((tile >> 7) >= nblocks) return;
-    const uint64_t block = block0 + (tile >> 7);
-    const uint32_t row = (uint32_t)(tile & 127u);
-
-    for (uint32_t qi0 = 0; qi0 < npat; qi0 += PB) {
-        uint32_t q[PB], L[PB], dead[PB], u[PB][KMAX + 1];
-        const ipcr_dev_pattern *pp[PB];
-        uint32_t Lmax = 0;
-#pragma unroll
-        for (int b = 0; b < PB; ++b) {
-            const bool on = qi0 + (uint32_t)b < npat; // wave-uniform
-            q[b] = on ? (sel ? sel[qi0 + (uint32_t)b] : qi0 + (uint32_t)b) : 0u;
-            pp[b] = pats + q[b];
-            L[b] = on ? pp[b]->len : 0u;
-            dead[b] = on ? 0u : 0xFFFFFFFFu;
-            Lmax = L[b] > Lmax ? L[b] : Lmax;
-#pragma unroll
-            for (int t = 0; t <= KMAX; ++t) u[b][t] = 0u;
-        }
-        for (uint32_t j = 0; j < Lmax; ++j) {
-            const uint32_t lo = fetch_row(planes, block, row + j, 0, lane);
-            const uint32_t hi = fetch_row(planes, block, row + j, 1, lane);
-            const uint32_t inv = fetch_row(planes, block, row + j, 2, lane);
-            const uint32_t isA = ~lo & ~hi, isC = lo & ~hi, isG = ~lo & hi, isT = lo & hi;
-            uint32_t gone = 0xFFFFFFFFu; // positions no pattern of the pass can still match
-#pragma unroll
-            for (int b = 0; b < PB; ++b) {
-                if (j < L[b]) { // wave-uniform
-                    const uint32_t m = pp[b]->mask[j];
-                    const uint32_t match = (isA & ((m & 1u) ? 0xFFFFFFFFu : 0u)) | (isC & ((m & 2u) ? 0xFFFFFFFFu : 0u)) |
-                                           (isG & ((m & 4u) ? 0xFFFFFFFFu : 0u)) | (isT & ((m & 8u) ? 0xFFFFFFFFu : 0u));
-                    const uint32_t mm = ~match | inv;
-                    if (m & 16u) {
-                        dead[b] |= mm;
-                    } else {
-#pragma unroll
-                        for (int t = KMAX; t >= 1; --t)
-                            if ((uint32_t)t <= max_mm + 1u) u[b][t] |= ((t == 1) ? 0xFFFFFFFFu : u[b][t - 1]) & mm;
-                    }
-                }
-                uint32_t over = 0u;
-#pragma unroll
-                for (int t = 1; t <= KMAX; ++t)
-                    if ((uint32_t)t == max_mm + 1u) over = u[b][t];
-                gone &= dead[b] | over;
-            }
-            if (__ballot(gone != 0xFFFFFFFFu) == 0ull) { // every position of these 64 words is out for every pattern of the pass
-#pragma unroll
-                for (int b = 0; b < PB; ++b) dead[b] = 0xFFFFFFFFu;
-                break;
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < PB; ++b) {
-            uint32_t over = 0u;
-#pragma unroll
-            for (int t = 1; t <= KMAX; ++t)
-                if ((uint32_t)t == max_mm + 1u) over = u[b][t];
-            const uint32_t alive = ~(dead[b] | over);
-            if (alive) { // one queue entry per surviving word: 32 strands of this row
-                const uint32_t shard = (uint32_t)block & (IPCR_QUEUE_SHARDS - 1u);
-                const unsigned long long idx = atomicAdd(qcount + shard * IPCR_QUEUE_COUNTER_STRIDE, 1ull);
-                if (idx < qcap) { // qcap = capacity of one shard's segment
-                    ipcr_queue_entry e;
-                    e.key = ((uint64_t)q[b] << 48) | ipcr_join_pos(block * 64u + lane, 0, row);
-                    e.bits = alive;
-                    e.pad = 0;
-                    queue[(uint64_t)shard * qcap + idx] = e;
-                }
-            }
-        }
-    }
-}
-
-template __global__ void filter_generic_kernel<4, 4>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t,
-                                                     uint32_t, const uint32_t *, ipcr_queue_entry *, uint64_t,
-                                                     unsigned long long *);
-template __global__ void filter_generic_kernel<17, 2>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t,
-                                                      uint32_t, const uint32_t *, ipcr_queue_entry *, uint64_t,
-                                                      unsigned long long *);
-
 // ------------------------------------------------------- table-driven filter, a row quad per wave
-// The same count as filter_generic_kernel for max_mm <= 3, re-cut for the tile layout: a wave owns the FOUR start rows of one
-// row quad and walks down quad by quad -- one 16-byte load per plane and lane brings four rows (the layout's unit; the
-// row-at-a-time form used 4 of every 16 bytes its loads touched and issued sixteen times the loads for the same steps), every
-// row is decoded once and then steps 4 starts x PB patterns = 16 independent counters.  K1 = max_mm + 1 is a compile-time
-// constant (no branch per counter level); a protected position's mismatch goes straight into the top level (count >= K1: out),
-// so there is no separate dead mask.  Workgroups are dealt to the XCDs round-robin by the dispatcher: the index is turned
-// so that every XCD walks a contiguous eighth of the blocks and the rows a wave shares with the waves below it (it reads
-// ~4 quads past its own) come out of that XCD's L2 instead of crossing from HBM once per XCD.
+// Exact bit-sliced k-mismatch count for every pattern of the panel, with the pattern as data (any panel, no hiprtc).  Each lane
+// owns one column (a word = 32 strands of one row); pattern position j compares row r + j.  Mismatches outside the protected
+// window feed a thermometer counter u[t] = "count >= t + 1"; a mismatch inside it goes straight into the top level (count >=
+// K1 = max_mm + 1: out), so there is no separate dead mask.  Survivors go to the candidate queue, a word per entry.
+// A wave owns the FOUR start rows of one row quad and walks down quad by quad: one 16-byte load per plane and lane brings four
+// rows (the layout's unit), every row is decoded once and then steps 4 starts x PB patterns = 16 independent counters, 8
+// vector instructions a step (four v_and_or for the mismatch mask, one select + K1 for the counters at k = 2); the pattern's
+// masks live in scalar registers (a word = four positions, read once per quad) and every test on them is scalar work.  K1 is
+// a compile-time constant, PB follows from what 4 x PB x K1 counters leave of the registers.  Rows >= 128 continue in the next
+// strand: the same words one bit down, with bit 0 of the next column's word on top.  Workgroups are dealt to the XCDs
+// round-robin by the dispatcher: the index is turned so that every XCD walks a contiguous eighth of the blocks and the rows a
+// wave shares with the waves below it (it reads ~4 quads past its own) come out of that XCD's L2.
+// Round 4, before: a wave per ROW (one dword per lane and row out of every 16 bytes, four patterns per walk, run-time counter
+// depth): 6.39 ms per 3 Gb for C2's four patterns, 4.1 x the algorithmic bytes from HBM, 2.70 G vector instructions; this
+// form 1.58 ms with the compiler's mask expression (profiles/r04_c2g_*: 1.0005 x the algorithmic bytes, 0.99 G vector
+// instructions = the time: issue-bound).
 __device__ __forceinline__ uint4 fetch_quad(const uint4 *__restrict__ planes4, uint64_t block, uint32_t quad, uint32_t plane, uint32_t lane) {
     if (quad < 32u) return planes4[((block * 32u + quad) * 3u + plane) * 64u + lane];
     const uint32_t q2 = quad - 32u; // the next strand: the same words one bit down, the next column's bit 0 on top
@@ -421,6 +315,12 @@ __device__ __forceinline__ uint4 fetch_quad(const uint4 *__restrict__ planes4, u
     const uint4 nxt = (lane < 63u) ? planes4[((block * 32u + q2) * 3u + plane) * 64u + lane + 1u]
                                    : planes4[(((block + 1u) * 32u + q2) * 3u + plane) * 64u];
     return make_uint4((own.x >> 1) | (nxt.x << 31), (own.y >> 1) | (nxt.y << 31), (own.z >> 1) | (nxt.z << 31), (own.w >> 1) | (nxt.w << 31));
+}
+
+__device__ __forceinline__ uint32_t and_or_s(uint32_t v, uint32_t smask, uint32_t acc) { // (v & smask) | acc, smask wave-uniform
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "s"(smask), "v"(acc));
+    return r;
 }
 
 template <int K1, int PB>
@@ -483,7 +383,9 @@ __global__ __launch_bounds__(256) void filter_generic_quad_kernel(const uint32_t
                             const uint32_t w = i >= s ? curw[b] : prevw[b];
                             const uint32_t nA = (uint32_t)((int32_t)(w << (31 - sh)) >> 31), nC = (uint32_t)((int32_t)(w << (30 - sh)) >> 31),
                                            nG = (uint32_t)((int32_t)(w << (29 - sh)) >> 31), nT = (uint32_t)((int32_t)(w << (28 - sh)) >> 31);
-                            const uint32_t mm = inv | (isA & nA) | (isC & nC) | (isG & nG) | (isT & nT);
+                            // inv | (isA & nA) | (isC & nC) | (isG & nG) | (isT & nT) as one chain of four v_and_or_b32, each with its mask
+                            // straight from the scalar register (left to itself the compiler makes four ANDs and two three-way ORs)
+                            const uint32_t mm = and_or_s(isT, nT, and_or_s(isG, nG, and_or_s(isC, nC, and_or_s(isA, nA, inv))));
                             // a mismatch at a protected position goes into the top level whatever the count below it (the lower levels take
                             // it too: the position is out either way) -- no branch, K1 + 1 operations
                             const uint32_t prot = ~(uint32_t)((int32_t)(w << (27 - sh)) >> 31);
@@ -525,15 +427,6 @@ __global__ __launch_bounds__(256) void filter_generic_quad_kernel(const uint32_t
             }
     }
 }
-
-template __global__ void filter_generic_quad_kernel<1, 4>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t, const uint32_t *,
-                                                          ipcr_queue_entry *, uint64_t, unsigned long long *);
-template __global__ void filter_generic_quad_kernel<2, 4>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t, const uint32_t *,
-                                                          ipcr_queue_entry *, uint64_t, unsigned long long *);
-template __global__ void filter_generic_quad_kernel<3, 4>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t, const uint32_t *,
-                                                          ipcr_queue_entry *, uint64_t, unsigned long long *);
-template __global__ void filter_generic_quad_kernel<4, 4>(const uint32_t *, uint64_t, uint64_t, const ipcr_dev_pattern *, uint32_t, const uint32_t *,
-                                                          ipcr_queue_entry *, uint64_t, unsigned long long *);
 
 // ------------------------------------------------------------------------------ verify
 // verifyAt (core/engine/ac.go:186-213) / the inner loop of FindMatches
@@ -909,29 +802,31 @@ hipError_t launch_filter_generic(hipStream_t st, const uint32_t *planes, uint64_
                                  ipcr_queue_entry *queue, uint64_t qcap, unsigned long long *qcount,
                                  hipEvent_t start, hipEvent_t stop) {
     if (nblocks == 0 || npat == 0) return hipSuccess;
-    // max_mm <= 3: a wave per (block, row quad), IPCR_GENERIC_QUAD=0: the row-at-a-time form (kept for comparison and for k > 3)
-    static const bool quad = [] { const char *e = getenv("IPCR_GENERIC_QUAD"); return !(e && e[0] == '0'); }();
-    if (quad && max_mm <= 3u && nblocks * 8u <= 0x7FFFFFFFull) {
-        const dim3 qgrid((uint32_t)(nblocks * 8u)); // 32 row quads per block, 4 waves per workgroup
-#define IPCR_QUAD_LAUNCH(K1) hipExtLaunchKernelGGL((filter_generic_quad_kernel<K1, 4>), qgrid, dim3(256), 0, st, start, stop, 0, planes, block0, nblocks, \
-                                                   pats, npat, sel, queue, qcap, qcount)
-        switch (max_mm) {
-        case 0: IPCR_QUAD_LAUNCH(1); break;
-        case 1: IPCR_QUAD_LAUNCH(2); break;
-        case 2: IPCR_QUAD_LAUNCH(3); break;
-        default: IPCR_QUAD_LAUNCH(4); break;
-        }
-#undef IPCR_QUAD_LAUNCH
-        return hipGetLastError();
+    if (max_mm > 16u || nblocks * 8u > 0x7FFFFFFFull) return hipErrorInvalidValue; // (IPCR_MAX_MM; 2^28 blocks = 7e13 bases)
+    const dim3 qgrid((uint32_t)(nblocks * 8u)); // a wave per (block, row quad): 32 row quads per block, 4 waves per workgroup
+    // counter depth K1 = max_mm + 1 at compile time; patterns per walk by what 4 start rows x PB x K1 counters leave of the registers
+#define IPCR_QUAD_LAUNCH(K1, PB) hipExtLaunchKernelGGL((filter_generic_quad_kernel<K1, PB>), qgrid, dim3(256), 0, st, start, stop, 0, planes, block0, nblocks, \
+                                                       pats, npat, sel, queue, qcap, qcount); break
+    switch (max_mm) {
+    case 0: IPCR_QUAD_LAUNCH(1, 4);
+    case 1: IPCR_QUAD_LAUNCH(2, 4);
+    case 2: IPCR_QUAD_LAUNCH(3, 4);
+    case 3: IPCR_QUAD_LAUNCH(4, 4);
+    case 4: IPCR_QUAD_LAUNCH(5, 2);
+    case 5: IPCR_QUAD_LAUNCH(6, 2);
+    case 6: IPCR_QUAD_LAUNCH(7, 2);
+    case 7: IPCR_QUAD_LAUNCH(8, 2);
+    case 8: IPCR_QUAD_LAUNCH(9, 1);
+    case 9: IPCR_QUAD_LAUNCH(10, 1);
+    case 10: IPCR_QUAD_LAUNCH(11, 1);
+    case 11: IPCR_QUAD_LAUNCH(12, 1);
+    case 12: IPCR_QUAD_LAUNCH(13, 1);
+    case 13: IPCR_QUAD_LAUNCH(14, 1);
+    case 14: IPCR_QUAD_LAUNCH(15, 1);
+    case 15: IPCR_QUAD_LAUNCH(16, 1);
+    default: IPCR_QUAD_LAUNCH(17, 1);
     }
-    const uint64_t tiles = nblocks * 128u; // one wave per (block, row)
-    const dim3 grid((uint32_t)((tiles + 3u) / 4u));
-    if (max_mm <= 3u)
-        hipExtLaunchKernelGGL((filter_generic_kernel<4, 4>), grid, dim3(256), 0, st, start, stop, 0, planes, block0, nblocks, pats,
-                              npat, max_mm, sel, queue, qcap, qcount);
-    else
-        hipExtLaunchKernelGGL((filter_generic_kernel<17, 2>), grid, dim3(256), 0, st, start, stop, 0, planes, block0, nblocks, pats,
-                              npat, max_mm, sel, queue, qcap, qcount);
+#undef IPCR_QUAD_LAUNCH
     return hipGetLastError();
 }
 

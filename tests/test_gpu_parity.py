@@ -1,8 +1,6 @@
 """GPU parity: the HIP path (through the C ABI, via the ipcr_amd mirror of the reference API)
 against the CPU oracle on the same inputs.  Bit-exact, including emission order."""
-import os
 import random
-import sys
 from collections import Counter
 
 import pytest
@@ -231,20 +229,12 @@ def test_windows_across_strand_and_block_ends(hip, monkeypatch, roll):
         check(hip, cfg, "".join(seq).encode(), hip.primer.AddSelfPairs(pairs), specialize=True)
 
 
-@pytest.mark.parametrize("quad", ["1", "0"])
-def test_table_driven_filter_across_strand_column_and_block_ends(hip, quad):
-    """the table-driven filter in both forms -- a wave per row quad (four start rows, 16-byte loads; max_mm <= 3) and, in a
-    child process with IPCR_GENERIC_QUAD=0, a wave per row -- on sites whose windows start in the last rows of a strand
-    (the walk continues in the next strand: the same words one bit down), in the last strand of a column (the next
-    column's bit 0 comes in on top) and of a block (lane 63's neighbour is column 0 of the next block: p near 262144),
-    k = 0..3 with and without a terminal window, IUPAC primers, junk bytes; vs the oracle"""
-    if quad == "0":   # the switch is read once per process
-        import subprocess
-        env = dict(os.environ, IPCR_GENERIC_QUAD="0")
-        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
-                            "test_table_driven_filter_across_strand_column_and_block_ends and 1"], env=env, capture_output=True, text=True)
-        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-        return
+def test_table_driven_filter_across_strand_column_and_block_ends(hip):
+    """the table-driven filter (a wave per row quad: four start rows, 16-byte loads, the pattern's masks in scalar registers;
+    kernels.hip: filter_generic_quad_kernel) on sites whose windows start in the last rows of a strand (the walk continues
+    in the next strand: the same words one bit down), in the last strand of a column (the next column's bit 0 comes in on
+    top) and of a block (lane 63's neighbour is column 0 of the next block: p near 262144), k = 0..3 with and without a
+    terminal window (counter depths 1..4), IUPAC primers, junk bytes; vs the oracle.  Larger k: test_large_k_on_every_kernel"""
     rng = random.Random(777)
     E, P = hip.engine, hip.primer.Pair
     n = 270000
@@ -1867,7 +1857,7 @@ def test_device_slots_large_panel_and_native_pool(hip, monkeypatch, tmp_path):
 @pytest.mark.parametrize("kind", ["specialised", "specialised_long", "table_driven"])
 def test_large_k_on_every_kernel(hip, k, kind):
     """k = 5, 8, 16 (the seed index stops at k = 3; beyond it panels go to the specialised filter in groups, or to
-    filter_generic_kernel<17>): primers of up to 32 nt (the specialised filter verifies its own survivors), primers of
+    filter_generic_quad_kernel<K1 = k + 1>, two patterns per walk up to k = 7, one beyond): primers of up to 32 nt (the specialised filter verifies its own survivors), primers of
     40-60 nt (filtered by their 20 positions next to the protected end, every survivor through the stand-alone verifier)
     and the table-driven kernel, on random sequence with junk bytes and sites planted with up to k substitutions outside
     the 3' window; HitCap 10000 and 0; vs the oracle (core/primer/match.go:67-84, core/engine/ac.go:186-213)"""

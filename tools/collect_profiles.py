@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = {"c2": "ipcr_filter", "c2n": "ipcr_filter", "c3": "ipcr_filter", "c4": "ipcr_index_filter", "c4n": "ipcr_index_filter",
-          "c2g": "filter_generic_"}   # c2g: C2 through the table-driven kernel (IPCR_SPECIALIZE=0): filter_generic_quad_kernel (k <= 3) / filter_generic_kernel
+          "c2g": "filter_generic_quad_kernel"}   # c2g: C2 through the table-driven kernel (IPCR_SPECIALIZE=0)
 ALG_BYTES = 1_125_000_000   # 3.0e9 bases x 0.375 B: what one sweep of the benchmark genome reads
 
 
@@ -39,10 +39,13 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
-    line = open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]
+    if os.path.exists(os.path.join(src, "bench.json")):
+        line = open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]
+        with open(os.path.join(dst, f"{tag}_bench.json"), "w") as fh:
+            fh.write(line + "\n")
+    else:   # only the prof stage was run this time (profile_round.sh <tag> prof "..."): the committed line stays
+        line = open(os.path.join(dst, f"{tag}_bench.json")).read().strip().splitlines()[-1]
     bench = json.loads(line)
-    with open(os.path.join(dst, f"{tag}_bench.json"), "w") as fh:
-        fh.write(line + "\n")
     serial = os.path.join(src, "bench_serial.json")
     if os.path.exists(serial):
         with open(os.path.join(dst, f"{tag}_bench_serial.json"), "w") as fh:
@@ -132,7 +135,7 @@ def kernel_stats_row(path):
     with open(path, newline="") as fh:
         for row in csv.DictReader(fh):
             name = row.get("Name", "")
-            if "ipcr_filter" in name or "ipcr_index_filter" in name or ("_c2g_" in path and "filter_generic_" in name):
+            if "ipcr_filter" in name or "ipcr_index_filter" in name or ("_c2g_" in path and "filter_generic_quad_kernel" in name):
                 tot = float(row.get("TotalDurationNs", 0) or 0)
                 if best is None or tot > best[3]:
                     best = (name.split("(")[0], int(row["Calls"]), float(row["AverageNs"]) / 1e3, tot)
