@@ -298,7 +298,8 @@ __global__ void lcg_fill_kernel(uint8_t *__restrict__ out, uint64_t n, uint32_t 
 // K1 = max_mm + 1: out), so there is no separate dead mask.  Survivors go to the candidate queue, a word per entry.
 // A wave owns the FOUR start rows of one row quad and walks down quad by quad: one 16-byte load per plane and lane brings four
 // rows (the layout's unit), every row is decoded once and then steps 4 starts x PB patterns = 16 independent counters, 8
-// vector instructions a step (four v_and_or for the mismatch mask, one select + K1 for the counters at k = 2); the pattern's
+// vector instructions a step (four and-ors for the mismatch mask, one select + K1 and-ors for the counters at k = 2, every
+// and-or a two-cycle v_bitop3_b32); the pattern's
 // masks live in scalar registers (a word = four positions, read once per quad) and every test on them is scalar work.  K1 is
 // a compile-time constant, PB follows from what 4 x PB x K1 counters leave of the registers.  Rows >= 128 continue in the next
 // strand: the same words one bit down, with bit 0 of the next column's word on top.  Workgroups are dealt to the XCDs
@@ -317,11 +318,9 @@ __device__ __forceinline__ uint4 fetch_quad(const uint4 *__restrict__ planes4, u
     return make_uint4((own.x >> 1) | (nxt.x << 31), (own.y >> 1) | (nxt.y << 31), (own.z >> 1) | (nxt.z << 31), (own.w >> 1) | (nxt.w << 31));
 }
 
-__device__ __forceinline__ uint32_t and_or_s(uint32_t v, uint32_t smask, uint32_t acc) { // (v & smask) | acc, smask wave-uniform
-    uint32_t r;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "s"(smask), "v"(acc));
-    return r;
-}
+// (a & b) | c as ONE v_bitop3_b32 (truth table 0xEA): it issues in two cycles where v_and_or_b32 -- the compiler's choice for the
+// same expression -- and v_or3_b32 take four (tools/ubench/valu_rates.hip); the walk below is bound by vector issue
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA); }
 
 template <int K1, int PB>
 __global__ __launch_bounds__(256) void filter_generic_quad_kernel(const uint32_t *__restrict__ planes,
@@ -383,16 +382,16 @@ __global__ __launch_bounds__(256) void filter_generic_quad_kernel(const uint32_t
                             const uint32_t w = i >= s ? curw[b] : prevw[b];
                             const uint32_t nA = (uint32_t)((int32_t)(w << (31 - sh)) >> 31), nC = (uint32_t)((int32_t)(w << (30 - sh)) >> 31),
                                            nG = (uint32_t)((int32_t)(w << (29 - sh)) >> 31), nT = (uint32_t)((int32_t)(w << (28 - sh)) >> 31);
-                            // inv | (isA & nA) | (isC & nC) | (isG & nG) | (isT & nT) as one chain of four v_and_or_b32, each with its mask
-                            // straight from the scalar register (left to itself the compiler makes four ANDs and two three-way ORs)
-                            const uint32_t mm = and_or_s(isT, nT, and_or_s(isG, nG, and_or_s(isC, nC, and_or_s(isA, nA, inv))));
+                            // inv | (isA & nA) | (isC & nC) | (isG & nG) | (isT & nT): a chain of four and-ors, each mask straight from its
+                            // scalar register (left to itself the compiler makes four ANDs and two three-way ORs)
+                            const uint32_t mm = and_or(isT, nT, and_or(isG, nG, and_or(isC, nC, and_or(isA, nA, inv))));
                             // a mismatch at a protected position goes into the top level whatever the count below it (the lower levels take
                             // it too: the position is out either way) -- no branch, K1 + 1 operations
                             const uint32_t prot = ~(uint32_t)((int32_t)(w << (27 - sh)) >> 31);
                             if (K1 > 1) {
-                                u[s][b][K1 - 1] |= (u[s][b][K1 > 1 ? K1 - 2 : 0] | prot) & mm;
+                                u[s][b][K1 - 1] = and_or(u[s][b][K1 > 1 ? K1 - 2 : 0] | prot, mm, u[s][b][K1 - 1]);
 #pragma unroll
-                                for (int t = K1 - 2; t >= 1; --t) u[s][b][t] |= u[s][b][t - 1] & mm;
+                                for (int t = K1 - 2; t >= 1; --t) u[s][b][t] = and_or(u[s][b][t - 1], mm, u[s][b][t]);
                             }
                             u[s][b][0] |= mm;
                         }
