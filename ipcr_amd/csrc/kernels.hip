@@ -367,27 +367,34 @@ __global__ __launch_bounds__(256) void filter_generic_quad_kernel(const uint32_t
 #pragma unroll
             for (int b = 0; b < PB; ++b) // (scalar registers: every mask test below is scalar work, the lanes only AND and OR)
                 curw[b] = q * 4u < L[b] ? ~(uint32_t)__builtin_amdgcn_readfirstlane((int)mw[b][q]) : 0u; // complemented: bit set = base NOT allowed / not protected
+            uint32_t isA[4], isC[4], isG[4], isT[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint32_t lo = los[i], hi = his[i], inv = ivs[i];
-                const uint32_t isA = ~lo & ~hi, isC = lo & ~hi, isG = ~lo & hi, isT = lo & hi;
+                isA[i] = ~los[i] & ~his[i]; isC[i] = los[i] & ~his[i]; isG[i] = ~los[i] & his[i]; isT[i] = los[i] & his[i];
+            }
+            // row i of the quad is position 4 q + (i - s) of the pattern for start row s: the seven offsets d = i - s each name ONE
+            // mask byte of a pattern (this quad's word or the one before), so its five scalar masks are made once per offset and
+            // serve the 4 - |d| (row, start) pairs that share it (made per step, the scalar instructions bound the walk); the
+            // count does not depend on the order its positions arrive in
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int jj = (int)(q * 4u) + i - s; // the pattern position this row is for start row s (wave-uniform)
-                    if (i < s && jj < 0) continue;        // (rows above the start row: the first quad only)
+            for (int b = 0; b < PB; ++b) {
 #pragma unroll
-                    for (int b = 0; b < PB; ++b) {
-                        if ((uint32_t)jj < L[b]) { // wave-uniform
-                            const int sh = 8 * ((i - s) & 3); // position 4 q + (i - s): this quad's word, or the one before
-                            const uint32_t w = i >= s ? curw[b] : prevw[b];
-                            const uint32_t nA = (uint32_t)((int32_t)(w << (31 - sh)) >> 31), nC = (uint32_t)((int32_t)(w << (30 - sh)) >> 31),
-                                           nG = (uint32_t)((int32_t)(w << (29 - sh)) >> 31), nT = (uint32_t)((int32_t)(w << (28 - sh)) >> 31);
+                for (int d = -3; d <= 3; ++d) {
+                    const uint32_t jj = q * 4u + (uint32_t)d; // (wraps below zero in the first quad: not < L)
+                    if (jj < L[b]) {                          // wave-uniform
+                        const int sh = 8 * (d & 3);
+                        const uint32_t w = d >= 0 ? curw[b] : prevw[b];
+                        const uint32_t nA = (uint32_t)((int32_t)(w << (31 - sh)) >> 31), nC = (uint32_t)((int32_t)(w << (30 - sh)) >> 31),
+                                       nG = (uint32_t)((int32_t)(w << (29 - sh)) >> 31), nT = (uint32_t)((int32_t)(w << (28 - sh)) >> 31);
+                        const uint32_t prot = ~(uint32_t)((int32_t)(w << (27 - sh)) >> 31);
+#pragma unroll
+                        for (int i = (d > 0 ? d : 0); i <= (d < 0 ? 3 + d : 3); ++i) {
+                            const int s = i - d;
                             // inv | (isA & nA) | (isC & nC) | (isG & nG) | (isT & nT): a chain of four and-ors, each mask straight from its
                             // scalar register (left to itself the compiler makes four ANDs and two three-way ORs)
-                            const uint32_t mm = and_or(isT, nT, and_or(isG, nG, and_or(isC, nC, and_or(isA, nA, inv))));
+                            const uint32_t mm = and_or(isT[i], nT, and_or(isG[i], nG, and_or(isC[i], nC, and_or(isA[i], nA, ivs[i]))));
                             // a mismatch at a protected position goes into the top level whatever the count below it (the lower levels take
                             // it too: the position is out either way) -- no branch, K1 + 1 operations
-                            const uint32_t prot = ~(uint32_t)((int32_t)(w << (27 - sh)) >> 31);
                             if (K1 > 1) {
                                 u[s][b][K1 - 1] = and_or(u[s][b][K1 > 1 ? K1 - 2 : 0] | prot, mm, u[s][b][K1 - 1]);
 #pragma unroll
