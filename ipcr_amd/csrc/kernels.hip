@@ -323,7 +323,7 @@ __device__ __forceinline__ uint4 fetch_quad(const uint4 *__restrict__ planes4, u
 __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA); }
 
 template <int K1, int PB>
-__global__ __launch_bounds__(256) void filter_generic_quad_kernel(const uint32_t *__restrict__ planes,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K1 <= 3 ? 5 : 3))) void filter_generic_quad_kernel(const uint32_t *__restrict__ planes,
                                                                   uint64_t block0, uint64_t nblocks, // blocks [block0, block0 + nblocks)
                                                                   const ipcr_dev_pattern *__restrict__ pats, uint32_t npat,
                                                                   const uint32_t *__restrict__ sel, // pattern subset or null
@@ -387,20 +387,30 @@ __global__ __launch_bounds__(256) void filter_generic_quad_kernel(const uint32_t
                         const uint32_t nA = (uint32_t)((int32_t)(w << (31 - sh)) >> 31), nC = (uint32_t)((int32_t)(w << (30 - sh)) >> 31),
                                        nG = (uint32_t)((int32_t)(w << (29 - sh)) >> 31), nT = (uint32_t)((int32_t)(w << (28 - sh)) >> 31);
                         const uint32_t prot = ~(uint32_t)((int32_t)(w << (27 - sh)) >> 31);
+                        // inv | (isA & nA) | (isC & nC) | (isG & nG) | (isT & nT): a chain of four and-ors per row, each mask straight from
+                        // its scalar register (left to itself the compiler makes four ANDs and two three-way ORs); the rows' chains are
+                        // written side by side: they do not depend on each other
+                        const int I0 = (d > 0 ? d : 0), I1 = (d < 0 ? 3 + d : 3);
+                        uint32_t mm[4];
 #pragma unroll
-                        for (int i = (d > 0 ? d : 0); i <= (d < 0 ? 3 + d : 3); ++i) {
+                        for (int i = I0; i <= I1; ++i) mm[i] = and_or(isA[i], nA, ivs[i]);
+#pragma unroll
+                        for (int i = I0; i <= I1; ++i) mm[i] = and_or(isC[i], nC, mm[i]);
+#pragma unroll
+                        for (int i = I0; i <= I1; ++i) mm[i] = and_or(isG[i], nG, mm[i]);
+#pragma unroll
+                        for (int i = I0; i <= I1; ++i) mm[i] = and_or(isT[i], nT, mm[i]);
+                        // a mismatch at a protected position goes into the top level whatever the count below it (the lower levels take
+                        // it too: the position is out either way) -- no branch, K1 + 1 operations
+#pragma unroll
+                        for (int i = I0; i <= I1; ++i) {
                             const int s = i - d;
-                            // inv | (isA & nA) | (isC & nC) | (isG & nG) | (isT & nT): a chain of four and-ors, each mask straight from its
-                            // scalar register (left to itself the compiler makes four ANDs and two three-way ORs)
-                            const uint32_t mm = and_or(isT[i], nT, and_or(isG[i], nG, and_or(isC[i], nC, and_or(isA[i], nA, ivs[i]))));
-                            // a mismatch at a protected position goes into the top level whatever the count below it (the lower levels take
-                            // it too: the position is out either way) -- no branch, K1 + 1 operations
                             if (K1 > 1) {
-                                u[s][b][K1 - 1] = and_or(u[s][b][K1 > 1 ? K1 - 2 : 0] | prot, mm, u[s][b][K1 - 1]);
+                                u[s][b][K1 - 1] = and_or(u[s][b][K1 > 1 ? K1 - 2 : 0] | prot, mm[i], u[s][b][K1 - 1]);
 #pragma unroll
-                                for (int t = K1 - 2; t >= 1; --t) u[s][b][t] = and_or(u[s][b][t - 1], mm, u[s][b][t]);
+                                for (int t = K1 - 2; t >= 1; --t) u[s][b][t] = and_or(u[s][b][t - 1], mm[i], u[s][b][t]);
                             }
-                            u[s][b][0] |= mm;
+                            u[s][b][0] |= mm[i];
                         }
                     }
                 }
