@@ -299,16 +299,17 @@ __global__ void lcg_fill_kernel(uint8_t *__restrict__ out, uint64_t n, uint32_t 
 // A wave owns the FOUR start rows of one row quad and walks down quad by quad: one 16-byte load per plane and lane brings four
 // rows (the layout's unit), every row is decoded once and then steps 4 starts x PB patterns = 16 independent counters, 8
 // vector instructions a step (four and-ors for the mismatch mask, one select + K1 and-ors for the counters at k = 2, every
-// and-or a two-cycle v_bitop3_b32); the pattern's
-// masks live in scalar registers (a word = four positions, read once per quad) and every test on them is scalar work.  K1 is
-// a compile-time constant, PB follows from what 4 x PB x K1 counters leave of the registers.  Rows >= 128 continue in the next
-// strand: the same words one bit down, with bit 0 of the next column's word on top.  Workgroups are dealt to the XCDs
-// round-robin by the dispatcher: the index is turned so that every XCD walks a contiguous eighth of the blocks and the rows a
-// wave shares with the waves below it (it reads ~4 quads past its own) come out of that XCD's L2.
+// and-or a two-cycle v_bitop3_b32).  The pattern's masks live in scalar registers (a word = four positions, read once per
+// quad), every test on them is scalar work, and the five masks of a position are made once per offset d = row - start, not
+// once per step (the scalar unit bound the walk before that).  K1 is a compile-time constant, PB follows from what 4 x PB x
+// K1 counters leave of the registers.  Rows >= 128 continue in the next strand: the same words one bit down, with bit 0 of the
+// next column's word on top.  Workgroups are dealt to the XCDs round-robin by the dispatcher: the index is turned so that
+// every XCD walks a contiguous eighth of the blocks and the rows a wave shares with the waves below it (it reads ~4 quads past
+// its own) come out of that XCD's L2.
 // Round 4, before: a wave per ROW (one dword per lane and row out of every 16 bytes, four patterns per walk, run-time counter
 // depth): 6.39 ms per 3 Gb for C2's four patterns, 4.1 x the algorithmic bytes from HBM, 2.70 G vector instructions; this
-// form 1.58 ms with the compiler's mask expression (profiles/r04_c2g_*: 1.0005 x the algorithmic bytes, 0.99 G vector
-// instructions = the time: issue-bound).
+// form 1.08 ms, 1.0005 x the algorithmic bytes, 0.79 G vector + 0.40 G scalar instructions (profiles/r04_c2g_*; DESIGN 4.4
+// has the steps in between).
 __device__ __forceinline__ uint4 fetch_quad(const uint4 *__restrict__ planes4, uint64_t block, uint32_t quad, uint32_t plane, uint32_t lane) {
     if (quad < 32u) return planes4[((block * 32u + quad) * 3u + plane) * 64u + lane];
     const uint32_t q2 = quad - 32u; // the next strand: the same words one bit down, the next column's bit 0 on top
@@ -319,7 +320,7 @@ __device__ __forceinline__ uint4 fetch_quad(const uint4 *__restrict__ planes4, u
 }
 
 // (a & b) | c as ONE v_bitop3_b32 (truth table 0xEA): it issues in two cycles where v_and_or_b32 -- the compiler's choice for the
-// same expression -- and v_or3_b32 take four (tools/ubench/valu_rates.hip); the walk below is bound by vector issue
+// same expression -- and v_or3_b32 take four (tools/ubench/valu_rates.hip)
 __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA); }
 
 template <int K1, int PB>
