@@ -141,7 +141,10 @@ ipcr_status ensure_slot(ipcr_exchange *x, int slot) {
         if (x->d_stage) (void)hipFree(x->d_stage);
         x->d_stage = nullptr;
         XHIP(hipMalloc(&x->d_stage, nb));
-        XHIP(hipMemset(x->d_stage, 0, nb));
+        // on the exchange's own stream, in front of the copies that fill the block: hipMemset runs on the null stream and does not
+        // wait for the device, x->stream is non-blocking -- the fill could land AFTER the header and records staged below and the
+        // rank would report zero hits (seen once in test_hit_cap_bounds_device_memory after a redo had regrown the buffer)
+        XHIP(hipMemsetAsync(x->d_stage, 0, nb, x->stream));
         x->stage_cap = x->cap;
     }
     return IPCR_OK;

@@ -1122,6 +1122,7 @@ ipcr_status genome_alloc(ipcr_genome *g, uint64_t cap_cols, uint32_t max_records
     HIPCHK(hipMalloc((void **)&g->d_block_rec, (blocks + 1) * 4ull));
     HIPCHK(hipMalloc((void **)&g->d_rec_len, (uint64_t)max_records * 8ull));
     HIPCHK(hipMemset(g->d_flags, 0, (uint64_t)max_records * 4ull));
+    HIPCHK(hipStreamSynchronize(nullptr)); // (the fill runs on the null stream; the genome's stream is non-blocking and must not overtake it)
     return IPCR_OK;
 }
 
@@ -2301,6 +2302,7 @@ ipcr_status scan_collect(const ipcr_panel *p, ipcr_scratch *s, ipcr_genome *g) {
             s->d_counts = nullptr;
             HIPCHK(hipMalloc(&s->d_hitbuf, (want + 2) * sizeof(ipcr_hit_rec)));
             HIPCHK(hipMemset(s->d_hitbuf, 0, 64));
+            HIPCHK(hipStreamSynchronize(nullptr)); // (null-stream fill: done before the sweep on the scratch's non-blocking stream counts into it)
             s->d_counts = static_cast<unsigned long long *>(s->d_hitbuf);
             s->d_hits = static_cast<ipcr_hit_rec *>(s->d_hitbuf) + 2;
             s->hcap = want;
@@ -2759,6 +2761,7 @@ ipcr_status ipcr_scratch_create_on(const ipcr_panel *p, int32_t device, ipcr_scr
         memset(raw->pinned, 0, 64 + PREFIX_HITS * sizeof(ipcr_hit) + 64);
         HIPCHK(hipMalloc((void **)&raw->d_tickets, 65 * 128));
         HIPCHK(hipMemset(raw->d_tickets, 0, 65 * 128));
+        HIPCHK(hipStreamSynchronize(nullptr)); // (the three fills above run on the null stream: done before the first sweep on the scratch's own, non-blocking stream)
         raw->counted_in = p->live_scratches;
         raw->counted_in->fetch_add(1);
         return IPCR_OK;
