@@ -817,3 +817,24 @@ def test_fasta_host_packer_equals_the_streaming_reader(tmp_path):
         open(path, "w", newline="").write(">x\n" + "\n".join(lines) + "\n")
         rc = fn(path.encode())
         assert rc < 0, (case, kind, rc)
+
+
+def test_null_stream_fills_are_waited_for():
+    """Every stream the library creates is non-blocking, and hipMemset(dev, ...) runs on the null stream without waiting for the
+    device: a fill of fresh device memory that is followed by work on one of the library's streams can land AFTER that work
+    (round 4: the exchange's staging block was cleared after its header had been staged -- a rank reported zero hits).  The
+    rule the sources keep: a synchronous-looking hipMemset is followed, before anything else touches the memory, by
+    hipStreamSynchronize(nullptr); fills that belong to a stream's order use hipMemsetAsync on that stream."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = 0
+    for path in sorted(glob.glob(os.path.join(root, "ipcr_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(root, "ipcr_amd", "csrc", "*.hip"))):
+        lines = open(path).read().split("\n")
+        for i, line in enumerate(lines):
+            if re.search(r"\bhipMemset(D8|D16|D32)?\s*\(", line) and "//" not in line.split("hipMemset")[0]:
+                seen += 1
+                window = "\n".join(lines[i:i + 12])
+                assert "hipStreamSynchronize(nullptr)" in window or "hipDeviceSynchronize()" in window, \
+                    "%s:%d: hipMemset on the null stream is not waited for before the library's non-blocking streams go on" % (os.path.basename(path), i + 1)
+    assert seen >= 3
